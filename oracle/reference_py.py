@@ -1,0 +1,334 @@
+"""ORACLE (test infrastructure, not product code): pure-Python restatement of the host-side pre-pass of one MPC
+solve - rows a10, a11, a12 of SURVEY.md section 8 plus the time grid and target trajectories (A.5-A.8).
+
+Each function cites the reference file:line it follows (paths relative to /root/reference).  [OCS2-upstream]
+marks behaviour of un-vendored OCS2 (`ocs2_core/misc/Lookup.h`, `ocs2_oc/oc_data/TimeDiscretization.cpp`,
+`ocs2_core/misc/LinearInterpolation.h`, `ocs2_core/reference/ModeSchedule.cpp`) restated from the published sources.
+Parity status: UNPINNED (no reference fixtures exist); pinned by the hand-derived known answers of SURVEY.md
+section 8(c)(4) in tests/test_reference_oracle.py.
+"""
+import bisect
+import math
+
+import numpy as np
+
+STANCE = 3
+EVENT_NONE, EVENT_PRE, EVENT_POST = 0, 1, 2
+LIMIT_EPS = 1e-9  # [OCS2-upstream] numeric_traits::limitEpsilon
+WEAK_EPS = 1e-6   # [OCS2-upstream] numeric_traits::weakEpsilon
+
+
+def mode_flags(mode):
+    """modeNumber2StanceLeg, include/ocs2_bipedal_robot/gait/MotionPhaseDefinition.h:57-76."""
+    return {0: (False, False, False, False), 1: (True, True, False, False), 2: (False, False, True, True),
+            3: (True, True, True, True)}[mode]
+
+
+def find_index_in_time_array(times, t):
+    """[OCS2-upstream] lookup::findIndexInTimeArray = std::lower_bound."""
+    return bisect.bisect_left(times, t)
+
+
+def mode_at_time(event_times, modes, t):
+    """[OCS2-upstream] ModeSchedule::modeAtTime: t exactly on an event belongs to the earlier mode."""
+    return modes[find_index_in_time_array(event_times, t)]
+
+
+class GaitSchedule:
+    """src/gait/GaitSchedule.cpp:40-137."""
+
+    def __init__(self, event_times, mode_sequence, template, phase_transition_stance_time):
+        self.event_times = list(event_times)
+        self.mode_sequence = list(mode_sequence)
+        self.template = (list(template[0]), list(template[1]))
+        self.phase_transition_stance_time = phase_transition_stance_time
+
+    def insert_mode_sequence_template(self, template, start_time, final_time):  # :46-73
+        self.template = (list(template[0]), list(template[1]))
+        ev, ms = self.event_times, self.mode_sequence
+        index = bisect.bisect_left(ev, start_time)
+        if index < len(ev):
+            del ev[index:]
+            del ms[index + 1:]
+        stance_time = self.phase_transition_stance_time
+        if ms and ms[-1] == STANCE:
+            stance_time = 0.0
+        if stance_time > 0.0:
+            ev.append(start_time)
+            ms.append(STANCE)
+        self._tile(start_time + stance_time, final_time)
+
+    def get_mode_schedule(self, lower, upper):  # :78-102
+        ev, ms = self.event_times, self.mode_sequence
+        index = bisect.bisect_left(ev, lower)
+        if index > 0:
+            del ev[:index - 1]
+            del ms[:index - 1]
+            ms[0] = STANCE
+        tiling_start = upper if not ev else ev[-1]
+        del ev[-1:]
+        del ms[-1:]
+        self._tile(tiling_start, upper)
+        return list(ev), list(ms)
+
+    def _tile(self, start_time, final_time):  # :107-137
+        ev, ms = self.event_times, self.mode_sequence
+        t_times, t_modes = self.template
+        if len(t_modes) == 0:
+            return
+        if ev and start_time <= ev[-1]:
+            raise RuntimeError("The initial time for template-tiling is not greater than the last event time.")
+        ev.append(start_time)
+        while ev[-1] < final_time:
+            for i in range(len(t_modes)):
+                ms.append(t_modes[i])
+                ev.append(ev[-1] + (t_times[i + 1] - t_times[i]))
+        ms.append(STANCE)
+
+
+class CubicSpline:
+    """src/foot_planner/CubicSpline.cpp:38-72."""
+
+    def __init__(self, start, end):  # nodes are (time, position, velocity)
+        self.t0, self.t1 = start[0], end[0]
+        self.dt = end[0] - start[0]
+        dp = end[1] - start[1]
+        dv = end[2] - start[2]
+        self.dc0 = 0.0
+        self.dc1 = start[2]
+        self.dc2 = -(3.0 * start[2] + dv)
+        self.dc3 = 2.0 * start[2] + dv
+        self.c0 = self.dc0 * self.dt + start[1]
+        self.c1 = self.dc1 * self.dt
+        self.c2 = self.dc2 * self.dt + 3.0 * dp
+        self.c3 = self.dc3 * self.dt - 2.0 * dp
+
+    def position(self, t):
+        tn = (t - self.t0) / self.dt
+        return self.c3 * tn * tn * tn + self.c2 * tn * tn + self.c1 * tn + self.c0
+
+    def velocity(self, t):
+        tn = (t - self.t0) / self.dt
+        return (3.0 * self.c3 * tn * tn + 2.0 * self.c2 * tn + self.c1) / self.dt
+
+
+class SplineCpg:
+    """src/foot_planner/SplineCpg.cpp:38-53."""
+
+    def __init__(self, lift_off, mid_height, touch_down):
+        self.mid_time = (lift_off[0] + touch_down[0]) / 2
+        self.left = CubicSpline(lift_off, (self.mid_time, mid_height, 0.0))
+        self.right = CubicSpline((self.mid_time, mid_height, 0.0), touch_down)
+
+    def position(self, t):
+        return self.left.position(t) if t < self.mid_time else self.right.position(t)
+
+    def velocity(self, t):
+        return self.left.velocity(t) if t < self.mid_time else self.right.velocity(t)
+
+
+class SwingTrajectoryPlanner:
+    """src/foot_planner/SwingTrajectoryPlanner.cpp:50-219 (terrain height 0, SwitchedModelReferenceManager.cpp:66-67)."""
+
+    def __init__(self, cfg, num_feet=4):
+        self.cfg = cfg
+        self.num_feet = num_feet
+        self.events = None
+        self.traj = None
+
+    def update(self, event_times, mode_sequence, terrain_height=0.0):
+        n = len(mode_sequence)
+        flags = [[mode_flags(mode_sequence[p])[j] for p in range(n)] for j in range(self.num_feet)]
+        self.traj = []
+        for j in range(self.num_feet):
+            row = []
+            for p in range(n):
+                if not flags[j][p]:
+                    start, final = self._find_index(p, flags[j])
+                    if start < 0:
+                        raise RuntimeError("The time of take-off for the first swing of the EE with ID %d is not defined." % j)
+                    if final >= n - 1:
+                        raise RuntimeError("The time of touch-down for the last swing of the EE with ID %d is not defined." % j)
+                    t_start, t_final = event_times[start], event_times[final]
+                    scaling = min(1.0, (t_final - t_start) / self.cfg["swingTimeScale"])
+                    lift_off = (t_start, terrain_height, scaling * self.cfg["liftOffVelocity"])
+                    touch_down = (t_final, terrain_height, scaling * self.cfg["touchDownVelocity"])
+                    mid = min(terrain_height, terrain_height) + scaling * self.cfg["swingHeight"]
+                    row.append(SplineCpg(lift_off, mid, touch_down))
+                else:
+                    row.append(SplineCpg((0.0, terrain_height, 0.0), terrain_height, (1.0, terrain_height, 0.0)))
+            self.traj.append(row)
+        self.events = list(event_times)
+
+    @staticmethod
+    def _find_index(index, flag):  # :159-186
+        n = len(flag)
+        start = -1
+        for ip in range(index - 1, -1, -1):
+            if flag[ip]:
+                start = ip
+                break
+        final = n - 1
+        for ip in range(index + 1, n):
+            if flag[ip]:
+                final = ip - 1
+                break
+        return start, final
+
+    def z_velocity(self, leg, t):  # :52-55
+        return self.traj[leg][find_index_in_time_array(self.events, t)].velocity(t)
+
+    def z_position(self, leg, t):  # :57-60
+        return self.traj[leg][find_index_in_time_array(self.events, t)].position(t)
+
+
+def time_discretization_with_events(t0, tf, dt, event_times, dt_min=10.0 * LIMIT_EPS):
+    """[OCS2-upstream] ocs2_oc/oc_data/TimeDiscretization.cpp timeDiscretizationWithEvents.
+    Returns [(time, event)], event in {NONE, PRE, POST}."""
+    assert dt > 0 and tf > t0
+    out = [(t0, EVENT_NONE)]
+    next_event = find_index_in_time_array(event_times, t0)
+    t_next = t0
+    while out[-1][0] < tf:
+        t_next = t_next + dt
+        ev = EVENT_NONE
+        if next_event < len(event_times) and t_next >= event_times[next_event]:
+            t_next = event_times[next_event]
+            ev = EVENT_PRE
+            next_event += 1
+        if t_next >= tf:
+            t_next = tf
+            ev = EVENT_NONE
+        if t_next > out[-1][0] + dt_min:
+            out.append((t_next, ev))
+        else:  # points are close together -> overwrite the old point
+            out[-1] = (t_next, ev)
+        if ev == EVENT_PRE:
+            out.append((t_next, EVENT_POST))
+    return out
+
+
+def interval_start(node):
+    """[OCS2-upstream] getIntervalStart: post-event nodes are nudged +weakEpsilon."""
+    return node[0] + WEAK_EPS if node[1] == EVENT_POST else node[0]
+
+
+def interval_end(node):
+    """[OCS2-upstream] getIntervalEnd: pre-event nodes are nudged -weakEpsilon."""
+    return node[0] - WEAK_EPS if node[1] == EVENT_PRE else node[0]
+
+
+def rot_zyx(zyx):
+    z, y, x = zyx
+    cz, sz, cy, sy, cx, sx = math.cos(z), math.sin(z), math.cos(y), math.sin(y), math.cos(x), math.sin(x)
+    return np.array([[cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx],
+                     [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx],
+                     [-sy, cy * sx, cy * cx]])
+
+
+def target_pose_to_target_trajectories(model, target_pose, t_now, x_now, t_reach):
+    """bipedal_controllers/src/TargetTrajectoriesPublisher.cpp:40-58."""
+    nx = model["nx"]
+    cur = np.array(x_now[6:12], float)
+    cur[2] = model["com_height"]
+    cur[4] = 0.0
+    cur[5] = 0.0
+    xs = np.zeros((2, nx))
+    xs[0, 6:12] = cur
+    xs[0, 12:] = model["default_joint_state"]
+    xs[1, 6:12] = target_pose
+    xs[1, 12:] = model["default_joint_state"]
+    return np.array([t_now, t_reach]), xs
+
+
+def cmd_vel_to_target_trajectories(model, cmd_vel, t_now, x_now, time_to_target):
+    """bipedal_controllers/src/TargetTrajectoriesPublisher.cpp:76-99 (TIME_TO_TARGET passed explicitly)."""
+    cur = np.array(x_now[6:12], float)
+    vrot = rot_zyx(cur[3:6]) @ np.asarray(cmd_vel[:3], float)
+    target = np.array([cur[0] + vrot[0] * time_to_target, cur[1] + vrot[1] * time_to_target, model["com_height"],
+                       cur[3] + cmd_vel[3] * time_to_target, 0.0, 0.0])
+    times, xs = target_pose_to_target_trajectories(model, target, t_now, x_now, t_now + time_to_target)
+    xs[0, 0:3] = vrot
+    xs[1, 0:3] = vrot
+    return times, xs
+
+
+def goal_to_target_trajectories(model, goal, t_now, x_now):
+    """bipedal_controllers/src/TargetTrajectoriesPublisher.cpp:30-38,60-74."""
+    cur = np.array(x_now[6:12], float)
+    target = np.array([goal[0], goal[1], model["com_height"], goal[3], 0.0, 0.0])
+    d = target - cur
+    t_rot = abs(d[3]) / model["target_rotation_velocity"]
+    t_dis = math.sqrt(d[0] * d[0] + d[1] * d[1]) / model["target_displacement_velocity"]
+    return target_pose_to_target_trajectories(model, target, t_now, x_now, t_now + max(t_rot, t_dis))
+
+
+def interpolate_target(times, xs, t):
+    """[OCS2-upstream] TargetTrajectories::getDesiredState -> LinearInterpolation::interpolate (clamped)."""
+    n = len(times)
+    if n == 1 or t <= times[0]:
+        return np.array(xs[0])
+    if t >= times[-1]:
+        return np.array(xs[-1])
+    i = bisect.bisect_left(times, t) - 1
+    alpha = (times[i + 1] - t) / (times[i + 1] - times[i])
+    return alpha * xs[i] + (1.0 - alpha) * xs[i + 1]
+
+
+def node_arrays(model, t0, tf, dt, event_times, mode_sequence, target_times, target_states, planner=None):
+    """Everything the solver needs per shooting interval: kind (0 intermediate / 1 event),
+    interval start time ti, duration, mode id, swing references and x_ref, plus the node times."""
+    grid = time_discretization_with_events(t0, tf, dt, event_times)
+    if planner is None:
+        raise ValueError("planner required")
+    N = len(grid) - 1
+    nx = model["nx"]
+    kind = np.zeros(N, np.int32)
+    ti = np.zeros(N)
+    dts = np.zeros(N)
+    mode = np.zeros(N, np.int32)
+    zref = np.zeros((N, 4))
+    zdref = np.zeros((N, 4))
+    xref = np.zeros((N, nx))
+    for k in range(N):
+        if grid[k][1] == EVENT_PRE:
+            kind[k] = 1
+            ti[k] = grid[k][0]
+            mode[k] = mode_at_time(event_times, mode_sequence, ti[k])
+            xref[k] = interpolate_target(target_times, target_states, ti[k])
+            continue
+        ti[k] = interval_start(grid[k])
+        dts[k] = interval_end(grid[k + 1]) - ti[k]
+        mode[k] = mode_at_time(event_times, mode_sequence, ti[k])
+        for j in range(4):
+            zref[k, j] = planner.z_position(j, ti[k])
+            zdref[k, j] = planner.z_velocity(j, ti[k])
+        xref[k] = interpolate_target(target_times, target_states, ti[k])
+    times = np.array([g[0] for g in grid])
+    return dict(N=N, kind=kind, ti=ti, dt=dts, mode=mode, zref=zref, zdref=zdref, xref=xref, times=times,
+                events=np.array([g[1] for g in grid], np.int32))
+
+
+def weight_compensating_input(model, mode):
+    """include/ocs2_bipedal_robot/common/utils.h:63-76."""
+    flags = mode_flags(mode)
+    n = sum(flags)
+    u = np.zeros(model["nu"])
+    if n > 0:
+        w = model["robot_mass"] * 9.81
+        for i in range(4):
+            if flags[i]:
+                u[3 * i + 2] = w / n
+    return u
+
+
+def cold_start(model, nodes, x0):
+    """[OCS2-upstream] SqpSolver::initializeStateInputTrajectories without a previous solution +
+    BipedalRobotInitializer::compute (src/initialization/BipedalRobotInitializer.cpp:56-63)."""
+    N = nodes["N"]
+    x = np.tile(np.asarray(x0, float), (N + 1, 1))
+    u = np.zeros((N, model["nu"]))
+    for k in range(N):
+        if nodes["kind"][k] == 0:
+            u[k] = weight_compensating_input(model, int(nodes["mode"][k]))
+    return x, u
