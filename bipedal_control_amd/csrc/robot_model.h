@@ -1,0 +1,63 @@
+// Host-side model constants of the MPC problem: what BipedalRobotInterface assembles at construction
+// (ocs2_bipedal_robot/src/BipedalRobotInterface.cpp:67-204) reduced to plain arrays the kernels consume.
+#pragma once
+#include <string>
+#include <vector>
+
+namespace bpmpc {
+
+constexpr int kMaxJoints = 12;            // leg joints (H1: 10, G1 / OpenLoong class: 12)
+constexpr int kMaxBodies = kMaxJoints + 1;
+constexpr int kMaxState = 12 + kMaxJoints;
+constexpr int kNumContacts = 4;           // 3-DoF contact points (two per foot), task.info contactNames3DoF
+constexpr int kMaxEqRows = 16;            // FLY: 4 x (3 zero-force + 1 normal-velocity)
+
+// mode ids: include/ocs2_bipedal_robot/gait/MotionPhaseDefinition.h:47-52
+enum Mode { FLY = 0, LF = 1, RF = 2, STANCE = 3 };
+int mode_from_string(const std::string& s);  // unknown names map to 0 like the reference's std::map lookup
+
+struct ModeSchedule {
+  std::vector<double> event_times;
+  std::vector<int> modes;  // event_times.size() + 1
+};
+struct ModeTemplate {
+  std::vector<double> switching_times;
+  std::vector<int> modes;  // switching_times.size() - 1
+};
+
+struct SwingConfig { double lift_off_velocity = 0, touch_down_velocity = 0, swing_height = 0.1, swing_time_scale = 0.15; };
+struct SqpConfig { double dt = 0.015; int sqp_iteration = 1; double delta_tol = 1e-4, g_max = 1e-2, g_min = 1e-6;
+                   // [OCS2-upstream] sqp::Settings defaults not present in task.info
+                   double alpha_decay = 0.5, alpha_min = 1e-4, gamma_c = 1e-6, armijo_factor = 1e-4, cost_tol = 1e-4; };
+
+struct RobotModel {
+  int nj = 0, nx = 0, nu = 0;
+  std::vector<std::string> joint_names, contact_names;
+  // kinematic tree: body 0 = floating base (welded links merged), joint j (1..nj) moves body j
+  int parent[kMaxBodies] = {};
+  double Rfix[kMaxBodies][9] = {}, pfix[kMaxBodies][3] = {}, axis[kMaxBodies][3] = {};
+  double mass[kMaxBodies] = {}, com[kMaxBodies][3] = {}, inertia[kMaxBodies][9] = {};
+  int contact_body[kNumContacts] = {};
+  double contact_off[kNumContacts][3] = {};
+  double robot_mass = 0;
+  std::vector<double> Q, R, initial_state, default_joint_state;
+  double com_height = 0, target_displacement_velocity = 0, target_rotation_velocity = 0;
+  double friction_coefficient = 0.7, cone_regularization = 25.0, cone_gripper_force = 0.0, cone_hessian_shift = 1e-6;
+  double barrier_mu = 0.1, barrier_delta = 5.0;
+  double position_error_gain = 0, phase_transition_stance_time = 0;
+  double time_horizon = 1.0;
+  SwingConfig swing;
+  SqpConfig sqp;
+  ModeSchedule initial_mode_schedule;
+  ModeTemplate default_template;
+};
+
+// Throws std::runtime_error (bad files, unsupported joints, dimension overflow).
+RobotModel load_robot_model(const std::string& urdf_path, const std::string& task_info, const std::string& reference_info);
+ModeTemplate load_mode_template(const std::string& gait_info, const std::string& name);
+
+// World positions of the contact points and their 3 x nj Jacobians w.r.t. the leg joints at configuration
+// q = [p(3), zyx(3), joints(nj)] (host double precision; used for the input-cost matrix and by tests).
+void contact_points(const RobotModel& m, const double* q, double pos[kNumContacts][3], double* jac_joints /*12 x nj or null*/);
+
+}  // namespace bpmpc
