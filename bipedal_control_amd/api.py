@@ -1,0 +1,312 @@
+"""Host-side mirror of the reference's operator interface for the MPC hot path, over the C ABI (include/bpmpc.h).
+
+Names follow the reference so that code reads like its call sites:
+  BipedalRobotInterface(taskFile, urdfFile, referenceFile)   ocs2_bipedal_robot/include/ocs2_bipedal_robot/BipedalRobotInterface.h:56-127
+  GaitSchedule.insertModeSequenceTemplate / getModeSchedule  ocs2_bipedal_robot/src/gait/GaitSchedule.cpp:46-102
+  loadModeSequenceTemplate                                   ocs2_bipedal_robot/src/gait/ModeSequenceTemplate.cpp:50-71
+  cmdVelToTargetTrajectories / goalToTargetTrajectories      bipedal_controllers/src/TargetTrajectoriesPublisher.cpp:60-99
+  BatchedSqpMpc(interface, ...)                              the SqpMpc construction sites bipedal_controllers/src/BipedalController.cpp:303-306
+                                                             and ocs2_bipedal_robot_ros/src/BipedalRobotSqpMpcNode.cpp:70, for a batch of problems
+Errors: the reference throws std::runtime_error / std::invalid_argument; here every non-zero status of the C ABI
+raises BpmpcError carrying bpmpc_last_error().
+"""
+import ctypes as C
+import os
+from collections import namedtuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+ModeSchedule = namedtuple("ModeSchedule", ["eventTimes", "modeSequence"])
+ModeSequenceTemplate = namedtuple("ModeSequenceTemplate", ["switchingTimes", "modeSequence"])
+TargetTrajectories = namedtuple("TargetTrajectories", ["timeTrajectory", "stateTrajectory"])
+
+MODE_NUMBER = {"FLY": 0, "LF": 1, "RF": 2, "STANCE": 3}
+
+
+class BpmpcError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("bpmpc status %d: %s" % (status, message))
+        self.status = status
+
+
+class _Settings(C.Structure):
+    _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("max_nodes", C.c_int), ("sqp_iterations", C.c_int), ("dt", C.c_double),
+                ("return_gains", C.c_int), ("profile", C.c_int), ("stream", C.c_void_p)]
+
+
+class _Schedule(C.Structure):
+    _fields_ = [("n_events", C.c_int), ("event_times", _dp), ("modes", _ip)]
+
+
+class _Target(C.Structure):
+    _fields_ = [("n_points", C.c_int), ("times", _dp), ("states", _dp)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("iterations", C.c_int), ("status", C.c_int), ("reserved", C.c_int),
+                ("merit_before", C.c_double), ("dynamics_sse_before", C.c_double), ("equality_sse_before", C.c_double),
+                ("merit_after", C.c_double), ("dynamics_sse_after", C.c_double), ("equality_sse_after", C.c_double),
+                ("step_size", C.c_double), ("armijo_descent", C.c_double), ("dx_norm", C.c_double), ("du_norm", C.c_double)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libbpmpc.so")
+
+
+def load_library():
+    """Loads the in-tree HIP library; raises if it has not been built (no fallback of any kind)."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise BpmpcError(-4, "libbpmpc.so is missing - build it with `python -m bipedal_control_amd.build` (hipcc, gfx950)")
+        lib = C.CDLL(path)
+        lib.bpmpc_last_error.restype = C.c_char_p
+        lib.bpmpc_version.restype = C.c_char_p
+        _LIB = lib
+    return _LIB
+
+
+def _check(rc):
+    if rc < 0:
+        raise BpmpcError(rc, load_library().bpmpc_last_error().decode())
+    return rc
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class BipedalRobotInterface:
+    """Problem definition: model constants + settings (BipedalRobotInterface.cpp:67-204)."""
+
+    def __init__(self, taskFile, urdfFile, referenceFile):
+        lib = load_library()
+        self._h = C.c_void_p()
+        _check(lib.bpmpc_model_create(str(urdfFile).encode(), str(taskFile).encode(), str(referenceFile).encode(), C.byref(self._h)))
+        nx, nu, nc, nj = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(lib.bpmpc_model_dims(self._h, C.byref(nx), C.byref(nu), C.byref(nc), C.byref(nj)))
+        self.stateDim, self.inputDim, self.numThreeDofContacts, self.actuatedDofNum = nx.value, nu.value, nc.value, nj.value
+        self.taskFile, self.urdfFile, self.referenceFile = str(taskFile), str(urdfFile), str(referenceFile)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.bpmpc_model_destroy(self._h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def get(self, name, capacity=4096):
+        out = np.zeros(capacity)
+        n = _check(load_library().bpmpc_model_get(self._h, name.encode(), _d(out), capacity))
+        return out[:n].copy()
+
+    def getInitialState(self):
+        return self.get("initial_state")
+
+    def jointNames(self):
+        buf = C.create_string_buffer(256)
+        names = []
+        for j in range(self.actuatedDofNum):
+            _check(load_library().bpmpc_model_joint_name(self._h, j, buf, 256))
+            names.append(buf.value.decode())
+        return names
+
+    def robotMass(self):
+        return float(self.get("robot_mass")[0])
+
+    def sqpSettings(self):
+        v = self.get("sqp")
+        return dict(dt=v[0], sqpIteration=int(v[1]), deltaTol=v[2], g_max=v[3], g_min=v[4])
+
+    def mpcSettings(self):
+        return dict(timeHorizon=float(self.get("time_horizon")[0]))
+
+    def costMatrices(self):
+        nx, nu = self.stateDim, self.inputDim
+        return self.get("Q").reshape(nx, nx), self.get("R").reshape(nu, nu)
+
+    # --- target trajectories (TargetTrajectoriesPublisher.cpp:60-99)
+    def cmdVelToTargetTrajectories(self, cmdVel, time, state, timeToTarget=None):
+        if timeToTarget is None:
+            timeToTarget = self.mpcSettings()["timeHorizon"]
+        cmd, x = _f64(cmdVel), _f64(state)
+        times, states = np.zeros(2), np.zeros((2, self.stateDim))
+        _check(load_library().bpmpc_cmd_vel_to_targets(self._h, _d(cmd), C.c_double(time), _d(x), C.c_double(timeToTarget), _d(times), _d(states)))
+        return TargetTrajectories(times, states)
+
+    def goalToTargetTrajectories(self, goal, time, state):
+        g, x = _f64(goal), _f64(state)
+        times, states = np.zeros(2), np.zeros((2, self.stateDim))
+        _check(load_library().bpmpc_goal_to_targets(self._h, _d(g), C.c_double(time), _d(x), _d(times), _d(states)))
+        return TargetTrajectories(times, states)
+
+
+def loadModeSequenceTemplate(filename, topicName):
+    times, modes, n = np.zeros(65), np.zeros(64, np.int32), C.c_int()
+    _check(load_library().bpmpc_gait_load_template(str(filename).encode(), topicName.encode(), _d(times), _i(modes), 64, C.byref(n)))
+    return ModeSequenceTemplate(times[:n.value + 1].copy(), modes[:n.value].copy())
+
+
+class GaitSchedule:
+    """GaitSchedule(initModeSchedule, defaultModeSequenceTemplate, phaseTransitionStanceTime) as loaded by
+    BipedalRobotInterface::loadGaitSchedule (BipedalRobotInterface.cpp:209-234)."""
+
+    def __init__(self, interface):
+        self._h = C.c_void_p()
+        _check(load_library().bpmpc_gait_create(interface.handle, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.bpmpc_gait_destroy(self._h)
+            self._h = None
+
+    def insertModeSequenceTemplate(self, modeSequenceTemplate, startTime, finalTime):
+        t, m = _f64(modeSequenceTemplate.switchingTimes), np.ascontiguousarray(modeSequenceTemplate.modeSequence, np.int32)
+        _check(load_library().bpmpc_gait_insert_template(self._h, _d(t), _i(m), len(m), C.c_double(startTime), C.c_double(finalTime)))
+
+    def getModeSchedule(self, lowerBoundTime, upperBoundTime, capacity=4096):
+        ev, ms, n = np.zeros(capacity), np.zeros(capacity, np.int32), C.c_int()
+        _check(load_library().bpmpc_gait_mode_schedule(self._h, C.c_double(lowerBoundTime), C.c_double(upperBoundTime), _d(ev), _i(ms), capacity, C.byref(n)))
+        return ModeSchedule(ev[:n.value].copy(), ms[:n.value + 1].copy())
+
+
+def swing_reference(interface, modeSchedule, times):
+    """SwingTrajectoryPlanner::update + getZpositionConstraint / getZvelocityConstraint (SwingTrajectoryPlanner.cpp:50-118)."""
+    ev, ms, t = _f64(modeSchedule.eventTimes), np.ascontiguousarray(modeSchedule.modeSequence, np.int32), _f64(times)
+    z, zd = np.zeros((len(t), 4)), np.zeros((len(t), 4))
+    _check(load_library().bpmpc_swing_reference(interface.handle, _d(ev), _i(ms), len(ev), _d(t), len(t), _d(z), _d(zd)))
+    return z, zd
+
+
+def time_discretization_with_events(initTime, finalTime, dt, eventTimes, capacity=8192):
+    ev = _f64(eventTimes)
+    t, e, n = np.zeros(capacity), np.zeros(capacity, np.int32), C.c_int()
+    _check(load_library().bpmpc_time_grid(C.c_double(initTime), C.c_double(finalTime), C.c_double(dt), _d(ev), len(ev), _d(t), _i(e), capacity, C.byref(n)))
+    return t[:n.value].copy(), e[:n.value].copy()
+
+
+class BatchedSqpMpc:
+    """A batch of independent SqpMpc instances on one MI355X.  `run` plays the role of MPC_BASE::run(t, x) /
+    MPC_MRT_Interface::advanceMpc() (BipedalController.cpp:339) for every problem of the batch at once."""
+
+    def __init__(self, interface, max_batch, max_nodes, sqp_iterations=0, dt=0.0, return_gains=False, profile=False, device=0, stream=None):
+        lib = load_library()
+        self.interface = interface
+        self.max_batch, self.max_nodes = int(max_batch), int(max_nodes)
+        self.nx, self.nu = interface.stateDim, interface.inputDim
+        self.return_gains = bool(return_gains)
+        st = _Settings(int(device), self.max_batch, self.max_nodes, int(sqp_iterations), float(dt), int(bool(return_gains)), int(bool(profile)),
+                       C.c_void_p(stream) if stream else None)
+        self._h = C.c_void_p()
+        _check(lib.bpmpc_solver_create(interface.handle, C.byref(st), C.byref(self._h)))
+        self._keep = None
+        self.batch = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.bpmpc_solver_destroy(self._h)
+            self._h = None
+
+    # ---- argument marshalling
+    def _marshal(self, t0, x0, modeSchedules, targetTrajectories, warm_x, warm_u):
+        x0 = _f64(x0).reshape(-1, self.nx)
+        B = x0.shape[0]
+        t0 = _f64(np.broadcast_to(np.asarray(t0, float), (B,)))
+        if isinstance(modeSchedules, ModeSchedule):
+            modeSchedules = [modeSchedules]
+        if isinstance(targetTrajectories, TargetTrajectories):
+            targetTrajectories = [targetTrajectories] * B
+        keep = [t0, x0]
+        sched = (_Schedule * len(modeSchedules))()
+        for i, ms in enumerate(modeSchedules):
+            ev, mo = _f64(ms.eventTimes), np.ascontiguousarray(ms.modeSequence, np.int32)
+            keep += [ev, mo]
+            sched[i] = _Schedule(len(ev), _d(ev), _i(mo))
+        tg = (_Target * B)()
+        for i, tt in enumerate(targetTrajectories):
+            ts, xs = _f64(tt.timeTrajectory), _f64(tt.stateTrajectory)
+            keep += [ts, xs]
+            tg[i] = _Target(len(ts), _d(ts), _d(xs))
+        wx = wu = None
+        if warm_x is not None:
+            wx, wu = _f64(warm_x), _f64(warm_u)
+            assert wx.size == B * (self.max_nodes + 1) * self.nx and wu.size == B * self.max_nodes * self.nu
+            keep += [wx, wu]
+        return B, t0, x0, sched, len(modeSchedules), tg, wx, wu, keep
+
+    def setup(self, t0, x0, modeSchedules, targetTrajectories, horizon=None, warm_x=None, warm_u=None):
+        if horizon is None:
+            horizon = self.interface.mpcSettings()["timeHorizon"]
+        B, t0, x0, sched, ns, tg, wx, wu, keep = self._marshal(t0, x0, modeSchedules, targetTrajectories, warm_x, warm_u)
+        _check(load_library().bpmpc_solver_setup(self._h, B, C.c_double(horizon), _d(t0), _d(x0), sched, ns, tg, _d(wx), _d(wu)))
+        self.batch = B
+        return self.layout()
+
+    def layout(self):
+        b, n, g, nx, nu = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(load_library().bpmpc_solver_layout(self._h, C.byref(b), C.byref(n), C.byref(g), C.byref(nx), C.byref(nu)))
+        return dict(batch=b.value, n_nodes_max=n.value, n_grids=g.value, nx=nx.value, nu=nu.value)
+
+    def reset(self):
+        _check(load_library().bpmpc_solver_reset(self._h))
+
+    def enqueue(self):
+        _check(load_library().bpmpc_solver_run(self._h))
+
+    def synchronize(self):
+        _check(load_library().bpmpc_solver_sync(self._h))
+
+    def stage(self, name):
+        _check(load_library().bpmpc_solver_stage(self._h, name.encode()))
+
+    def fetch(self, gains=False):
+        B, N = self.batch, self.max_nodes
+        t = np.zeros((B, N + 1))
+        x = np.zeros((B, N + 1, self.nx))
+        u = np.zeros((B, N, self.nu))
+        K = np.zeros((B, N, self.nu, self.nx)) if gains else None
+        stats = (Stats * B)()
+        _check(load_library().bpmpc_solver_fetch(self._h, _d(t), _d(x), _d(u), _d(K), stats))
+        return t, x, u, K, list(stats)
+
+    def run(self, t0, x0, modeSchedules, targetTrajectories, horizon=None, warm_x=None, warm_u=None, gains=False):
+        """One MPC solve for every problem: returns (t, x, u, K, stats) with strides max_nodes (see stats[b].n_nodes)."""
+        self.setup(t0, x0, modeSchedules, targetTrajectories, horizon, warm_x, warm_u)
+        self.enqueue()
+        self.synchronize()
+        return self.fetch(gains)
+
+    def read(self, name):
+        """Named device buffer as a flat float64 array (tests / debugging)."""
+        lib = load_library()
+        N, B, nx, nu = self.max_nodes, self.max_batch, self.nx, self.nu
+        cap = B * (N + 1) * max(nx * nx, 16 * nx) + 64
+        out = np.zeros(cap)
+        n = _check(lib.bpmpc_solver_read(self._h, name.encode(), _d(out), C.c_long(cap)))
+        return out[:n].copy()
+
+    def kernel_time(self, kernel, reset=True):
+        ms, n = C.c_double(), C.c_int()
+        _check(load_library().bpmpc_solver_kernel_time(self._h, kernel.encode(), int(reset), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def device_trajectories(self):
+        xp, up = _dp(), _dp()
+        _check(load_library().bpmpc_solver_device_trajectories(self._h, C.byref(xp), C.byref(up)))
+        return C.cast(xp, C.c_void_p).value, C.cast(up, C.c_void_p).value

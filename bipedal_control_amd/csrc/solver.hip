@@ -1,0 +1,658 @@
+// Batched SQP solver on one MI355X: device buffers, kernel launches and the solver part of the C ABI (include/bpmpc.h).
+// Kernel bodies live in kernels/*.h; this file only maps (problem, node) -> workgroup and owns HBM.
+//
+// HBM layout (FP64; B = problems, N = max_nodes, slot s = b*N + k, nx = nu = 12 + nj):
+//   iterate      x[B][(N+1)][nx], u[B][N][nu]                      coalesced 176-B rows per node
+//   LQ model     A,Q [s][nx*nx]  B [s][nx*nu]  R [s][nu*nu]  P [s][nu*nx]  b,q [s][nx]  r [s][nu]  c [s]
+//                C [s][16*nx]  D [s][16*nu]  e [s][16]  nc [s]     one contiguous block per node and quantity: every
+//                                                                  wavefront streams its node with 512-B bursts
+//   projection   Px,Pu,Pe,nut and the projected LQ model At..rt with the same per-node blocking
+//   grids        per distinct (t0, schedule): kind, mode, dt, start, zref, zdref  [n_grids][N]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/bpmpc.h"
+#include "capi_internal.h"
+#include "device_model.h"
+#include "kernels/linesearch.h"
+#include "kernels/node_lq.h"
+#include "kernels/project_node.h"
+#include "kernels/riccati.h"
+#include "reference_gen.h"
+
+namespace bpmpc {
+
+#define HIP_CHECK(expr)                                                                                     \
+  do {                                                                                                      \
+    hipError_t err_ = (expr);                                                                               \
+    if (err_ != hipSuccess) throw DeviceError(std::string(#expr) + ": " + hipGetErrorString(err_));         \
+  } while (0)
+
+struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// ------------------------------------------------------------------------------------------------ device views
+struct Buffers {
+  // grids
+  int *g_kind, *g_mode, *g_nodes;
+  double *g_dt, *g_start, *g_zref, *g_zdref;
+  // problems
+  int* p_grid;
+  double *p_x0, *p_tgt_t, *p_tgt_x;
+  int* p_tgt_n;
+  // iterate
+  double *x, *u, *x_init, *u_init, *xref;
+  // LQ
+  double *A, *B, *b, *Q, *R, *P, *q, *r, *c, *C, *D, *e, *perf;
+  int* nc;
+  // projection
+  double *Px, *Pu, *Pe, *At, *Bt, *bt, *Qt, *Rt, *Pt, *qt, *rt;
+  int* nut;
+  // riccati
+  double *Kt, *kt, *dx, *du, *K, *summary, *dx0;
+  // line search
+  double *trial_perf, *base, *alpha, *stats;
+  int *done, *active, *iterations, *remaining;
+};
+
+struct Launch {
+  const DeviceModel* model;
+  Buffers buf;
+  int batch, N;  // N = node stride (max_nodes)
+  int cold;
+  LineSearchSettings ls;
+};
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_prepare(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  const int s = blockIdx.x, b = s / L.N, k = s % L.N;
+  const int g = L.buf.p_grid[b];
+  const int n = L.buf.g_nodes[g];
+  if (k >= n) return;
+  const size_t gs = (size_t)g * L.N + k;
+  prepare_node<NJ>(*L.model, L.buf.g_kind[gs], L.buf.g_mode[gs], L.buf.g_start[gs], L.cold != 0, k == n - 1, L.buf.p_tgt_n[b],
+                   L.buf.p_tgt_t + (size_t)b * kMaxTargetPoints, L.buf.p_tgt_x + (size_t)b * kMaxTargetPoints * NX, L.buf.p_x0 + (size_t)b * NX,
+                   L.buf.xref + (size_t)s * NX, L.buf.x + ((size_t)b * (L.N + 1) + k) * NX, L.buf.u + (size_t)s * NU,
+                   L.buf.x + ((size_t)b * (L.N + 1) + k + 1) * NX);
+}
+
+template <int NJ>
+__device__ __forceinline__ NodeInputs node_inputs(const Launch& L, int b, int k) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  const int g = L.buf.p_grid[b];
+  const size_t gs = (size_t)g * L.N + k, s = (size_t)b * L.N + k;
+  NodeInputs in;
+  in.kind = L.buf.g_kind[gs];
+  in.mode = L.buf.g_mode[gs];
+  in.dt = L.buf.g_dt[gs];
+  in.x = L.buf.x + ((size_t)b * (L.N + 1) + k) * NX;
+  in.xnext = in.x + NX;
+  in.u = L.buf.u + s * NU;
+  in.xref = L.buf.xref + s * NX;
+  in.zref = L.buf.g_zref + gs * 4;
+  in.zdref = L.buf.g_zdref + gs * 4;
+  return in;
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ NodeWorkspace<NJ> ws;
+  const int sidx = blockIdx.x, b = sidx / L.N, k = sidx % L.N;
+  if (!L.buf.active[b]) return;
+  if (k >= L.buf.g_nodes[L.buf.p_grid[b]]) return;
+  const size_t s = sidx;
+  const NodeInputs in = node_inputs<NJ>(L, b, k);
+  NodeLQOut out;
+  out.A = L.buf.A + s * NX * NX; out.B = L.buf.B + s * NX * NU; out.b = L.buf.b + s * NX;
+  out.Q = L.buf.Q + s * NX * NX; out.R = L.buf.R + s * NU * NU; out.P = L.buf.P + s * NU * NX;
+  out.q = L.buf.q + s * NX; out.r = L.buf.r + s * NU; out.c = L.buf.c + s;
+  out.C = L.buf.C + s * kMaxEqRows * NX; out.D = L.buf.D + s * kMaxEqRows * NU; out.e = L.buf.e + s * kMaxEqRows;
+  out.nc = L.buf.nc + s; out.perf = L.buf.perf + s * 3;
+  linearize_node<NJ>(*L.model, ws, in, out);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_project(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ ProjectWorkspace<NJ> ws;
+  const int sidx = blockIdx.x, b = sidx / L.N, k = sidx % L.N;
+  if (!L.buf.active[b]) return;
+  const int g = L.buf.p_grid[b];
+  if (k >= L.buf.g_nodes[g]) return;
+  const size_t s = sidx;
+  ProjectIn in;
+  in.kind = L.buf.g_kind[(size_t)g * L.N + k];
+  in.nc = L.buf.nc[s];
+  in.C = L.buf.C + s * kMaxEqRows * NX; in.D = L.buf.D + s * kMaxEqRows * NU; in.e = L.buf.e + s * kMaxEqRows;
+  in.A = L.buf.A + s * NX * NX; in.B = L.buf.B + s * NX * NU; in.b = L.buf.b + s * NX;
+  in.Q = L.buf.Q + s * NX * NX; in.R = L.buf.R + s * NU * NU; in.P = L.buf.P + s * NU * NX; in.q = L.buf.q + s * NX; in.r = L.buf.r + s * NU;
+  ProjectOut out;
+  out.Px = L.buf.Px + s * NU * NX; out.Pu = L.buf.Pu + s * NU * NU; out.Pe = L.buf.Pe + s * NU; out.nut = L.buf.nut + s;
+  out.At = L.buf.At + s * NX * NX; out.Bt = L.buf.Bt + s * NX * NU; out.bt = L.buf.bt + s * NX;
+  out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
+  out.rt = L.buf.rt + s * NU;
+  project_node<NJ>(ws, in, out);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kRiccatiThreads) void k_riccati(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ RiccatiWorkspace<NJ> ws;
+  const int b = blockIdx.x;
+  if (!L.buf.active[b]) return;
+  const size_t s0 = (size_t)b * L.N;
+  // dx0 = x_measured - x_0
+  double* dx0 = L.buf.dx0 + (size_t)b * NX;
+  if (threadIdx.x < NX) dx0[threadIdx.x] = L.buf.p_x0[(size_t)b * NX + threadIdx.x] - L.buf.x[(size_t)b * (L.N + 1) * NX + threadIdx.x];
+  __syncthreads();
+  RiccatiIO io;
+  io.N = L.buf.g_nodes[L.buf.p_grid[b]];
+  io.nut = L.buf.nut + s0;
+  io.At = L.buf.At + s0 * NX * NX; io.Bt = L.buf.Bt + s0 * NX * NU; io.bt = L.buf.bt + s0 * NX;
+  io.Qt = L.buf.Qt + s0 * NX * NX; io.Rt = L.buf.Rt + s0 * NU * NU; io.Pt = L.buf.Pt + s0 * NU * NX; io.qt = L.buf.qt + s0 * NX;
+  io.rt = L.buf.rt + s0 * NU;
+  io.Px = L.buf.Px + s0 * NU * NX; io.Pu = L.buf.Pu + s0 * NU * NU; io.Pe = L.buf.Pe + s0 * NU;
+  io.dx0 = dx0;
+  io.Kt = L.buf.Kt + s0 * NU * NX; io.kt = L.buf.kt + s0 * NU;
+  io.dx = L.buf.dx + (size_t)b * (L.N + 1) * NX; io.du = L.buf.du + s0 * NU;
+  io.K = L.buf.K ? L.buf.K + s0 * NU * NX : nullptr;
+  io.summary = L.buf.summary + (size_t)b * 4;
+  riccati_problem<NJ>(ws, io);
+}
+
+template <int NJ>
+__device__ __forceinline__ ProblemLS problem_ls(const Launch& L, int b) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  ProblemLS p;
+  const size_t s0 = (size_t)b * L.N;
+  p.n_nodes = L.buf.g_nodes[L.buf.p_grid[b]];
+  p.node_perf = L.buf.perf + s0 * 3;
+  p.trial_perf = L.buf.trial_perf + s0 * 3;
+  p.x0 = L.buf.p_x0 + (size_t)b * NX;
+  p.x = L.buf.x + (size_t)b * (L.N + 1) * NX;
+  p.u = L.buf.u + s0 * NU;
+  p.dx = L.buf.dx + (size_t)b * (L.N + 1) * NX;
+  p.du = L.buf.du + s0 * NU;
+  p.summary = L.buf.summary + (size_t)b * 4;
+  p.base = L.buf.base + (size_t)b * 3;
+  p.alpha = L.buf.alpha + b;
+  p.done = L.buf.done + b;
+  p.active = L.buf.active + b;
+  p.iterations = L.buf.iterations + b;
+  p.stats = L.buf.stats + (size_t)b * kStatsStride;
+  p.remaining = L.buf.remaining;
+  return p;
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_ls_begin(Launch L) {
+  __shared__ double partial[3 * kWave + 2];
+  linesearch_begin<NJ>(partial, problem_ls<NJ>(L, blockIdx.x));
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_trial(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ TrialWorkspace<NJ> ws;
+  const int sidx = blockIdx.x, b = sidx / L.N, k = sidx % L.N;
+  if (L.buf.done[b]) return;
+  if (k >= L.buf.g_nodes[L.buf.p_grid[b]]) return;
+  const NodeInputs in = node_inputs<NJ>(L, b, k);
+  const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
+  trial_node<NJ>(*L.model, ws, in, L.buf.alpha[b], dx, L.buf.du + (size_t)sidx * NU, dx + NX, L.buf.trial_perf + (size_t)sidx * 3);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_ls_decide(Launch L) {
+  __shared__ double partial[3 * kWave + 2];
+  linesearch_decide<NJ>(partial, problem_ls<NJ>(L, blockIdx.x), L.ls);
+}
+
+// ------------------------------------------------------------------------------------------------ solver object
+struct KernelTimer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double total_ms = 0.0;
+  int launches = 0;
+};
+
+}  // namespace bpmpc
+
+using namespace bpmpc;
+
+struct bpmpc_solver {
+  RobotModel rm;
+  DeviceModel dm;
+  DeviceModel* d_model = nullptr;
+  bpmpc_settings settings{};
+  int nx = 0, nu = 0;
+  int batch = 0, n_grids = 0, n_nodes_max = 0;
+  bool cold = true;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Buffers buf{};
+  std::vector<void*> allocations;
+  std::map<std::string, std::pair<void*, size_t>> named;   // name -> (device ptr, element count)  (doubles unless in int_named)
+  std::map<std::string, bool> is_int;
+  std::vector<double> node_times;                          // host copy: [n_grids][N+1]
+  std::vector<int> grid_nodes, grid_of_problem;
+  std::map<std::string, KernelTimer> timers;
+  int* h_remaining = nullptr;                              // pinned
+  LineSearchSettings ls{};
+
+  template <typename T>
+  T* alloc(const char* name, size_t count, bool integer = false) {
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, count * sizeof(T)));
+    HIP_CHECK(hipMemsetAsync(p, 0, count * sizeof(T), stream));
+    allocations.push_back(p);
+    if (name) { named[name] = {p, count}; is_int[name] = integer; }
+    return static_cast<T*>(p);
+  }
+
+  Launch launch_params() const {
+    Launch L;
+    L.model = d_model;
+    L.buf = buf;
+    L.batch = batch;
+    L.N = settings.max_nodes;
+    L.cold = cold ? 1 : 0;
+    L.ls = ls;
+    return L;
+  }
+
+  void time_begin(const char* cls, hipEvent_t* a, hipEvent_t* b) {
+    if (!settings.profile) return;
+    HIP_CHECK(hipEventCreate(a));
+    HIP_CHECK(hipEventCreate(b));
+    HIP_CHECK(hipEventRecord(*a, stream));
+    (void)cls;
+  }
+  void time_end(const char* cls, hipEvent_t a, hipEvent_t b) {
+    if (!settings.profile) return;
+    HIP_CHECK(hipEventRecord(b, stream));
+    timers[cls].pending.emplace_back(a, b);
+  }
+  void collect_timers() {
+    for (auto& kv : timers) {
+      for (auto& pr : kv.second.pending) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventSynchronize(pr.second));
+        HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        kv.second.total_ms += ms;
+        kv.second.launches += 1;
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+      }
+      kv.second.pending.clear();
+    }
+  }
+
+  template <int NJ> void stage_prepare();
+  template <int NJ> void stage_linearize();
+  template <int NJ> void stage_project();
+  template <int NJ> void stage_riccati();
+  template <int NJ> void stage_linesearch();
+  template <int NJ> void run_iterations();
+};
+
+#define TIMED_LAUNCH(cls, kernel, grid, block, L)                                   \
+  do {                                                                              \
+    hipEvent_t ev_a_, ev_b_;                                                        \
+    time_begin(cls, &ev_a_, &ev_b_);                                                \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, L);              \
+    HIP_CHECK(hipGetLastError());                                                   \
+    time_end(cls, ev_a_, ev_b_);                                                    \
+  } while (0)
+
+template <int NJ> void bpmpc_solver::stage_prepare() {
+  const Launch L = launch_params();
+  TIMED_LAUNCH("prepare", k_prepare<NJ>, batch * settings.max_nodes, kWave, L);
+}
+template <int NJ> void bpmpc_solver::stage_linearize() {
+  const Launch L = launch_params();
+  TIMED_LAUNCH("linearize", k_linearize<NJ>, batch * settings.max_nodes, kWave, L);
+}
+template <int NJ> void bpmpc_solver::stage_project() {
+  const Launch L = launch_params();
+  TIMED_LAUNCH("project", k_project<NJ>, batch * settings.max_nodes, kWave, L);
+}
+template <int NJ> void bpmpc_solver::stage_riccati() {
+  const Launch L = launch_params();
+  TIMED_LAUNCH("riccati", k_riccati<NJ>, batch, kRiccatiThreads, L);
+}
+template <int NJ> void bpmpc_solver::stage_linesearch() {
+  const Launch L = launch_params();
+  HIP_CHECK(hipMemsetAsync(buf.remaining, 0, sizeof(int), stream));
+  hipEvent_t ev_a, ev_b;
+  time_begin("linesearch", &ev_a, &ev_b);
+  hipLaunchKernelGGL(k_ls_begin<NJ>, dim3(batch), dim3(kWave), 0, stream, L);
+  // alpha = 1, 1/2, ... >= alpha_min  ([OCS2-upstream] SqpSolver::takeStep do-while)
+  int max_trials = 0;
+  for (double a = 1.0; a >= ls.alpha_min; a *= ls.alpha_decay) ++max_trials;
+  for (int t = 0; t < max_trials; ++t) {
+    hipLaunchKernelGGL(k_trial<NJ>, dim3(batch * settings.max_nodes), dim3(kWave), 0, stream, L);
+    hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kWave), 0, stream, L);
+    HIP_CHECK(hipGetLastError());
+    // one 4-byte read-back per trial round: stop as soon as every problem has accepted (or given up)
+    HIP_CHECK(hipMemcpyAsync(h_remaining, buf.remaining, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (*h_remaining <= 0) break;
+  }
+  time_end("linesearch", ev_a, ev_b);
+}
+template <int NJ> void bpmpc_solver::run_iterations() {
+  const int iters = ls.max_iterations;
+  for (int it = 0; it < iters; ++it) {
+    stage_linearize<NJ>();
+    stage_project<NJ>();
+    stage_riccati<NJ>();
+    stage_linesearch<NJ>();
+  }
+}
+
+#define DISPATCH_NJ(self, call)                                        \
+  do {                                                                 \
+    if ((self)->rm.nj == 10) (self)->template call<10>();              \
+    else if ((self)->rm.nj == 12) (self)->template call<12>();         \
+    else throw std::runtime_error("unsupported joint count");          \
+  } while (0)
+
+namespace {
+
+int translate(const std::exception& e) {
+  set_last_error(e.what());
+  if (dynamic_cast<const DeviceError*>(&e)) return BPMPC_ERR_DEVICE;
+  if (dynamic_cast<const std::invalid_argument*>(&e)) return BPMPC_ERR_INVALID_ARGUMENT;
+  if (dynamic_cast<const std::length_error*>(&e)) return BPMPC_ERR_CAPACITY;
+  return BPMPC_ERR_IO;
+}
+
+void allocate(bpmpc_solver* s) {
+  const size_t B = s->settings.max_batch, N = s->settings.max_nodes, NX = s->nx, NU = s->nu, S = B * N;
+  Buffers& b = s->buf;
+  b.g_kind = s->alloc<int>("g_kind", S, true); b.g_mode = s->alloc<int>("g_mode", S, true); b.g_nodes = s->alloc<int>("g_nodes", B, true);
+  b.g_dt = s->alloc<double>("g_dt", S); b.g_start = s->alloc<double>("g_start", S);
+  b.g_zref = s->alloc<double>("g_zref", S * 4); b.g_zdref = s->alloc<double>("g_zdref", S * 4);
+  b.p_grid = s->alloc<int>("p_grid", B, true);
+  b.p_x0 = s->alloc<double>("x0", B * NX);
+  b.p_tgt_t = s->alloc<double>(nullptr, B * kMaxTargetPoints); b.p_tgt_x = s->alloc<double>(nullptr, B * kMaxTargetPoints * NX);
+  b.p_tgt_n = s->alloc<int>(nullptr, B);
+  b.x = s->alloc<double>("x", B * (N + 1) * NX); b.u = s->alloc<double>("u", S * NU);
+  b.x_init = s->alloc<double>(nullptr, B * (N + 1) * NX); b.u_init = s->alloc<double>(nullptr, S * NU);
+  b.xref = s->alloc<double>("xref", S * NX);
+  b.A = s->alloc<double>("A", S * NX * NX); b.B = s->alloc<double>("B", S * NX * NU); b.b = s->alloc<double>("b", S * NX);
+  b.Q = s->alloc<double>("Q", S * NX * NX); b.R = s->alloc<double>("R", S * NU * NU); b.P = s->alloc<double>("P", S * NU * NX);
+  b.q = s->alloc<double>("q", S * NX); b.r = s->alloc<double>("r", S * NU); b.c = s->alloc<double>("c", S);
+  b.C = s->alloc<double>("C", S * kMaxEqRows * NX); b.D = s->alloc<double>("D", S * kMaxEqRows * NU); b.e = s->alloc<double>("e", S * kMaxEqRows);
+  b.perf = s->alloc<double>("perf", S * 3); b.nc = s->alloc<int>("nc", S, true);
+  b.Px = s->alloc<double>("Px", S * NU * NX); b.Pu = s->alloc<double>("Pu", S * NU * NU); b.Pe = s->alloc<double>("Pe", S * NU);
+  b.At = s->alloc<double>("At", S * NX * NX); b.Bt = s->alloc<double>("Bt", S * NX * NU); b.bt = s->alloc<double>("bt", S * NX);
+  b.Qt = s->alloc<double>("Qt", S * NX * NX); b.Rt = s->alloc<double>("Rt", S * NU * NU); b.Pt = s->alloc<double>("Pt", S * NU * NX);
+  b.qt = s->alloc<double>("qt", S * NX); b.rt = s->alloc<double>("rt", S * NU); b.nut = s->alloc<int>("nut", S, true);
+  b.Kt = s->alloc<double>("Kt", S * NU * NX); b.kt = s->alloc<double>("kt", S * NU);
+  b.dx = s->alloc<double>("dx", B * (N + 1) * NX); b.du = s->alloc<double>("du", S * NU);
+  b.K = s->settings.return_gains ? s->alloc<double>("K", S * NU * NX) : nullptr;
+  b.summary = s->alloc<double>("summary", B * 4); b.dx0 = s->alloc<double>(nullptr, B * NX);
+  b.trial_perf = s->alloc<double>("trial_perf", S * 3); b.base = s->alloc<double>("base", B * 3); b.alpha = s->alloc<double>("alpha", B);
+  b.stats = s->alloc<double>("stats", B * kStatsStride);
+  b.done = s->alloc<int>("done", B, true); b.active = s->alloc<int>("active", B, true); b.iterations = s->alloc<int>("iterations", B, true);
+  b.remaining = s->alloc<int>(nullptr, 1);
+}
+
+template <typename T>
+void upload(bpmpc_solver* s, T* dst, const std::vector<T>& src) {
+  if (!src.empty()) HIP_CHECK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s->stream));
+}
+
+void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
+           int n_schedules, const bpmpc_target* targets, const double* warm_x, const double* warm_u) {
+  if (batch < 1 || batch > s->settings.max_batch) throw std::length_error("batch exceeds the solver's max_batch");
+  if (!(horizon > 0) || !t0 || !x0 || !schedules || !targets) throw std::invalid_argument("solve: null or invalid argument");
+  if (n_schedules != 1 && n_schedules != batch) throw std::invalid_argument("n_schedules must be 1 or batch");
+  if ((warm_x == nullptr) != (warm_u == nullptr)) throw std::invalid_argument("warm_x and warm_u must be given together");
+  const int N = s->settings.max_nodes, NX = s->nx, NU = s->nu;
+  const double dt = s->settings.dt > 0 ? s->settings.dt : s->rm.sqp.dt;
+  const int G = n_schedules;
+  if (G == 1)
+    for (int b = 1; b < batch; ++b)
+      if (t0[b] != t0[0]) throw std::invalid_argument("a shared schedule needs identical t0 for all problems");
+  const size_t S = (size_t)G * N;
+  std::vector<int> kind(S, 0), mode(S, STANCE), nodes(G, 0), pgrid(batch, 0);
+  std::vector<double> gdt(S, 0.0), gstart(S, 0.0), zref(S * 4, 0.0), zdref(S * 4, 0.0);
+  s->node_times.assign((size_t)G * (N + 1), 0.0);
+  SwingPlanner planner(s->rm.swing);
+  int nmax = 0;
+  for (int g = 0; g < G; ++g) {
+    const bpmpc_mode_schedule& sc = schedules[g];
+    if (sc.n_events < 0 || !sc.modes || (sc.n_events > 0 && !sc.event_times)) throw std::invalid_argument("invalid mode schedule");
+    ModeSchedule ms;
+    ms.event_times.assign(sc.event_times, sc.event_times + sc.n_events);
+    ms.modes.assign(sc.modes, sc.modes + sc.n_events + 1);
+    planner.update(ms);
+    const double ts = t0[G == 1 ? 0 : g];
+    const NodeTable tab = build_node_table(s->rm, ts, ts + horizon, dt, ms, planner);
+    if (tab.N > N) throw std::length_error("time grid has " + std::to_string(tab.N) + " intervals, solver max_nodes is " + std::to_string(N));
+    nodes[g] = tab.N;
+    nmax = std::max(nmax, tab.N);
+    for (int k = 0; k < tab.N; ++k) {
+      const size_t i = (size_t)g * N + k;
+      kind[i] = tab.kind[k]; mode[i] = tab.mode[k]; gdt[i] = tab.dt[k]; gstart[i] = tab.start[k];
+      for (int c = 0; c < 4; ++c) { zref[4 * i + c] = tab.zref[4 * k + c]; zdref[4 * i + c] = tab.zdref[4 * k + c]; }
+    }
+    std::copy(tab.node_time.begin(), tab.node_time.end(), s->node_times.begin() + (size_t)g * (N + 1));
+  }
+  std::vector<double> tgt_t((size_t)batch * kMaxTargetPoints, 0.0), tgt_x((size_t)batch * kMaxTargetPoints * NX, 0.0);
+  std::vector<int> tgt_n(batch, 0);
+  for (int b = 0; b < batch; ++b) {
+    pgrid[b] = (G == 1) ? 0 : b;
+    const bpmpc_target& t = targets[b];
+    if (t.n_points < 1 || t.n_points > kMaxTargetPoints || !t.times || !t.states) throw std::invalid_argument("target trajectories need 1..8 points");
+    tgt_n[b] = t.n_points;
+    std::copy(t.times, t.times + t.n_points, tgt_t.begin() + (size_t)b * kMaxTargetPoints);
+    std::copy(t.states, t.states + (size_t)t.n_points * NX, tgt_x.begin() + (size_t)b * kMaxTargetPoints * NX);
+  }
+  s->batch = batch; s->n_grids = G; s->n_nodes_max = nmax; s->cold = (warm_x == nullptr);
+  s->grid_nodes = nodes; s->grid_of_problem = pgrid;
+  Buffers& bf = s->buf;
+  upload(s, bf.g_kind, kind); upload(s, bf.g_mode, mode); upload(s, bf.g_nodes, nodes); upload(s, bf.g_dt, gdt); upload(s, bf.g_start, gstart);
+  upload(s, bf.g_zref, zref); upload(s, bf.g_zdref, zdref); upload(s, bf.p_grid, pgrid);
+  upload(s, bf.p_tgt_t, tgt_t); upload(s, bf.p_tgt_x, tgt_x); upload(s, bf.p_tgt_n, tgt_n);
+  HIP_CHECK(hipMemcpyAsync(bf.p_x0, x0, (size_t)batch * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  if (!s->cold) {
+    HIP_CHECK(hipMemcpyAsync(bf.x, warm_x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_CHECK(hipMemcpyAsync(bf.u, warm_u, (size_t)batch * N * NU * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(s->stream));  // the host staging vectors go out of scope
+  DISPATCH_NJ(s, stage_prepare);
+  HIP_CHECK(hipMemcpyAsync(bf.x_init, bf.x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(bf.u_init, bf.u, (size_t)batch * N * NU * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  // activate
+  std::vector<int> ones(batch, 1);
+  upload(s, bf.active, ones);
+  HIP_CHECK(hipMemsetAsync(bf.iterations, 0, sizeof(int) * batch, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+}
+
+void reset(bpmpc_solver* s) {
+  const size_t N = s->settings.max_nodes;
+  HIP_CHECK(hipMemcpyAsync(s->buf.x, s->buf.x_init, (size_t)s->batch * (N + 1) * s->nx * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(s->buf.u, s->buf.u_init, (size_t)s->batch * N * s->nu * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  HIP_CHECK(hipMemsetAsync(s->buf.iterations, 0, sizeof(int) * s->batch, s->stream));
+  HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)s->buf.active, 1, s->batch, s->stream));
+}
+
+void fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double* out_K, bpmpc_stats* stats) {
+  const size_t N = s->settings.max_nodes, NX = s->nx, NU = s->nu, B = s->batch;
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  if (out_x) HIP_CHECK(hipMemcpy(out_x, s->buf.x, B * (N + 1) * NX * sizeof(double), hipMemcpyDeviceToHost));
+  if (out_u) HIP_CHECK(hipMemcpy(out_u, s->buf.u, B * N * NU * sizeof(double), hipMemcpyDeviceToHost));
+  if (out_K) {
+    if (!s->buf.K) throw std::invalid_argument("gains requested but the solver was created with return_gains = 0");
+    HIP_CHECK(hipMemcpy(out_K, s->buf.K, B * N * NU * NX * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (out_t)
+    for (size_t b = 0; b < B; ++b) {
+      const int g = s->grid_of_problem[b];
+      std::copy(s->node_times.begin() + (size_t)g * (N + 1), s->node_times.begin() + (size_t)g * (N + 1) + s->grid_nodes[g] + 1, out_t + b * (N + 1));
+    }
+  if (stats) {
+    std::vector<double> raw(B * kStatsStride);
+    HIP_CHECK(hipMemcpy(raw.data(), s->buf.stats, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < B; ++b) {
+      const double* r = &raw[b * kStatsStride];
+      bpmpc_stats& st = stats[b];
+      st.n_nodes = s->grid_nodes[s->grid_of_problem[b]];
+      st.iterations = (int)r[1]; st.status = (int)r[2]; st.reserved = 0;
+      st.merit_before = r[3]; st.dynamics_sse_before = r[4]; st.equality_sse_before = r[5];
+      st.merit_after = r[6]; st.dynamics_sse_after = r[7]; st.equality_sse_after = r[8];
+      st.step_size = r[9]; st.armijo_descent = r[10]; st.dx_norm = r[11]; st.du_norm = r[12];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings, bpmpc_solver** out) {
+  if (!model || !settings || !out) { set_last_error("bpmpc_solver_create: null argument"); return BPMPC_ERR_INVALID_ARGUMENT; }
+  *out = nullptr;
+  if (settings->max_batch < 1 || settings->max_nodes < 1) { set_last_error("bpmpc_solver_create: max_batch and max_nodes must be positive"); return BPMPC_ERR_INVALID_ARGUMENT; }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || settings->device < 0 || settings->device >= count) {
+    set_last_error("bpmpc_solver_create: no usable HIP device (this engine has no CPU path)");
+    return BPMPC_ERR_NO_DEVICE;
+  }
+  std::unique_ptr<bpmpc_solver> s(new bpmpc_solver);
+  try {
+    s->rm = model_of(model);
+    if (s->rm.nj != 10 && s->rm.nj != 12) { set_last_error("only 10- and 12-joint bipeds are instantiated"); return BPMPC_ERR_UNSUPPORTED; }
+    s->dm = make_device_model(s->rm);
+    s->settings = *settings;
+    s->nx = s->rm.nx; s->nu = s->rm.nu;
+    HIP_CHECK(hipSetDevice(settings->device));
+    if (settings->stream) { s->stream = static_cast<hipStream_t>(settings->stream); }
+    else { HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s->d_model), sizeof(DeviceModel)));
+    HIP_CHECK(hipMemcpy(s->d_model, &s->dm, sizeof(DeviceModel), hipMemcpyHostToDevice));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_remaining), sizeof(int)));
+    const SqpConfig& q = s->rm.sqp;
+    s->ls = LineSearchSettings{q.g_max, q.g_min, q.alpha_decay, q.alpha_min, q.gamma_c, q.armijo_factor, q.delta_tol, q.cost_tol,
+                               settings->sqp_iterations > 0 ? settings->sqp_iterations : q.sqp_iteration};
+    allocate(s.get());
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+  } catch (const std::exception& e) {
+    const int rc = translate(e);
+    bpmpc_solver_destroy(s.release());
+    return rc;
+  }
+  *out = s.release();
+  return BPMPC_OK;
+}
+
+void bpmpc_solver_destroy(bpmpc_solver* s) {
+  if (!s) return;
+  if (s->stream) hipStreamSynchronize(s->stream);
+  for (void* p : s->allocations) hipFree(p);
+  if (s->d_model) hipFree(s->d_model);
+  if (s->h_remaining) hipHostFree(s->h_remaining);
+  if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
+  delete s;
+}
+
+#define API_GUARD(solver, ...)                                                                    \
+  if (!(solver)) { set_last_error("null solver handle"); return BPMPC_ERR_INVALID_ARGUMENT; }      \
+  try { HIP_CHECK(hipSetDevice((solver)->settings.device)); __VA_ARGS__; }                               \
+  catch (const std::exception& e) { return translate(e); }                                        \
+  return BPMPC_OK;
+
+int bpmpc_solver_setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
+                       int n_schedules, const bpmpc_target* targets, const double* warm_x, const double* warm_u) {
+  API_GUARD(s, setup(s, batch, horizon, t0, x0, schedules, n_schedules, targets, warm_x, warm_u))
+}
+int bpmpc_solver_reset(bpmpc_solver* s) { API_GUARD(s, reset(s)) }
+int bpmpc_solver_run(bpmpc_solver* s) {
+  API_GUARD(s, { if (s->batch < 1) throw std::invalid_argument("bpmpc_solver_run before bpmpc_solver_setup"); DISPATCH_NJ(s, run_iterations); })
+}
+int bpmpc_solver_sync(bpmpc_solver* s) { API_GUARD(s, { HIP_CHECK(hipStreamSynchronize(s->stream)); s->collect_timers(); }) }
+int bpmpc_solver_fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double* out_K, bpmpc_stats* stats) {
+  API_GUARD(s, fetch(s, out_t, out_x, out_u, out_K, stats))
+}
+int bpmpc_solve_batch(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
+                      int n_schedules, const bpmpc_target* targets, const double* warm_x, const double* warm_u, double* out_t, double* out_x,
+                      double* out_u, double* out_K, bpmpc_stats* stats) {
+  API_GUARD(s, {
+    setup(s, batch, horizon, t0, x0, schedules, n_schedules, targets, warm_x, warm_u);
+    DISPATCH_NJ(s, run_iterations);
+    fetch(s, out_t, out_x, out_u, out_K, stats);
+    s->collect_timers();
+  })
+}
+int bpmpc_solver_stage(bpmpc_solver* s, const char* stage) {
+  API_GUARD(s, {
+    if (!stage || s->batch < 1) throw std::invalid_argument("bpmpc_solver_stage: no stage name or no setup");
+    const std::string n(stage);
+    // an explicit stage request always applies to every problem of the batch
+    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)s->buf.active, 1, s->batch, s->stream));
+    if (n == "linearize") DISPATCH_NJ(s, stage_linearize);
+    else if (n == "project") DISPATCH_NJ(s, stage_project);
+    else if (n == "riccati") DISPATCH_NJ(s, stage_riccati);
+    else if (n == "linesearch") DISPATCH_NJ(s, stage_linesearch);
+    else throw std::invalid_argument("unknown stage " + n);
+  })
+}
+int bpmpc_solver_read(bpmpc_solver* s, const char* name, double* out, long capacity) {
+  if (!s || !name || !out) { set_last_error("bpmpc_solver_read: null argument"); return BPMPC_ERR_INVALID_ARGUMENT; }
+  try {
+    HIP_CHECK(hipSetDevice(s->settings.device));
+    auto it = s->named.find(name);
+    if (it == s->named.end()) throw std::invalid_argument(std::string("unknown buffer ") + name);
+    const size_t n = it->second.second;
+    if ((long)n > capacity) throw std::length_error("bpmpc_solver_read: capacity too small");
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (s->is_int[name]) {
+      std::vector<int> tmp(n);
+      HIP_CHECK(hipMemcpy(tmp.data(), it->second.first, n * sizeof(int), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n; ++i) out[i] = tmp[i];
+    } else {
+      HIP_CHECK(hipMemcpy(out, it->second.first, n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return (int)n;
+  } catch (const std::exception& e) { return translate(e); }
+}
+int bpmpc_solver_device_trajectories(bpmpc_solver* s, double** x_dev, double** u_dev) {
+  if (!s) { set_last_error("null solver handle"); return BPMPC_ERR_INVALID_ARGUMENT; }
+  if (x_dev) *x_dev = s->buf.x;
+  if (u_dev) *u_dev = s->buf.u;
+  return BPMPC_OK;
+}
+int bpmpc_solver_kernel_time(bpmpc_solver* s, const char* kernel, int reset_after, double* total_ms, int* launches) {
+  API_GUARD(s, {
+    if (!kernel) throw std::invalid_argument("null kernel class");
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->collect_timers();
+    KernelTimer& t = s->timers[kernel];
+    if (total_ms) *total_ms = t.total_ms;
+    if (launches) *launches = t.launches;
+    if (reset_after) { t.total_ms = 0.0; t.launches = 0; }
+  })
+}
+int bpmpc_solver_layout(const bpmpc_solver* s, int* batch, int* n_nodes_max, int* n_grids, int* nx, int* nu) {
+  if (!s) { set_last_error("null solver handle"); return BPMPC_ERR_INVALID_ARGUMENT; }
+  if (batch) *batch = s->batch;
+  if (n_nodes_max) *n_nodes_max = s->n_nodes_max;
+  if (n_grids) *n_grids = s->n_grids;
+  if (nx) *nx = s->nx;
+  if (nu) *nu = s->nu;
+  return BPMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+"""Synthetic problem sets = the configurations of BASELINE.json, built through the product's own
+reference-manager API so that bench.py, smoke() and the GPU tests all see the same inputs."""
+import os
+
+import numpy as np
+
+from .api import BipedalRobotInterface, GaitSchedule, ModeSchedule, loadModeSequenceTemplate
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H1 = dict(task=os.path.join(ROOT, "assets/h1/task.info"), urdf=os.path.join(ROOT, "assets/h1/h1_mpc.urdf"),
+          reference=os.path.join(ROOT, "assets/h1/reference.info"), gait=os.path.join(ROOT, "assets/h1/gait.info"))
+DT = 0.015
+SEED = 20241008
+# phase offset of the steady-state gait: the template starts 3.5 periods-halves before t = 0 so that t0 = 0 is mid-swing
+GAIT_START = -1.225
+
+
+def h1_interface():
+    return BipedalRobotInterface(H1["task"], H1["urdf"], H1["reference"])
+
+
+def perturbed_initial_states(itf, batch, seed=SEED):
+    """x0_b = initialState + U(-a, a) per block."""
+    rng = np.random.default_rng(seed)
+    nx, nj = itf.stateDim, itf.actuatedDofNum
+    amp = np.concatenate([np.full(3, 0.1), np.full(3, 0.05), [0.05, 0.05, 0.02], np.full(3, 0.05), np.full(nj, 0.05)])
+    return itf.getInitialState()[None, :] + rng.uniform(-1.0, 1.0, size=(batch, nx)) * amp[None, :]
+
+
+def gait_schedule(itf, gait_name, t0, horizon, gait_file=None, start=GAIT_START):
+    """Steady-state schedule of a named gait as the reference's GaitSchedule would hold it at solve time."""
+    gs = GaitSchedule(itf)
+    if gait_name != "stance":
+        tmpl = loadModeSequenceTemplate(gait_file or H1["gait"], gait_name)
+        gs.insertModeSequenceTemplate(tmpl, start, t0 + 2 * horizon)
+    return gs.getModeSchedule(t0 - horizon, t0 + 2 * horizon)
+
+
+def stance_problem(itf, n_intervals=20):
+    """Config 1: H1 stance, horizon N*dt, single problem, constant target."""
+    horizon = n_intervals * DT
+    x0 = itf.getInitialState()[None, :]
+    sched = gait_schedule(itf, "stance", 0.0, horizon)
+    xs = np.zeros((2, itf.stateDim))
+    xs[:, 8] = float(itf.get("com_height")[0])
+    xs[:, 12:] = itf.get("default_joint_state")
+    from .api import TargetTrajectories
+    return dict(t0=0.0, x0=x0, schedule=sched, targets=[TargetTrajectories(np.array([0.0, horizon]), xs)], horizon=horizon)
+
+
+def trot_problem(itf, batch, n_intervals=100, cmd_vel=(0.3, 0.0, 0.0, 0.0), gait="trot", seed=SEED, offset=0):
+    """Config 2/3: H1 trot, horizon N*dt, `batch` perturbed initial states starting at problem index `offset`."""
+    horizon = n_intervals * DT
+    x0 = perturbed_initial_states(itf, offset + batch, seed)[offset:]
+    sched = gait_schedule(itf, gait, 0.0, horizon)
+    targets = [itf.cmdVelToTargetTrajectories(cmd_vel, 0.0, x0[b], horizon) for b in range(batch)]
+    return dict(t0=0.0, x0=x0, schedule=sched, targets=targets, horizon=horizon)
+
+
+def max_nodes_for(n_intervals, horizon, period_min=0.03):
+    """Upper bound of grid intervals: every event adds at most two nodes."""
+    return int(n_intervals + 2 * (horizon / period_min) + 4)

@@ -1,0 +1,178 @@
+/* bpmpc - C ABI of the MI355X-native batched NMPC engine (libbpmpc.so).
+ *
+ * Drop-in boundary for the OCS2 SQP hot path of zitongbai/bipedal_control.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference tree).  Plain C: pointers, sizes,
+ * ints and doubles only; row-major contiguous host arrays owned by the caller unless a function says "device";
+ * every call returns 0 on success or a negative bpmpc_status (never throws across the ABI); a textual reason is
+ * available from bpmpc_last_error() (thread local).  A solver handle is not re-entrant (one calling thread per
+ * handle, like the reference's single MPC thread, bipedal_controllers/src/BipedalController.cpp:332-351);
+ * different handles are independent.  There is NO CPU fallback: creating a solver without a HIP device fails.
+ *
+ * State / input layout (ocs2_centroidal_model convention used by the reference, task.info:181-210,247-278):
+ *   x = [h_lin/m (3), h_ang/m (3), base position (3), yaw, pitch, roll, leg joints (nj)]          nx = 12 + nj
+ *   u = [F_0, F_1, F_2, F_3 (world frame, 3 each), leg joint velocities (nj)]                      nu = 12 + nj
+ * Mode ids: FLY 0, LF 1, RF 2, STANCE 3 (ocs2_bipedal_robot/include/ocs2_bipedal_robot/gait/MotionPhaseDefinition.h:47-52).
+ */
+#ifndef BPMPC_H
+#define BPMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  BPMPC_OK = 0,
+  BPMPC_ERR_INVALID_ARGUMENT = -1,
+  BPMPC_ERR_IO = -2,            /* file missing / malformed (the reference throws std::invalid_argument / runtime_error) */
+  BPMPC_ERR_UNSUPPORTED = -3,
+  BPMPC_ERR_NO_DEVICE = -4,     /* no usable HIP device: the engine has no CPU path */
+  BPMPC_ERR_DEVICE = -5,        /* HIP runtime error */
+  BPMPC_ERR_CAPACITY = -6,      /* caller buffer or solver capacity too small */
+  BPMPC_ERR_NUMERICAL = -7      /* non positive-definite stage Hessian etc. */
+} bpmpc_status;
+
+const char* bpmpc_last_error(void);
+const char* bpmpc_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Model = what BipedalRobotInterface builds at construction
+ *   ocs2_bipedal_robot/src/BipedalRobotInterface.cpp:67-204 (constructor + setupOptimalConrolProblem),
+ *   :239-291 (input-cost matrix), :298-315 (friction-cone settings), src/common/ModelSettings.cpp:40-67.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct bpmpc_model bpmpc_model;
+
+int bpmpc_model_create(const char* urdf_path, const char* task_info_path, const char* reference_info_path, bpmpc_model** out);
+void bpmpc_model_destroy(bpmpc_model* model);
+/* CentroidalModelInfo.stateDim / inputDim / numThreeDofContacts / actuatedDofNum */
+int bpmpc_model_dims(const bpmpc_model* model, int* nx, int* nu, int* n_contacts, int* n_joints);
+/* Named constant blocks, copied into out[0..capacity); returns the element count or a negative status.
+ * Names: "initial_state" (BipedalRobotInterface::getInitialState), "default_joint_state", "Q", "R", "robot_mass",
+ * "com_height", "body_mass", "body_com", "body_inertia", "joint_parent", "joint_rotation", "joint_offset", "joint_axis",
+ * "contact_body", "contact_offset", "cone" (mu, regularization, gripper force, hessian shift, barrier mu, barrier delta),
+ * "swing" (liftOffVelocity, touchDownVelocity, swingHeight, swingTimeScale), "sqp" (dt, sqpIteration, deltaTol, g_max, g_min),
+ * "time_horizon", "position_error_gain", "phase_transition_stance_time". */
+int bpmpc_model_get(const bpmpc_model* model, const char* name, double* out, int capacity);
+/* joint name j (DFS order = state order); returns length or negative status */
+int bpmpc_model_joint_name(const bpmpc_model* model, int j, char* out, int capacity);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Host pre-pass of a solve = SolverBase::preRun hooks of the reference:
+ *   GaitSchedule                          ocs2_bipedal_robot/src/gait/GaitSchedule.cpp:40-137
+ *   loadModeSequenceTemplate              ocs2_bipedal_robot/src/gait/ModeSequenceTemplate.cpp:50-71
+ *   SwitchedModelReferenceManager         ocs2_bipedal_robot/src/reference_manager/SwitchedModelReferenceManager.cpp:55-69
+ *   SwingTrajectoryPlanner                ocs2_bipedal_robot/src/foot_planner/SwingTrajectoryPlanner.cpp:50-219
+ *   cmdVel / goal -> TargetTrajectories   bipedal_controllers/src/TargetTrajectoriesPublisher.cpp:30-99
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct bpmpc_gait bpmpc_gait;
+
+/* GaitSchedule(initialModeSchedule, defaultModeSequenceTemplate, phaseTransitionStanceTime) from reference.info */
+int bpmpc_gait_create(const bpmpc_model* model, bpmpc_gait** out);
+void bpmpc_gait_destroy(bpmpc_gait* gait);
+/* loadModeSequenceTemplate(gait.info, name): switching_times[n_modes+1], modes[n_modes] */
+int bpmpc_gait_load_template(const char* gait_info_path, const char* name, double* switching_times, int* modes, int capacity, int* n_modes);
+/* GaitSchedule::insertModeSequenceTemplate */
+int bpmpc_gait_insert_template(bpmpc_gait* gait, const double* switching_times, const int* modes, int n_modes, double start_time,
+                               double final_time);
+/* GaitSchedule::getModeSchedule(lower, upper) (mutating, like the reference): event_times[n_events], modes[n_events+1] */
+int bpmpc_gait_mode_schedule(bpmpc_gait* gait, double lower, double upper, double* event_times, int* modes, int capacity, int* n_events);
+/* SwingTrajectoryPlanner::update(schedule, terrain 0) then getZpositionConstraint / getZvelocityConstraint at n_t times:
+ * z[n_t*4], zdot[n_t*4] */
+int bpmpc_swing_reference(const bpmpc_model* model, const double* event_times, const int* modes, int n_events, const double* t, int n_t,
+                          double* z, double* zdot);
+/* [OCS2-upstream] timeDiscretizationWithEvents(t0, tf, dt, eventTimes): node_times[n], node_events[n] (0 none, 1 pre, 2 post) */
+int bpmpc_time_grid(double t0, double tf, double dt, const double* event_times, int n_events, double* node_times, int* node_events,
+                    int capacity, int* n_nodes);
+/* cmdVelToTargetTrajectories / goalToTargetTrajectories: two-point trajectory times[2], states[2*nx] */
+int bpmpc_cmd_vel_to_targets(const bpmpc_model* model, const double cmd_vel[4], double t_now, const double* x_now, double time_to_target,
+                             double* times, double* states);
+int bpmpc_goal_to_targets(const bpmpc_model* model, const double goal[4], double t_now, const double* x_now, double* times, double* states);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Solver = SqpMpc / SqpSolver::runImpl for a BATCH of independent MPC problems on one MI355X
+ *   construction sites replaced: bipedal_controllers/src/BipedalController.cpp:303-306,
+ *                                ocs2_bipedal_robot_ros/src/BipedalRobotSqpMpcNode.cpp:70
+ *   run site replaced:           MPC_MRT_Interface::advanceMpc(), BipedalController.cpp:339
+ *   settings:                    task.info:66-83 (sqp), :169-179 (mpc)
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct bpmpc_solver bpmpc_solver;
+
+typedef struct {
+  int device;           /* HIP device ordinal */
+  int max_batch;        /* capacity in problems */
+  int max_nodes;        /* capacity in shooting intervals per problem (event nodes included) */
+  int sqp_iterations;   /* <= 0: sqp.sqpIteration of task.info */
+  double dt;            /* <= 0: sqp.dt of task.info */
+  int return_gains;     /* allocate and compute the feedback gains K (sqp.useFeedbackPolicy) */
+  int profile;          /* time every kernel class with HIP events (bpmpc_solver_kernel_time) */
+  void* stream;         /* hipStream_t to run on; NULL = a stream owned by the solver */
+} bpmpc_settings;
+
+typedef struct {
+  int n_events;
+  const double* event_times;  /* [n_events] */
+  const int* modes;           /* [n_events + 1] */
+} bpmpc_mode_schedule;
+
+typedef struct {
+  int n_points;
+  const double* times;        /* [n_points] */
+  const double* states;       /* [n_points * nx] */
+} bpmpc_target;
+
+typedef struct {
+  int n_nodes;                /* shooting intervals of this problem */
+  int iterations;             /* SQP iterations performed */
+  int status;                 /* 0 ok, 1 line search took no step, 2 numerical failure */
+  int reserved;
+  double merit_before, dynamics_sse_before, equality_sse_before;   /* PerformanceIndex of the last linearisation */
+  double merit_after, dynamics_sse_after, equality_sse_after;      /* after the accepted step */
+  double step_size;           /* alpha of the last iteration (0 = rejected) */
+  double armijo_descent;
+  double dx_norm, du_norm;
+} bpmpc_stats;
+
+int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings, bpmpc_solver** out);
+void bpmpc_solver_destroy(bpmpc_solver* solver);
+
+/* One call = host pre-pass + upload + SQP iteration(s) + download, for `batch` problems with horizon [t0, t0 + horizon].
+ *   t0[batch], x0[batch*nx] (measured state)
+ *   schedules: n_schedules == 1 (shared; all t0 must be equal) or == batch
+ *   targets[batch]
+ *   warm_x[batch*(max_nodes+1)*nx], warm_u[batch*max_nodes*nu]: initial iterate on this solve's grid, or NULL for the
+ *     cold start of BipedalRobotInitializer::compute (src/initialization/BipedalRobotInitializer.cpp:56-63)
+ * outputs (strides use max_nodes; entries beyond n_nodes are untouched):
+ *   out_t[batch*(max_nodes+1)], out_x[batch*(max_nodes+1)*nx], out_u[batch*max_nodes*nu],
+ *   out_K[batch*max_nodes*nu*nx] (nullable; needs return_gains), stats[batch] */
+int bpmpc_solve_batch(bpmpc_solver* solver, int batch, double horizon, const double* t0, const double* x0,
+                      const bpmpc_mode_schedule* schedules, int n_schedules, const bpmpc_target* targets, const double* warm_x,
+                      const double* warm_u, double* out_t, double* out_x, double* out_u, double* out_K, bpmpc_stats* stats);
+
+/* The same work split into stages so that a caller can keep everything resident in HBM between solves
+ * (bench.py times bpmpc_solver_run only; inputs are already on the device when the timed region starts). */
+int bpmpc_solver_setup(bpmpc_solver* solver, int batch, double horizon, const double* t0, const double* x0,
+                       const bpmpc_mode_schedule* schedules, int n_schedules, const bpmpc_target* targets, const double* warm_x,
+                       const double* warm_u);
+int bpmpc_solver_reset(bpmpc_solver* solver);   /* restore the initial iterate of the last setup (device-side copy, async) */
+int bpmpc_solver_run(bpmpc_solver* solver);     /* enqueue the SQP iteration(s) on the solver's stream */
+int bpmpc_solver_sync(bpmpc_solver* solver);
+int bpmpc_solver_fetch(bpmpc_solver* solver, double* out_t, double* out_x, double* out_u, double* out_K, bpmpc_stats* stats);
+/* Run one stage of an iteration on the current iterate (parity tests, roofline measurement):
+ * "linearize", "project", "riccati", "linesearch". */
+int bpmpc_solver_stage(bpmpc_solver* solver, const char* stage);
+/* Copy a named device buffer to the host (tests): "x","u","xref","A","B","b","Q","R","P","q","r","c","C","D","e","nc","perf",
+ * "Px","Pu","Pe","nut","At","Bt","bt","Qt","Rt","Pt","qt","rt","dx","du","K","summary".  Integer buffers are converted to
+ * double.  Returns the element count or a negative status. */
+int bpmpc_solver_read(bpmpc_solver* solver, const char* name, double* out, long capacity);
+/* Device pointers of the iterate, for zero-copy hand-off (e.g. an RCCL gather through torch.distributed):
+ * x: batch*(max_nodes+1)*nx doubles, u: batch*max_nodes*nu doubles. */
+int bpmpc_solver_device_trajectories(bpmpc_solver* solver, double** x_dev, double** u_dev);
+/* Accumulated HIP-event time of one kernel class since the last call with reset != 0 (needs settings.profile):
+ * "prepare","linearize","project","riccati","linesearch". */
+int bpmpc_solver_kernel_time(bpmpc_solver* solver, const char* kernel, int reset, double* total_ms, int* launches);
+/* Sizes chosen by the last setup: nodes per problem (max over the batch) and number of distinct grids. */
+int bpmpc_solver_layout(const bpmpc_solver* solver, int* batch, int* n_nodes_max, int* n_grids, int* nx, int* nu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPMPC_H */

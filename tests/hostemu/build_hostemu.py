@@ -1,0 +1,23 @@
+"""TEST-ONLY build of the CPU lane-emulation of the kernel bodies (see hostemu.cpp)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libbpmpc_hostemu.so")
+
+
+def build(force=False):
+    csrc = os.path.join(ROOT, "bipedal_control_amd", "csrc")
+    srcs = [os.path.join(HERE, "hostemu.cpp")] + [os.path.join(csrc, f) for f in ("info_tree.cpp", "urdf_tree.cpp", "robot_model.cpp", "device_model.cpp")]
+    newest = max(os.path.getmtime(p) for p in srcs)
+    for root, _, files in os.walk(os.path.join(csrc, "kernels")):
+        newest = max([newest] + [os.path.getmtime(os.path.join(root, f)) for f in files])
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
+        return LIB
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DBPMPC_HOST_EMULATION", "-o", LIB] + srcs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(True))

@@ -1,0 +1,159 @@
+"""GPU parity tests (through the C ABI): HIP path vs the CPU oracle on the same seeded inputs.
+Tolerances (FP64 both sides; different summation order and analytic-vs-AD derivatives):
+  LQ model entries                 1e-11 relative to max(1, |oracle|_max) per quantity
+  QP step dx, du, K                1e-9  relative to max(1, |oracle|_max)
+  solve output x, u                1e-8  relative
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import bipedal_control_amd as bp
+    from bipedal_control_amd import scenarios
+    from tests import oracle_bridge as ob
+    itf = scenarios.h1_interface()
+    return dict(bp=bp, sc=scenarios, ob=ob, itf=itf)
+
+
+def _views(mpc, name, per_node):
+    raw = mpc.read(name)
+    return raw.reshape(mpc.max_batch, mpc.max_nodes, *per_node) if per_node is not None else raw
+
+
+def test_linearize_matches_oracle(ctx):
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=3, n_intervals=30)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=48)
+    lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    # move away from the cold start so that every term is exercised: one accepted step first
+    mpc.enqueue(); mpc.synchronize()
+    mpc.stage("linearize"); mpc.synchronize()
+    nx = nu = itf.stateDim
+    x = mpc.read("x").reshape(3, 49, nx); u = mpc.read("u").reshape(3, 48, nu)
+    shapes = dict(A=(nx, nx), B=(nx, nu), b=(nx,), Q=(nx, nx), R=(nu, nu), P=(nu, nx), q=(nx,), r=(nu,), c=(), C=(16, nx), D=(16, nu), e=(16,), perf=(3,))
+    dev = {k: _views(mpc, k, s) for k, s in shapes.items()}
+    nc = mpc.read("nc").reshape(3, 48)
+    om = ob.h1_oracle()
+    worst = {}
+    for b in range(3):
+        nodes = ob.oracle_nodes(prob, b)
+        assert nodes["N"] == lay["n_nodes_max"]
+        for k in range(nodes["N"]):
+            o = om.node_lq(nodes["kind"][k], nodes["dt"][k], x[b, k], u[b, k], x[b, k + 1], nodes["xref"][k], nodes["mode"][k], nodes["zref"][k], nodes["zdref"][k])
+            assert int(nc[b, k]) == o["nc"]
+            for name in shapes:
+                worst[name] = max(worst.get(name, 0.0), _rel(dev[name][b, k], o[name]))
+    assert max(worst.values()) < 1e-11, worst
+
+
+def test_qp_step_matches_oracle(ctx):
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=2, n_intervals=40)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=2, max_nodes=56, return_gains=True)
+    mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    mpc.enqueue(); mpc.synchronize()      # generic iterate
+    for st in ("linearize", "project", "riccati"):
+        mpc.stage(st)
+    mpc.synchronize()
+    nx = nu = itf.stateDim
+    x = mpc.read("x").reshape(2, 57, nx); u = mpc.read("u").reshape(2, 56, nu)
+    dx = mpc.read("dx").reshape(2, 57, nx); du = mpc.read("du").reshape(2, 56, nu); K = mpc.read("K").reshape(2, 56, nu, nx)
+    om = ob.h1_oracle()
+    for b in range(2):
+        nodes = ob.oracle_nodes(prob, b)
+        N = nodes["N"]
+        odx, odu, oK = om.qp_step(nodes, prob["x0"][b], x[b, :N + 1], u[b, :N])
+        assert _rel(dx[b, :N + 1], odx) < 1e-9
+        assert _rel(du[b, :N], odu) < 1e-9
+        assert _rel(K[b, :N], oK) < 1e-9
+
+
+@pytest.mark.parametrize("iterations", [1, 3])
+def test_solve_matches_oracle(ctx, iterations):
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=4, n_intervals=50)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=64, sqp_iterations=iterations, return_gains=True)
+    t, x, u, K, stats = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    for b in range(4):
+        xo, uo, Ko, st = ob.oracle_solve_like(prob, b, iterations=iterations)
+        n = stats[b].n_nodes
+        its = int(sum(1 for r in st if r[10] > 0))
+        assert stats[b].iterations == its
+        assert abs(stats[b].step_size - st[its - 1][3]) == 0.0
+        assert _rel(x[b, :n + 1], xo) < 1e-8
+        assert _rel(u[b, :n], uo) < 1e-8
+        assert _rel(K[b, :n], Ko) < 1e-7
+        assert _rel(stats[b].merit_after, st[its - 1][4]) < 1e-9
+
+
+def test_stance_config1(ctx):
+    """BASELINE.json configs[0]: H1 stance, N = 20, single problem, cold start."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.stance_problem(itf, 20)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=1, max_nodes=24)
+    t, x, u, K, stats = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    xo, uo, Ko, st = ob.oracle_solve_like(prob, 0)
+    assert stats[0].n_nodes == 20
+    assert np.allclose(t[0, :21], np.arange(21) * 0.015, atol=1e-12)
+    assert _rel(x[0, :21], xo) < 1e-8 and _rel(u[0, :20], uo) < 1e-8
+    # stance: joint velocities are pinned by the zero-velocity constraints
+    assert np.abs(u[0, 0, 12:]).max() < 1e-9
+
+
+def test_full_size_properties(ctx):
+    """BASELINE.json configs[1] size: batch 256, N = 100.  Size-independent properties instead of the slow oracle:
+    (a) a problem's solution does not depend on its batch neighbours or position (bitwise),
+    (b) the linearised equality constraints hold for the QP step: C dx + D du + e = 0,
+    (c) the QP step satisfies the linearised dynamics dx+ = A dx + B du + b,
+    (d) three SQP iterations drive the constraint violation down."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    B, N = 256, 100
+    prob = sc.trot_problem(itf, batch=B, n_intervals=N)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=112, sqp_iterations=3)
+    mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    for st in ("linearize", "project", "riccati"):
+        mpc.stage(st)
+    mpc.synchronize()
+    nx = nu = itf.stateDim
+    n = mpc.layout()["n_nodes_max"]
+    dx = mpc.read("dx").reshape(B, 113, nx); du = mpc.read("du").reshape(B, 112, nu)
+    A = mpc.read("A").reshape(B, 112, nx, nx); Bm = mpc.read("B").reshape(B, 112, nx, nu); bv = mpc.read("b").reshape(B, 112, nx)
+    C = mpc.read("C").reshape(B, 112, 16, nx); D = mpc.read("D").reshape(B, 112, 16, nu); e = mpc.read("e").reshape(B, 112, 16)
+    kind = mpc.read("g_kind")[:n]
+    inter = kind == 0
+    res_dyn = np.einsum("bkij,bkj->bki", A[:, :n], dx[:, :n]) + np.einsum("bkij,bkj->bki", Bm[:, :n], du[:, :n]) + bv[:, :n] - dx[:, 1:n + 1]
+    assert np.abs(res_dyn).max() < 1e-9
+    res_eq = np.einsum("bkij,bkj->bki", C[:, :n], dx[:, :n]) + np.einsum("bkij,bkj->bki", D[:, :n], du[:, :n]) + e[:, :n]
+    # D is rank deficient (two contact points per rigid foot): exactly rank(D) rows are eliminated, the nc - rank rows
+    # left out by the FullPivLU rank decision hold only to first order (|violation| * |step|).
+    nc = mpc.read("nc").reshape(B, 112)[:, :n]
+    nut = mpc.read("nut").reshape(B, 112)[:, :n]
+    violated = (np.abs(res_eq) > 1e-8).sum(axis=2)
+    dropped = nc - (nu - nut)
+    assert np.all(violated[:, inter] <= dropped[:, inter]) and dropped[:, inter].max() <= 2
+    Pu = mpc.read("Pu").reshape(B, 112, nu, nu)[:, :n]
+    DPu = np.einsum("bkij,bkjl->bkil", D[:, :n], Pu)
+    assert np.abs(DPu[:, inter]).max() < 1e-10
+    mpc.reset(); mpc.enqueue(); mpc.synchronize()
+    t, x, u, K, stats = mpc.fetch()
+    assert all(s.status == 0 for s in stats)
+    viol0 = np.array([np.sqrt(s.dynamics_sse_before + s.equality_sse_before) for s in stats])
+    viol1 = np.array([np.sqrt(s.dynamics_sse_after + s.equality_sse_after) for s in stats])
+    # cold-start violation is O(0.1 .. 1); three filter-line-search iterations must bring every problem far below that
+    assert np.all(viol1 < 5e-2) and np.median(viol1) < 5e-3 and np.all(viol1 <= viol0 + 1e-12)
+    # (a) permutation / sub-batch invariance, bitwise
+    sub = [200, 3, 77]
+    prob2 = dict(prob, x0=prob["x0"][sub], targets=[prob["targets"][i] for i in sub])
+    mpc2 = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=112, sqp_iterations=3)
+    t2, x2, u2, _, _ = mpc2.run(prob2["t0"], prob2["x0"], prob2["schedule"], prob2["targets"], horizon=prob2["horizon"])
+    for j, i in enumerate(sub):
+        assert np.array_equal(x2[j], x[i]) and np.array_equal(u2[j], u[i])
