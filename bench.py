@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py - MPC solves/s of the H1 trot workload (BASELINE.json configs[1]) on N MI355X.
+
+One "step" = one MPC solve (task.info: 1 SQP iteration = linearise every shooting node, eliminate the equality
+constraints, Riccati sweep, filter line search, step) of a batch of independent problems per GPU, inputs already resident
+in HBM.  Ranks own disjoint problem slices (weak scaling: 256 problems per GPU); the only collective is the final
+all-gather of the optimal trajectories over RCCL, which is inside the timed step for N > 1.
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (linearisation sweep) and, at N = 1,
+`cpu_baseline` (the single-thread C++ oracle timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_NODE_H1 = 26444          # algorithmic bytes of one materialised node linearisation
+HBM_PEAK_GBS = 8000.0              # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="problems per GPU")
+    ap.add_argument("--intervals", type=int, default=100, help="horizon in shooting intervals of dt = 0.015 s")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU baseline (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not wrap kernels in HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import bipedal_control_amd as bp
+    from bipedal_control_amd import scenarios
+
+    itf = scenarios.h1_interface()
+    B, NI = args.batch, args.intervals
+    prob = scenarios.trot_problem(itf, batch=B, n_intervals=NI, offset=rank * B)
+    max_nodes = NI + 16
+    stream = torch.cuda.current_stream().cuda_stream
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=max_nodes, profile=not args.no_profile, device=local, stream=stream)
+    lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    n_nodes = lay["n_nodes_max"]
+    kinds = mpc.read("g_kind")[:n_nodes]
+    n_intermediate = int((kinds == 0).sum())
+    nx, nu = itf.stateDim, itf.inputDim
+
+    # result buffers owned by torch so that RCCL can gather them
+    x_loc = torch.empty((B, max_nodes + 1, nx), dtype=torch.float64, device="cuda")
+    u_loc = torch.empty((B, max_nodes, nu), dtype=torch.float64, device="cuda")
+    if world > 1:
+        x_all = torch.empty((world * B, max_nodes + 1, nx), dtype=torch.float64, device="cuda")
+        u_all = torch.empty((world * B, max_nodes, nu), dtype=torch.float64, device="cuda")
+
+    def step():
+        mpc.reset()        # device-side restore of the cold-start iterate: every step solves the same problems
+        mpc.enqueue()      # 1 SQP iteration per problem, all on the GPU
+        mpc.export_trajectories(x_loc.data_ptr(), u_loc.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(x_all, x_loc)
+            dist.all_gather_into_tensor(u_all, u_loc)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    mpc.synchronize()
+    for k in ("prepare", "linearize", "project", "riccati", "linesearch"):
+        mpc.kernel_time(k, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    mpc.synchronize()
+
+    t, x, u, _, stats = mpc.fetch()
+    ok = sum(1 for s in stats if s.status == 0)
+    ktimes = {k: mpc.kernel_time(k, reset=False) for k in ("linearize", "project", "riccati", "linesearch")}
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        lin_ms, lin_n = ktimes["linearize"]
+        roofline = None
+        if lin_n > 0:
+            avg_s = 1e-3 * lin_ms / lin_n
+            alg_bytes = BYTES_PER_NODE_H1 * B * n_intermediate
+            achieved = alg_bytes / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "linearize_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("batch") == B and tj.get("intervals") == NI:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"kernel": "k_linearize<10>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_us": round(1e6 * avg_s, 2),
+                        "algorithmic_bytes_per_launch": alg_bytes, "node_linearizations_per_s": round(B * n_intermediate / avg_s, 1)}
+        out = {"metric": "MPC solves/s (H1, horizon=%d)" % NI, "value": round(value, 2), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "Unitree H1 trot, horizon=%d intervals (dt 0.015), batch=%d perturbed initial states per GPU, "
+                                      "cold start, 1 SQP iteration (BASELINE.json configs[1])" % (NI, B),
+                          "global_batch": world * B, "shooting_nodes": n_nodes, "intermediate_nodes": n_intermediate, "nx": nx, "nu": nu,
+                          "parallelism": "problem-sharded x%d, all-gather of trajectories" % world, "accepted_steps": ok},
+               "ms_per_solve": round(ms_per_step / B, 6),
+               "kernel_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in ktimes.items()},
+               "roofline": roofline}
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(prob, min(args.cpu_sample, B), x, u, stats)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(prob, sample, x_gpu, u_gpu, stats):
+    """Single-thread C++ oracle (a port of the same SQP iteration; the reference itself cannot be built here) on the
+    first `sample` problems of the same workload; doubles as an end-to-end parity check of the timed run."""
+    import numpy as np
+    from tests import oracle_bridge as ob
+    from oracle import reference_py as rp
+    m, om = ob.h1_model(), ob.h1_oracle()
+    s = m["sqp"]
+    pre = []
+    for b in range(sample):
+        nodes = ob.oracle_nodes(prob, b)
+        xi, ui = rp.cold_start(m, nodes, prob["x0"][b])
+        pre.append((nodes, xi, ui))
+    worst = 0.0
+    t0 = time.perf_counter()
+    sols = [om.solve(nodes, prob["x0"][b], xi, ui, iterations=1, g_max=s["g_max"], g_min=s["g_min"], delta_tol=s["deltaTol"])
+            for b, (nodes, xi, ui) in enumerate(pre)]
+    dt = time.perf_counter() - t0
+    for b, (xo, uo, _, _) in enumerate(sols):
+        n = stats[b].n_nodes
+        worst = max(worst, float(np.abs(x_gpu[b, :n + 1] - xo).max()))
+    try:
+        cpu_name = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        cpu_name = "unknown"
+    return {"value": round(sample / dt, 3), "unit": "solves/s", "cores": 1, "kind": "port", "ms_per_solve": round(1e3 * dt / sample, 3),
+            "sample": "%d of the same H1 trot problems (horizon and SQP iteration count as on the GPU), solve only, "
+                      "reference pre-pass excluded" % sample,
+            "host_cpu": cpu_name, "host_cores": os.cpu_count(), "max_abs_x_diff_vs_gpu": worst}
+
+
+if __name__ == "__main__":
+    main()

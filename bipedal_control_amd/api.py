@@ -310,3 +310,7 @@ class BatchedSqpMpc:
         xp, up = _dp(), _dp()
         _check(load_library().bpmpc_solver_device_trajectories(self._h, C.byref(xp), C.byref(up)))
         return C.cast(xp, C.c_void_p).value, C.cast(up, C.c_void_p).value
+
+    def export_trajectories(self, x_dst_ptr, u_dst_ptr):
+        """Async D2D copy of the iterate into device buffers given by raw pointers (e.g. torch tensors' data_ptr())."""
+        _check(load_library().bpmpc_solver_export_trajectories(self._h, C.c_void_p(x_dst_ptr), C.c_void_p(u_dst_ptr)))

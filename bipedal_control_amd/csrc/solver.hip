@@ -634,6 +634,13 @@ int bpmpc_solver_device_trajectories(bpmpc_solver* s, double** x_dev, double** u
   if (u_dev) *u_dev = s->buf.u;
   return BPMPC_OK;
 }
+int bpmpc_solver_export_trajectories(bpmpc_solver* s, double* x_dst_dev, double* u_dst_dev) {
+  API_GUARD(s, {
+    const size_t N = s->settings.max_nodes;
+    if (x_dst_dev) HIP_CHECK(hipMemcpyAsync(x_dst_dev, s->buf.x, (size_t)s->batch * (N + 1) * s->nx * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    if (u_dst_dev) HIP_CHECK(hipMemcpyAsync(u_dst_dev, s->buf.u, (size_t)s->batch * N * s->nu * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  })
+}
 int bpmpc_solver_kernel_time(bpmpc_solver* s, const char* kernel, int reset_after, double* total_ms, int* launches) {
   API_GUARD(s, {
     if (!kernel) throw std::invalid_argument("null kernel class");

@@ -166,6 +166,9 @@ int bpmpc_solver_read(bpmpc_solver* solver, const char* name, double* out, long 
 /* Device pointers of the iterate, for zero-copy hand-off (e.g. an RCCL gather through torch.distributed):
  * x: batch*(max_nodes+1)*nx doubles, u: batch*max_nodes*nu doubles. */
 int bpmpc_solver_device_trajectories(bpmpc_solver* solver, double** x_dev, double** u_dev);
+/* Asynchronous device-to-device copy of the iterate into caller-owned device buffers (same shapes as above) on the
+ * solver's stream - e.g. torch tensors that are then all-gathered over RCCL. */
+int bpmpc_solver_export_trajectories(bpmpc_solver* solver, double* x_dst_dev, double* u_dst_dev);
 /* Accumulated HIP-event time of one kernel class since the last call with reset != 0 (needs settings.profile):
  * "prepare","linearize","project","riccati","linesearch". */
 int bpmpc_solver_kernel_time(bpmpc_solver* solver, const char* kernel, int reset, double* total_ms, int* launches);
