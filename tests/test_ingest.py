@@ -1,0 +1,95 @@
+"""Model ingest: product C++ ingest (through the C ABI) vs the oracle's independent
+Python ingest, plus hand-derived known answers."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ingest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+A = os.path.join(ROOT, "assets", "h1")
+REF = "/root/reference/bipedal_robot_example/unitree_h1"
+
+
+@pytest.fixture(scope="module")
+def both():
+    import bipedal_control_amd as bp
+    itf = bp.BipedalRobotInterface(os.path.join(A, "task.info"), os.path.join(A, "h1_mpc.urdf"), os.path.join(A, "reference.info"))
+    m = ingest.build_model(os.path.join(A, "h1_mpc.urdf"), os.path.join(A, "task.info"), os.path.join(A, "reference.info"))
+    return itf, m
+
+
+def test_dimensions_and_joint_order(both):
+    itf, m = both
+    assert (itf.stateDim, itf.inputDim, itf.numThreeDofContacts, itf.actuatedDofNum) == (22, 22, 4, 10)
+    # depth-first order with children in joint-name order = jointNames order of task.info:18-30
+    assert itf.jointNames() == m["joint_names"] == ["left_hip_yaw_joint", "left_hip_roll_joint", "left_hip_pitch_joint", "left_knee_joint",
+                                                    "left_ankle_joint", "right_hip_yaw_joint", "right_hip_roll_joint", "right_hip_pitch_joint",
+                                                    "right_knee_joint", "right_ankle_joint"]
+
+
+def test_known_answers(both):
+    itf, m = both
+    # total mass 51.641 kg; sole frames at (0.19,0,-0.06) / (-0.1,0,-0.06) on the ankle links
+    assert abs(itf.robotMass() - 51.641) < 1e-12 and abs(m["robot_mass"] - 51.641) < 1e-12
+    assert abs(itf.get("body_mass").sum() - 51.641) < 1e-12
+    off = itf.get("contact_offset").reshape(4, 3)
+    assert np.allclose(off, [[0.19, 0, -0.06], [-0.1, 0, -0.06], [0.19, 0, -0.06], [-0.1, 0, -0.06]], atol=0)
+    assert list(itf.get("contact_body")) == [5, 5, 10, 10]
+    assert list(itf.get("joint_parent")) == [0, 1, 2, 3, 4, 0, 6, 7, 8, 9]
+    ax = itf.get("joint_axis").reshape(10, 3)
+    assert np.array_equal(ax[:5], [[0, 0, 1], [1, 0, 0], [0, 1, 0], [0, 1, 0], [0, 1, 0]]) and np.array_equal(ax[5:], ax[:5])
+    x0 = itf.getInitialState()
+    assert x0[8] == 0.93 and np.array_equal(x0[12:17], [0, 0, -0.5, 1.0, -0.5])
+    # task.info:247-278: force block of R = 5 * 1e-3 on the diagonal
+    Q, R = itf.costMatrices()
+    assert np.allclose(np.diag(R)[:12], 5e-3, rtol=1e-15) and np.count_nonzero(R[:12, 12:]) == 0
+    assert np.array_equal(np.diag(Q)[:6], [15, 15, 30, 5000, 5000, 10])
+    # joint block = J^T (2.0 I) J: symmetric positive definite, legs decoupled
+    Rj = R[12:, 12:]
+    assert np.allclose(Rj, Rj.T, atol=1e-15) and np.linalg.eigvalsh(Rj).min() > 0 and np.abs(Rj[:5, 5:]).max() == 0
+    assert list(itf.get("cone")) == [0.5, 25.0, 0.0, 1e-6, 0.1, 5.0]
+    assert list(itf.get("swing")) == [0.05, 0.0, 0.05, 0.15]
+
+
+def test_product_matches_oracle_ingest(both):
+    itf, m = both
+    nb = m["nj"] + 1
+    pairs = [("body_mass", m["mass"]), ("body_com", m["com"]), ("body_inertia", m["inertia"]), ("joint_rotation", m["Rfix"]),
+             ("joint_offset", m["pfix"]), ("joint_axis", m["axis"]), ("contact_offset", m["contact_off"]), ("Q", m["Q"]), ("R", m["R"]),
+             ("initial_state", m["initial_state"]), ("default_joint_state", m["default_joint_state"])]
+    for name, ref in pairs:
+        got = itf.get(name)
+        ref = np.asarray(ref, float).reshape(-1)
+        assert got.shape == ref.shape, name
+        assert np.abs(got - ref).max() <= 1e-15 * max(1.0, np.abs(ref).max()), name
+    assert nb == 11
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_reduced_assets_equal_reference_files():
+    """The reduced assets and the reference's full data files give the identical flat model (both ingests)."""
+    import bipedal_control_amd as bp
+    urdf = os.path.join(REF, "h1_description/urdf/h1_with_sole.urdf")
+    task = os.path.join(REF, "h1_ocs2_config/config/task/task.info")
+    refi = os.path.join(REF, "h1_ocs2_config/config/command/reference.info")
+    full = ingest.model_blob(ingest.build_model(urdf, task, refi))
+    red = ingest.model_blob(ingest.build_model(os.path.join(A, "h1_mpc.urdf"), os.path.join(A, "task.info"), os.path.join(A, "reference.info")))
+    assert np.array_equal(full, red)
+    a = bp.BipedalRobotInterface(task, urdf, refi)
+    b = bp.BipedalRobotInterface(os.path.join(A, "task.info"), os.path.join(A, "h1_mpc.urdf"), os.path.join(A, "reference.info"))
+    for name in ("body_mass", "body_com", "body_inertia", "joint_rotation", "joint_offset", "Q", "R", "initial_state", "sqp", "swing", "cone"):
+        assert np.array_equal(a.get(name), b.get(name)), name
+    g1 = bp.loadModeSequenceTemplate(os.path.join(REF, "h1_ocs2_config/config/command/gait.info"), "flying_trot")
+    g2 = bp.loadModeSequenceTemplate(os.path.join(A, "gait.info"), "flying_trot")
+    assert np.array_equal(g1.switchingTimes, g2.switchingTimes) and np.array_equal(g1.modeSequence, g2.modeSequence)
+
+
+def test_error_behaviour():
+    """The reference throws on missing files (BipedalRobotInterface.cpp:71-90); the C ABI returns an error status."""
+    import bipedal_control_amd as bp
+    with pytest.raises(bp.BpmpcError):
+        bp.BipedalRobotInterface("/nonexistent/task.info", os.path.join(A, "h1_mpc.urdf"), os.path.join(A, "reference.info"))
+    with pytest.raises(bp.BpmpcError):
+        bp.loadModeSequenceTemplate(os.path.join(A, "gait.info"), "no_such_gait")
