@@ -25,6 +25,7 @@
 #include "kernels/node_lq.h"
 #include "kernels/project_node.h"
 #include "kernels/riccati.h"
+#include "kernels/riccati_fast.h"
 #include "reference_gen.h"
 
 namespace bpmpc {
@@ -56,6 +57,7 @@ struct Buffers {
   int* nut;
   // riccati
   double *Kt, *kt, *dx, *du, *K, *summary, *dx0;
+  double *Acl, *bcl, *kff, *mvec, *mscal, *rprof;
   // line search
   double *trial_perf, *base, *alpha, *stats;
   int *done, *active, *iterations, *remaining;
@@ -166,6 +168,35 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati(Launch L) {
   io.K = L.buf.K ? L.buf.K + s0 * NU * NX : nullptr;
   io.summary = L.buf.summary + (size_t)b * 4;
   riccati_problem<NJ>(ws, io);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kRiccatiThreads) void k_riccati_fast(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ RiccatiFastWorkspace<NJ> ws;
+  const int b = blockIdx.x;
+  if (!L.buf.active[b]) return;
+  const size_t s0 = (size_t)b * L.N;
+  double* dx0 = L.buf.dx0 + (size_t)b * NX;
+  if (threadIdx.x < NX) dx0[threadIdx.x] = L.buf.p_x0[(size_t)b * NX + threadIdx.x] - L.buf.x[(size_t)b * (L.N + 1) * NX + threadIdx.x];
+  __syncthreads();
+  RiccatiFastIO io;
+  io.base.N = L.buf.g_nodes[L.buf.p_grid[b]];
+  io.base.nut = L.buf.nut + s0;
+  io.base.At = L.buf.At + s0 * NX * NX; io.base.Bt = L.buf.Bt + s0 * NX * NU; io.base.bt = L.buf.bt + s0 * NX;
+  io.base.Qt = L.buf.Qt + s0 * NX * NX; io.base.Rt = L.buf.Rt + s0 * NU * NU; io.base.Pt = L.buf.Pt + s0 * NU * NX;
+  io.base.qt = L.buf.qt + s0 * NX; io.base.rt = L.buf.rt + s0 * NU;
+  io.base.Px = L.buf.Px + s0 * NU * NX; io.base.Pu = L.buf.Pu + s0 * NU * NU; io.base.Pe = L.buf.Pe + s0 * NU;
+  io.base.dx0 = dx0;
+  io.base.Kt = nullptr; io.base.kt = nullptr;
+  io.base.dx = L.buf.dx + (size_t)b * (L.N + 1) * NX; io.base.du = L.buf.du + s0 * NU;
+  io.base.K = nullptr;
+  io.base.summary = L.buf.summary + (size_t)b * 4;
+  io.Acl = L.buf.Acl + s0 * NX * NX; io.bcl = L.buf.bcl + s0 * NX; io.kff = L.buf.kff + s0 * NU;
+  io.mvec = L.buf.mvec + s0 * NX; io.mscal = L.buf.mscal + s0;
+  io.Kfull = L.buf.K + s0 * NU * NX;
+  io.prof = L.buf.rprof ? L.buf.rprof + (size_t)b * 8 : nullptr;
+  riccati_fast<NJ>(ws, io);
 }
 
 template <int NJ>
@@ -326,7 +357,8 @@ template <int NJ> void bpmpc_solver::stage_project() {
 }
 template <int NJ> void bpmpc_solver::stage_riccati() {
   const Launch L = launch_params();
-  TIMED_LAUNCH("riccati", k_riccati<NJ>, batch, kRiccatiThreads, L);
+  if (settings.reference_kernels) TIMED_LAUNCH("riccati", k_riccati<NJ>, batch, kRiccatiThreads, L);
+  else TIMED_LAUNCH("riccati", k_riccati_fast<NJ>, batch, kRiccatiThreads, L);
 }
 template <int NJ> void bpmpc_solver::stage_linesearch() {
   const Launch L = launch_params();
@@ -399,7 +431,10 @@ void allocate(bpmpc_solver* s) {
   b.qt = s->alloc<double>("qt", S * NX); b.rt = s->alloc<double>("rt", S * NU); b.nut = s->alloc<int>("nut", S, true);
   b.Kt = s->alloc<double>("Kt", S * NU * NX); b.kt = s->alloc<double>("kt", S * NU);
   b.dx = s->alloc<double>("dx", B * (N + 1) * NX); b.du = s->alloc<double>("du", S * NU);
-  b.K = s->settings.return_gains ? s->alloc<double>("K", S * NU * NX) : nullptr;
+  b.K = s->alloc<double>("K", S * NU * NX);   // feedback gains (also the forward roll-out operator of the fast Riccati kernel)
+  b.Acl = s->alloc<double>("Acl", S * NX * NX); b.bcl = s->alloc<double>(nullptr, S * NX); b.kff = s->alloc<double>(nullptr, S * NU);
+  b.mvec = s->alloc<double>(nullptr, S * NX); b.mscal = s->alloc<double>(nullptr, S);
+  b.rprof = s->alloc<double>("rprof", B * 8);
   b.summary = s->alloc<double>("summary", B * 4); b.dx0 = s->alloc<double>(nullptr, B * NX);
   b.trial_perf = s->alloc<double>("trial_perf", S * 3); b.base = s->alloc<double>("base", B * 3); b.alpha = s->alloc<double>("alpha", B);
   b.stats = s->alloc<double>("stats", B * kStatsStride);
@@ -495,7 +530,6 @@ void fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double*
   if (out_x) HIP_CHECK(hipMemcpy(out_x, s->buf.x, B * (N + 1) * NX * sizeof(double), hipMemcpyDeviceToHost));
   if (out_u) HIP_CHECK(hipMemcpy(out_u, s->buf.u, B * N * NU * sizeof(double), hipMemcpyDeviceToHost));
   if (out_K) {
-    if (!s->buf.K) throw std::invalid_argument("gains requested but the solver was created with return_gains = 0");
     HIP_CHECK(hipMemcpy(out_K, s->buf.K, B * N * NU * NX * sizeof(double), hipMemcpyDeviceToHost));
   }
   if (out_t)

@@ -105,6 +105,7 @@ typedef struct {
   int return_gains;     /* allocate and compute the feedback gains K (sqp.useFeedbackPolicy) */
   int profile;          /* time every kernel class with HIP events (bpmpc_solver_kernel_time) */
   void* stream;         /* hipStream_t to run on; NULL = a stream owned by the solver */
+  int reference_kernels; /* != 0: run the lane-emulation-verified reference kernel bodies instead of the fast variants (debugging) */
 } bpmpc_settings;
 
 typedef struct {
