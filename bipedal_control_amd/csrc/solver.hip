@@ -24,6 +24,7 @@
 #include "kernels/linesearch.h"
 #include "kernels/node_lq.h"
 #include "kernels/project_node.h"
+#include "kernels/project_fast.h"
 #include "kernels/riccati.h"
 #include "kernels/riccati_fast.h"
 #include "reference_gen.h"
@@ -142,6 +143,29 @@ __global__ __launch_bounds__(kWave) void k_project(Launch L) {
   out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
   out.rt = L.buf.rt + s * NU;
   project_node<NJ>(ws, in, out);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_project_fast(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ ProjectFastWorkspace<NJ> ws;
+  const int sidx = blockIdx.x, b = sidx / L.N, k = sidx % L.N;
+  if (!L.buf.active[b]) return;
+  const int g = L.buf.p_grid[b];
+  if (k >= L.buf.g_nodes[g]) return;
+  const size_t s = sidx;
+  ProjectIn in;
+  in.kind = L.buf.g_kind[(size_t)g * L.N + k];
+  in.nc = L.buf.nc[s];
+  in.C = L.buf.C + s * kMaxEqRows * NX; in.D = L.buf.D + s * kMaxEqRows * NU; in.e = L.buf.e + s * kMaxEqRows;
+  in.A = L.buf.A + s * NX * NX; in.B = L.buf.B + s * NX * NU; in.b = L.buf.b + s * NX;
+  in.Q = L.buf.Q + s * NX * NX; in.R = L.buf.R + s * NU * NU; in.P = L.buf.P + s * NU * NX; in.q = L.buf.q + s * NX; in.r = L.buf.r + s * NU;
+  ProjectOut out;
+  out.Px = L.buf.Px + s * NU * NX; out.Pu = L.buf.Pu + s * NU * NU; out.Pe = L.buf.Pe + s * NU; out.nut = L.buf.nut + s;
+  out.At = L.buf.At + s * NX * NX; out.Bt = L.buf.Bt + s * NX * NU; out.bt = L.buf.bt + s * NX;
+  out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
+  out.rt = L.buf.rt + s * NU;
+  project_fast<NJ>(ws, in, out, (b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr);
 }
 
 template <int NJ>
@@ -353,7 +377,8 @@ template <int NJ> void bpmpc_solver::stage_linearize() {
 }
 template <int NJ> void bpmpc_solver::stage_project() {
   const Launch L = launch_params();
-  TIMED_LAUNCH("project", k_project<NJ>, batch * settings.max_nodes, kWave, L);
+  if (settings.reference_kernels) TIMED_LAUNCH("project", k_project<NJ>, batch * settings.max_nodes, kWave, L);
+  else TIMED_LAUNCH("project", k_project_fast<NJ>, batch * settings.max_nodes, kWave, L);
 }
 template <int NJ> void bpmpc_solver::stage_riccati() {
   const Launch L = launch_params();
