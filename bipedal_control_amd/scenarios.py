@@ -9,6 +9,11 @@ from .api import BipedalRobotInterface, GaitSchedule, ModeSchedule, loadModeSequ
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H1 = dict(task=os.path.join(ROOT, "assets/h1/task.info"), urdf=os.path.join(ROOT, "assets/h1/h1_mpc.urdf"),
           reference=os.path.join(ROOT, "assets/h1/reference.info"), gait=os.path.join(ROOT, "assets/h1/gait.info"))
+# the reference's own 12-leg-joint robot (nx = nu = 24): stands in for BASELINE.json configs[3] ("G1 ... different DoF"),
+# for which the reference ships no OCS2 configuration
+OPENLOONG = dict(task=os.path.join(ROOT, "assets/openloong/task.info"), urdf=os.path.join(ROOT, "assets/openloong/openloong_mpc.urdf"),
+                 reference=os.path.join(ROOT, "assets/openloong/reference.info"), gait=os.path.join(ROOT, "assets/openloong/gait.info"))
+ROBOTS = {"h1": H1, "openloong": OPENLOONG}
 DT = 0.015
 SEED = 20241008
 # phase offset of the steady-state gait: the template starts 3.5 periods-halves before t = 0 so that t0 = 0 is mid-swing
@@ -17,6 +22,13 @@ GAIT_START = -1.225
 
 def h1_interface():
     return BipedalRobotInterface(H1["task"], H1["urdf"], H1["reference"])
+
+
+def interface(robot="h1"):
+    r = ROBOTS[robot]
+    itf = BipedalRobotInterface(r["task"], r["urdf"], r["reference"])
+    itf.gaitFile = r["gait"]
+    return itf
 
 
 def perturbed_initial_states(itf, batch, seed=SEED):
@@ -31,7 +43,7 @@ def gait_schedule(itf, gait_name, t0, horizon, gait_file=None, start=GAIT_START)
     """Steady-state schedule of a named gait as the reference's GaitSchedule would hold it at solve time."""
     gs = GaitSchedule(itf)
     if gait_name != "stance":
-        tmpl = loadModeSequenceTemplate(gait_file or H1["gait"], gait_name)
+        tmpl = loadModeSequenceTemplate(gait_file or getattr(itf, "gaitFile", H1["gait"]), gait_name)
         gs.insertModeSequenceTemplate(tmpl, start, t0 + 2 * horizon)
     return gs.getModeSchedule(t0 - horizon, t0 + 2 * horizon)
 
@@ -60,3 +72,19 @@ def trot_problem(itf, batch, n_intervals=100, cmd_vel=(0.3, 0.0, 0.0, 0.0), gait
 def max_nodes_for(n_intervals, horizon, period_min=0.03):
     """Upper bound of grid intervals: every event adds at most two nodes."""
     return int(n_intervals + 2 * (horizon / period_min) + 4)
+
+
+def gait_sweep_problem(itf, gaits, commands, n_intervals=150, seed=SEED):
+    """Config 5 in miniature: one problem per (gait, velocity command); every problem has its OWN mode schedule.
+    `commands` is a list of (v_x, omega_z)."""
+    horizon = n_intervals * DT
+    nb = len(gaits) * len(commands)
+    x0 = perturbed_initial_states(itf, nb, seed)
+    schedules, targets = [], []
+    for g in gaits:
+        sched = gait_schedule(itf, g, 0.0, horizon)
+        for (vx, wz) in commands:
+            b = len(schedules)
+            schedules.append(sched)
+            targets.append(itf.cmdVelToTargetTrajectories((vx, 0.0, 0.0, wz), 0.0, x0[b], horizon))
+    return dict(t0=np.zeros(nb), x0=x0, schedule=schedules, targets=targets, horizon=horizon)

@@ -11,20 +11,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ASSETS = os.path.join(ROOT, "assets", "h1")
 
 
+_URDF = {"h1": "h1_mpc.urdf", "openloong": "openloong_mpc.urdf"}
+
+
 @functools.lru_cache(maxsize=None)
+def model(robot="h1"):
+    d = os.path.join(ROOT, "assets", robot)
+    return ingest.build_model(os.path.join(d, _URDF[robot]), os.path.join(d, "task.info"), os.path.join(d, "reference.info"))
+
+
+@functools.lru_cache(maxsize=None)
+def oracle(robot="h1"):
+    return oracle_py.OracleModel(ingest.model_blob(model(robot)))
+
+
 def h1_model():
-    return ingest.build_model(os.path.join(ASSETS, "h1_mpc.urdf"), os.path.join(ASSETS, "task.info"), os.path.join(ASSETS, "reference.info"))
+    return model("h1")
 
 
-@functools.lru_cache(maxsize=None)
 def h1_oracle():
-    return oracle_py.OracleModel(ingest.model_blob(h1_model()))
+    return oracle("h1")
 
 
-def oracle_nodes(prob, b, dt=0.015):
+def oracle_nodes(prob, b, dt=0.015, robot="h1"):
     """Per-interval arrays of problem b computed by the oracle's own pre-pass from the scenario's schedule / targets."""
-    m = h1_model()
-    ev, ms = list(map(float, prob["schedule"].eventTimes)), list(map(int, prob["schedule"].modeSequence))
+    m = model(robot)
+    sched = prob["schedule"][b] if isinstance(prob["schedule"], list) else prob["schedule"]
+    ev, ms = list(map(float, sched.eventTimes)), list(map(int, sched.modeSequence))
     planner = rp.SwingTrajectoryPlanner(m["swing"])
     planner.update(ev, ms)
     tt = prob["targets"][b if len(prob["targets"]) > 1 else 0]
@@ -32,9 +45,9 @@ def oracle_nodes(prob, b, dt=0.015):
     return rp.node_arrays(m, t0, t0 + prob["horizon"], dt, ev, ms, np.asarray(tt.timeTrajectory), np.asarray(tt.stateTrajectory), planner)
 
 
-def oracle_solve_like(prob, b, iterations=1, x_init=None, u_init=None):
-    m, om = h1_model(), h1_oracle()
-    nodes = oracle_nodes(prob, b)
+def oracle_solve_like(prob, b, iterations=1, x_init=None, u_init=None, robot="h1"):
+    m, om = model(robot), oracle(robot)
+    nodes = oracle_nodes(prob, b, robot=robot)
     x0 = prob["x0"][b]
     if x_init is None:
         x_init, u_init = rp.cold_start(m, nodes, x0)

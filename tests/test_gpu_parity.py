@@ -157,3 +157,53 @@ def test_full_size_properties(ctx):
     t2, x2, u2, _, _ = mpc2.run(prob2["t0"], prob2["x0"], prob2["schedule"], prob2["targets"], horizon=prob2["horizon"])
     for j, i in enumerate(sub):
         assert np.array_equal(x2[j], x[i]) and np.array_equal(u2[j], u[i])
+
+
+def test_openloong_24_dof_class(ctx):
+    """nx = nu = 24 (12 leg joints): the reference's OpenLoong configuration, the dimension class of BASELINE.json
+    configs[3].  Same tolerances as H1."""
+    bp, sc, ob = ctx["bp"], ctx["sc"], ctx["ob"]
+    itf = sc.interface("openloong")
+    assert itf.stateDim == 24
+    prob = sc.trot_problem(itf, batch=3, n_intervals=40, gait="standing_trot")
+    mpc = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=64, return_gains=True)
+    t, x, u, K, stats = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    for b in range(3):
+        xo, uo, Ko, st = ob.oracle_solve_like(prob, b, robot="openloong")
+        n = stats[b].n_nodes
+        assert stats[b].step_size == st[0][3]
+        assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8 and _rel(K[b, :n], Ko) < 1e-7
+    # reference kernels (lane-emulation verified) and fast kernels agree
+    ref = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=64, reference_kernels=True)
+    t2, x2, u2, _, _ = ref.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    assert _rel(x2, x) < 1e-9 and _rel(u2, u) < 1e-9
+
+
+def test_per_problem_schedules_gait_sweep(ctx):
+    """BASELINE.json configs[4] in miniature: every problem carries its own gait (mode schedule, swing references, grid)."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    gaits = ["stance", "trot", "standing_trot", "flying_trot"]
+    prob = sc.gait_sweep_problem(itf, gaits, [(0.3, 0.0), (-0.2, 0.3)], n_intervals=60)
+    nb = 8
+    mpc = bp.BatchedSqpMpc(itf, max_batch=nb, max_nodes=96)
+    t, x, u, K, stats = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    assert mpc.layout()["n_grids"] == nb
+    counts = set()
+    for b in range(nb):
+        xo, uo, _, st = ob.oracle_solve_like(prob, b)
+        n = stats[b].n_nodes
+        counts.add(n)
+        assert n == xo.shape[0] - 1
+        assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8
+    assert len(counts) >= 3      # different gaits => different numbers of event nodes
+
+
+def test_reference_and_fast_kernels_agree(ctx):
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=6, n_intervals=50, gait="flying_trot")
+    a = bp.BatchedSqpMpc(itf, max_batch=6, max_nodes=72, sqp_iterations=2)
+    b = bp.BatchedSqpMpc(itf, max_batch=6, max_nodes=72, sqp_iterations=2, reference_kernels=True)
+    ra = a.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    rb = b.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    assert _rel(ra[1], rb[1]) < 1e-9 and _rel(ra[2], rb[2]) < 1e-9
+    assert [s.step_size for s in ra[4]] == [s.step_size for s in rb[4]]

@@ -102,3 +102,33 @@ def test_qp_step_pipeline(emu, n_intervals, seed):
     assert np.abs(du - du2).max() < 1e-11 * max(1, np.abs(du).max())
     assert np.abs(K - K2).max() < 1e-10 * max(1, np.abs(K).max())
     assert summ[3] == 0 and abs(summ[1] - np.sum(dx ** 2)) < 1e-9 * np.sum(dx ** 2) and abs(summ[2] - np.sum(du ** 2)) < 1e-9 * np.sum(du ** 2)
+
+
+def test_node_linearization_24_dof(hostemu_lib):
+    """Same check for the 12-leg-joint robot (nx = nu = 24, OpenLoong)."""
+    import os
+    A = os.path.join(ob.ROOT, "assets", "openloong")
+    h = hostemu_lib.emu_model_create(os.path.join(A, "openloong_mpc.urdf").encode(), os.path.join(A, "task.info").encode(), os.path.join(A, "reference.info").encode())
+    assert h
+    h = C.c_void_p(h)
+    m, om = ob.model("openloong"), ob.oracle("openloong")
+    rng = np.random.default_rng(21)
+    nx = nu = 24
+    worst = 0.0
+    for mode in range(4):
+        x = m["initial_state"] + 0.15 * rng.standard_normal(nx)
+        xn = x + 0.03 * rng.standard_normal(nx)
+        xr = m["initial_state"] + 0.1 * rng.standard_normal(nx)
+        u = rp.weight_compensating_input(m, 3) + rng.standard_normal(nu) * np.r_[np.full(12, 20.0), np.full(12, 0.6)]
+        zr, zd = rng.uniform(0, 0.05, 4), rng.uniform(-0.4, 0.4, 4)
+        a = om.node_lq(0, 0.015, x, u, xn, xr, mode, zr, zd)
+        o = dict(A=np.zeros((nx, nx)), B=np.zeros((nx, nu)), b=np.zeros(nx), Q=np.zeros((nx, nx)), R=np.zeros((nu, nu)), P=np.zeros((nu, nx)),
+                 q=np.zeros(nx), r=np.zeros(nu), c=np.zeros(1), C=np.zeros((16, nx)), D=np.zeros((16, nu)), e=np.zeros(16), perf=np.zeros(3))
+        nc = C.c_int(0)
+        hostemu_lib.emu_linearize_node(h, 0, mode, C.c_double(0.015), d(x), d(u), d(xn), d(xr), d(zr), d(zd), d(o["A"]), d(o["B"]), d(o["b"]),
+                                       d(o["Q"]), d(o["R"]), d(o["P"]), d(o["q"]), d(o["r"]), d(o["c"]), d(o["C"]), d(o["D"]), d(o["e"]),
+                                       C.byref(nc), d(o["perf"]))
+        assert nc.value == a["nc"]
+        for k in ("A", "B", "b", "Q", "R", "q", "r", "C", "D", "e", "perf"):
+            worst = max(worst, np.abs(np.asarray(a[k]) - o[k]).max() / max(1.0, np.abs(np.asarray(a[k])).max()))
+    assert worst < 1e-13, worst
