@@ -45,8 +45,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BPMPC_BENCH_FORCE_DIST") == "1"   # the latter exercises RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     import bipedal_control_amd as bp
@@ -67,7 +69,7 @@ def main():
     # result buffers owned by torch so that RCCL can gather them
     x_loc = torch.empty((B, max_nodes + 1, nx), dtype=torch.float64, device="cuda")
     u_loc = torch.empty((B, max_nodes, nu), dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         x_all = torch.empty((world * B, max_nodes + 1, nx), dtype=torch.float64, device="cuda")
         u_all = torch.empty((world * B, max_nodes, nu), dtype=torch.float64, device="cuda")
 
@@ -75,12 +77,12 @@ def main():
         mpc.reset()        # device-side restore of the cold-start iterate: every step solves the same problems
         mpc.enqueue()      # 1 SQP iteration per problem, all on the GPU
         mpc.export_trajectories(x_loc.data_ptr(), u_loc.data_ptr())
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(x_all, x_loc)
             dist.all_gather_into_tensor(u_all, u_loc)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -95,7 +97,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -139,7 +141,9 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(prob, min(args.cpu_sample, B), x, u, stats)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        # the gathered block of this rank must equal its local result
+        assert torch.equal(x_all[rank * B:(rank + 1) * B], x_loc) and torch.equal(u_all[rank * B:(rank + 1) * B], u_loc)
         dist.barrier()
         dist.destroy_process_group()
 
