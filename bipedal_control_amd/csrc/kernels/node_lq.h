@@ -30,6 +30,7 @@ struct NodeLQOut {
   double *C, *D, *e;         // 16*NX, 16*NU, 16 (rows >= nc zero filled)
   int* nc;
   double* perf;              // cost, dynamics SSE, equality SSE
+  double* prof = nullptr;    // debug: cycles per phase (BPMPC_LINEARIZE_PROFILE)
 };
 
 template <int NJ>
@@ -37,7 +38,7 @@ struct NodeWorkspace {
   static constexpr int NX = 12 + NJ, NU = 12 + NJ;
   CentroidalWorkspace<NJ> k;
   double x0[NX], xn[NX], xref[NX], dx[NX], du[NU];
-  double f1[NX], Ar1[9][NX], Br1[9][NU];
+  double f1[NX];
   double bvec[NX], evec[kMaxEqRows];
   double cone[kNumContacts][16];   // per contact: value, p, p', p'', grad(3), hess(6 sym: xx xy xz yy yz zz)
   double partial[kWave];
@@ -153,6 +154,13 @@ BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, cons
     return;
   }
 
+#if defined(BPMPC_LINEARIZE_PROFILE) && !defined(BPMPC_HOST_EMULATION)
+  long long lq_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long lq_prev = clock64();
+#define LQPROF(slot) do { const long long tn_ = clock64(); lq_t[slot] += tn_ - lq_prev; lq_prev = tn_; } while (0)
+#else
+#define LQPROF(slot) ((void)0)
+#endif
   const double dt = in.dt, hdt = 0.5 * in.dt;
   const int mode = in.mode;
   // ---- load the node
@@ -166,53 +174,63 @@ BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, cons
     if (tid < NU) k.u[tid] = in.u[tid];
     if (tid == kWave - 1) enumerate_rows<NJ>(mode, ws);
   }
-  BP_SYNC();
+  cache_model<NJ>(md, k);
+  LQPROF(0);
   eval_centroidal<NJ, true, true>(md, k);
+  LQPROF(1);
 
-  // ---- equality-constraint rows (linear model) straight to HBM; cone terms; keep k1
+  // ---- equality-constraint rows (linear model) straight to HBM, one lane per column of [C | D]:
+  //        d v_i / d(x|u) = J_base (d v_base / d(x|u)) + [0 | d(J_i v)/dq]  resp.  + [0 | J_joints]
+  //      the lane keeps its column of d v_base/d(x|u) (rows 3..8 of Ar / Br) in registers across the rows.
   BP_LANES(tid, kWave) {
     const int nc = ws.nc;
-    for (int idx = tid; idx < kMaxEqRows * NX; idx += kWave) {
-      const int row = idx / NX, c = idx % NX;
-      double val = 0.0;
-      if (row < nc && ws.row_type[row] != 0) {
-        const int i = ws.row_contact[row], a = ws.row_axis[row];
-        const double* Jr = k.J[3 * i + a];
-        // d v_i / dx = J_base (d v_base / dx) + [0 | d(J_i v)/dq]
-        for (int l = 0; l < 6; ++l) val += Jr[l] * k.Ar[3 + l][c];
-        if (c >= 6) {
-          val += k.DJv[3 * i + a][c - 6];
-          if (md.pos_gain != 0.0 && a == 2) val += md.pos_gain * Jr[c - 6];
+    if (tid < NX + NU) {
+      const bool is_x = tid < NX;
+      const int c = is_x ? tid : tid - NX;
+      double vb[6];
+      for (int l = 0; l < 6; ++l) vb[l] = is_x ? k.Ar[3 + l][c] : k.Br[3 + l][c];
+      double* dst = is_x ? out.C + c : out.D + c;
+      const int ld = is_x ? NX : NU;
+      for (int row = 0; row < kMaxEqRows; ++row) {
+        double val = 0.0;
+        if (row < nc) {
+          const int i = ws.row_contact[row], a = ws.row_axis[row], type = ws.row_type[row];
+          if (type == 0) {
+            val = (!is_x && c == 3 * i + a) ? 1.0 : 0.0;                 // ZeroForceConstraint.cpp:64-72
+          } else {
+            const double* Jr = k.J[3 * i + a];
+            for (int l = 0; l < 6; ++l) val += Jr[l] * vb[l];
+            if (is_x) {
+              if (c >= 6) {
+                val += k.DJv[3 * i + a][c - 6];
+                if (md.pos_gain != 0.0 && a == 2) val += md.pos_gain * Jr[c - 6];
+              }
+            } else if (c >= 12) {
+              val += Jr[6 + (c - 12)];
+            }
+          }
         }
+        dst[row * ld] = val;
       }
-      out.C[idx] = val;
-    }
-    for (int idx = tid; idx < kMaxEqRows * NU; idx += kWave) {
-      const int row = idx / NU, c = idx % NU;
-      double val = 0.0;
-      if (row < nc) {
-        const int i = ws.row_contact[row], a = ws.row_axis[row];
-        if (ws.row_type[row] == 0) {
-          val = (c == 3 * i + a) ? 1.0 : 0.0;                 // ZeroForceConstraint.cpp:64-72
-        } else {
-          const double* Jr = k.J[3 * i + a];
-          for (int l = 0; l < 6; ++l) val += Jr[l] * k.Br[3 + l][c];
-          if (c >= 12) val += Jr[6 + (c - 12)];
-        }
-      }
-      out.D[idx] = val;
-    }
-    if (tid < kMaxEqRows) {
-      const double ev = tid < nc ? eq_row_value<NJ>(md, ws, in, tid) : 0.0;
-      ws.evec[tid] = ev;
-      out.e[tid] = ev;
+    } else if (tid < NX + NU + kMaxEqRows) {
+      const int row = tid - NX - NU;
+      const double ev = row < nc ? eq_row_value<NJ>(md, ws, in, row) : 0.0;
+      ws.evec[row] = ev;
+      out.e[row] = ev;
     }
     if (tid >= 32 && tid < 32 + kNumContacts) {
       const int i = tid - 32;
       if (stance_flag(mode, i)) cone_terms(md, &k.u[3 * i], true, ws.cone[i]);
     }
-    for (int idx = tid; idx < 9 * NX; idx += kWave) ws.Ar1[idx / NX][idx % NX] = k.Ar[idx / NX][idx % NX];
-    for (int idx = tid; idx < 9 * NU; idx += kWave) ws.Br1[idx / NU][idx % NU] = k.Br[idx / NU][idx % NU];
+  }
+  BP_SYNC();
+  // keep k1 (Ar1/Br1 share LDS with the contact Jacobians, which are dead from here on)
+  BP_LANES(tid, kWave) {
+    if (tid < NX + NU) {
+      const bool is_x = tid < NX;
+      const int c = is_x ? tid : tid - NX;
+      for (int r = 0; r < 9; ++r) { if (is_x) k.Ar1[r][c] = k.Ar[r][c]; else k.Br1[r][c] = k.Br[r][c]; }
+    }
     if (tid < NX) ws.f1[tid] = k.f[tid];
   }
   BP_SYNC();
@@ -220,40 +238,39 @@ BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, cons
     if (tid < NX) k.x[tid] = ws.x0[tid] + dt * ws.f1[tid];
   }
   BP_SYNC();
+  LQPROF(2);
   eval_centroidal<NJ, true, false>(md, k);
+  LQPROF(3);
 
   // ---- RK2 sensitivities ([OCS2-upstream] SensitivityIntegrator rk2):
   //   A = I + dt/2 (A1 + A2 + dt A2 A1),  B = dt/2 (B1 + B2 + dt A2 B1),  b = x + dt/2 (f1 + f2) - x_next
   // Rows 0..2 and 12.. of A1/A2 vanish and rows 0..2 / 12.. of B1/B2 are constants ([I/m | 0] and [0 | I]).
+  // One lane per column of [A | B]: the lane holds its k1 and k2 columns (rows 3..11) in registers, reads the 9x9 block
+  // A2[3:12, 3:12] as LDS broadcasts and writes one coalesced row of A and of B per step.
   BP_LANES(tid, kWave) {
     const double imt = 1.0 / md.robot_mass;
-    for (int idx = tid; idx < NX * NX; idx += kWave) {
-      const int r = idx / NX, c = idx % NX;
-      double val = (r == c) ? 1.0 : 0.0;
-      if (r >= 3 && r < 12) {
-        const int rr = r - 3;
-        double prod = 0.0;
-        for (int l = 0; l < 9; ++l) prod += k.Ar[rr][3 + l] * ws.Ar1[l][c];
-        val += hdt * (ws.Ar1[rr][c] + k.Ar[rr][c] + dt * prod);
+    if (tid < NX + NU) {
+      const bool is_x = tid < NX;
+      const int c = is_x ? tid : tid - NX;
+      double c1[9], c2[9];
+      for (int l = 0; l < 9; ++l) { c1[l] = is_x ? k.Ar1[l][c] : k.Br1[l][c]; c2[l] = is_x ? k.Ar[l][c] : k.Br[l][c]; }
+      double* dst = is_x ? out.A + c : out.B + c;
+      const int ld = is_x ? NX : NU;
+      for (int r = 0; r < NX; ++r) {
+        double val;
+        if (r < 3) {
+          val = is_x ? (r == c ? 1.0 : 0.0) : ((c < 12 && (c % 3) == r) ? dt * imt : 0.0);
+        } else if (r >= 12) {
+          val = is_x ? (r == c ? 1.0 : 0.0) : (c == r ? dt : 0.0);
+        } else {
+          const int rr = r - 3;
+          double prod = 0.0;
+          for (int l = 0; l < 9; ++l) prod += k.Ar[rr][3 + l] * c1[l];
+          if (!is_x) prod += (c < 12) ? k.Ar[rr][c % 3] * imt : k.Ar[rr][c];   // A2[:,0:3] (I/m) and A2[:,12+j] identity blocks of B1
+          val = (is_x && r == c ? 1.0 : 0.0) + hdt * (c1[rr] + c2[rr] + dt * prod);
+        }
+        dst[r * ld] = val;
       }
-      out.A[idx] = val;
-    }
-    for (int idx = tid; idx < NX * NU; idx += kWave) {
-      const int r = idx / NU, c = idx % NU;
-      double val;
-      if (r < 3) {
-        val = (c < 12 && (c % 3) == r) ? dt * imt : 0.0;
-      } else if (r >= 12) {
-        val = (c == r) ? dt : 0.0;
-      } else {
-        const int rr = r - 3;
-        double prod = 0.0;
-        for (int l = 0; l < 9; ++l) prod += k.Ar[rr][3 + l] * ws.Br1[l][c];
-        if (c < 12) prod += k.Ar[rr][c % 3] * imt;   // A2[:,0:3] * (I/m) block of B1 rows 0..2
-        else prod += k.Ar[rr][c];                    // A2[:,12+j] * identity block of B1 rows 12..
-        val = hdt * (ws.Br1[rr][c] + k.Br[rr][c] + dt * prod);
-      }
-      out.B[idx] = val;
     }
     if (tid < NX) {
       const double bb = ws.x0[tid] + hdt * ws.f1[tid] + hdt * k.f[tid] - ws.xn[tid];
@@ -264,6 +281,7 @@ BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, cons
     if (tid < NU) ws.du[tid] = k.u[tid] - nominal_input(md, mode, tid);
   }
   BP_SYNC();
+  LQPROF(4);
   // ---- cost: tracking + soft cones, multiplied by dt
   BP_LANES(tid, kWave) {
     // total first-derivative of the barrier over active cones: every active cone shifts ALL diagonal entries by
@@ -271,26 +289,36 @@ BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, cons
     double shift = 0.0;
     for (int i = 0; i < kNumContacts; ++i)
       if (stance_flag(mode, i)) shift += -ws.cone[i][2] * md.cone_shift;
-    for (int idx = tid; idx < NX * NX; idx += kWave) {
-      const int r = idx / NX, c = idx % NX;
-      double val = md.Q[idx];
-      if (r == c) val += shift;
-      out.Q[idx] = dt * val;
-    }
-    for (int idx = tid; idx < NU * NU; idx += kWave) {
-      const int r = idx / NU, c = idx % NU;
-      double val = md.R[idx];
-      if (r == c) val += shift;
-      if (r < 12 && c < 12 && r / 3 == c / 3 && stance_flag(mode, r / 3)) {
-        const double* cn = ws.cone[r / 3];
-        const int a = r % 3, b = c % 3;
-        const int lo = a < b ? a : b, hi = a < b ? b : a;
-        const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);  // xx xy xz yy yz zz
-        val += cn[3] * cn[4 + a] * cn[4 + b] + cn[2] * cn[7 + sidx];
+    // lanes 0..NX-1: column c of Q; lanes NX..NX+NU-1: column c of R; the remaining lanes zero P
+    if (tid < NX) {
+      const int c = tid;
+      double col[NX];
+      for (int r = 0; r < NX; ++r) col[r] = md.Q[r * NX + c];   // all reads first: the stores below may alias for the compiler
+      for (int r = 0; r < NX; ++r) {
+        double val = col[r];
+        if (r == c) val += shift;
+        out.Q[r * NX + c] = dt * val;
       }
-      out.R[idx] = dt * val;
+    } else if (tid < NX + NU) {
+      const int c = tid - NX;
+      const bool cone_col = c < 12 && stance_flag(mode, c / 3);
+      double col[NU];
+      for (int r = 0; r < NU; ++r) col[r] = md.R[r * NU + c];
+      for (int r = 0; r < NU; ++r) {
+        double val = col[r];
+        if (r == c) val += shift;
+        if (cone_col && r < 12 && r / 3 == c / 3) {
+          const double* cn = ws.cone[r / 3];
+          const int a = r % 3, b = c % 3;
+          const int lo = a < b ? a : b, hi = a < b ? b : a;
+          const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);  // xx xy xz yy yz zz
+          val += cn[3] * cn[4 + a] * cn[4 + b] + cn[2] * cn[7 + sidx];
+        }
+        out.R[r * NU + c] = dt * val;
+      }
+    } else {
+      for (int idx = tid - NX - NU; idx < NU * NX; idx += kWave - NX - NU) out.P[idx] = 0.0;
     }
-    for (int idx = tid; idx < NU * NX; idx += kWave) out.P[idx] = 0.0;
     double part = 0.0;
     if (tid < NX) {
       double acc = 0.0;
@@ -322,6 +350,10 @@ BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, cons
       out.perf[0] = dt * c; out.perf[1] = dt * dyn; out.perf[2] = dt * eq;
     }
   }
+  LQPROF(5);
+#if defined(BPMPC_LINEARIZE_PROFILE) && !defined(BPMPC_HOST_EMULATION)
+  if (out.prof && threadIdx.x == 0) for (int i = 0; i < 8; ++i) out.prof[i] = (double)lq_t[i];
+#endif
   (void)G;
 }
 
@@ -362,7 +394,7 @@ BP_DEVICE void node_performance(const DeviceModel& md, NodeWorkspace<NJ>& ws, co
     }
     if (tid == kWave - 1) enumerate_rows<NJ>(mode, ws);
   }
-  BP_SYNC();
+  cache_model<NJ>(md, k);
   eval_centroidal<NJ, false, true>(md, k);
   BP_LANES(tid, kWave) {
     if (tid < kMaxEqRows) ws.evec[tid] = tid < ws.nc ? eq_row_value<NJ>(md, ws, in, tid) : 0.0;

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
   out.q = L.buf.q + s * NX; out.r = L.buf.r + s * NU; out.c = L.buf.c + s;
   out.C = L.buf.C + s * kMaxEqRows * NX; out.D = L.buf.D + s * kMaxEqRows * NU; out.e = L.buf.e + s * kMaxEqRows;
   out.nc = L.buf.nc + s; out.perf = L.buf.perf + s * 3;
+  out.prof = (b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
   linearize_node<NJ>(*L.model, ws, in, out);
 }
 
@@ -672,6 +673,17 @@ int bpmpc_solver_read(bpmpc_solver* s, const char* name, double* out, long capac
   if (!s || !name || !out) { set_last_error("bpmpc_solver_read: null argument"); return BPMPC_ERR_INVALID_ARGUMENT; }
   try {
     HIP_CHECK(hipSetDevice(s->settings.device));
+#if defined(BPMPC_EVAL_PROFILE)
+    if (std::string(name) == "evprof") {
+      long long tmp[16];
+      HIP_CHECK(hipStreamSynchronize(s->stream));
+      HIP_CHECK(hipMemcpyFromSymbol(tmp, HIP_SYMBOL(g_evprof), sizeof(tmp)));
+      for (int i = 0; i < 16; ++i) out[i] = (double)tmp[i];
+      long long zero[16] = {0};
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_evprof), zero, sizeof(zero)));
+      return 16;
+    }
+#endif
     auto it = s->named.find(name);
     if (it == s->named.end()) throw std::invalid_argument(std::string("unknown buffer ") + name);
     const size_t n = it->second.second;

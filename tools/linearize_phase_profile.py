@@ -1,0 +1,12 @@
+# Needs libbpmpc.so built with -DBPMPC_LINEARIZE_PROFILE; cycles per phase of the linearize kernel (problem 0, nodes 0..31).
+import numpy as np, bipedal_control_amd as bp
+from bipedal_control_amd import scenarios
+itf=scenarios.h1_interface()
+prob=scenarios.trot_problem(itf,batch=256,n_intervals=100)
+mpc=bp.BatchedSqpMpc(itf,256,116)
+mpc.setup(prob["t0"],prob["x0"],prob["schedule"],prob["targets"],horizon=prob["horizon"])
+mpc.stage("linearize"); mpc.synchronize(); mpc.stage("linearize"); mpc.synchronize()
+r=mpc.read("rprof").reshape(256,8)[:32]
+r=r[r.sum(axis=1)>0]
+print("cycles: load, eval1(+EE), constraints+k1 copy, eval2, RK2 A/B/b, cost+perf")
+print(r.mean(axis=0).round(0), r.mean(axis=0).sum())
