@@ -293,6 +293,22 @@ class BatchedSqpMpc:
         self.synchronize()
         return self.fetch(gains)
 
+    def solve_batch(self, t0, x0, modeSchedules, targetTrajectories, horizon=None, warm_x=None, warm_u=None, gains=False):
+        """The single-call entry point bpmpc_solve_batch (host buffers in, host buffers out)."""
+        if horizon is None:
+            horizon = self.interface.mpcSettings()["timeHorizon"]
+        B, t0, x0, sched, ns, tg, wx, wu, keep = self._marshal(t0, x0, modeSchedules, targetTrajectories, warm_x, warm_u)
+        N = self.max_nodes
+        t = np.zeros((B, N + 1))
+        x = np.zeros((B, N + 1, self.nx))
+        u = np.zeros((B, N, self.nu))
+        K = np.zeros((B, N, self.nu, self.nx)) if gains else None
+        stats = (Stats * B)()
+        _check(load_library().bpmpc_solve_batch(self._h, B, C.c_double(horizon), _d(t0), _d(x0), sched, ns, tg, _d(wx), _d(wu), _d(t), _d(x),
+                                                _d(u), _d(K), stats))
+        self.batch = B
+        return t, x, u, K, list(stats)
+
     def read(self, name):
         """Named device buffer as a flat float64 array (tests / debugging)."""
         lib = load_library()
