@@ -125,7 +125,7 @@ def main():
                         traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"kernel": "k_linearize<10>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"kernel": "k_linearize_fast<10>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_us": round(1e6 * avg_s, 2),
                         "algorithmic_bytes_per_launch": alg_bytes, "node_linearizations_per_s": round(B * n_intermediate / avg_s, 1)}
         out = {"metric": "MPC solves/s (H1, horizon=%d)" % NI, "value": round(value, 2), "unit": "solves/s", "n_gpus": world, "steps": args.steps,

@@ -19,6 +19,7 @@ DeviceModel make_device_model(const RobotModel& m) {
       chain[n++] = c;
     }
     d.depth[b] = n;
+    if (n > d.max_depth) d.max_depth = n;
     for (int k = 0; k < n; ++k) d.path[b][k] = chain[n - 1 - k];
     for (int i = 0; i < 9; ++i) d.Rfix[b][i] = m.Rfix[b][i];
     for (int i = 0; i < 3; ++i) { d.pfix[b][i] = m.pfix[b][i]; d.axis[b][i] = m.axis[b][i]; d.com[b][i] = m.com[b][i]; }

@@ -9,6 +9,7 @@ struct DeviceModel {
   int nj;
   int parent[kMaxBodies];              // parent body of body b (b >= 1)
   int depth[kMaxBodies];               // number of joints between the base and body b
+  int max_depth;                       // longest chain
   int path[kMaxBodies][kMaxJoints];    // path[b][d] = d-th body on the way base -> b (path[b][depth[b]-1] == b)
   unsigned subtree[kMaxBodies];        // bit c set: body c belongs to the subtree rooted at body b
   unsigned contact_path[kNumContacts]; // bit j set: joint j (1..nj) moves contact point i

@@ -1,0 +1,634 @@
+// Fast node linearisation (HIP only; the lane-emulated reference with identical mathematics is node_lq.h +
+// centroidal_eval.h).
+//
+// Several nodes per wavefront: a node owns LPN = 16 lanes (nx = 22) or 32 lanes (nx = 24), one lane per generalised
+// coordinate g (0-2 base translation, 3-5 yaw/pitch/roll, 6.. leg joints; lane g >= 5 also owns body g - 5).  All
+// per-column quantities (world axis, composite inertia, momentum-matrix column, twist, d(Av)/dq column, contact Jacobian
+// columns, the columns of df/dx and df/du) live in that lane's registers, so one instruction serves every node of the
+// wave.  Cross-lane traffic inside a node is limited to: the Euler sin/cos (shuffles), chain walks and subtree sums over
+// small LDS tables, three 16-lane DPP all-reduces, and the 9 x 12 block of the second RK2 stage.
+// Each lane plays up to four column roles when the dense LQ model is written:
+//   x column 6+g (q_g, every lane), x column g (momentum, lanes 0..5), u column g (force, lanes 0..11),
+//   u column 12+(g-6) (joint velocity, lanes 6..).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "node_lq.h"
+#include "riccati_fast.h"   // lds_wave_sync
+
+namespace bpmpc {
+
+template <int NJ>
+struct LinFastCfg {
+  static constexpr int NB = NJ + 1, G = 6 + NJ, NX = 12 + NJ, NU = 12 + NJ;
+  static constexpr int LPN = (G <= 16) ? 16 : 32;   // lanes per node
+  static constexpr int NPW = kWave / LPN;           // nodes per wavefront
+};
+
+template <int NJ>
+struct LinFastNodeLds {
+  using C = LinFastCfg<NJ>;
+  // node inputs, staged once so that nothing is loaded from global memory after the first output store
+  double x[C::NX], u[C::NU], xnext[C::NX], xref[C::NX], zref[kNumContacts], zdref[kNumContacts];
+  union {                        // chain tables (dead after the walks)  <->  second-stage block and cost vectors
+    double T[C::G][12];          // joint-local transform of body g-5: E (9) | pfix (3)
+    struct { double a2[9][12]; double dx[C::NX], du[C::NU]; };   // rows 3..11, x columns 0..11 of the stage-two Jacobian
+  };
+  union {
+    double comp[C::NB][10];      // per body mass / first moment / inertia about o0
+    double hb[C::NB][6];         // per body momentum about o0
+  };
+  double og[C::G][3];            // joint origins
+  double wv[C::G][3];            // a_g * v_g
+  double cpos[kNumContacts][3], cvel[kNumContacts][3];
+  double cone[kNumContacts][16];
+  // node-level results of the two stages: A_b^{-1} blocks, 1/m, contact points and com
+  double X12[2][9], X22[2][9], cps[2][kNumContacts][3], com[2][3];
+  // parked stage-one columns: rows 3..11 of column 6+g and rows 6..11 of the joint-velocity column of lane g
+  double park[C::LPN][15];
+};
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ double row16_allreduce_add(double x) {
+#define BP_ROR_ADD(n)                                                                                           \
+  {                                                                                                             \
+    const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x120 + n, 0xf, 0xf, false);              \
+    const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x120 + n, 0xf, 0xf, false);              \
+    x += __hiloint2double(hi_, lo_);                                                                            \
+  }
+  BP_ROR_ADD(1) BP_ROR_ADD(2) BP_ROR_ADD(4) BP_ROR_ADD(8)
+#undef BP_ROR_ADD
+  return x;
+}
+template <int LPN>
+__device__ __forceinline__ double node_allreduce_add(double x) {
+  x = row16_allreduce_add(x);
+  if (LPN == 32) x += __shfl_xor(x, 16);
+  return x;
+}
+
+// per-lane tree bookkeeping of the body this lane owns (the inertial constants are read from the model at their
+// single point of use to keep register live ranges short)
+struct LaneBody {
+  int depth, body;
+  unsigned subtree;              // members of the subtree this lane's coordinate moves (bodies)
+};
+
+// result of one evaluation of the centroidal dynamics in this lane (the momentum and force columns are rebuilt from the
+// node-level quantities kept in LDS: X12/X22 and the contact points)
+struct LaneEval {
+  double ar_q[9];   // rows 3..11 of column 6+g of df/dx
+  double br_j[6];   // rows 6..11 of column 12+(g-6) of df/du (lanes 6..); its rows 3..5 are zero
+  double fh[6];     // rows 0..5 of f (identical in all lanes)
+  double vg;        // f[6+g]
+};
+
+// rows 3..11 of the momentum column g (lanes 0..5) of df/dx: [0; m A_b^{-1}]
+__device__ __forceinline__ double momentum_col(const double* X12, const double* X22, double im, double mass_total, int g, int rr) {
+  if (rr < 3) return 0.0;
+  const int i = rr - 3;
+  double e;
+  if (i < 3) e = g < 3 ? (g == i ? im : 0.0) : (g < 6 ? X12[3 * i + (g - 3)] : 0.0);
+  else e = (g >= 3 && g < 6) ? X22[3 * (i - 3) + (g - 3)] : 0.0;
+  return mass_total * e;
+}
+// rows 3..11 of the force column g (lanes 0..11) of df/du: [ [p_i - com]_x / m ; 0 ]
+__device__ __forceinline__ double force_col(const double (*cp)[3], const double* com, double imt, int g, int rr) {
+  if (rr >= 3 || g >= 12) return 0.0;
+  const int i = g / 3, k = g % 3;
+  if (k == rr) return 0.0;
+  const int other = 3 - rr - k;
+  const double d = (cp[i][other] - com[other]) * imt;
+  return (k == (rr + 2) % 3) ? d : -d;
+}
+
+template <int NJ>
+struct LaneKin {    // what the contact part needs from the evaluation
+  double ah[3], og[3], omg[3], vog[3], vb[6];
+  double sy, cy, sp, cp;   // Euler sines / cosines (world axes of the Euler joints)
+};
+
+// One evaluation of the centroidal dynamics for the node owned by this lane group.  `stage` selects where the node-level
+// results (A_b^{-1} blocks, contact points, com) are kept in LDS.
+template <int NJ>
+__device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<NJ>& nl, int stage, const LaneBody& lb, const int* path, int g,
+                                          const double (&xh)[6], const double (&pb)[3], double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin) {
+  using C = LinFastCfg<NJ>;
+  constexpr int NB = C::NB, G = C::G, LPN = C::LPN;
+  const bool is_joint = g >= 6 && g < G, is_body = g >= 5 && g < G;
+  const double mass_total = md.robot_mass;
+  // ---- sin/cos of the own angle; Euler sin/cos to everybody
+  double sg = 0.0, cg = 1.0;
+  if (g >= 3 && g < G) sincos(qg, &sg, &cg);
+  const double sy = __shfl(sg, 3, LPN), cy = __shfl(cg, 3, LPN), sp = __shfl(sg, 4, LPN), cp = __shfl(cg, 4, LPN), sr = __shfl(sg, 5, LPN),
+               cr = __shfl(cg, 5, LPN);
+  kin.sy = sy; kin.cy = cy; kin.sp = sp; kin.cp = cp;
+  // ---- joint-local transforms to LDS, chain walk
+  if (is_joint) {
+    const double* a = md.axis[lb.body];
+    const double v = 1.0 - cg;
+    const double rot[9] = {cg + v * a[0] * a[0],        v * a[0] * a[1] - sg * a[2], v * a[0] * a[2] + sg * a[1],
+                           v * a[1] * a[0] + sg * a[2], cg + v * a[1] * a[1],        v * a[1] * a[2] - sg * a[0],
+                           v * a[2] * a[0] - sg * a[1], v * a[2] * a[1] + sg * a[0], cg + v * a[2] * a[2]};
+    double E[9];
+    mat3_mul(md.Rfix[lb.body], rot, E);
+    for (int i = 0; i < 9; ++i) nl.T[g][i] = E[i];
+    for (int i = 0; i < 3; ++i) nl.T[g][9 + i] = md.pfix[lb.body][i];
+  }
+  lds_wave_sync();
+  double R[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                 -sp, cp * sr, cp * cr};
+  double o[3] = {pb[0], pb[1], pb[2]};
+  const int maxdepth = md.max_depth;
+#pragma nounroll
+  for (int d = 0; d < maxdepth; ++d) {
+    const bool on = is_joint && d < lb.depth;
+    const int gj = on ? 5 + path[d] : 6;
+    double Ej[9], pj[3], t[3], Rn[9];
+    for (int i = 0; i < 9; ++i) Ej[i] = nl.T[gj][i];
+    for (int i = 0; i < 3; ++i) pj[i] = nl.T[gj][9 + i];
+    mat3_vec(R, pj, t);
+    mat3_mul(R, Ej, Rn);
+    for (int i = 0; i < 3; ++i) o[i] = on ? o[i] + t[i] : o[i];
+    for (int i = 0; i < 9; ++i) R[i] = on ? Rn[i] : R[i];
+  }
+  // world axis and origin of the own coordinate (Euler ZYX = three successive revolute joints: z, rotated y, rotated x)
+  double ah[3] = {0.0, 0.0, 0.0};
+  if (g < 3) ah[g] = 1.0;
+  else if (g == 3) { ah[2] = 1.0; }
+  else if (g == 4) { ah[0] = -sy; ah[1] = cy; }
+  else if (g == 5) { ah[0] = cy * cp; ah[1] = sy * cp; ah[2] = -sp; }
+  else if (g < G) mat3_vec(R, md.axis[lb.body], ah);
+  for (int i = 0; i < 3; ++i) { kin.ah[i] = ah[i]; kin.og[i] = o[i]; }
+  // ---- body quantities, contact positions
+  double cw[3] = {0.0, 0.0, 0.0}, Iwb[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (is_body) {
+    double cb[3], d[3];
+    mat3_vec(R, md.com[lb.body], cb);
+    for (int i = 0; i < 3; ++i) { cw[i] = cb[i] + o[i]; d[i] = cw[i] - pb[i]; }
+    const double* I = md.inertia[lb.body];
+    const double Ib[9] = {I[0], I[1], I[2], I[1], I[3], I[4], I[2], I[4], I[5]};
+    double T[9];
+    mat3_mul(R, Ib, T);
+    Iwb[0] = T[0] * R[0] + T[1] * R[1] + T[2] * R[2];
+    Iwb[1] = T[0] * R[3] + T[1] * R[4] + T[2] * R[5];
+    Iwb[2] = T[0] * R[6] + T[1] * R[7] + T[2] * R[8];
+    Iwb[3] = T[3] * R[3] + T[4] * R[4] + T[5] * R[5];
+    Iwb[4] = T[3] * R[6] + T[4] * R[7] + T[5] * R[8];
+    Iwb[5] = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
+    const double m = md.mass[lb.body];
+    const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    double* cm = nl.comp[lb.body];
+    cm[0] = m;
+    cm[1] = m * d[0]; cm[2] = m * d[1]; cm[3] = m * d[2];
+    cm[4] = Iwb[0] + m * (dd - d[0] * d[0]);
+    cm[5] = Iwb[1] - m * d[0] * d[1];
+    cm[6] = Iwb[2] - m * d[0] * d[2];
+    cm[7] = Iwb[3] + m * (dd - d[1] * d[1]);
+    cm[8] = Iwb[4] - m * d[1] * d[2];
+    cm[9] = Iwb[5] + m * (dd - d[2] * d[2]);
+    for (int i = 0; i < kNumContacts; ++i)
+      if (md.contact_body[i] == lb.body) {
+        double t[3];
+        mat3_vec(R, md.contact_off[i], t);
+        for (int a = 0; a < 3; ++a) { const double pv = o[a] + t[a]; nl.cpos[i][a] = pv; nl.cps[stage][i][a] = pv; }
+      }
+  }
+  lds_wave_sync();
+  // ---- subtree sums -> composite mass, com, inertia about the composite com (lanes below 5 see the whole robot)
+  double s[10];
+  for (int c = 0; c < 10; ++c) s[c] = 0.0;
+#pragma nounroll
+  for (int m = NB - 1; m >= 0; --m) {
+    const double sel = ((lb.subtree >> m) & 1u) ? 1.0 : 0.0;
+    for (int c = 0; c < 10; ++c) s[c] += sel * nl.comp[m][c];
+  }
+  const double Mc = s[0];
+  const double invM = Mc > 0.0 ? 1.0 / Mc : 0.0;
+  const double Dv[3] = {s[1] * invM, s[2] * invM, s[3] * invM};
+  const double DD = Dv[0] * Dv[0] + Dv[1] * Dv[1] + Dv[2] * Dv[2];
+  const double Cc[3] = {pb[0] + Dv[0], pb[1] + Dv[1], pb[2] + Dv[2]};
+  const double Ic[6] = {s[4] - Mc * (DD - Dv[0] * Dv[0]), s[5] + Mc * Dv[0] * Dv[1], s[6] + Mc * Dv[0] * Dv[2],
+                        s[7] - Mc * (DD - Dv[1] * Dv[1]), s[8] + Mc * Dv[1] * Dv[2], s[9] - Mc * (DD - Dv[2] * Dv[2])};
+  // whole-robot mass and com from lane 5 (the base body lane)
+  const double Mtot = __shfl(Mc, 5, LPN);
+  const double com[3] = {__shfl(Cc[0], 5, LPN), __shfl(Cc[1], 5, LPN), __shfl(Cc[2], 5, LPN)};
+  if (g == 0) for (int i = 0; i < 3; ++i) nl.com[stage][i] = com[i];
+  // ---- centroidal momentum matrix column
+  double Ac[6];
+  if (g < 3) {
+    for (int i = 0; i < 3; ++i) { Ac[i] = (i == g) ? Mtot : 0.0; Ac[3 + i] = 0.0; }
+  } else {
+    const double rC[3] = {Cc[0] - o[0], Cc[1] - o[1], Cc[2] - o[2]};
+    double vC[3], t[3], Iw[3];
+    cross3(ah, rC, vC);
+    const double dC[3] = {Cc[0] - com[0], Cc[1] - com[1], Cc[2] - com[2]};
+    cross3(dC, vC, t);
+    sym3_mul(Ic, ah, Iw);
+    for (int i = 0; i < 3; ++i) { Ac[i] = Mc * vC[i]; Ac[3 + i] = Iw[i] + Mc * t[i]; }
+  }
+  if (g >= G) for (int i = 0; i < 6; ++i) Ac[i] = 0.0;
+  // ---- base velocity: rhs = m hbar - A_j v_j, A_b^{-1} blocks (kept in LDS, every later use re-reads them)
+  const double im = 1.0 / Mtot;
+  double th[3], pd[3];
+  {
+    double rhs[6];
+    for (int i = 0; i < 6; ++i) {
+      const double part = is_joint ? Ac[i] * ujg : 0.0;
+      rhs[i] = mass_total * xh[i] - node_allreduce_add<LPN>(part);
+    }
+    double A12[9], A22[9], X12[9], X22[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) { A12[3 * i + j] = __shfl(Ac[i], 3 + j, LPN); A22[3 * i + j] = __shfl(Ac[3 + i], 3 + j, LPN); }
+    const double* M = A22;
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double idet = 1.0 / (M[0] * c00 + M[1] * c01 + M[2] * c02);
+    X22[0] = c00 * idet; X22[1] = (M[2] * M[7] - M[1] * M[8]) * idet; X22[2] = (M[1] * M[5] - M[2] * M[4]) * idet;
+    X22[3] = c01 * idet; X22[4] = (M[0] * M[8] - M[2] * M[6]) * idet; X22[5] = (M[2] * M[3] - M[0] * M[5]) * idet;
+    X22[6] = c02 * idet; X22[7] = (M[1] * M[6] - M[0] * M[7]) * idet; X22[8] = (M[0] * M[4] - M[1] * M[3]) * idet;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) X12[3 * i + j] = -im * (A12[3 * i] * X22[j] + A12[3 * i + 1] * X22[3 + j] + A12[3 * i + 2] * X22[6 + j]);
+    if (g < 9) { nl.X12[stage][g] = X12[g]; nl.X22[stage][g] = X22[g]; }
+    mat3_vec(X22, &rhs[3], th);
+    mat3_vec(X12, &rhs[3], pd);
+    for (int i = 0; i < 3; ++i) pd[i] += im * rhs[i];
+  }
+  for (int i = 0; i < 3; ++i) { kin.vb[i] = pd[i]; kin.vb[3 + i] = th[i]; }
+  const double vg = g < 3 ? pd[g] : (g < 6 ? th[g - 3] : (g < G ? ujg : 0.0));
+  ev.vg = vg;
+  // ---- flow map rows 0..5
+  {
+    double lin[3] = {0.0, 0.0, -9.81 * mass_total}, ang[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < kNumContacts; ++i) {
+      const double r[3] = {nl.cpos[i][0] - com[0], nl.cpos[i][1] - com[1], nl.cpos[i][2] - com[2]};
+      const double Fi[3] = {nl.u[3 * i], nl.u[3 * i + 1], nl.u[3 * i + 2]};
+      lin[0] += Fi[0]; lin[1] += Fi[1]; lin[2] += Fi[2];
+      ang[0] += r[1] * Fi[2] - r[2] * Fi[1];
+      ang[1] += r[2] * Fi[0] - r[0] * Fi[2];
+      ang[2] += r[0] * Fi[1] - r[1] * Fi[0];
+    }
+    for (int i = 0; i < 3; ++i) { ev.fh[i] = lin[i] / mass_total; ev.fh[3 + i] = ang[i] / mass_total; }
+  }
+  // ---- twists: omega_g = sum over the revolute ancestors (self included) of a v, v_og = velocity of the joint origin
+  if (g >= 3 && g < G) {
+    for (int i = 0; i < 3; ++i) { nl.wv[g][i] = ah[i] * vg; nl.og[g][i] = o[i]; }
+  }
+  lds_wave_sync();
+  double om[3] = {0.0, 0.0, 0.0}, vo[3] = {pd[0], pd[1], pd[2]};
+  {
+    const int top = g < 3 ? 2 : (g < 6 ? g : 5);        // Euler joints up to the own one (joints and bodies: all three)
+    for (int k = 3; k <= 5; ++k) {
+      const double sel = k <= top ? 1.0 : 0.0;
+      for (int i = 0; i < 3; ++i) om[i] += sel * nl.wv[k][i];
+    }
+    double prev[3] = {pb[0], pb[1], pb[2]};
+#pragma nounroll
+    for (int d = 0; d < maxdepth; ++d) {
+      const bool on = is_joint && d < lb.depth;
+      const int gj = on ? 5 + path[d] : 6;
+      const double oj[3] = {nl.og[gj][0], nl.og[gj][1], nl.og[gj][2]};
+      const double wj[3] = {nl.wv[gj][0], nl.wv[gj][1], nl.wv[gj][2]};
+      const double r[3] = {oj[0] - prev[0], oj[1] - prev[1], oj[2] - prev[2]};
+      double t[3];
+      cross3(om, r, t);
+      for (int i = 0; i < 3; ++i) {
+        vo[i] = on ? vo[i] + t[i] : vo[i];
+        om[i] = on ? om[i] + wj[i] : om[i];
+        prev[i] = on ? oj[i] : prev[i];
+      }
+    }
+  }
+  for (int i = 0; i < 3; ++i) { kin.omg[i] = om[i]; kin.vog[i] = vo[i]; }
+  // ---- body momenta about o0 (hb shares LDS with comp, which is dead now), subtree momenta
+  if (is_body) {
+    const double rc[3] = {cw[0] - o[0], cw[1] - o[1], cw[2] - o[2]};
+    double t[3], l[3], Iw[3], L[3];
+    cross3(om, rc, t);
+    const double mb = md.mass[lb.body];
+    for (int i = 0; i < 3; ++i) l[i] = mb * (vo[i] + t[i]);
+    sym3_mul(Iwb, om, Iw);
+    const double d0[3] = {cw[0] - pb[0], cw[1] - pb[1], cw[2] - pb[2]};
+    cross3(d0, l, L);
+    for (int i = 0; i < 3; ++i) { nl.hb[lb.body][i] = l[i]; nl.hb[lb.body][3 + i] = Iw[i] + L[i]; }
+  }
+  lds_wave_sync();
+  double hs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma nounroll
+  for (int m = NB - 1; m >= 0; --m) {
+    const double sel = ((lb.subtree >> m) & 1u) ? 1.0 : 0.0;
+    for (int c = 0; c < 6; ++c) hs[c] += sel * nl.hb[m][c];
+  }
+  const double ltot[3] = {__shfl(hs[0], 5, LPN), __shfl(hs[1], 5, LPN), __shfl(hs[2], 5, LPN)};
+  // ---- column 6+g: d(A v)/dq_g -> d v_base/dq_g, angular-momentum-rate row; joint-velocity column
+  {
+    double dl[3] = {0.0, 0.0, 0.0}, dL[3] = {0.0, 0.0, 0.0};
+    if (g >= 3 && g < G) {
+      const double* l = hs;
+      const double sv[3] = {pb[0] - o[0], pb[1] - o[1], pb[2] - o[2]};
+      double t[3], Lk[3];
+      cross3(sv, l, t);
+      for (int i = 0; i < 3; ++i) Lk[i] = hs[3 + i] + t[i];
+      double wp[3], up[3], vC[3], rC[3], linp[3], angp[3], Iw[3];
+      cross3(ah, om, wp);
+      cross3(ah, vo, up);
+      for (int i = 0; i < 3; ++i) rC[i] = Cc[i] - o[i];
+      cross3(wp, rC, t);
+      for (int i = 0; i < 3; ++i) vC[i] = up[i] + t[i];
+      for (int i = 0; i < 3; ++i) linp[i] = Mc * vC[i];
+      sym3_mul(Ic, wp, Iw);
+      cross3(rC, vC, t);
+      for (int i = 0; i < 3; ++i) angp[i] = Iw[i] + Mc * t[i];
+      double al[3], aL[3], dLk[3];
+      cross3(ah, l, al);
+      cross3(ah, Lk, aL);
+      for (int i = 0; i < 3; ++i) { dl[i] = al[i] - linp[i]; dLk[i] = aL[i] - angp[i]; }
+      const double sc[3] = {o[0] - com[0], o[1] - com[1], o[2] - com[2]};
+      const double jc[3] = {Ac[0] * im, Ac[1] * im, Ac[2] * im};
+      double t2[3];
+      cross3(sc, dl, t);
+      cross3(jc, ltot, t2);
+      for (int i = 0; i < 3; ++i) dL[i] = dLk[i] + t[i] - t2[i];
+    }
+    const double* X12 = nl.X12[stage];
+    const double* X22 = nl.X22[stage];
+    for (int i = 0; i < 3; ++i) {
+      ev.ar_q[3 + i] = -(im * dl[i] + X12[3 * i] * dL[0] + X12[3 * i + 1] * dL[1] + X12[3 * i + 2] * dL[2]);
+      ev.ar_q[6 + i] = -(X22[3 * i] * dL[0] + X22[3 * i + 1] * dL[1] + X22[3 * i + 2] * dL[2]);
+      ev.br_j[i] = -(im * Ac[i] + X12[3 * i] * Ac[3] + X12[3 * i + 1] * Ac[4] + X12[3 * i + 2] * Ac[5]);
+      ev.br_j[3 + i] = -(X22[3 * i] * Ac[3] + X22[3 * i + 1] * Ac[4] + X22[3 * i + 2] * Ac[5]);
+    }
+    if (!is_joint) for (int i = 0; i < 6; ++i) ev.br_j[i] = 0.0;
+    const double jcm[3] = {Ac[0] / Mtot, Ac[1] / Mtot, Ac[2] / Mtot};
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < kNumContacts; ++i) {
+      double jcol[3] = {0.0, 0.0, 0.0};
+      if (g < 3) jcol[g] = 1.0;
+      else if (g < G && (g < 6 || ((md.contact_path[i] >> (g - 5)) & 1u))) {
+        const double r[3] = {nl.cpos[i][0] - o[0], nl.cpos[i][1] - o[1], nl.cpos[i][2] - o[2]};
+        cross3(ah, r, jcol);
+      }
+      const double d[3] = {jcol[0] - jcm[0], jcol[1] - jcm[1], jcol[2] - jcm[2]};
+      const double Fi[3] = {nl.u[3 * i], nl.u[3 * i + 1], nl.u[3 * i + 2]};
+      acc[0] += d[1] * Fi[2] - d[2] * Fi[1];
+      acc[1] += d[2] * Fi[0] - d[0] * Fi[2];
+      acc[2] += d[0] * Fi[1] - d[1] * Fi[0];
+    }
+    const double imt = 1.0 / mass_total;
+    for (int r = 0; r < 3; ++r) ev.ar_q[r] = acc[r] * imt;
+  }
+}
+
+template <int NJ>
+__device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNodeLds<NJ>& nl, const int (*path_table)[NJ], bool valid,
+                                               const NodeInputs& in, const NodeLQOut& out, int g) {
+  using C = LinFastCfg<NJ>;
+  constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN;
+  if (!valid) return;
+  if (in.kind == 1) {  // event node: identity jump map, no input, no cost (LPN lanes write the node)
+    double d2 = 0.0;
+    for (int idx = g; idx < NX * NX; idx += LPN) { out.A[idx] = (idx / NX == idx % NX) ? 1.0 : 0.0; out.Q[idx] = 0.0; }
+    for (int idx = g; idx < NX * NU; idx += LPN) { out.B[idx] = 0.0; out.P[idx] = 0.0; }
+    for (int idx = g; idx < NU * NU; idx += LPN) out.R[idx] = 0.0;
+    for (int idx = g; idx < kMaxEqRows * NX; idx += LPN) out.C[idx] = 0.0;
+    for (int idx = g; idx < kMaxEqRows * NU; idx += LPN) out.D[idx] = 0.0;
+    for (int idx = g; idx < kMaxEqRows; idx += LPN) out.e[idx] = 0.0;
+    for (int idx = g; idx < NX; idx += LPN) {
+      const double d = in.x[idx] - in.xnext[idx];
+      out.b[idx] = d; out.q[idx] = 0.0; out.r[idx] = 0.0;
+      d2 += d * d;
+    }
+    d2 = node_allreduce_add<LPN>(d2);
+    if (g == 0) { out.c[0] = 0.0; out.nc[0] = 0; out.perf[0] = 0.0; out.perf[1] = d2; out.perf[2] = 0.0; }
+    return;
+  }
+  const bool is_joint = g >= 6 && g < G;
+  const double dt = in.dt, hdt = 0.5 * in.dt;
+  const int mode = in.mode;
+  const double mass_total = md.robot_mass, imt = 1.0 / md.robot_mass;
+  // ---- stage the node inputs in LDS: after this block nothing is read from global memory except model constants
+  for (int idx = g; idx < NX; idx += LPN) { nl.x[idx] = in.x[idx]; nl.u[idx] = in.u[idx]; nl.xnext[idx] = in.xnext[idx]; nl.xref[idx] = in.xref[idx]; }
+  if (g < kNumContacts) { nl.zref[g] = in.zref[g]; nl.zdref[g] = in.zdref[g]; }
+  LaneBody lb;
+  {
+    const int body = (g >= 5 && g < G) ? g - 5 : 0;
+    lb.body = body;
+    lb.depth = md.depth[body];
+    lb.subtree = md.subtree[body];     // lanes below 5 move the whole robot (body 0's subtree)
+  }
+  const int* path = path_table[lb.body];
+  lds_wave_sync();
+  double xh[6], pb[3];
+  for (int i = 0; i < 6; ++i) xh[i] = nl.x[i];
+  for (int i = 0; i < 3; ++i) pb[i] = nl.x[6 + i];
+  const double qg = g < G ? nl.x[6 + g] : 0.0;
+  const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
+
+  LaneEval e1;
+  LaneKin<NJ> kin;
+  eval_lane<NJ>(md, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
+  // park the stage-one columns in LDS for the RK2 combination
+  for (int rr = 0; rr < 9; ++rr) nl.park[g][rr] = e1.ar_q[rr];
+  for (int rr = 0; rr < 6; ++rr) nl.park[g][9 + rr] = e1.br_j[rr];
+  const double f1h_g = g < 6 ? e1.fh[g] : 0.0, v1g = e1.vg;
+
+  // =========================== contact part (first stage only) ===========================
+  if (g >= 5 && g < G)
+    for (int i = 0; i < kNumContacts; ++i)
+      if (md.contact_body[i] == lb.body) {
+        const double r[3] = {nl.cpos[i][0] - kin.og[0], nl.cpos[i][1] - kin.og[1], nl.cpos[i][2] - kin.og[2]};
+        double t[3];
+        cross3(kin.omg, r, t);
+        for (int a = 0; a < 3; ++a) nl.cvel[i][a] = kin.vog[a] + t[a];
+      }
+  if (g < kNumContacts && stance_flag(mode, g)) cone_terms(md, &nl.u[3 * g], true, nl.cone[g]);
+  lds_wave_sync();
+  // rows in registration order zeroForce_i, zeroVelocity_i, normalVelocity_i (src/BipedalRobotInterface.cpp:187-191)
+  int row = 0;
+  double eq_sse = 0.0;
+  for (int i = 0; i < kNumContacts; ++i) {
+    const bool stance = stance_flag(mode, i);
+    const double cp_i[3] = {nl.cpos[i][0], nl.cpos[i][1], nl.cpos[i][2]};
+    const double cv_i[3] = {nl.cvel[i][0], nl.cvel[i][1], nl.cvel[i][2]};
+    // own columns of J_i and d(J_i v)/dq
+    double Jc[3] = {0.0, 0.0, 0.0}, DJ[3] = {0.0, 0.0, 0.0};
+    if (g < 3) Jc[g] = 1.0;
+    else if (g < G && (g < 6 || ((md.contact_path[i] >> (g - 5)) & 1u))) {
+      const double r[3] = {cp_i[0] - kin.og[0], cp_i[1] - kin.og[1], cp_i[2] - kin.og[2]};
+      cross3(kin.ah, r, Jc);
+      const double dv[3] = {cv_i[0] - kin.vog[0], cv_i[1] - kin.vog[1], cv_i[2] - kin.vog[2]};
+      double t1[3], wa[3], t2[3];
+      cross3(kin.ah, dv, t1);
+      cross3(kin.omg, kin.ah, wa);
+      cross3(wa, r, t2);
+      for (int k = 0; k < 3; ++k) DJ[k] = t1[k] + t2[k];
+    }
+    // J_i,base (d v_base / d column) = d(pdot) + d(omega_base) x (p_i - o0),  d(omega_base) = W d(thetadot)
+    const double rb[3] = {cp_i[0] - pb[0], cp_i[1] - pb[1], cp_i[2] - pb[2]};
+    auto base_part = [&](const double* col6, double* outv) {
+      const double th0 = col6[3], th1 = col6[4], th2 = col6[5];
+      const double w[3] = {-kin.sy * th1 + kin.cy * kin.cp * th2, kin.cy * th1 + kin.sy * kin.cp * th2, th0 - kin.sp * th2};
+      double t[3];
+      cross3(w, rb, t);
+      for (int a = 0; a < 3; ++a) outv[a] = col6[a] + t[a];
+    };
+    double bq[3], bh[3], bj[3], hcol[6];
+    for (int l = 0; l < 6; ++l) hcol[l] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, g, 3 + l);
+    base_part(&e1.ar_q[3], bq);
+    base_part(hcol, bh);
+    base_part(e1.br_j, bj);
+    const int nrows = stance ? 3 : 4;
+    for (int rr = 0; rr < nrows; ++rr) {
+      const int type = stance ? 1 : (rr < 3 ? 0 : 2);
+      const int a = (type == 2) ? 2 : rr;
+      double vq = 0.0, vh = 0.0, vf = 0.0, vj = 0.0, ev;
+      if (type == 0) {
+        vf = (g == 3 * i + a) ? 1.0 : 0.0;                           // ZeroForceConstraint.cpp:64-72
+        ev = nl.u[3 * i + a];
+      } else {
+        vq = bq[a] + DJ[a];
+        if (md.pos_gain != 0.0 && a == 2) vq += md.pos_gain * Jc[a];
+        vh = bh[a];
+        vj = bj[a] + Jc[a];
+        ev = cv_i[a];
+        if (type == 1) { if (md.pos_gain != 0.0 && a == 2) ev += md.pos_gain * cp_i[2]; }
+        else { ev -= nl.zdref[i]; if (md.pos_gain != 0.0) ev += md.pos_gain * (cp_i[2] - nl.zref[i]); }
+      }
+      if (g < G) out.C[row * NX + 6 + g] = vq;
+      if (g < 6) out.C[row * NX + g] = vh;
+      if (g < 12) out.D[row * NU + g] = vf;
+      if (is_joint) out.D[row * NU + 12 + g - 6] = vj;
+      if (g == 0) out.e[row] = ev;
+      eq_sse += ev * ev;
+      ++row;
+    }
+  }
+  const int nc = row;
+  for (; row < kMaxEqRows; ++row) {
+    if (g < G) out.C[row * NX + 6 + g] = 0.0;
+    if (g < 6) out.C[row * NX + g] = 0.0;
+    if (g < 12) out.D[row * NU + g] = 0.0;
+    if (is_joint) out.D[row * NU + 12 + g - 6] = 0.0;
+    if (g == 0) out.e[row] = 0.0;
+  }
+
+  // =========================== second RK2 stage ===========================
+  LaneEval e2;
+  {
+    double xh2[6], pb2[3];
+    for (int i = 0; i < 6; ++i) xh2[i] = xh[i] + dt * e1.fh[i];
+    for (int i = 0; i < 3; ++i) pb2[i] = pb[i] + dt * kin.vb[i];
+    const double qg2 = qg + dt * e1.vg;
+    LaneKin<NJ> kin2;
+    eval_lane<NJ>(md, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
+  }
+  // A2[rows 3..11][x columns 0..11] to LDS (a2 shares storage with the chain tables, dead now): columns 0..5 are the
+  // momentum columns of lanes 0..5, columns 6..11 the q columns of lanes 0..5
+  lds_wave_sync();
+  if (g < 6)
+    for (int r = 0; r < 9; ++r) { nl.a2[r][g] = momentum_col(nl.X12[1], nl.X22[1], imt, mass_total, g, r); nl.a2[r][6 + g] = e2.ar_q[r]; }
+  lds_wave_sync();
+  // rows of A and B;  A = I + dt/2 (A1 + A2 + dt A2 A1),  B = dt/2 (B1 + B2 + dt A2 B1)
+  double c1q[9], c1h[9], c1f[9], c1j[9];
+  for (int rr = 0; rr < 9; ++rr) {
+    c1q[rr] = nl.park[g][rr];
+    c1h[rr] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, g, rr);
+    c1f[rr] = force_col(nl.cps[0], nl.com[0], imt, g, rr);
+    c1j[rr] = rr < 3 ? 0.0 : nl.park[g][9 + rr - 3];
+  }
+  for (int r = 0; r < NX; ++r) {
+    double aq, ah_, bf, bj;
+    if (r < 3 || r >= 12) {
+      aq = (r == 6 + g) ? 1.0 : 0.0;
+      ah_ = (r == g) ? 1.0 : 0.0;
+      bf = (r < 3 && (g % 3) == r) ? dt * imt : 0.0;
+      bj = (r >= 12 && r == 12 + g - 6) ? dt : 0.0;
+    } else {
+      const int rr = r - 3;
+      double sq = 0.0, sh = 0.0, sf = 0.0, sj = 0.0;
+      for (int l = 0; l < 9; ++l) {
+        const double a = nl.a2[rr][3 + l];
+        sq += a * c1q[l]; sh += a * c1h[l]; sf += a * c1f[l]; sj += a * c1j[l];
+      }
+      // B1 rows 0..2 are (1/m) on the force components, rows 12.. are the identity on the joint velocities
+      sf += nl.a2[rr][g % 3] * imt;
+      sj += e2.ar_q[rr];
+      const double e2h = momentum_col(nl.X12[1], nl.X22[1], imt, mass_total, g, rr);
+      const double e2f = force_col(nl.cps[1], nl.com[1], imt, g, rr);
+      const double e2j = rr < 3 ? 0.0 : e2.br_j[rr - 3];
+      aq = ((r == 6 + g) ? 1.0 : 0.0) + hdt * (c1q[rr] + e2.ar_q[rr] + dt * sq);
+      ah_ = ((r == g) ? 1.0 : 0.0) + hdt * (c1h[rr] + e2h + dt * sh);
+      bf = hdt * (c1f[rr] + e2f + dt * sf);
+      bj = hdt * (c1j[rr] + e2j + dt * sj);
+    }
+    if (g < G) out.A[r * NX + 6 + g] = aq;
+    if (g < 6) out.A[r * NX + g] = ah_;
+    if (g < 12) out.B[r * NU + g] = bf;
+    if (is_joint) out.B[r * NU + 12 + g - 6] = bj;
+  }
+  // b = x + dt/2 (f1 + f2) - x_next
+  double dyn_sse = 0.0;
+  if (g < G) {
+    const double bb = qg + hdt * v1g + hdt * e2.vg - nl.xnext[6 + g];
+    out.b[6 + g] = bb;
+    dyn_sse += bb * bb;
+  }
+  if (g < 6) {
+    const double bb = xh[g] + hdt * f1h_g + hdt * e2.fh[g] - nl.xnext[g];
+    out.b[g] = bb;
+    dyn_sse += bb * bb;
+  }
+  // =========================== cost ===========================
+  lds_wave_sync();   // a2 is dead: its storage becomes dx / du
+  if (g < G) nl.dx[6 + g] = qg - nl.xref[6 + g];
+  if (g < 6) nl.dx[g] = xh[g] - nl.xref[g];
+  if (g < 12) nl.du[g] = nl.u[g] - nominal_input(md, mode, g);
+  if (is_joint) nl.du[12 + g - 6] = ujg;
+  lds_wave_sync();
+  double shift = 0.0;
+  for (int i = 0; i < kNumContacts; ++i)
+    if (stance_flag(mode, i)) shift += -nl.cone[i][2] * md.cone_shift;
+  double cost = 0.0;
+  {
+    const int cq = 6 + g, ch = g, cf = g, cj = 12 + g - 6;
+    double accq = 0.0, acch = 0.0, accf = 0.0, accj = 0.0;
+    for (int r = 0; r < NX; ++r) {
+      const double dxr = nl.dx[r], dur = nl.du[r];
+      // gradient entries use row c of the weight (as the reference kernel), the written element is (r, c)
+      if (g < G) { accq += md.Q[cq * NX + r] * dxr; out.Q[r * NX + cq] = dt * (md.Q[r * NX + cq] + (r == cq ? shift : 0.0)); }
+      if (g < 6) { acch += md.Q[ch * NX + r] * dxr; out.Q[r * NX + ch] = dt * (md.Q[r * NX + ch] + (r == ch ? shift : 0.0)); }
+      if (g < 12) {
+        accf += md.R[cf * NU + r] * dur;
+        double w = md.R[r * NU + cf];
+        if (r == cf) w += shift;
+        if (stance_flag(mode, cf / 3) && r < 12 && r / 3 == cf / 3) {
+          const double* cn = nl.cone[r / 3];
+          const int a = r % 3, b2 = cf % 3;
+          const int lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
+          const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
+          w += cn[3] * cn[4 + a] * cn[4 + b2] + cn[2] * cn[7 + sidx];
+        }
+        out.R[r * NU + cf] = dt * w;
+      }
+      if (is_joint) { accj += md.R[cj * NU + r] * dur; out.R[r * NU + cj] = dt * (md.R[r * NU + cj] + (r == cj ? shift : 0.0)); }
+    }
+    if (g < G) { out.q[cq] = dt * accq; cost += 0.5 * nl.dx[cq] * accq; }
+    if (g < 6) { out.q[ch] = dt * acch; cost += 0.5 * nl.dx[ch] * acch; }
+    if (g < 12) {
+      cost += 0.5 * nl.du[cf] * accf;
+      if (stance_flag(mode, cf / 3)) accf += nl.cone[cf / 3][2] * nl.cone[cf / 3][4 + cf % 3];
+      out.r[cf] = dt * accf;
+    }
+    if (is_joint) { out.r[cj] = dt * accj; cost += 0.5 * nl.du[cj] * accj; }
+    if (g < kNumContacts && stance_flag(mode, g)) cost += nl.cone[g][1];
+  }
+  for (int idx = g; idx < NU * NX; idx += LPN) out.P[idx] = 0.0;
+  cost = node_allreduce_add<LPN>(cost);
+  dyn_sse = node_allreduce_add<LPN>(dyn_sse);
+  if (g == 0) {
+    out.c[0] = dt * cost;
+    out.nc[0] = nc;
+    out.perf[0] = dt * cost; out.perf[1] = dt * dyn_sse; out.perf[2] = dt * eq_sse;
+  }
+}
+
+}  // namespace bpmpc

@@ -23,6 +23,7 @@
 #include "device_model.h"
 #include "kernels/linesearch.h"
 #include "kernels/node_lq.h"
+#include "kernels/linearize_fast.h"
 #include "kernels/project_node.h"
 #include "kernels/project_fast.h"
 #include "kernels/riccati.h"
@@ -121,6 +122,31 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
   out.nc = L.buf.nc + s; out.perf = L.buf.perf + s * 3;
   out.prof = (b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
   linearize_node<NJ>(*L.model, ws, in, out);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_linearize_fast(Launch L) {
+  using C = LinFastCfg<NJ>;
+  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
+  __shared__ LinFastNodeLds<NJ> lds[NPW];
+  __shared__ int path_table[NJ + 1][NJ];   // chain tables of the model, shared by the nodes of the wave
+  for (int idx = threadIdx.x; idx < (NJ + 1) * NJ; idx += kWave) path_table[idx / NJ][idx % NJ] = L.model->path[idx / NJ][idx % NJ];
+  __syncthreads();
+  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
+  const long long sidx = (long long)blockIdx.x * NPW + sub;
+  const int total = L.batch * L.N;
+  bool valid = sidx < total;
+  const int b = valid ? (int)(sidx / L.N) : 0, k = valid ? (int)(sidx % L.N) : 0;
+  valid = valid && L.buf.active[b] && k < L.buf.g_nodes[L.buf.p_grid[b]];
+  const size_t s = valid ? (size_t)sidx : 0;
+  const NodeInputs in = node_inputs<NJ>(L, b, k);
+  NodeLQOut out;
+  out.A = L.buf.A + s * NX * NX; out.B = L.buf.B + s * NX * NU; out.b = L.buf.b + s * NX;
+  out.Q = L.buf.Q + s * NX * NX; out.R = L.buf.R + s * NU * NU; out.P = L.buf.P + s * NU * NX;
+  out.q = L.buf.q + s * NX; out.r = L.buf.r + s * NU; out.c = L.buf.c + s;
+  out.C = L.buf.C + s * kMaxEqRows * NX; out.D = L.buf.D + s * kMaxEqRows * NU; out.e = L.buf.e + s * kMaxEqRows;
+  out.nc = L.buf.nc + s; out.perf = L.buf.perf + s * 3;
+  linearize_fast<NJ>(*L.model, lds[sub], path_table, valid, in, out, g);
 }
 
 template <int NJ>
@@ -374,7 +400,12 @@ template <int NJ> void bpmpc_solver::stage_prepare() {
 }
 template <int NJ> void bpmpc_solver::stage_linearize() {
   const Launch L = launch_params();
-  TIMED_LAUNCH("linearize", k_linearize<NJ>, batch * settings.max_nodes, kWave, L);
+  if (settings.reference_kernels) {
+    TIMED_LAUNCH("linearize", k_linearize<NJ>, batch * settings.max_nodes, kWave, L);
+  } else {
+    constexpr int NPW = LinFastCfg<NJ>::NPW;
+    TIMED_LAUNCH("linearize", k_linearize_fast<NJ>, (batch * settings.max_nodes + NPW - 1) / NPW, kWave, L);
+  }
 }
 template <int NJ> void bpmpc_solver::stage_project() {
   const Launch L = launch_params();
