@@ -23,6 +23,7 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", LIB]
+    cmd += os.environ.get("BPMPC_EXTRA_FLAGS", "").split()      # e.g. -DBPMPC_PROJECT_PROFILE for tools/*_phase_profile.py
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -67,6 +67,18 @@ __device__ __forceinline__ double node_allreduce_add(double x) {
   return x;
 }
 
+// v[g] for g < 6 (0 otherwise) without dynamic register indexing (which would push the array into scratch memory)
+__device__ __forceinline__ double lane_pick6(const double (&v)[6], int g) {
+  double out = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double vi = v[i];
+    asm volatile("" : "+v"(vi));
+    out = (g == i) ? vi : out;
+  }
+  return out;
+}
+
 // per-lane tree bookkeeping of the body this lane owns (the inertial constants are read from the model at their
 // single point of use to keep register live ranges short)
 struct LaneBody {
@@ -110,7 +122,7 @@ struct LaneKin {    // what the contact part needs from the evaluation
 
 // One evaluation of the centroidal dynamics for the node owned by this lane group.  `stage` selects where the node-level
 // results (A_b^{-1} blocks, contact points, com) are kept in LDS.
-template <int NJ>
+template <int NJ, bool DERIV = true, bool TWIST = true>
 __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<NJ>& nl, int stage, const LaneBody& lb, const int* path, int g,
                                           const double (&xh)[6], const double (&pb)[3], double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin) {
   using C = LinFastCfg<NJ>;
@@ -154,7 +166,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
   }
   // world axis and origin of the own coordinate (Euler ZYX = three successive revolute joints: z, rotated y, rotated x)
   double ah[3] = {0.0, 0.0, 0.0};
-  if (g < 3) ah[g] = 1.0;
+  if (g < 3) { ah[0] = g == 0 ? 1.0 : 0.0; ah[1] = g == 1 ? 1.0 : 0.0; ah[2] = g == 2 ? 1.0 : 0.0; }
   else if (g == 3) { ah[2] = 1.0; }
   else if (g == 4) { ah[0] = -sy; ah[1] = cy; }
   else if (g == 5) { ah[0] = cy * cp; ah[1] = sy * cp; ah[2] = -sp; }
@@ -254,7 +266,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
     for (int i = 0; i < 3; ++i) pd[i] += im * rhs[i];
   }
   for (int i = 0; i < 3; ++i) { kin.vb[i] = pd[i]; kin.vb[3 + i] = th[i]; }
-  const double vg = g < 3 ? pd[g] : (g < 6 ? th[g - 3] : (g < G ? ujg : 0.0));
+  const double vg = g == 0 ? pd[0] : g == 1 ? pd[1] : g == 2 ? pd[2] : g == 3 ? th[0] : g == 4 ? th[1] : g == 5 ? th[2] : (g < G ? ujg : 0.0);
   ev.vg = vg;
   // ---- flow map rows 0..5
   {
@@ -269,12 +281,13 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
     }
     for (int i = 0; i < 3; ++i) { ev.fh[i] = lin[i] / mass_total; ev.fh[3 + i] = ang[i] / mass_total; }
   }
+  double om[3] = {0.0, 0.0, 0.0}, vo[3] = {pd[0], pd[1], pd[2]};
+  if constexpr (TWIST) {
   // ---- twists: omega_g = sum over the revolute ancestors (self included) of a v, v_og = velocity of the joint origin
   if (g >= 3 && g < G) {
     for (int i = 0; i < 3; ++i) { nl.wv[g][i] = ah[i] * vg; nl.og[g][i] = o[i]; }
   }
   lds_wave_sync();
-  double om[3] = {0.0, 0.0, 0.0}, vo[3] = {pd[0], pd[1], pd[2]};
   {
     const int top = g < 3 ? 2 : (g < 6 ? g : 5);        // Euler joints up to the own one (joints and bodies: all three)
     for (int k = 3; k <= 5; ++k) {
@@ -299,6 +312,8 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
     }
   }
   for (int i = 0; i < 3; ++i) { kin.omg[i] = om[i]; kin.vog[i] = vo[i]; }
+  }
+  if constexpr (DERIV) {
   // ---- body momenta about o0 (hb shares LDS with comp, which is dead now), subtree momenta
   if (is_body) {
     const double rc[3] = {cw[0] - o[0], cw[1] - o[1], cw[2] - o[2]};
@@ -362,7 +377,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
     double acc[3] = {0.0, 0.0, 0.0};
     for (int i = 0; i < kNumContacts; ++i) {
       double jcol[3] = {0.0, 0.0, 0.0};
-      if (g < 3) jcol[g] = 1.0;
+      if (g < 3) { jcol[0] = g == 0 ? 1.0 : 0.0; jcol[1] = g == 1 ? 1.0 : 0.0; jcol[2] = g == 2 ? 1.0 : 0.0; }
       else if (g < G && (g < 6 || ((md.contact_path[i] >> (g - 5)) & 1u))) {
         const double r[3] = {nl.cpos[i][0] - o[0], nl.cpos[i][1] - o[1], nl.cpos[i][2] - o[2]};
         cross3(ah, r, jcol);
@@ -375,6 +390,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
     }
     const double imt = 1.0 / mass_total;
     for (int r = 0; r < 3; ++r) ev.ar_q[r] = acc[r] * imt;
+  }
   }
 }
 
@@ -425,11 +441,11 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
 
   LaneEval e1;
   LaneKin<NJ> kin;
-  eval_lane<NJ>(md, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
+  eval_lane<NJ, true, true>(md, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
   // park the stage-one columns in LDS for the RK2 combination
   for (int rr = 0; rr < 9; ++rr) nl.park[g][rr] = e1.ar_q[rr];
   for (int rr = 0; rr < 6; ++rr) nl.park[g][9 + rr] = e1.br_j[rr];
-  const double f1h_g = g < 6 ? e1.fh[g] : 0.0, v1g = e1.vg;
+  const double f1h_g = lane_pick6(e1.fh, g), v1g = e1.vg;
 
   // =========================== contact part (first stage only) ===========================
   if (g >= 5 && g < G)
@@ -451,7 +467,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
     const double cv_i[3] = {nl.cvel[i][0], nl.cvel[i][1], nl.cvel[i][2]};
     // own columns of J_i and d(J_i v)/dq
     double Jc[3] = {0.0, 0.0, 0.0}, DJ[3] = {0.0, 0.0, 0.0};
-    if (g < 3) Jc[g] = 1.0;
+    if (g < 3) { Jc[0] = g == 0 ? 1.0 : 0.0; Jc[1] = g == 1 ? 1.0 : 0.0; Jc[2] = g == 2 ? 1.0 : 0.0; }
     else if (g < G && (g < 6 || ((md.contact_path[i] >> (g - 5)) & 1u))) {
       const double r[3] = {cp_i[0] - kin.og[0], cp_i[1] - kin.og[1], cp_i[2] - kin.og[2]};
       cross3(kin.ah, r, Jc);
@@ -519,7 +535,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
     for (int i = 0; i < 3; ++i) pb2[i] = pb[i] + dt * kin.vb[i];
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
-    eval_lane<NJ>(md, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
+    eval_lane<NJ, true, true>(md, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
   }
   // A2[rows 3..11][x columns 0..11] to LDS (a2 shares storage with the chain tables, dead now): columns 0..5 are the
   // momentum columns of lanes 0..5, columns 6..11 the q columns of lanes 0..5
@@ -573,14 +589,14 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
     dyn_sse += bb * bb;
   }
   if (g < 6) {
-    const double bb = xh[g] + hdt * f1h_g + hdt * e2.fh[g] - nl.xnext[g];
+    const double bb = lane_pick6(xh, g) + hdt * f1h_g + hdt * lane_pick6(e2.fh, g) - nl.xnext[g];
     out.b[g] = bb;
     dyn_sse += bb * bb;
   }
   // =========================== cost ===========================
   lds_wave_sync();   // a2 is dead: its storage becomes dx / du
   if (g < G) nl.dx[6 + g] = qg - nl.xref[6 + g];
-  if (g < 6) nl.dx[g] = xh[g] - nl.xref[g];
+  if (g < 6) nl.dx[g] = lane_pick6(xh, g) - nl.xref[g];
   if (g < 12) nl.du[g] = nl.u[g] - nominal_input(md, mode, g);
   if (is_joint) nl.du[12 + g - 6] = ujg;
   lds_wave_sync();
@@ -630,5 +646,126 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
     out.perf[0] = dt * cost; out.perf[1] = dt * dyn_sse; out.perf[2] = dt * eq_sse;
   }
 }
+
+// Value-only metrics of x + alpha dx, u + alpha du at one node for the filter line search (same lane layout as
+// linearize_fast; reference version: trial_node in linesearch.h).
+template <int NJ>
+__device__ __forceinline__ void trial_fast(const DeviceModel& md, LinFastNodeLds<NJ>& nl, const int (*path_table)[NJ], bool valid,
+                                           const NodeInputs& in, double alpha, const double* dx, const double* du, const double* dxn,
+                                           double* perf, int g) {
+  using C = LinFastCfg<NJ>;
+  constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN;
+  if (!valid) return;
+  if (in.kind == 1) {
+    double d2 = 0.0;
+    for (int idx = g; idx < NX; idx += LPN) {
+      const double d = (in.x[idx] + alpha * dx[idx]) - (in.xnext[idx] + alpha * dxn[idx]);
+      d2 += d * d;
+    }
+    d2 = node_allreduce_add<LPN>(d2);
+    if (g == 0) { perf[0] = 0.0; perf[1] = d2; perf[2] = 0.0; }
+    return;
+  }
+  const bool is_joint = g >= 6 && g < G;
+  const double dt = in.dt, hdt = 0.5 * in.dt;
+  const int mode = in.mode;
+  for (int idx = g; idx < NX; idx += LPN) {
+    nl.x[idx] = in.x[idx] + alpha * dx[idx];
+    nl.u[idx] = in.u[idx] + alpha * du[idx];
+    nl.xnext[idx] = in.xnext[idx] + alpha * dxn[idx];
+    nl.xref[idx] = in.xref[idx];
+  }
+  if (g < kNumContacts) { nl.zref[g] = in.zref[g]; nl.zdref[g] = in.zdref[g]; }
+  LaneBody lb;
+  {
+    const int body = (g >= 5 && g < G) ? g - 5 : 0;
+    lb.body = body;
+    lb.depth = md.depth[body];
+    lb.subtree = md.subtree[body];
+  }
+  const int* path = path_table[lb.body];
+  lds_wave_sync();
+  double xh[6], pb[3];
+  for (int i = 0; i < 6; ++i) xh[i] = nl.x[i];
+  for (int i = 0; i < 3; ++i) pb[i] = nl.x[6 + i];
+  const double qg = g < G ? nl.x[6 + g] : 0.0;
+  const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
+  LaneEval e1;
+  LaneKin<NJ> kin;
+  eval_lane<NJ, false, true>(md, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
+  if (g >= 5 && g < G)
+    for (int i = 0; i < kNumContacts; ++i)
+      if (md.contact_body[i] == lb.body) {
+        const double r[3] = {nl.cpos[i][0] - kin.og[0], nl.cpos[i][1] - kin.og[1], nl.cpos[i][2] - kin.og[2]};
+        double t[3];
+        cross3(kin.omg, r, t);
+        for (int a = 0; a < 3; ++a) nl.cvel[i][a] = kin.vog[a] + t[a];
+      }
+  if (g < kNumContacts && stance_flag(mode, g)) cone_terms(md, &nl.u[3 * g], false, nl.cone[g]);
+  lds_wave_sync();
+  double eq_sse = 0.0;
+  for (int i = 0; i < kNumContacts; ++i) {
+    const double cz = nl.cpos[i][2];
+    if (stance_flag(mode, i)) {
+      for (int a = 0; a < 3; ++a) {
+        double ev = nl.cvel[i][a];
+        if (md.pos_gain != 0.0 && a == 2) ev += md.pos_gain * cz;
+        eq_sse += ev * ev;
+      }
+    } else {
+      for (int a = 0; a < 3; ++a) { const double ev = nl.u[3 * i + a]; eq_sse += ev * ev; }
+      double ev = nl.cvel[i][2] - nl.zdref[i];
+      if (md.pos_gain != 0.0) ev += md.pos_gain * (cz - nl.zref[i]);
+      eq_sse += ev * ev;
+    }
+  }
+  double cone_pen = 0.0;
+  if (g < kNumContacts && stance_flag(mode, g)) cone_pen = nl.cone[g][1];
+  LaneEval e2;
+  {
+    double xh2[6], pb2[3];
+    for (int i = 0; i < 6; ++i) xh2[i] = xh[i] + dt * e1.fh[i];
+    for (int i = 0; i < 3; ++i) pb2[i] = pb[i] + dt * kin.vb[i];
+    const double qg2 = qg + dt * e1.vg;
+    LaneKin<NJ> kin2;
+    eval_lane<NJ, false, false>(md, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
+  }
+  double dyn_sse = 0.0;
+  if (g < G) {
+    const double bb = qg + hdt * e1.vg + hdt * e2.vg - nl.xnext[6 + g];
+    dyn_sse += bb * bb;
+  }
+  if (g < 6) {
+    const double f1 = lane_pick6(e1.fh, g), f2 = lane_pick6(e2.fh, g);
+    const double bb = lane_pick6(xh, g) + hdt * f1 + hdt * f2 - nl.xnext[g];
+    dyn_sse += bb * bb;
+  }
+  lds_wave_sync();   // the chain tables are dead: their storage becomes dx / du
+  if (g < G) nl.dx[6 + g] = qg - nl.xref[6 + g];
+  if (g < 6) nl.dx[g] = lane_pick6(xh, g) - nl.xref[g];
+  if (g < 12) nl.du[g] = nl.u[g] - nominal_input(md, mode, g);
+  if (is_joint) nl.du[12 + g - 6] = ujg;
+  lds_wave_sync();
+  double cost = cone_pen;
+  {
+    const int cq = 6 + g, ch = g, cf = g, cj = 12 + g - 6;
+    double accq = 0.0, acch = 0.0, accf = 0.0, accj = 0.0;
+    for (int r = 0; r < NX; ++r) {
+      const double dxr = nl.dx[r], dur = nl.du[r];
+      if (g < G) accq += md.Q[cq * NX + r] * dxr;
+      if (g < 6) acch += md.Q[ch * NX + r] * dxr;
+      if (g < 12) accf += md.R[cf * NU + r] * dur;
+      if (is_joint) accj += md.R[cj * NU + r] * dur;
+    }
+    if (g < G) cost += 0.5 * nl.dx[cq] * accq;
+    if (g < 6) cost += 0.5 * nl.dx[ch] * acch;
+    if (g < 12) cost += 0.5 * nl.du[cf] * accf;
+    if (is_joint) cost += 0.5 * nl.du[cj] * accj;
+  }
+  cost = node_allreduce_add<LPN>(cost);
+  dyn_sse = node_allreduce_add<LPN>(dyn_sse);
+  if (g == 0) { perf[0] = dt * cost; perf[1] = dt * dyn_sse; perf[2] = dt * eq_sse; }
+}
+
 
 }  // namespace bpmpc

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
 }
 
 template <int NJ>
-__global__ __launch_bounds__(kWave) void k_linearize_fast(Launch L) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
   using C = LinFastCfg<NJ>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
   __shared__ LinFastNodeLds<NJ> lds[NPW];
@@ -293,6 +293,26 @@ __global__ __launch_bounds__(kWave) void k_trial(Launch L) {
 }
 
 template <int NJ>
+__global__ __launch_bounds__(kWave) void k_trial_fast(Launch L) {
+  using C = LinFastCfg<NJ>;
+  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
+  __shared__ LinFastNodeLds<NJ> lds[NPW];
+  __shared__ int path_table[NJ + 1][NJ];
+  for (int idx = threadIdx.x; idx < (NJ + 1) * NJ; idx += kWave) path_table[idx / NJ][idx % NJ] = L.model->path[idx / NJ][idx % NJ];
+  __syncthreads();
+  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
+  const long long sidx = (long long)blockIdx.x * NPW + sub;
+  const int total = L.batch * L.N;
+  bool valid = sidx < total;
+  const int b = valid ? (int)(sidx / L.N) : 0, k = valid ? (int)(sidx % L.N) : 0;
+  valid = valid && !L.buf.done[b] && k < L.buf.g_nodes[L.buf.p_grid[b]];
+  const size_t s = valid ? (size_t)sidx : 0;
+  const NodeInputs in = node_inputs<NJ>(L, b, k);
+  const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
+  trial_fast<NJ>(*L.model, lds[sub], path_table, valid, in, L.buf.alpha[b], dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
+}
+
+template <int NJ>
 __global__ __launch_bounds__(kWave) void k_ls_decide(Launch L) {
   __shared__ double partial[3 * kWave + 2];
   linesearch_decide<NJ>(partial, problem_ls<NJ>(L, blockIdx.x), L.ls);
@@ -427,7 +447,12 @@ template <int NJ> void bpmpc_solver::stage_linesearch() {
   int max_trials = 0;
   for (double a = 1.0; a >= ls.alpha_min; a *= ls.alpha_decay) ++max_trials;
   for (int t = 0; t < max_trials; ++t) {
-    hipLaunchKernelGGL(k_trial<NJ>, dim3(batch * settings.max_nodes), dim3(kWave), 0, stream, L);
+    if (settings.reference_kernels) {
+      hipLaunchKernelGGL(k_trial<NJ>, dim3(batch * settings.max_nodes), dim3(kWave), 0, stream, L);
+    } else {
+      constexpr int NPW = LinFastCfg<NJ>::NPW;
+      hipLaunchKernelGGL(k_trial_fast<NJ>, dim3((batch * settings.max_nodes + NPW - 1) / NPW), dim3(kWave), 0, stream, L);
+    }
     hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kWave), 0, stream, L);
     HIP_CHECK(hipGetLastError());
     // one 4-byte read-back per trial round: stop as soon as every problem has accepted (or given up)
