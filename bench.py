@@ -90,7 +90,7 @@ def main():
         step()
     fence()
     mpc.synchronize()
-    for k in ("prepare", "linearize", "project", "riccati", "linesearch"):
+    for k in ("prepare", "linearize", "project_lu", "project", "riccati", "linesearch"):
         mpc.kernel_time(k, reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -105,7 +105,7 @@ def main():
 
     t, x, u, _, stats = mpc.fetch()
     ok = sum(1 for s in stats if s.status == 0)
-    ktimes = {k: mpc.kernel_time(k, reset=False) for k in ("linearize", "project", "riccati", "linesearch")}
+    ktimes = {k: mpc.kernel_time(k, reset=False) for k in ("linearize", "project_lu", "project", "riccati", "linesearch")}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps

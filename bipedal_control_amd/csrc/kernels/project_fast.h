@@ -25,20 +25,11 @@ namespace bpmpc {
 
 template <int NJ>
 struct ProjectFastWorkspace {
-  static constexpr int NX = 12 + NJ, NU = 12 + NJ, LD = NX + 2, NRHS = NX + 1 + NU;
-  struct Factors {
-    alignas(16) double U[kMaxEqRows][NU + 2];      // ordered upper factor (position space)
-    alignas(16) double Y[kMaxEqRows][NRHS + 1];    // ordered right-hand sides [c | U12], overwritten by the solutions
-  };
-  union {                                          // the factors are dead once Px, Pu, Pe exist; R Pu reuses their space
-    Factors f;
-    alignas(16) double RPu[NU][LD];
-  };
-  alignas(16) double Px[NU][LD], Pu[NU][LD], R[NU][LD], RPx[NU][LD];
+  static constexpr int NX = 12 + NJ, NU = 12 + NJ, LD = NX + 2;
+  alignas(16) double Px[NU][LD], Pu[NU][LD], R[NU][LD], RPx[NU][LD], RPu[NU][LD];
   alignas(16) double Bd[9][LD];                    // dense rows 3..11 of B
-  alignas(16) double Pe[NU], rr[NU], idiag[kMaxEqRows];
+  alignas(16) double Pe[NU], rr[NU];
   double bscale[NX];                               // the single entry of the sparse rows of B (rows 0..2, 12..)
-  int lane_at_pos[NU];
 };
 
 __device__ __forceinline__ double select16(const double (&v)[kMaxEqRows], int r) {
@@ -105,21 +96,17 @@ __device__ __forceinline__ void project_fast(ProjectFastWorkspace<NJ>& ws, const
 #define LPROF(slot) ((void)0)
 #endif
 
-  const int rows = in.nc;                     // <= 16, wave uniform
-  const bool is_d = lane < NU;                // column of D
-  const bool is_rhs = lane >= NU && lane < NU + NX + 1;   // column of [C | e]
-  // ---- all HBM reads of this node, back to back
-  double v[kMaxEqRows];
-  {
-    const double* src = is_d ? in.D + lane : (lane < NU + NX ? in.C + (lane - NU) : in.e);
-    const int stride = is_d ? NU : (lane < NU + NX ? NX : 1);
-    const bool valid = lane < NU + NX + 1;
+  // ---- all HBM reads of this node, back to back (Px, Pu, Pe, nut come from the LU kernel, project_lu4.h)
+  const int nut = out.nut[0];
+  double pR[IT_R], pB[IT_B], pA[IT_A][2], pQ[IT_Q][4], pvec[3], pPx[IT_R], pPu[IT_R];
 #pragma unroll
-    for (int r = 0; r < kMaxEqRows; ++r) v[r] = valid ? src[r * stride] : 0.0;   // rows >= nc are zero in HBM
+  for (int it = 0; it < IT_R; ++it) {
+    const int idx = lane + it * kWave;
+    const bool ok = idx < NU * NU;
+    pR[it] = ok ? in.R[idx] : 0.0;
+    pPx[it] = ok ? out.Px[idx] : 0.0;
+    pPu[it] = ok ? out.Pu[idx] : 0.0;
   }
-  double pR[IT_R], pB[IT_B], pA[IT_A][2], pQ[IT_Q][4], pvec[3];
-#pragma unroll
-  for (int it = 0; it < IT_R; ++it) { const int idx = lane + it * kWave; pR[it] = idx < NU * NU ? in.R[idx] : 0.0; }
 #pragma unroll
   for (int it = 0; it < IT_B; ++it) { const int idx = lane + it * kWave; pB[it] = idx < 9 * NU ? in.B[3 * NU + idx] : 0.0; }
 #pragma unroll
@@ -141,126 +128,23 @@ __device__ __forceinline__ void project_fast(ProjectFastWorkspace<NJ>& ws, const
   pvec[1] = lane < NX ? in.q[lane] : 0.0;
   pvec[2] = lane < NU ? in.r[lane] : 0.0;
   const double bsc = lane < NX ? ((lane < 3 || lane >= 12) ? in.B[lane * NU + lane] : 0.0) : 0.0;
-  for (int idx = lane; idx < NU * LD; idx += kWave) { (&ws.Px[0][0])[idx] = 0.0; (&ws.Pu[0][0])[idx] = 0.0; }
-  if (lane < NU) ws.Pe[lane] = 0.0;
+  const double pe = lane < NU ? out.Pe[lane] : 0.0;
   PPROF(0);
-
-  // ---- LU with complete pivoting.  rowpos[r]: current position of physical row r; colpos: position of this lane's column.
-  int rowpos[kMaxEqRows];
 #pragma unroll
-  for (int r = 0; r < kMaxEqRows; ++r) rowpos[r] = r;
-  int colpos = lane;                          // meaningful for D lanes
-  const int size = rows < NU ? rows : NU;
-  int nonzero = size;
-  double maxpivot = 0.0;
-#pragma nounroll
-  for (int k = 0; k < size; ++k) {
-    // candidate of this lane: first maximum over the not yet pivoted rows (positions >= k) of its column
-    double best = -1.0;
-    int brow = 0, bpos = 0x7fff;
-#pragma unroll
-    for (int r = 0; r < kMaxEqRows; ++r) {
-      const int rp = rowpos[r];
-      const double a = (r < rows && rp >= k) ? fabs(v[r]) : -2.0;   // pivoted rows never win
-      const bool take = (a > best) || (a == best && rp < bpos);
-      best = take ? a : best;
-      brow = take ? r : brow;
-      bpos = take ? rp : bpos;
-    }
-    if (!is_d || colpos < k) best = -1.0;
-    LPROF(0);
-    const double pivabs = wave_max_f64(best);
-    LPROF(1);
-    if (pivabs == 0.0) { nonzero = k; break; }
-    // winner: among the lanes that hold the maximum, smallest (column position, row position)
-    unsigned long long tied = __ballot(best == pivabs);
-    int plane = __ffsll((long long)tied) - 1;
-    if (__popcll(tied) > 1) {
-      int wcol = 0x7fff, wpos = 0x7fff;
-      while (tied) {
-        const int l = __ffsll((long long)tied) - 1;
-        tied &= tied - 1;
-        const int c = __builtin_amdgcn_readlane(colpos, l), p = __builtin_amdgcn_readlane(bpos, l);
-        if (c < wcol || (c == wcol && p < wpos)) { wcol = c; wpos = p; plane = l; }
-      }
-    }
-    const int pr = __builtin_amdgcn_readlane(brow, plane), ppos = __builtin_amdgcn_readlane(bpos, plane);
-    const int pcpos = __builtin_amdgcn_readlane(colpos, plane);
-    if (pivabs > maxpivot) maxpivot = pivabs;
-    LPROF(2);
-    // logical swaps: row at position k <-> pivot row, column at position k <-> pivot column
-#pragma unroll
-    for (int r = 0; r < kMaxEqRows; ++r) { if (rowpos[r] == k) rowpos[r] = ppos; else if (r == pr) rowpos[r] = k; }
-    if (is_d) { if (colpos == k) colpos = pcpos; else if (lane == plane) colpos = k; }
-    // eliminate: factors = pivot column (broadcast from its lane), pivot row element of this lane
-    LPROF(3);
-    const double vp = select16(v, pr);
-    const double piv = readlane_f64(vp, plane);
-    const double scale = vp * (1.0 / piv);
-    const bool update = (is_d && colpos > k) || is_rhs;
-#pragma unroll
-    for (int r = 0; r < kMaxEqRows; ++r) {
-      if (r < rows && rowpos[r] > k) {        // uniform
-        const double f = readlane_f64(v[r], plane);
-        if (update) v[r] -= f * scale;
-      }
-    }
-    LPROF(4);
+  for (int it = 0; it < IT_R; ++it) {
+    const int idx = lane + it * kWave;
+    if (idx < NU * NU) { ws.R[idx / NU][idx % NU] = pR[it]; ws.Px[idx / NU][idx % NU] = pPx[it]; ws.Pu[idx / NU][idx % NU] = pPu[it]; }
   }
-  PPROF(1);
-  // ---- ordered factors to LDS, staged inputs to LDS, rank (threshold of Eigen::FullPivLU::rank)
-  if (is_d) ws.lane_at_pos[colpos] = lane;
-#pragma unroll
-  for (int r = 0; r < kMaxEqRows; ++r) {
-    if (r < rows) {
-      const int p = rowpos[r];
-      if (is_d) ws.f.U[p][colpos] = v[r];
-      else if (is_rhs) ws.f.Y[p][lane - NU] = v[r];
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < IT_R; ++it) { const int idx = lane + it * kWave; if (idx < NU * NU) ws.R[idx / NU][idx % NU] = pR[it]; }
 #pragma unroll
   for (int it = 0; it < IT_B; ++it) { const int idx = lane + it * kWave; if (idx < 9 * NU) ws.Bd[idx / NU][idx % NU] = pB[it]; }
   if (lane < NX) ws.bscale[lane] = bsc;
-  lds_wave_sync();
-  const double thr = fabs(maxpivot) * (2.220446049250313e-16 * size);
-  int rank = 0;
-  for (int i = 0; i < nonzero; ++i) rank += (fabs(ws.f.U[i][i]) > thr) ? 1 : 0;
-  const int nut = NU - rank;
-  // kernel right-hand sides U12 and reciprocal diagonal
-  for (int idx = lane; idx < rank * nut; idx += kWave) ws.f.Y[idx / nut][NX + 1 + idx % nut] = ws.f.U[idx / nut][rank + idx % nut];
-  if (lane < rank) ws.idiag[lane] = 1.0 / ws.f.U[lane][lane];
-  lds_wave_sync();
-  PPROF(2);
-  // ---- back substitution, one lane per right-hand side
-  if (lane < NX + 1 + nut) {
-    double y[kMaxEqRows];
-#pragma unroll
-    for (int i = kMaxEqRows - 1; i >= 0; --i) {
-      if (i < rank) {                         // uniform
-        double t = ws.f.Y[i][lane];
-#pragma unroll
-        for (int l = i + 1; l < kMaxEqRows; ++l)
-          if (l < rank) t -= ws.f.U[i][l] * y[l];
-        y[i] = t * ws.idiag[i];
-      }
-    }
-    // scatter through the column permutation: Px = -Q [y; 0], Pe likewise, Pu = Q [-U11^-1 U12; I]
-#pragma unroll
-    for (int i = 0; i < kMaxEqRows; ++i) {
-      if (i < rank) {
-        const int row = ws.lane_at_pos[i];
-        if (lane < NX) ws.Px[row][lane] = -y[i];
-        else if (lane == NX) ws.Pe[row] = -y[i];
-        else ws.Pu[row][lane - NX - 1] = -y[i];
-      }
-    }
-    if (lane > NX) ws.Pu[ws.lane_at_pos[rank + (lane - NX - 1)]][lane - NX - 1] = 1.0;
+  if (lane < NU) ws.Pe[lane] = pe;
+  if (lane < 2 * NU) {                          // the padding columns are read by the 2x2 tiles
+    double* rowp = lane < NU ? ws.Px[lane] : ws.Pu[lane - NU];
+    rowp[NU] = 0.0; rowp[NU + 1] = 0.0;
   }
   lds_wave_sync();
   PPROF(3);
-  if (lane == 0) out.nut[0] = nut;
   const int nt2 = (nut + 1) / 2;
   // ---- products.  P1: RPx = R Px (H2 x H2 tiles), RPu = R Pu (H2 x nt2 tiles), rr = r + R Pe; projection to HBM
   for (int w = lane; w < H2 * H2 + H2 * nt2; w += kWave) {
@@ -283,9 +167,7 @@ __device__ __forceinline__ void project_fast(ProjectFastWorkspace<NJ>& ws, const
 #pragma unroll
     for (int l = 0; l < NU; ++l) t += ws.R[l][lane] * ws.Pe[l];
     ws.rr[lane] = t;
-    out.Pe[lane] = ws.Pe[lane];
   }
-  for (int idx = lane; idx < NU * NX; idx += kWave) { out.Px[idx] = ws.Px[idx / NX][idx % NX]; out.Pu[idx] = ws.Pu[idx / NU][idx % NU]; }
   lds_wave_sync();
   PPROF(4);
   // ---- P2: everything that goes to HBM.  At = A + B Px, Bt = B Pu (column pairs per lane; sparse rows of B are one entry)

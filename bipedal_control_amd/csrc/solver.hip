@@ -26,6 +26,7 @@
 #include "kernels/linearize_fast.h"
 #include "kernels/project_node.h"
 #include "kernels/project_fast.h"
+#include "kernels/project_lu4.h"
 #include "kernels/riccati.h"
 #include "kernels/riccati_fast.h"
 #include "reference_gen.h"
@@ -133,10 +134,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   for (int idx = threadIdx.x; idx < (NJ + 1) * NJ; idx += kWave) path_table[idx / NJ][idx % NJ] = L.model->path[idx / NJ][idx % NJ];
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
-  const long long sidx = (long long)blockIdx.x * NPW + sub;
+  const int sidx = blockIdx.x * NPW + sub;   // batch * max_nodes < 2^31 is checked at creation
   const int total = L.batch * L.N;
   bool valid = sidx < total;
-  const int b = valid ? (int)(sidx / L.N) : 0, k = valid ? (int)(sidx % L.N) : 0;
+  const int b = valid ? sidx / L.N : 0, k = valid ? sidx % L.N : 0;
   valid = valid && L.buf.active[b] && k < L.buf.g_nodes[L.buf.p_grid[b]];
   const size_t s = valid ? (size_t)sidx : 0;
   const NodeInputs in = node_inputs<NJ>(L, b, k);
@@ -170,6 +171,30 @@ __global__ __launch_bounds__(kWave) void k_project(Launch L) {
   out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
   out.rt = L.buf.rt + s * NU;
   project_node<NJ>(ws, in, out);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_project_lu(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ ProjectLuLds lds[kLuNodes];
+  const int sub = threadIdx.x / kLuLanes, j = threadIdx.x % kLuLanes;
+  const int sidx = blockIdx.x * kLuNodes + sub;
+  bool valid = sidx < L.batch * L.N;
+  const int b = valid ? sidx / L.N : 0, k = valid ? sidx % L.N : 0;
+  const int g = L.buf.p_grid[b];
+  valid = valid && L.buf.active[b] && k < L.buf.g_nodes[g];
+  const size_t s = valid ? (size_t)sidx : 0;
+  double* Px = L.buf.Px + s * NU * NX;
+  double* Pu = L.buf.Pu + s * NU * NU;
+  double* Pe = L.buf.Pe + s * NU;
+  if (valid && L.buf.g_kind[(size_t)g * L.N + k] == 1) {   // event node: no input
+    for (int idx = j; idx < NU * NX; idx += kLuLanes) { Px[idx] = 0.0; Pu[idx] = 0.0; }
+    for (int idx = j; idx < NU; idx += kLuLanes) Pe[idx] = 0.0;
+    if (j == 0) L.buf.nut[s] = 0;
+    valid = false;
+  }
+  project_lu4<NJ>(lds[sub], valid, L.buf.nc[s], L.buf.D + s * kMaxEqRows * NU, L.buf.C + s * kMaxEqRows * NX, L.buf.e + s * kMaxEqRows, Px, Pu, Pe,
+                  L.buf.nut + s, sub, j);
 }
 
 template <int NJ>
@@ -301,10 +326,10 @@ __global__ __launch_bounds__(kWave) void k_trial_fast(Launch L) {
   for (int idx = threadIdx.x; idx < (NJ + 1) * NJ; idx += kWave) path_table[idx / NJ][idx % NJ] = L.model->path[idx / NJ][idx % NJ];
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
-  const long long sidx = (long long)blockIdx.x * NPW + sub;
+  const int sidx = blockIdx.x * NPW + sub;   // batch * max_nodes < 2^31 is checked at creation
   const int total = L.batch * L.N;
   bool valid = sidx < total;
-  const int b = valid ? (int)(sidx / L.N) : 0, k = valid ? (int)(sidx % L.N) : 0;
+  const int b = valid ? sidx / L.N : 0, k = valid ? sidx % L.N : 0;
   valid = valid && !L.buf.done[b] && k < L.buf.g_nodes[L.buf.p_grid[b]];
   const size_t s = valid ? (size_t)sidx : 0;
   const NodeInputs in = node_inputs<NJ>(L, b, k);
@@ -430,7 +455,10 @@ template <int NJ> void bpmpc_solver::stage_linearize() {
 template <int NJ> void bpmpc_solver::stage_project() {
   const Launch L = launch_params();
   if (settings.reference_kernels) TIMED_LAUNCH("project", k_project<NJ>, batch * settings.max_nodes, kWave, L);
-  else TIMED_LAUNCH("project", k_project_fast<NJ>, batch * settings.max_nodes, kWave, L);
+  else {
+    TIMED_LAUNCH("project_lu", k_project_lu<NJ>, (batch * settings.max_nodes + kLuNodes - 1) / kLuNodes, kWave, L);
+    TIMED_LAUNCH("project", k_project_fast<NJ>, batch * settings.max_nodes, kWave, L);
+  }
 }
 template <int NJ> void bpmpc_solver::stage_riccati() {
   const Launch L = launch_params();
@@ -642,6 +670,7 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
   if (!model || !settings || !out) { set_last_error("bpmpc_solver_create: null argument"); return BPMPC_ERR_INVALID_ARGUMENT; }
   *out = nullptr;
   if (settings->max_batch < 1 || settings->max_nodes < 1) { set_last_error("bpmpc_solver_create: max_batch and max_nodes must be positive"); return BPMPC_ERR_INVALID_ARGUMENT; }
+  if ((long long)settings->max_batch * settings->max_nodes > 0x3fffffffLL) { set_last_error("bpmpc_solver_create: max_batch * max_nodes exceeds 2^30"); return BPMPC_ERR_CAPACITY; }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || settings->device < 0 || settings->device >= count) {
     set_last_error("bpmpc_solver_create: no usable HIP device (this engine has no CPU path)");
