@@ -26,8 +26,12 @@ namespace bpmpc {
 constexpr int kLuLanes = 16;                 // lanes per node
 constexpr int kLuNodes = kWave / kLuLanes;   // nodes per wavefront
 
+template <int NJ>
 struct ProjectLuLds {                        // per node
-  alignas(16) double U[kMaxEqRows][kMaxEqRows];   // upper factor, rows and columns by position
+  union {
+    alignas(16) double U[kMaxEqRows][kMaxEqRows];   // upper factor, rows and columns by position
+    double tile[12 + NJ][12 + NJ + 2];         // output staging: rows of Px | Pe | pad, then rows of Pu
+  };
   double idiag[kMaxEqRows];
   int colat[32];                             // physical column of D at position p
 };
@@ -129,7 +133,7 @@ __device__ __forceinline__ void lu_step(LuLane& s, int j) {
 
 // `valid` false: the lanes run along with an empty problem (nc = 0) and write nothing.
 template <int NJ>
-__device__ __forceinline__ void project_lu4(ProjectLuLds& nl, bool valid, int nc, const double* D, const double* C, const double* e, double* Px,
+__device__ __forceinline__ void project_lu4(ProjectLuLds<NJ>& nl, bool valid, int nc, const double* D, const double* C, const double* e, double* Px,
                                             double* Pu, double* Pe, int* nut_out, int sub, int j) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ, R = kMaxEqRows;
   static_assert(NU > 16 && NU <= 32 && NX + 1 <= 32 && R == 16, "lane layout");
@@ -193,6 +197,9 @@ __device__ __forceinline__ void project_lu4(ProjectLuLds& nl, bool valid, int nc
     }
     const double id = nl.idiag[i];
     vd0[i] = t0 * id; vd1[i] = t1 * id; vr0[i] = t2 * id; vr1[i] = t3 * id;
+    // pin the results here: otherwise the solves of the second-slot columns are sunk into the predicated output blocks
+    // below, which keeps every U entry alive in registers until then
+    asm volatile("" : "+v"(vd0[i]), "+v"(vd1[i]), "+v"(vr0[i]), "+v"(vr1[i]));
     __builtin_amdgcn_sched_barrier(0);         // keep the LDS reads of later rows from being hoisted (register pressure)
   }
   // ---- Px = -Q [y; 0], Pe likewise, Pu = Q [-U11^-1 U12; I]; the pivot columns of D fill the zero columns nut.. of Pu
@@ -200,19 +207,55 @@ __device__ __forceinline__ void project_lu4(ProjectLuLds& nl, bool valid, int nc
   const bool free0 = cpos0 >= rank, free1 = cpos1 >= rank;
   const int kc0 = free0 ? cpos0 - rank : nut + cpos0;
   const int kc1 = free1 ? cpos1 - rank : nut + cpos1;
-  if (valid) {
+  // The results are permuted through an LDS tile (it overlays U, which is dead now) and leave in row order with
+  // immediate-offset stores; writing them straight from the solve needs a computed 64-bit address per element, which
+  // tripled the register count of the kernel.
+  lds_wave_sync();
+#pragma unroll
+  for (int p = 0; p < NU; ++p) {
+    const int row = nl.colat[p];
+    nl.tile[row][j] = (p < R && p < rank) ? -vr0[p < R ? p : 0] : 0.0;
+  }
+  if (has_c1 || is_e) {                        // columns 16.. of Px and Pe (kept in column NX of the tile)
 #pragma unroll
     for (int p = 0; p < NU; ++p) {
       const int row = nl.colat[p];
-      const bool piv = p < rank;
-      const double y0 = p < R ? vd0[p < R ? p : 0] : 0.0, y1 = p < R ? vd1[p < R ? p : 0] : 0.0;
-      const double y2 = p < R ? vr0[p < R ? p : 0] : 0.0, y3 = p < R ? vr1[p < R ? p : 0] : 0.0;
-      Px[row * NX + j] = piv ? -y2 : 0.0;
-      if (has_c1) Px[row * NX + 16 + j] = piv ? -y3 : 0.0;
-      else if (is_e) Pe[row] = piv ? -y3 : 0.0;
-      Pu[row * NU + kc0] = free0 ? (piv ? -y0 : (p == cpos0 ? 1.0 : 0.0)) : 0.0;
-      if (has_d1) Pu[row * NU + kc1] = free1 ? (piv ? -y1 : (p == cpos1 ? 1.0 : 0.0)) : 0.0;
-      __builtin_amdgcn_sched_barrier(0);
+      nl.tile[row][16 + j] = (p < R && p < rank) ? -vr1[p < R ? p : 0] : 0.0;
+    }
+  }
+  lds_wave_sync();
+  if (valid) {
+#pragma unroll
+    for (int row = 0; row < NU; ++row) Px[row * NX + j] = nl.tile[row][j];
+    if (has_c1) {
+#pragma unroll
+      for (int row = 0; row < NU; ++row) Px[row * NX + 16 + j] = nl.tile[row][16 + j];
+    }
+    Pe[j] = nl.tile[j][NX];
+    if (has_d1) Pe[16 + j] = nl.tile[16 + j][NX];
+  }
+  lds_wave_sync();
+#pragma unroll
+  for (int p = 0; p < NU; ++p) {
+    const int row = nl.colat[p];
+    const double y = p < R ? vd0[p < R ? p : 0] : 0.0;
+    nl.tile[row][kc0] = free0 ? (p < rank ? -y : (p == cpos0 ? 1.0 : 0.0)) : 0.0;
+  }
+  if (has_d1) {
+#pragma unroll
+    for (int p = 0; p < NU; ++p) {
+      const int row = nl.colat[p];
+      const double y = p < R ? vd1[p < R ? p : 0] : 0.0;
+      nl.tile[row][kc1] = free1 ? (p < rank ? -y : (p == cpos1 ? 1.0 : 0.0)) : 0.0;
+    }
+  }
+  lds_wave_sync();
+  if (valid) {
+#pragma unroll
+    for (int row = 0; row < NU; ++row) Pu[row * NU + j] = nl.tile[row][j];
+    if (has_d1) {
+#pragma unroll
+      for (int row = 0; row < NU; ++row) Pu[row * NU + 16 + j] = nl.tile[row][16 + j];
     }
     if (j == 0) nut_out[0] = nut;
   }

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kWave) void k_project(Launch L) {
 template <int NJ>
 __global__ __launch_bounds__(kWave) void k_project_lu(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ ProjectLuLds lds[kLuNodes];
+  __shared__ ProjectLuLds<NJ> lds[kLuNodes];
   const int sub = threadIdx.x / kLuLanes, j = threadIdx.x % kLuLanes;
   const int sidx = blockIdx.x * kLuNodes + sub;
   bool valid = sidx < L.batch * L.N;
