@@ -36,7 +36,8 @@ class BpmpcError(RuntimeError):
 
 class _Settings(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("max_nodes", C.c_int), ("sqp_iterations", C.c_int), ("dt", C.c_double),
-                ("return_gains", C.c_int), ("profile", C.c_int), ("stream", C.c_void_p), ("reference_kernels", C.c_int)]
+                ("return_gains", C.c_int), ("profile", C.c_int), ("stream", C.c_void_p), ("reference_kernels", C.c_int),
+                ("pipeline_chunks", C.c_int)]
 
 
 class _Schedule(C.Structure):
@@ -206,14 +207,14 @@ class BatchedSqpMpc:
     MPC_MRT_Interface::advanceMpc() (BipedalController.cpp:339) for every problem of the batch at once."""
 
     def __init__(self, interface, max_batch, max_nodes, sqp_iterations=0, dt=0.0, return_gains=False, profile=False, device=0, stream=None,
-                 reference_kernels=False):
+                 reference_kernels=False, pipeline_chunks=0):
         lib = load_library()
         self.interface = interface
         self.max_batch, self.max_nodes = int(max_batch), int(max_nodes)
         self.nx, self.nu = interface.stateDim, interface.inputDim
         self.return_gains = bool(return_gains)
         st = _Settings(int(device), self.max_batch, self.max_nodes, int(sqp_iterations), float(dt), int(bool(return_gains)), int(bool(profile)),
-                       C.c_void_p(stream) if stream else None, int(bool(reference_kernels)))
+                       C.c_void_p(stream) if stream else None, int(bool(reference_kernels)), int(pipeline_chunks))
         self._h = C.c_void_p()
         _check(lib.bpmpc_solver_create(interface.handle, C.byref(st), C.byref(self._h)))
         self._keep = None

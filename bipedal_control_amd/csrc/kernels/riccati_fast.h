@@ -49,6 +49,11 @@ struct RiccatiFastIO {
   double *mvec, *mscal;      // per node NX, 1
   double* Kfull;             // per node NU*NX (always materialised: it is the feedback gain K)
   double* prof;              // optional [8] per problem: accumulated cycles per phase (debug)
+  // The horizon can be swept in chunks (one launch each, latest stages first) so that the sweep of one chunk overlaps
+  // with the linearisation / projection of the earlier stages: this launch covers the stages [k_lo, k_hi) and hands
+  // S, s and the status to the next one through `carry` (NX*NX + NX + 1 doubles).  The roll-out runs when k_lo == 0.
+  int k_lo, k_hi;
+  double* carry;
 };
 
 // Workgroup barrier that orders LDS traffic only: outstanding global loads (the prefetch) and stores stay in flight.
@@ -107,11 +112,17 @@ __device__ __forceinline__ void riccati_fast(RiccatiFastWorkspace<NJ>& ws, const
   const int tid = threadIdx.x;
   const int N = io.base.N;
 
+  const int k_top = (io.k_hi < N ? io.k_hi : N) - 1;   // first stage of this launch
+  const bool resumed = io.k_hi < N;                    // a later chunk has already run: take over its value function
   for (int idx = tid; idx < NX * LD; idx += NT) { (&ws.S[0][0])[idx] = 0.0; (&ws.B[0][0])[idx] = 0.0; (&ws.Pu[0][0])[idx] = 0.0; (&ws.SB[0][0])[idx] = 0.0; }
   for (int idx = tid; idx < NU * LDM; idx += NT) (&ws.M[0][0])[idx] = 0.0;
   for (int idx = tid; idx < NU * LDG; idx += NT) (&ws.G0[0][0])[idx] = 0.0;
-  if (tid < NX) ws.s[tid] = 0.0;
-  if (tid == 0) ws.status = 0;
+  if (tid < NX) ws.s[tid] = resumed ? io.carry[NXX + tid] : 0.0;
+  if (tid == 0) ws.status = resumed ? (int)io.carry[NXX + NX] : 0;
+  if (resumed) {
+    __syncthreads();
+    for (int idx = tid; idx < NXX; idx += NT) ws.S[idx / NX][idx % NX] = io.carry[idx];
+  }
 
   // registers holding the prefetched stage
   double pA[E2], pB[E2], pQ[E2], pP[E2], pR[E2], pPx[E2], pPu[E2], pv[4];
@@ -136,7 +147,7 @@ __device__ __forceinline__ void riccati_fast(RiccatiFastWorkspace<NJ>& ws, const
       pv[3] = io.base.Pe[(size_t)k * NU + tid];
     }
   };
-  if (N > 0) prefetch(N - 1);
+  if (k_top >= io.k_lo) prefetch(k_top);
   __syncthreads();
 #ifdef BPMPC_RICCATI_PROFILE
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -146,7 +157,7 @@ __device__ __forceinline__ void riccati_fast(RiccatiFastWorkspace<NJ>& ws, const
 #define RPROF(slot) ((void)0)
 #endif
 
-  for (int k = N - 1; k >= 0; --k) {
+  for (int k = k_top; k >= io.k_lo; --k) {
     const int nt = io.base.nut[k];
     const int nt2 = (nt + 1) / 2;
     // ---- P0: registers -> LDS; M = [R | P r].  The projection kernel writes zeros beyond nt in B~, Pu, R~, P~, r~,
@@ -168,7 +179,7 @@ __device__ __forceinline__ void riccati_fast(RiccatiFastWorkspace<NJ>& ws, const
     if (tid < NX) { ws.b[tid] = pv[0]; ws.q[tid] = pv[1]; ws.r[tid] = pv[2]; ws.Pe[tid] = pv[3]; ws.M[tid][HC + NX] = pv[2]; }
     lds_barrier();
     RPROF(0);
-    if (k > 0) prefetch(k - 1);
+    if (k > io.k_lo) prefetch(k - 1);   // never beyond the chunk: earlier stages may not be projected yet
     RPROF(1);
     // ---- P1: SA = S A (H2 x H2 tiles), SB = S B (H2 x nt2 tiles), Sb = S b + s (H2 row pairs)
     for (int w = tid; w < 2 * H2 * H2 + H2; w += NT) {
@@ -364,6 +375,12 @@ __device__ __forceinline__ void riccati_fast(RiccatiFastWorkspace<NJ>& ws, const
     for (int i = 0; i < 8; ++i) io.prof[i] = (double)tacc[i];
 #endif
   __syncthreads();
+  if (io.k_lo > 0) {                                   // hand over to the launch that sweeps the earlier stages
+    for (int idx = tid; idx < NXX; idx += NT) io.carry[idx] = ws.S[idx / NX][idx % NX];
+    if (tid < NX) io.carry[NXX + tid] = ws.s[tid];
+    if (tid == 0) io.carry[NXX + NX] = (double)ws.status;
+    return;
+  }
 
   // ---- forward roll-out: dx_{k+1} = Acl_k dx_k + bcl_k (wave 0, one row per lane, next row prefetched)
   if (tid < NX) { const double v = io.base.dx0[tid]; ws.dx[0][tid] = v; io.base.dx[tid] = v; }

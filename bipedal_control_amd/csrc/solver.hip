@@ -61,6 +61,7 @@ struct Buffers {
   // riccati
   double *Kt, *kt, *dx, *du, *K, *summary, *dx0;
   double *Acl, *bcl, *kff, *mvec, *mscal, *rprof;
+  double* ric_carry;   // per problem NX*NX + NX + 1: value function and status handed from one horizon chunk to the next
   // line search
   double *trial_perf, *base, *alpha, *stats;
   int *done, *active, *iterations, *remaining;
@@ -70,6 +71,7 @@ struct Launch {
   const DeviceModel* model;
   Buffers buf;
   int batch, N;  // N = node stride (max_nodes)
+  int k0, klen;  // node range [k0, k0 + klen) of this launch (fast kernels; the horizon is pipelined in chunks)
   int cold;
   LineSearchSettings ls;
 };
@@ -134,12 +136,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   for (int idx = threadIdx.x; idx < (NJ + 1) * NJ; idx += kWave) path_table[idx / NJ][idx % NJ] = L.model->path[idx / NJ][idx % NJ];
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
-  const int sidx = blockIdx.x * NPW + sub;   // batch * max_nodes < 2^31 is checked at creation
-  const int total = L.batch * L.N;
-  bool valid = sidx < total;
-  const int b = valid ? sidx / L.N : 0, k = valid ? sidx % L.N : 0;
+  const int widx = blockIdx.x * NPW + sub;   // batch * max_nodes < 2^31 is checked at creation
+  bool valid = widx < L.batch * L.klen;
+  const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
   valid = valid && L.buf.active[b] && k < L.buf.g_nodes[L.buf.p_grid[b]];
-  const size_t s = valid ? (size_t)sidx : 0;
+  const size_t s = valid ? (size_t)b * L.N + k : 0;
   const NodeInputs in = node_inputs<NJ>(L, b, k);
   NodeLQOut out;
   out.A = L.buf.A + s * NX * NX; out.B = L.buf.B + s * NX * NU; out.b = L.buf.b + s * NX;
@@ -178,12 +179,12 @@ __global__ __launch_bounds__(kWave) void k_project_lu(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   __shared__ ProjectLuLds<NJ> lds[kLuNodes];
   const int sub = threadIdx.x / kLuLanes, j = threadIdx.x % kLuLanes;
-  const int sidx = blockIdx.x * kLuNodes + sub;
-  bool valid = sidx < L.batch * L.N;
-  const int b = valid ? sidx / L.N : 0, k = valid ? sidx % L.N : 0;
+  const int widx = blockIdx.x * kLuNodes + sub;
+  bool valid = widx < L.batch * L.klen;
+  const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
   const int g = L.buf.p_grid[b];
   valid = valid && L.buf.active[b] && k < L.buf.g_nodes[g];
-  const size_t s = valid ? (size_t)sidx : 0;
+  const size_t s = valid ? (size_t)b * L.N + k : 0;
   double* Px = L.buf.Px + s * NU * NX;
   double* Pu = L.buf.Pu + s * NU * NU;
   double* Pe = L.buf.Pe + s * NU;
@@ -201,11 +202,11 @@ template <int NJ>
 __global__ __launch_bounds__(kWave) void k_project_fast(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   __shared__ ProjectFastWorkspace<NJ> ws;
-  const int sidx = blockIdx.x, b = sidx / L.N, k = sidx % L.N;
+  const int b = blockIdx.x / L.klen, k = L.k0 + blockIdx.x % L.klen;
   if (!L.buf.active[b]) return;
   const int g = L.buf.p_grid[b];
   if (k >= L.buf.g_nodes[g]) return;
-  const size_t s = sidx;
+  const size_t s = (size_t)b * L.N + k;
   ProjectIn in;
   in.kind = L.buf.g_kind[(size_t)g * L.N + k];
   in.nc = L.buf.nc[s];
@@ -272,6 +273,9 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati_fast(Launch L) {
   io.mvec = L.buf.mvec + s0 * NX; io.mscal = L.buf.mscal + s0;
   io.Kfull = L.buf.K + s0 * NU * NX;
   io.prof = L.buf.rprof ? L.buf.rprof + (size_t)b * 8 : nullptr;
+  io.k_lo = L.k0;
+  io.k_hi = L.k0 + L.klen;
+  io.carry = L.buf.ric_carry + (size_t)b * (NX * NX + NX + 1);
   riccati_fast<NJ>(ws, io);
 }
 
@@ -326,12 +330,11 @@ __global__ __launch_bounds__(kWave) void k_trial_fast(Launch L) {
   for (int idx = threadIdx.x; idx < (NJ + 1) * NJ; idx += kWave) path_table[idx / NJ][idx % NJ] = L.model->path[idx / NJ][idx % NJ];
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
-  const int sidx = blockIdx.x * NPW + sub;   // batch * max_nodes < 2^31 is checked at creation
-  const int total = L.batch * L.N;
-  bool valid = sidx < total;
-  const int b = valid ? sidx / L.N : 0, k = valid ? sidx % L.N : 0;
+  const int widx = blockIdx.x * NPW + sub;
+  bool valid = widx < L.batch * L.klen;
+  const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
   valid = valid && !L.buf.done[b] && k < L.buf.g_nodes[L.buf.p_grid[b]];
-  const size_t s = valid ? (size_t)sidx : 0;
+  const size_t s = valid ? (size_t)b * L.N + k : 0;
   const NodeInputs in = node_inputs<NJ>(L, b, k);
   const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
   trial_fast<NJ>(*L.model, lds[sub], path_table, valid, in, L.buf.alpha[b], dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
@@ -364,6 +367,9 @@ struct bpmpc_solver {
   bool cold = true;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t producer_stream = nullptr;                   // linearisation + projection of the pipelined horizon chunks
+  hipEvent_t ev_go = nullptr;
+  std::vector<hipEvent_t> ev_chunk;
   Buffers buf{};
   std::vector<void*> allocations;
   std::map<std::string, std::pair<void*, size_t>> named;   // name -> (device ptr, element count)  (doubles unless in int_named)
@@ -390,21 +396,23 @@ struct bpmpc_solver {
     L.buf = buf;
     L.batch = batch;
     L.N = settings.max_nodes;
+    L.k0 = 0;
+    L.klen = settings.max_nodes;
     L.cold = cold ? 1 : 0;
     L.ls = ls;
     return L;
   }
 
-  void time_begin(const char* cls, hipEvent_t* a, hipEvent_t* b) {
+  void time_begin(const char* cls, hipEvent_t* a, hipEvent_t* b, hipStream_t on = nullptr) {
     if (!settings.profile) return;
     HIP_CHECK(hipEventCreate(a));
     HIP_CHECK(hipEventCreate(b));
-    HIP_CHECK(hipEventRecord(*a, stream));
+    HIP_CHECK(hipEventRecord(*a, on ? on : stream));
     (void)cls;
   }
-  void time_end(const char* cls, hipEvent_t a, hipEvent_t b) {
+  void time_end(const char* cls, hipEvent_t a, hipEvent_t b, hipStream_t on = nullptr) {
     if (!settings.profile) return;
-    HIP_CHECK(hipEventRecord(b, stream));
+    HIP_CHECK(hipEventRecord(b, on ? on : stream));
     timers[cls].pending.emplace_back(a, b);
   }
   void collect_timers() {
@@ -427,17 +435,19 @@ struct bpmpc_solver {
   template <int NJ> void stage_project();
   template <int NJ> void stage_riccati();
   template <int NJ> void stage_linesearch();
+  template <int NJ> void pipelined_backward();
   template <int NJ> void run_iterations();
 };
 
-#define TIMED_LAUNCH(cls, kernel, grid, block, L)                                   \
+#define TIMED_LAUNCH_ON(on, cls, kernel, grid, block, L)                            \
   do {                                                                              \
     hipEvent_t ev_a_, ev_b_;                                                        \
-    time_begin(cls, &ev_a_, &ev_b_);                                                \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, L);              \
+    time_begin(cls, &ev_a_, &ev_b_, on);                                            \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, on, L);                  \
     HIP_CHECK(hipGetLastError());                                                   \
-    time_end(cls, ev_a_, ev_b_);                                                    \
+    time_end(cls, ev_a_, ev_b_, on);                                                \
   } while (0)
+#define TIMED_LAUNCH(cls, kernel, grid, block, L) TIMED_LAUNCH_ON(stream, cls, kernel, grid, block, L)
 
 template <int NJ> void bpmpc_solver::stage_prepare() {
   const Launch L = launch_params();
@@ -457,7 +467,7 @@ template <int NJ> void bpmpc_solver::stage_project() {
   if (settings.reference_kernels) TIMED_LAUNCH("project", k_project<NJ>, batch * settings.max_nodes, kWave, L);
   else {
     TIMED_LAUNCH("project_lu", k_project_lu<NJ>, (batch * settings.max_nodes + kLuNodes - 1) / kLuNodes, kWave, L);
-    TIMED_LAUNCH("project", k_project_fast<NJ>, batch * settings.max_nodes, kWave, L);
+    TIMED_LAUNCH("project", k_project_fast<NJ>, batch * L.klen, kWave, L);
   }
 }
 template <int NJ> void bpmpc_solver::stage_riccati() {
@@ -490,12 +500,43 @@ template <int NJ> void bpmpc_solver::stage_linesearch() {
   }
   time_end("linesearch", ev_a, ev_b);
 }
+// Linearisation, projection and Riccati sweep of one SQP iteration with the horizon cut into chunks: the producers
+// (linearise, LU, change of variables) of chunk c+1 run on their own stream while the latency-bound Riccati sweep of
+// chunk c occupies one workgroup per problem.  Only stream/event ordering is used, no device-side waiting.
+template <int NJ> void bpmpc_solver::pipelined_backward() {
+  constexpr int NPW = LinFastCfg<NJ>::NPW;
+  const int chunks = settings.pipeline_chunks;
+  const int n = n_nodes_max;
+  HIP_CHECK(hipEventRecord(ev_go, stream));
+  HIP_CHECK(hipStreamWaitEvent(producer_stream, ev_go, 0));
+  for (int c = 0; c < chunks; ++c) {
+    // chunk c covers [lo, hi), latest stages first
+    const int hi = n - (int)((long long)n * c / chunks), lo = n - (int)((long long)n * (c + 1) / chunks);
+    if (hi <= lo) continue;
+    Launch L = launch_params();
+    L.k0 = lo;
+    L.klen = hi - lo;
+    const int nodes = batch * L.klen;
+    TIMED_LAUNCH_ON(producer_stream, "linearize", k_linearize_fast<NJ>, (nodes + NPW - 1) / NPW, kWave, L);
+    TIMED_LAUNCH_ON(producer_stream, "project_lu", k_project_lu<NJ>, (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
+    TIMED_LAUNCH_ON(producer_stream, "project", k_project_fast<NJ>, nodes, kWave, L);
+    HIP_CHECK(hipEventRecord(ev_chunk[c], producer_stream));
+    HIP_CHECK(hipStreamWaitEvent(stream, ev_chunk[c], 0));
+    if (c == 0) { L.klen = settings.max_nodes - lo; }   // problems on longer grids than n_nodes_max do not exist; keep k_hi >= N
+    TIMED_LAUNCH("riccati", k_riccati_fast<NJ>, batch, kRiccatiThreads, L);
+  }
+}
+
 template <int NJ> void bpmpc_solver::run_iterations() {
   const int iters = ls.max_iterations;
   for (int it = 0; it < iters; ++it) {
-    stage_linearize<NJ>();
-    stage_project<NJ>();
-    stage_riccati<NJ>();
+    if (!settings.reference_kernels && settings.pipeline_chunks > 1) {
+      pipelined_backward<NJ>();
+    } else {
+      stage_linearize<NJ>();
+      stage_project<NJ>();
+      stage_riccati<NJ>();
+    }
     stage_linesearch<NJ>();
   }
 }
@@ -520,6 +561,7 @@ int translate(const std::exception& e) {
 void allocate(bpmpc_solver* s) {
   const size_t B = s->settings.max_batch, N = s->settings.max_nodes, NX = s->nx, NU = s->nu, S = B * N;
   Buffers& b = s->buf;
+  b.ric_carry = s->alloc<double>("ric_carry", B * (NX * NX + NX + 1));
   b.g_kind = s->alloc<int>("g_kind", S, true); b.g_mode = s->alloc<int>("g_mode", S, true); b.g_nodes = s->alloc<int>("g_nodes", B, true);
   b.g_dt = s->alloc<double>("g_dt", S); b.g_start = s->alloc<double>("g_start", S);
   b.g_zref = s->alloc<double>("g_zref", S * 4); b.g_zdref = s->alloc<double>("g_zdref", S * 4);
@@ -686,6 +728,12 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     HIP_CHECK(hipSetDevice(settings->device));
     if (settings->stream) { s->stream = static_cast<hipStream_t>(settings->stream); }
     else { HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
+    if (s->settings.pipeline_chunks <= 0) s->settings.pipeline_chunks = 1;
+    if (s->settings.pipeline_chunks > 16) s->settings.pipeline_chunks = 16;
+    HIP_CHECK(hipStreamCreateWithFlags(&s->producer_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&s->ev_go, hipEventDisableTiming));
+    s->ev_chunk.resize(s->settings.pipeline_chunks);
+    for (auto& e : s->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s->d_model), sizeof(DeviceModel)));
     HIP_CHECK(hipMemcpy(s->d_model, &s->dm, sizeof(DeviceModel), hipMemcpyHostToDevice));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_remaining), sizeof(int)));
@@ -706,6 +754,9 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
 void bpmpc_solver_destroy(bpmpc_solver* s) {
   if (!s) return;
   if (s->stream) hipStreamSynchronize(s->stream);
+  if (s->producer_stream) { hipStreamSynchronize(s->producer_stream); hipStreamDestroy(s->producer_stream); }
+  if (s->ev_go) hipEventDestroy(s->ev_go);
+  for (hipEvent_t e : s->ev_chunk) if (e) hipEventDestroy(e);
   for (void* p : s->allocations) hipFree(p);
   if (s->d_model) hipFree(s->d_model);
   if (s->h_remaining) hipHostFree(s->h_remaining);

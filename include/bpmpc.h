@@ -106,6 +106,10 @@ typedef struct {
   int profile;          /* time every kernel class with HIP events (bpmpc_solver_kernel_time) */
   void* stream;         /* hipStream_t to run on; NULL = a stream owned by the solver */
   int reference_kernels; /* != 0: run the lane-emulation-verified reference kernel bodies instead of the fast variants (debugging) */
+  int pipeline_chunks;  /* > 1: sweep the horizon in that many chunks, the Riccati sweep of one chunk overlapping with the
+                           linearisation/projection of the earlier stages (fast kernels only, results are bit-identical).
+                           0 or 1 = one launch per stage.  Measured on MI355X: no gain (both sides are bound by LDS
+                           bandwidth), so it is off by default; see DESIGN.md. */
 } bpmpc_settings;
 
 typedef struct {

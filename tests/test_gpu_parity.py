@@ -207,3 +207,18 @@ def test_reference_and_fast_kernels_agree(ctx):
     rb = b.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
     assert _rel(ra[1], rb[1]) < 1e-9 and _rel(ra[2], rb[2]) < 1e-9
     assert [s.step_size for s in ra[4]] == [s.step_size for s in rb[4]]
+
+
+def test_pipelined_horizon_chunks_are_bit_identical(ctx):
+    """The chunked horizon pipeline (Riccati sweep of the late stages overlapping with the linearisation / projection of the
+    early ones) only reorders launches: every chunk count must give the same bits, also with grids of different lengths."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    gaits = ["stance", "trot", "standing_trot", "flying_trot"]
+    prob = sc.gait_sweep_problem(itf, gaits, [(0.3, 0.0), (-0.2, 0.3)], n_intervals=60)
+    results = []
+    for chunks in (1, 2, 4, 7, 16):
+        mpc = bp.BatchedSqpMpc(itf, max_batch=8, max_nodes=96, sqp_iterations=2, return_gains=True, pipeline_chunks=chunks)
+        results.append(mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"]))
+    for r in results[1:]:
+        assert np.array_equal(r[1], results[0][1]) and np.array_equal(r[2], results[0][2]) and np.array_equal(r[3], results[0][3])
+        assert [s.step_size for s in r[4]] == [s.step_size for s in results[0][4]]
