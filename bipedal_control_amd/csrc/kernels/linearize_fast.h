@@ -25,23 +25,50 @@ struct LinFastCfg {
   static constexpr int NPW = kWave / LPN;           // nodes per wavefront
 };
 
+// Model constants that the lanes index by their own coordinate, staged once per workgroup.  Reading them from global
+// memory inside the node would put vector loads behind the node's output stores (vmcnt retires in order on this
+// architecture), i.e. every such load would wait for the stores in flight.
+template <int NJ>
+struct LinFastShared {
+  using C = LinFastCfg<NJ>;
+  double Q[C::NX * C::NX], R[C::NU * C::NU];
+  double Rfix[C::NB][9], pfix[C::NB][3], axis[C::NB][3], com[C::NB][3], inertia[C::NB][6], mass[C::NB];
+  int depth[C::NB];
+  unsigned subtree[C::NB];
+  int path[C::NB][NJ];
+};
+template <int NJ>
+__device__ __forceinline__ void load_shared_model(const DeviceModel& md, LinFastShared<NJ>& sh, int tid, int nthreads) {
+  using C = LinFastCfg<NJ>;
+  for (int i = tid; i < C::NX * C::NX; i += nthreads) { sh.Q[i] = md.Q[i]; sh.R[i] = md.R[i]; }
+  for (int i = tid; i < C::NB * 9; i += nthreads) sh.Rfix[i / 9][i % 9] = md.Rfix[i / 9][i % 9];
+  for (int i = tid; i < C::NB * 6; i += nthreads) sh.inertia[i / 6][i % 6] = md.inertia[i / 6][i % 6];
+  for (int i = tid; i < C::NB * 3; i += nthreads) {
+    sh.pfix[i / 3][i % 3] = md.pfix[i / 3][i % 3];
+    sh.axis[i / 3][i % 3] = md.axis[i / 3][i % 3];
+    sh.com[i / 3][i % 3] = md.com[i / 3][i % 3];
+  }
+  for (int i = tid; i < C::NB; i += nthreads) { sh.mass[i] = md.mass[i]; sh.depth[i] = md.depth[i]; sh.subtree[i] = md.subtree[i]; }
+  for (int i = tid; i < C::NB * NJ; i += nthreads) sh.path[i / NJ][i % NJ] = md.path[i / NJ][i % NJ];
+}
+
 template <int NJ>
 struct LinFastNodeLds {
   using C = LinFastCfg<NJ>;
   // node inputs, staged once so that nothing is loaded from global memory after the first output store
-  double x[C::NX], u[C::NU], xnext[C::NX], xref[C::NX], zref[kNumContacts], zdref[kNumContacts];
+  double x[C::NX], u[C::NU], zref[kNumContacts], zdref[kNumContacts];
   union {                        // chain tables (dead after the walks)  <->  second-stage block and cost vectors
-    double T[C::G][12];          // joint-local transform of body g-5: E (9) | pfix (3)
+    double T[NJ][12];            // joint-local transform of joint g-6: E (9) | pfix (3)
     struct { double a2[9][12]; double dx[C::NX], du[C::NU]; };   // rows 3..11, x columns 0..11 of the stage-two Jacobian
   };
   union {
     double comp[C::NB][10];      // per body mass / first moment / inertia about o0
     double hb[C::NB][6];         // per body momentum about o0
   };
-  double og[C::G][3];            // joint origins
-  double wv[C::G][3];            // a_g * v_g
+  double og[C::G - 3][3];        // joint origins (coordinates 3..)
+  double wv[C::G - 3][3];        // a_g * v_g
   double cpos[kNumContacts][3], cvel[kNumContacts][3];
-  double cone[kNumContacts][16];
+  double cone[kNumContacts][13];
   // node-level results of the two stages: A_b^{-1} blocks, 1/m, contact points and com
   double X12[2][9], X22[2][9], cps[2][kNumContacts][3], com[2][3];
   // parked stage-one columns: rows 3..11 of column 6+g and rows 6..11 of the joint-velocity column of lane g
@@ -123,7 +150,7 @@ struct LaneKin {    // what the contact part needs from the evaluation
 // One evaluation of the centroidal dynamics for the node owned by this lane group.  `stage` selects where the node-level
 // results (A_b^{-1} blocks, contact points, com) are kept in LDS.
 template <int NJ, bool DERIV = true, bool TWIST = true>
-__device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<NJ>& nl, int stage, const LaneBody& lb, const int* path, int g,
+__device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ>& nl, int stage, const LaneBody& lb, const int* path, int g,
                                           const double (&xh)[6], const double (&pb)[3], double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin) {
   using C = LinFastCfg<NJ>;
   constexpr int NB = C::NB, G = C::G, LPN = C::LPN;
@@ -137,15 +164,15 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
   kin.sy = sy; kin.cy = cy; kin.sp = sp; kin.cp = cp;
   // ---- joint-local transforms to LDS, chain walk
   if (is_joint) {
-    const double* a = md.axis[lb.body];
+    const double* a = sh.axis[lb.body];
     const double v = 1.0 - cg;
     const double rot[9] = {cg + v * a[0] * a[0],        v * a[0] * a[1] - sg * a[2], v * a[0] * a[2] + sg * a[1],
                            v * a[1] * a[0] + sg * a[2], cg + v * a[1] * a[1],        v * a[1] * a[2] - sg * a[0],
                            v * a[2] * a[0] - sg * a[1], v * a[2] * a[1] + sg * a[0], cg + v * a[2] * a[2]};
     double E[9];
-    mat3_mul(md.Rfix[lb.body], rot, E);
-    for (int i = 0; i < 9; ++i) nl.T[g][i] = E[i];
-    for (int i = 0; i < 3; ++i) nl.T[g][9 + i] = md.pfix[lb.body][i];
+    mat3_mul(sh.Rfix[lb.body], rot, E);
+    for (int i = 0; i < 9; ++i) nl.T[g - 6][i] = E[i];
+    for (int i = 0; i < 3; ++i) nl.T[g - 6][9 + i] = sh.pfix[lb.body][i];
   }
   lds_wave_sync();
   double R[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
@@ -155,7 +182,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
 #pragma nounroll
   for (int d = 0; d < maxdepth; ++d) {
     const bool on = is_joint && d < lb.depth;
-    const int gj = on ? 5 + path[d] : 6;
+    const int gj = on ? path[d] - 1 : 0;   // joint index (0-based) of the d-th body on the chain
     double Ej[9], pj[3], t[3], Rn[9];
     for (int i = 0; i < 9; ++i) Ej[i] = nl.T[gj][i];
     for (int i = 0; i < 3; ++i) pj[i] = nl.T[gj][9 + i];
@@ -170,15 +197,15 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
   else if (g == 3) { ah[2] = 1.0; }
   else if (g == 4) { ah[0] = -sy; ah[1] = cy; }
   else if (g == 5) { ah[0] = cy * cp; ah[1] = sy * cp; ah[2] = -sp; }
-  else if (g < G) mat3_vec(R, md.axis[lb.body], ah);
+  else if (g < G) mat3_vec(R, sh.axis[lb.body], ah);
   for (int i = 0; i < 3; ++i) { kin.ah[i] = ah[i]; kin.og[i] = o[i]; }
   // ---- body quantities, contact positions
   double cw[3] = {0.0, 0.0, 0.0}, Iwb[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (is_body) {
     double cb[3], d[3];
-    mat3_vec(R, md.com[lb.body], cb);
+    mat3_vec(R, sh.com[lb.body], cb);
     for (int i = 0; i < 3; ++i) { cw[i] = cb[i] + o[i]; d[i] = cw[i] - pb[i]; }
-    const double* I = md.inertia[lb.body];
+    const double* I = sh.inertia[lb.body];
     const double Ib[9] = {I[0], I[1], I[2], I[1], I[3], I[4], I[2], I[4], I[5]};
     double T[9];
     mat3_mul(R, Ib, T);
@@ -188,7 +215,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
     Iwb[3] = T[3] * R[3] + T[4] * R[4] + T[5] * R[5];
     Iwb[4] = T[3] * R[6] + T[4] * R[7] + T[5] * R[8];
     Iwb[5] = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
-    const double m = md.mass[lb.body];
+    const double m = sh.mass[lb.body];
     const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
     double* cm = nl.comp[lb.body];
     cm[0] = m;
@@ -285,22 +312,22 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
   if constexpr (TWIST) {
   // ---- twists: omega_g = sum over the revolute ancestors (self included) of a v, v_og = velocity of the joint origin
   if (g >= 3 && g < G) {
-    for (int i = 0; i < 3; ++i) { nl.wv[g][i] = ah[i] * vg; nl.og[g][i] = o[i]; }
+    for (int i = 0; i < 3; ++i) { nl.wv[g - 3][i] = ah[i] * vg; nl.og[g - 3][i] = o[i]; }
   }
   lds_wave_sync();
   {
     const int top = g < 3 ? 2 : (g < 6 ? g : 5);        // Euler joints up to the own one (joints and bodies: all three)
     for (int k = 3; k <= 5; ++k) {
       const double sel = k <= top ? 1.0 : 0.0;
-      for (int i = 0; i < 3; ++i) om[i] += sel * nl.wv[k][i];
+      for (int i = 0; i < 3; ++i) om[i] += sel * nl.wv[k - 3][i];
     }
     double prev[3] = {pb[0], pb[1], pb[2]};
 #pragma nounroll
     for (int d = 0; d < maxdepth; ++d) {
       const bool on = is_joint && d < lb.depth;
-      const int gj = on ? 5 + path[d] : 6;
-      const double oj[3] = {nl.og[gj][0], nl.og[gj][1], nl.og[gj][2]};
-      const double wj[3] = {nl.wv[gj][0], nl.wv[gj][1], nl.wv[gj][2]};
+      const int gj = on ? path[d] - 1 : 0;   // joint index (0-based) of the d-th body on the chain
+      const double oj[3] = {nl.og[gj + 3][0], nl.og[gj + 3][1], nl.og[gj + 3][2]};
+      const double wj[3] = {nl.wv[gj + 3][0], nl.wv[gj + 3][1], nl.wv[gj + 3][2]};
       const double r[3] = {oj[0] - prev[0], oj[1] - prev[1], oj[2] - prev[2]};
       double t[3];
       cross3(om, r, t);
@@ -319,7 +346,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
     const double rc[3] = {cw[0] - o[0], cw[1] - o[1], cw[2] - o[2]};
     double t[3], l[3], Iw[3], L[3];
     cross3(om, rc, t);
-    const double mb = md.mass[lb.body];
+    const double mb = sh.mass[lb.body];
     for (int i = 0; i < 3; ++i) l[i] = mb * (vo[i] + t[i]);
     sym3_mul(Iwb, om, Iw);
     const double d0[3] = {cw[0] - pb[0], cw[1] - pb[1], cw[2] - pb[2]};
@@ -395,8 +422,15 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, LinFastNodeLds<
 }
 
 template <int NJ>
-__device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNodeLds<NJ>& nl, const int (*path_table)[NJ], bool valid,
+__device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ>& nl, bool valid,
                                                const NodeInputs& in, const NodeLQOut& out, int g) {
+#ifdef BPMPC_LINFAST_PROFILE
+  long long lf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long lf_prev = clock64();
+#define LFPROF(slot) do { const long long tn_ = clock64(); lf_t[slot] += tn_ - lf_prev; lf_prev = tn_; } while (0)
+#else
+#define LFPROF(slot) ((void)0)
+#endif
   using C = LinFastCfg<NJ>;
   constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN;
   if (!valid) return;
@@ -422,16 +456,19 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
   const int mode = in.mode;
   const double mass_total = md.robot_mass, imt = 1.0 / md.robot_mass;
   // ---- stage the node inputs in LDS: after this block nothing is read from global memory except model constants
-  for (int idx = g; idx < NX; idx += LPN) { nl.x[idx] = in.x[idx]; nl.u[idx] = in.u[idx]; nl.xnext[idx] = in.xnext[idx]; nl.xref[idx] = in.xref[idx]; }
+  for (int idx = g; idx < NX; idx += LPN) { nl.x[idx] = in.x[idx]; nl.u[idx] = in.u[idx]; }
+  // the entries of x_next and x_ref this lane needs later (rows 6+g and g)
+  const double xn_q = g < G ? in.xnext[6 + g] : 0.0, xn_h = g < 6 ? in.xnext[g] : 0.0;
+  const double xr_q = g < G ? in.xref[6 + g] : 0.0, xr_h = g < 6 ? in.xref[g] : 0.0;
   if (g < kNumContacts) { nl.zref[g] = in.zref[g]; nl.zdref[g] = in.zdref[g]; }
   LaneBody lb;
   {
     const int body = (g >= 5 && g < G) ? g - 5 : 0;
     lb.body = body;
-    lb.depth = md.depth[body];
-    lb.subtree = md.subtree[body];     // lanes below 5 move the whole robot (body 0's subtree)
+    lb.depth = sh.depth[body];
+    lb.subtree = sh.subtree[body];     // lanes below 5 move the whole robot (body 0's subtree)
   }
-  const int* path = path_table[lb.body];
+  const int* path = sh.path[lb.body];
   lds_wave_sync();
   double xh[6], pb[3];
   for (int i = 0; i < 6; ++i) xh[i] = nl.x[i];
@@ -439,9 +476,11 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
   const double qg = g < G ? nl.x[6 + g] : 0.0;
   const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
 
+  LFPROF(0);
   LaneEval e1;
   LaneKin<NJ> kin;
-  eval_lane<NJ, true, true>(md, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
+  eval_lane<NJ, true, true>(md, sh, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
+  LFPROF(1);
   // park the stage-one columns in LDS for the RK2 combination
   for (int rr = 0; rr < 9; ++rr) nl.park[g][rr] = e1.ar_q[rr];
   for (int rr = 0; rr < 6; ++rr) nl.park[g][9 + rr] = e1.br_j[rr];
@@ -527,6 +566,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
     if (g == 0) out.e[row] = 0.0;
   }
 
+  LFPROF(2);
   // =========================== second RK2 stage ===========================
   LaneEval e2;
   {
@@ -535,8 +575,9 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
     for (int i = 0; i < 3; ++i) pb2[i] = pb[i] + dt * kin.vb[i];
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
-    eval_lane<NJ, true, true>(md, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
+    eval_lane<NJ, true, true>(md, sh, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
   }
+  LFPROF(3);
   // A2[rows 3..11][x columns 0..11] to LDS (a2 shares storage with the chain tables, dead now): columns 0..5 are the
   // momentum columns of lanes 0..5, columns 6..11 the q columns of lanes 0..5
   lds_wave_sync();
@@ -584,19 +625,20 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
   // b = x + dt/2 (f1 + f2) - x_next
   double dyn_sse = 0.0;
   if (g < G) {
-    const double bb = qg + hdt * v1g + hdt * e2.vg - nl.xnext[6 + g];
+    const double bb = qg + hdt * v1g + hdt * e2.vg - xn_q;
     out.b[6 + g] = bb;
     dyn_sse += bb * bb;
   }
   if (g < 6) {
-    const double bb = lane_pick6(xh, g) + hdt * f1h_g + hdt * lane_pick6(e2.fh, g) - nl.xnext[g];
+    const double bb = lane_pick6(xh, g) + hdt * f1h_g + hdt * lane_pick6(e2.fh, g) - xn_h;
     out.b[g] = bb;
     dyn_sse += bb * bb;
   }
+  LFPROF(4);
   // =========================== cost ===========================
   lds_wave_sync();   // a2 is dead: its storage becomes dx / du
-  if (g < G) nl.dx[6 + g] = qg - nl.xref[6 + g];
-  if (g < 6) nl.dx[g] = lane_pick6(xh, g) - nl.xref[g];
+  if (g < G) nl.dx[6 + g] = qg - xr_q;
+  if (g < 6) nl.dx[g] = lane_pick6(xh, g) - xr_h;
   if (g < 12) nl.du[g] = nl.u[g] - nominal_input(md, mode, g);
   if (is_joint) nl.du[12 + g - 6] = ujg;
   lds_wave_sync();
@@ -610,11 +652,11 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
     for (int r = 0; r < NX; ++r) {
       const double dxr = nl.dx[r], dur = nl.du[r];
       // gradient entries use row c of the weight (as the reference kernel), the written element is (r, c)
-      if (g < G) { accq += md.Q[cq * NX + r] * dxr; out.Q[r * NX + cq] = dt * (md.Q[r * NX + cq] + (r == cq ? shift : 0.0)); }
-      if (g < 6) { acch += md.Q[ch * NX + r] * dxr; out.Q[r * NX + ch] = dt * (md.Q[r * NX + ch] + (r == ch ? shift : 0.0)); }
+      if (g < G) { accq += sh.Q[cq * NX + r] * dxr; out.Q[r * NX + cq] = dt * (sh.Q[r * NX + cq] + (r == cq ? shift : 0.0)); }
+      if (g < 6) { acch += sh.Q[ch * NX + r] * dxr; out.Q[r * NX + ch] = dt * (sh.Q[r * NX + ch] + (r == ch ? shift : 0.0)); }
       if (g < 12) {
-        accf += md.R[cf * NU + r] * dur;
-        double w = md.R[r * NU + cf];
+        accf += sh.R[cf * NU + r] * dur;
+        double w = sh.R[r * NU + cf];
         if (r == cf) w += shift;
         if (stance_flag(mode, cf / 3) && r < 12 && r / 3 == cf / 3) {
           const double* cn = nl.cone[r / 3];
@@ -625,7 +667,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
         }
         out.R[r * NU + cf] = dt * w;
       }
-      if (is_joint) { accj += md.R[cj * NU + r] * dur; out.R[r * NU + cj] = dt * (md.R[r * NU + cj] + (r == cj ? shift : 0.0)); }
+      if (is_joint) { accj += sh.R[cj * NU + r] * dur; out.R[r * NU + cj] = dt * (sh.R[r * NU + cj] + (r == cj ? shift : 0.0)); }
     }
     if (g < G) { out.q[cq] = dt * accq; cost += 0.5 * nl.dx[cq] * accq; }
     if (g < 6) { out.q[ch] = dt * acch; cost += 0.5 * nl.dx[ch] * acch; }
@@ -645,12 +687,17 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, LinFastNod
     out.nc[0] = nc;
     out.perf[0] = dt * cost; out.perf[1] = dt * dyn_sse; out.perf[2] = dt * eq_sse;
   }
+  LFPROF(5);
+#ifdef BPMPC_LINFAST_PROFILE
+  if (out.prof && g == 0)
+    for (int i = 0; i < 8; ++i) out.prof[i] = (double)lf_t[i];
+#endif
 }
 
 // Value-only metrics of x + alpha dx, u + alpha du at one node for the filter line search (same lane layout as
 // linearize_fast; reference version: trial_node in linesearch.h).
 template <int NJ>
-__device__ __forceinline__ void trial_fast(const DeviceModel& md, LinFastNodeLds<NJ>& nl, const int (*path_table)[NJ], bool valid,
+__device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ>& nl, bool valid,
                                            const NodeInputs& in, double alpha, const double* dx, const double* du, const double* dxn,
                                            double* perf, int g) {
   using C = LinFastCfg<NJ>;
@@ -672,18 +719,18 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, LinFastNodeLds
   for (int idx = g; idx < NX; idx += LPN) {
     nl.x[idx] = in.x[idx] + alpha * dx[idx];
     nl.u[idx] = in.u[idx] + alpha * du[idx];
-    nl.xnext[idx] = in.xnext[idx] + alpha * dxn[idx];
-    nl.xref[idx] = in.xref[idx];
   }
+  const double xn_q = g < G ? in.xnext[6 + g] + alpha * dxn[6 + g] : 0.0, xn_h = g < 6 ? in.xnext[g] + alpha * dxn[g] : 0.0;
+  const double xr_q = g < G ? in.xref[6 + g] : 0.0, xr_h = g < 6 ? in.xref[g] : 0.0;
   if (g < kNumContacts) { nl.zref[g] = in.zref[g]; nl.zdref[g] = in.zdref[g]; }
   LaneBody lb;
   {
     const int body = (g >= 5 && g < G) ? g - 5 : 0;
     lb.body = body;
-    lb.depth = md.depth[body];
-    lb.subtree = md.subtree[body];
+    lb.depth = sh.depth[body];
+    lb.subtree = sh.subtree[body];
   }
-  const int* path = path_table[lb.body];
+  const int* path = sh.path[lb.body];
   lds_wave_sync();
   double xh[6], pb[3];
   for (int i = 0; i < 6; ++i) xh[i] = nl.x[i];
@@ -692,7 +739,7 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, LinFastNodeLds
   const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
   LaneEval e1;
   LaneKin<NJ> kin;
-  eval_lane<NJ, false, true>(md, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
+  eval_lane<NJ, false, true>(md, sh, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
   if (g >= 5 && g < G)
     for (int i = 0; i < kNumContacts; ++i)
       if (md.contact_body[i] == lb.body) {
@@ -728,21 +775,21 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, LinFastNodeLds
     for (int i = 0; i < 3; ++i) pb2[i] = pb[i] + dt * kin.vb[i];
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
-    eval_lane<NJ, false, false>(md, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
+    eval_lane<NJ, false, false>(md, sh, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
   }
   double dyn_sse = 0.0;
   if (g < G) {
-    const double bb = qg + hdt * e1.vg + hdt * e2.vg - nl.xnext[6 + g];
+    const double bb = qg + hdt * e1.vg + hdt * e2.vg - xn_q;
     dyn_sse += bb * bb;
   }
   if (g < 6) {
     const double f1 = lane_pick6(e1.fh, g), f2 = lane_pick6(e2.fh, g);
-    const double bb = lane_pick6(xh, g) + hdt * f1 + hdt * f2 - nl.xnext[g];
+    const double bb = lane_pick6(xh, g) + hdt * f1 + hdt * f2 - xn_h;
     dyn_sse += bb * bb;
   }
   lds_wave_sync();   // the chain tables are dead: their storage becomes dx / du
-  if (g < G) nl.dx[6 + g] = qg - nl.xref[6 + g];
-  if (g < 6) nl.dx[g] = lane_pick6(xh, g) - nl.xref[g];
+  if (g < G) nl.dx[6 + g] = qg - xr_q;
+  if (g < 6) nl.dx[g] = lane_pick6(xh, g) - xr_h;
   if (g < 12) nl.du[g] = nl.u[g] - nominal_input(md, mode, g);
   if (is_joint) nl.du[12 + g - 6] = ujg;
   lds_wave_sync();
@@ -752,10 +799,10 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, LinFastNodeLds
     double accq = 0.0, acch = 0.0, accf = 0.0, accj = 0.0;
     for (int r = 0; r < NX; ++r) {
       const double dxr = nl.dx[r], dur = nl.du[r];
-      if (g < G) accq += md.Q[cq * NX + r] * dxr;
-      if (g < 6) acch += md.Q[ch * NX + r] * dxr;
-      if (g < 12) accf += md.R[cf * NU + r] * dur;
-      if (is_joint) accj += md.R[cj * NU + r] * dur;
+      if (g < G) accq += sh.Q[cq * NX + r] * dxr;
+      if (g < 6) acch += sh.Q[ch * NX + r] * dxr;
+      if (g < 12) accf += sh.R[cf * NU + r] * dur;
+      if (is_joint) accj += sh.R[cj * NU + r] * dur;
     }
     if (g < G) cost += 0.5 * nl.dx[cq] * accq;
     if (g < 6) cost += 0.5 * nl.dx[ch] * acch;

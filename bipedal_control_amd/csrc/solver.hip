@@ -132,8 +132,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   using C = LinFastCfg<NJ>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
   __shared__ LinFastNodeLds<NJ> lds[NPW];
-  __shared__ int path_table[NJ + 1][NJ];   // chain tables of the model, shared by the nodes of the wave
-  for (int idx = threadIdx.x; idx < (NJ + 1) * NJ; idx += kWave) path_table[idx / NJ][idx % NJ] = L.model->path[idx / NJ][idx % NJ];
+  __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the wave
+  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kWave);
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
   const int widx = blockIdx.x * NPW + sub;   // batch * max_nodes < 2^31 is checked at creation
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   out.q = L.buf.q + s * NX; out.r = L.buf.r + s * NU; out.c = L.buf.c + s;
   out.C = L.buf.C + s * kMaxEqRows * NX; out.D = L.buf.D + s * kMaxEqRows * NU; out.e = L.buf.e + s * kMaxEqRows;
   out.nc = L.buf.nc + s; out.perf = L.buf.perf + s * 3;
-  linearize_fast<NJ>(*L.model, lds[sub], path_table, valid, in, out, g);
+  out.prof = (valid && b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
+  linearize_fast<NJ>(*L.model, shared, lds[sub], valid, in, out, g);
 }
 
 template <int NJ>
@@ -326,8 +327,8 @@ __global__ __launch_bounds__(kWave) void k_trial_fast(Launch L) {
   using C = LinFastCfg<NJ>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
   __shared__ LinFastNodeLds<NJ> lds[NPW];
-  __shared__ int path_table[NJ + 1][NJ];
-  for (int idx = threadIdx.x; idx < (NJ + 1) * NJ; idx += kWave) path_table[idx / NJ][idx % NJ] = L.model->path[idx / NJ][idx % NJ];
+  __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the wave
+  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kWave);
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
   const int widx = blockIdx.x * NPW + sub;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(kWave) void k_trial_fast(Launch L) {
   const size_t s = valid ? (size_t)b * L.N + k : 0;
   const NodeInputs in = node_inputs<NJ>(L, b, k);
   const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
-  trial_fast<NJ>(*L.model, lds[sub], path_table, valid, in, L.buf.alpha[b], dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
+  trial_fast<NJ>(*L.model, shared, lds[sub], valid, in, L.buf.alpha[b], dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
 }
 
 template <int NJ>
