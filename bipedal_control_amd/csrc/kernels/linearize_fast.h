@@ -437,7 +437,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   if (in.kind == 1) {  // event node: identity jump map, no input, no cost (LPN lanes write the node)
     double d2 = 0.0;
     for (int idx = g; idx < NX * NX; idx += LPN) { out.A[idx] = (idx / NX == idx % NX) ? 1.0 : 0.0; out.Q[idx] = 0.0; }
-    for (int idx = g; idx < NX * NU; idx += LPN) { out.B[idx] = 0.0; out.P[idx] = 0.0; }
+    for (int idx = g; idx < NX * NU; idx += LPN) { out.B[idx] = 0.0; }
     for (int idx = g; idx < NU * NU; idx += LPN) out.R[idx] = 0.0;
     for (int idx = g; idx < kMaxEqRows * NX; idx += LPN) out.C[idx] = 0.0;
     for (int idx = g; idx < kMaxEqRows * NU; idx += LPN) out.D[idx] = 0.0;
@@ -679,7 +679,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     if (is_joint) { out.r[cj] = dt * accj; cost += 0.5 * nl.du[cj] * accj; }
     if (g < kNumContacts && stance_flag(mode, g)) cost += nl.cone[g][1];
   }
-  for (int idx = g; idx < NU * NX; idx += LPN) out.P[idx] = 0.0;
+  // P (cost cross term) is structurally zero for this problem: the buffer is zero-filled once at allocation and never written
   cost = node_allreduce_add<LPN>(cost);
   dyn_sse = node_allreduce_add<LPN>(dyn_sse);
   if (g == 0) {
