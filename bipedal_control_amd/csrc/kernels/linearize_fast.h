@@ -149,9 +149,18 @@ struct LaneKin {    // what the contact part needs from the evaluation
 
 // One evaluation of the centroidal dynamics for the node owned by this lane group.  `stage` selects where the node-level
 // results (A_b^{-1} blocks, contact points, com) are kept in LDS.
+#ifdef BPMPC_EVAL_PROFILE
+#define EVPROF(slot) do { if (evp) { const long long tn_ = clock64(); evp[slot] += tn_ - evp[9]; evp[9] = tn_; } } while (0)
+#else
+#define EVPROF(slot) ((void)0)
+#endif
 template <int NJ, bool DERIV = true, bool TWIST = true>
 __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ>& nl, int stage, const LaneBody& lb, const int* path, int g,
-                                          const double (&xh)[6], const double (&pb)[3], double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin) {
+                                          const double (&xh)[6], const double (&pb)[3], double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin,
+                                          long long* evp = nullptr) {
+#ifdef BPMPC_EVAL_PROFILE
+  if (evp) evp[9] = clock64();
+#endif
   using C = LinFastCfg<NJ>;
   constexpr int NB = C::NB, G = C::G, LPN = C::LPN;
   const bool is_joint = g >= 6 && g < G, is_body = g >= 5 && g < G;
@@ -162,6 +171,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
   const double sy = __shfl(sg, 3, LPN), cy = __shfl(cg, 3, LPN), sp = __shfl(sg, 4, LPN), cp = __shfl(cg, 4, LPN), sr = __shfl(sg, 5, LPN),
                cr = __shfl(cg, 5, LPN);
   kin.sy = sy; kin.cy = cy; kin.sp = sp; kin.cp = cp;
+  EVPROF(0);
   // ---- joint-local transforms to LDS, chain walk
   if (is_joint) {
     const double* a = sh.axis[lb.body];
@@ -199,6 +209,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
   else if (g == 5) { ah[0] = cy * cp; ah[1] = sy * cp; ah[2] = -sp; }
   else if (g < G) mat3_vec(R, sh.axis[lb.body], ah);
   for (int i = 0; i < 3; ++i) { kin.ah[i] = ah[i]; kin.og[i] = o[i]; }
+  EVPROF(1);
   // ---- body quantities, contact positions
   double cw[3] = {0.0, 0.0, 0.0}, Iwb[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (is_body) {
@@ -234,6 +245,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
       }
   }
   lds_wave_sync();
+  EVPROF(2);
   // ---- subtree sums -> composite mass, com, inertia about the composite com (lanes below 5 see the whole robot)
   double s[10];
   for (int c = 0; c < 10; ++c) s[c] = 0.0;
@@ -253,6 +265,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
   const double Mtot = __shfl(Mc, 5, LPN);
   const double com[3] = {__shfl(Cc[0], 5, LPN), __shfl(Cc[1], 5, LPN), __shfl(Cc[2], 5, LPN)};
   if (g == 0) for (int i = 0; i < 3; ++i) nl.com[stage][i] = com[i];
+  EVPROF(3);
   // ---- centroidal momentum matrix column
   double Ac[6];
   if (g < 3) {
@@ -267,6 +280,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
     for (int i = 0; i < 3; ++i) { Ac[i] = Mc * vC[i]; Ac[3 + i] = Iw[i] + Mc * t[i]; }
   }
   if (g >= G) for (int i = 0; i < 6; ++i) Ac[i] = 0.0;
+  EVPROF(3);
   // ---- base velocity: rhs = m hbar - A_j v_j, A_b^{-1} blocks (kept in LDS, every later use re-reads them)
   const double im = 1.0 / Mtot;
   double th[3], pd[3];
@@ -295,6 +309,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
   for (int i = 0; i < 3; ++i) { kin.vb[i] = pd[i]; kin.vb[3 + i] = th[i]; }
   const double vg = g == 0 ? pd[0] : g == 1 ? pd[1] : g == 2 ? pd[2] : g == 3 ? th[0] : g == 4 ? th[1] : g == 5 ? th[2] : (g < G ? ujg : 0.0);
   ev.vg = vg;
+  EVPROF(4);
   // ---- flow map rows 0..5
   {
     double lin[3] = {0.0, 0.0, -9.81 * mass_total}, ang[3] = {0.0, 0.0, 0.0};
@@ -310,6 +325,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
   }
   double om[3] = {0.0, 0.0, 0.0}, vo[3] = {pd[0], pd[1], pd[2]};
   if constexpr (TWIST) {
+  EVPROF(4);
   // ---- twists: omega_g = sum over the revolute ancestors (self included) of a v, v_og = velocity of the joint origin
   if (g >= 3 && g < G) {
     for (int i = 0; i < 3; ++i) { nl.wv[g - 3][i] = ah[i] * vg; nl.og[g - 3][i] = o[i]; }
@@ -341,6 +357,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
   for (int i = 0; i < 3; ++i) { kin.omg[i] = om[i]; kin.vog[i] = vo[i]; }
   }
   if constexpr (DERIV) {
+  EVPROF(5);
   // ---- body momenta about o0 (hb shares LDS with comp, which is dead now), subtree momenta
   if (is_body) {
     const double rc[3] = {cw[0] - o[0], cw[1] - o[1], cw[2] - o[2]};
@@ -361,6 +378,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
     for (int c = 0; c < 6; ++c) hs[c] += sel * nl.hb[m][c];
   }
   const double ltot[3] = {__shfl(hs[0], 5, LPN), __shfl(hs[1], 5, LPN), __shfl(hs[2], 5, LPN)};
+  EVPROF(6);
   // ---- column 6+g: d(A v)/dq_g -> d v_base/dq_g, angular-momentum-rate row; joint-velocity column
   {
     double dl[3] = {0.0, 0.0, 0.0}, dL[3] = {0.0, 0.0, 0.0};
@@ -419,6 +437,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
     for (int r = 0; r < 3; ++r) ev.ar_q[r] = acc[r] * imt;
   }
   }
+  EVPROF(7);
 }
 
 template <int NJ>
@@ -479,7 +498,12 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   LFPROF(0);
   LaneEval e1;
   LaneKin<NJ> kin;
+#ifdef BPMPC_EVAL_PROFILE
+  long long evacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  eval_lane<NJ, true, true>(md, sh, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin, evacc);
+#else
   eval_lane<NJ, true, true>(md, sh, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
+#endif
   LFPROF(1);
   // park the stage-one columns in LDS for the RK2 combination
   for (int rr = 0; rr < 9; ++rr) nl.park[g][rr] = e1.ar_q[rr];
@@ -691,6 +715,10 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
 #ifdef BPMPC_LINFAST_PROFILE
   if (out.prof && g == 0)
     for (int i = 0; i < 8; ++i) out.prof[i] = (double)lf_t[i];
+#endif
+#ifdef BPMPC_EVAL_PROFILE
+  if (out.prof && g == 0)
+    for (int i = 0; i < 8; ++i) out.prof[i] = (double)evacc[i];
 #endif
 }
 

@@ -78,6 +78,17 @@ __device__ __forceinline__ d2 lds_pair(const double* p) {  // 16-byte aligned pa
   return d2{v.x, v.y};
 }
 
+// 1 / x from v_rcp_f64 and two Newton steps (full double precision for normal x; the IEEE division sequence is several
+// times longer and sits on the critical path of every elimination step)
+__device__ __forceinline__ double fast_reciprocal(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
 // Gauss-Jordan on the columns held by the lanes of one wave: lane c owns column c of [H | G g] in v[0..ROWS), ROWS >= nt;
 // afterwards the lanes >= nt hold H^-1 times their column.  Returns false on a non-positive pivot.
 template <int ROWS>
@@ -90,12 +101,88 @@ __device__ __forceinline__ bool gauss_jordan_wave(double (&v)[ROWS], int nt) {
 #pragma unroll
       for (int i = 0; i < ROWS; ++i) f[i] = readlane_f64(v[i], p);
       ok = ok && (f[p] > 0.0);
-      const double row = v[p] * (1.0 / f[p]);
+      const double row = v[p] * fast_reciprocal(f[p]);
 #pragma unroll
       for (int i = 0; i < ROWS; ++i) v[i] = (i == p) ? row : v[i] - f[i] * row;
     }
   }
   return ok;
+}
+
+// Forward roll-out dx_{k+1} = Acl_k dx_k + bcl_k (wave 0, one row per lane, next row prefetched), then
+// du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms.
+template <int NJ>
+__device__ __forceinline__ void riccati_rollout(double (&wsdx)[2][12 + NJ], int status, const RiccatiFastIO& io) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ, NT = kRiccatiThreads;
+  constexpr int NXX = NX * NX, NXU = NX * NU;
+  const int tid = threadIdx.x;
+  const int N = io.base.N;
+  // ---- forward roll-out: dx_{k+1} = Acl_k dx_k + bcl_k (wave 0, one row per lane, next row prefetched)
+  if (tid < NX) { const double v = io.base.dx0[tid]; wsdx[0][tid] = v; io.base.dx[tid] = v; }
+  __syncthreads();
+  if (tid < kWave) {
+    double row[NX], nrow[NX], bc = 0.0, nbc = 0.0;
+    if (tid < NX && N > 0) {
+#pragma unroll
+      for (int l = 0; l < NX; ++l) row[l] = io.Acl[(size_t)tid * NX + l];
+      bc = io.bcl[tid];
+    }
+    for (int k = 0; k < N; ++k) {
+      if (tid < NX && k + 1 < N) {
+        const double* nr = io.Acl + (size_t)(k + 1) * NXX + (size_t)tid * NX;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) nrow[l] = nr[l];
+        nbc = io.bcl[(size_t)(k + 1) * NX + tid];
+      }
+      if (tid < NX) {
+        const double* cur = wsdx[k & 1];
+        double t = bc;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) t += row[l] * cur[l];
+        wsdx[(k + 1) & 1][tid] = t;
+        io.base.dx[(size_t)(k + 1) * NX + tid] = t;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) row[l] = nrow[l];
+        bc = nbc;
+      }
+      lds_wave_sync();
+    }
+  }
+  __syncthreads();
+  // ---- du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms
+  double acc_arm = 0.0, acc_x = 0.0, acc_u = 0.0;
+  for (int idx = tid; idx < N * NU; idx += NT) {
+    const int k = idx / NU, i = idx % NU;
+    const double* dxk = io.base.dx + (size_t)k * NX;
+    const double* Kr = io.Kfull + (size_t)k * NXU + (size_t)i * NX;
+    double t = io.kff[(size_t)k * NU + i];
+#pragma unroll
+    for (int l = 0; l < NX; ++l) t += Kr[l] * dxk[l];
+    if (io.base.nut[k] == 0) t = 0.0;   // event node: no input
+    io.base.du[idx] = t;
+    acc_u += t * t;
+    const double d = dxk[i];            // NU == NX: the same index walks the state vector
+    acc_x += d * d;
+    acc_arm += io.mvec[(size_t)k * NX + i] * d;
+    if (i == 0) acc_arm += io.mscal[k];
+  }
+  if (tid < NX) { const double d = io.base.dx[(size_t)N * NX + tid]; acc_x += d * d; }
+  __shared__ double red3[3][kRiccatiThreads / kWave];
+  for (int off = kWave / 2; off >= 1; off >>= 1) {
+    acc_arm += __shfl_down(acc_arm, off);
+    acc_x += __shfl_down(acc_x, off);
+    acc_u += __shfl_down(acc_u, off);
+  }
+  if ((tid & (kWave - 1)) == 0) { red3[0][tid / kWave] = acc_arm; red3[1][tid / kWave] = acc_x; red3[2][tid / kWave] = acc_u; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, x2 = 0.0, u2 = 0.0;
+    for (int w = 0; w < kRiccatiThreads / kWave; ++w) { a += red3[0][w]; x2 += red3[1][w]; u2 += red3[2][w]; }
+    io.base.summary[0] = a;
+    io.base.summary[1] = x2;
+    io.base.summary[2] = u2;
+    io.base.summary[3] = (double)status;
+  }
 }
 
 template <int NJ>
@@ -382,72 +469,7 @@ __device__ __forceinline__ void riccati_fast(RiccatiFastWorkspace<NJ>& ws, const
     return;
   }
 
-  // ---- forward roll-out: dx_{k+1} = Acl_k dx_k + bcl_k (wave 0, one row per lane, next row prefetched)
-  if (tid < NX) { const double v = io.base.dx0[tid]; ws.dx[0][tid] = v; io.base.dx[tid] = v; }
-  __syncthreads();
-  if (tid < kWave) {
-    double row[NX], nrow[NX], bc = 0.0, nbc = 0.0;
-    if (tid < NX && N > 0) {
-#pragma unroll
-      for (int l = 0; l < NX; ++l) row[l] = io.Acl[(size_t)tid * NX + l];
-      bc = io.bcl[tid];
-    }
-    for (int k = 0; k < N; ++k) {
-      if (tid < NX && k + 1 < N) {
-        const double* nr = io.Acl + (size_t)(k + 1) * NXX + (size_t)tid * NX;
-#pragma unroll
-        for (int l = 0; l < NX; ++l) nrow[l] = nr[l];
-        nbc = io.bcl[(size_t)(k + 1) * NX + tid];
-      }
-      if (tid < NX) {
-        const double* cur = ws.dx[k & 1];
-        double t = bc;
-#pragma unroll
-        for (int l = 0; l < NX; ++l) t += row[l] * cur[l];
-        ws.dx[(k + 1) & 1][tid] = t;
-        io.base.dx[(size_t)(k + 1) * NX + tid] = t;
-#pragma unroll
-        for (int l = 0; l < NX; ++l) row[l] = nrow[l];
-        bc = nbc;
-      }
-      lds_wave_sync();
-    }
-  }
-  __syncthreads();
-  // ---- du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms
-  double acc_arm = 0.0, acc_x = 0.0, acc_u = 0.0;
-  for (int idx = tid; idx < N * NU; idx += NT) {
-    const int k = idx / NU, i = idx % NU;
-    const double* dxk = io.base.dx + (size_t)k * NX;
-    const double* Kr = io.Kfull + (size_t)k * NXU + (size_t)i * NX;
-    double t = io.kff[(size_t)k * NU + i];
-#pragma unroll
-    for (int l = 0; l < NX; ++l) t += Kr[l] * dxk[l];
-    if (io.base.nut[k] == 0) t = 0.0;   // event node: no input
-    io.base.du[idx] = t;
-    acc_u += t * t;
-    const double d = dxk[i];            // NU == NX: the same index walks the state vector
-    acc_x += d * d;
-    acc_arm += io.mvec[(size_t)k * NX + i] * d;
-    if (i == 0) acc_arm += io.mscal[k];
-  }
-  if (tid < NX) { const double d = io.base.dx[(size_t)N * NX + tid]; acc_x += d * d; }
-  __shared__ double red3[3][kRiccatiThreads / kWave];
-  for (int off = kWave / 2; off >= 1; off >>= 1) {
-    acc_arm += __shfl_down(acc_arm, off);
-    acc_x += __shfl_down(acc_x, off);
-    acc_u += __shfl_down(acc_u, off);
-  }
-  if ((tid & (kWave - 1)) == 0) { red3[0][tid / kWave] = acc_arm; red3[1][tid / kWave] = acc_x; red3[2][tid / kWave] = acc_u; }
-  __syncthreads();
-  if (tid == 0) {
-    double a = 0.0, x2 = 0.0, u2 = 0.0;
-    for (int w = 0; w < kRiccatiThreads / kWave; ++w) { a += red3[0][w]; x2 += red3[1][w]; u2 += red3[2][w]; }
-    io.base.summary[0] = a;
-    io.base.summary[1] = x2;
-    io.base.summary[2] = u2;
-    io.base.summary[3] = (double)ws.status;
-  }
+  riccati_rollout<NJ>(ws.dx, ws.status, io);
 }
 
 }  // namespace bpmpc

@@ -1,0 +1,334 @@
+// Riccati sweep on the FP64 matrix cores (HIP only; reference with the same mathematics: riccati.h).
+//
+// One 256-thread workgroup per problem, as in riccati_fast.h, whose prefetch, Gauss-Jordan and roll-out are reused.  The
+// products of a stage are 16x16 output blocks accumulated with v_mfma_f64_16x16x4_f64:
+//   * one wavefront per output block; an MFMA reads one A and one B element per lane (a 16x4 and a 4x16 operand), so a
+//     22x22x22 product costs 2 x 64-lane LDS reads per 1024 multiply-adds instead of two 16-byte reads per four - the
+//     2x2-register-tile version was bound by LDS bandwidth and by the dependent-FMA latency of a single wave per SIMD;
+//     a chain of dependent MFMAs issues back to back (measured 64 cycles each, tools/probes/mfma_f64_probe.hip);
+//   * the stage data is staged in packed, zero-padded layouts so that the vectors ride along as extra columns:
+//         W  = [A~ | b~ | B~]         PW = [Px | Pe | Pu]        Qq = [Q~ | q~]        M = [P~ | r~ | R~]
+//         SW = sym(S) W  (+ s in the b column)                    -> [S A | S b + s | S B]
+//         M += B' SW                                              -> [G | g | H]
+//         Sn = Qq + A' SW(:, 0..nx)                               -> [Q + A'SA | q + A'(S b + s)]
+//         Y  = H^-1 [G g]                 (wave 0, registers; waves 1-3 compute Sn meanwhile)
+//         [S | s]     = Sn - G' Y         [Acl | bcl] = [A | b] - B Y         [K | kff] = [Px | Pe] - Pu Y
+//     so g, s, bcl, kff cost no extra instructions;
+//   * S is stored as computed and symmetrised when it is loaded as an operand (0.5 (S_ik + S_ki)), which saves the
+//     separate symmetrisation pass and its barrier.
+// Operand rows / columns beyond nx are masked to zero on load, so padding never carries stale values into a product.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "riccati_fast.h"
+
+#ifndef BPMPC_RICCATI_ABLATE
+#define BPMPC_RICCATI_ABLATE 0   // timing experiments: 1 no Gauss-Jordan, 2 no Acl/K stores, 3 no prefetch, 4 no mvec (wrong results)
+#endif
+
+namespace bpmpc {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kMaxRiccatiStages = 512;
+
+template <int NJ>
+struct RiccatiMfmaWorkspace {
+  static constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  static constexpr int RB = 32;                                  // padded rows (two 16-row blocks)
+  static constexpr int LDN = 34;                                 // leading dimension of the [.. | vector] blocks (nx + 1 <= 32 columns)
+  static constexpr int WC = NX + 1 + NU;                         // packed width [A | b | B]
+  static constexpr int LDW = ((WC + 15) / 16) * 16 + 2;
+  static_assert(NX + 1 <= 32 && NU <= 32, "two block rows / columns");
+  alignas(16) double S[RB][LDN];        // [S | s], not symmetrised
+  alignas(16) double Qq[RB][LDN];       // [Q~ | q~]
+  alignas(16) double Sn[RB][LDN];       // [Sn | sn]
+  alignas(16) double G0[RB][LDN];       // [G | g] before the elimination
+  alignas(16) double W[RB][LDW];        // [A~ | b~ | B~]
+  alignas(16) double PW[RB][LDW];       // [Px | Pe | Pu]
+  alignas(16) double SW[RB][LDW];       // sym(S) W
+  alignas(16) double M[RB][LDW];        // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
+  double r[NU];
+  alignas(16) double dx[2][NX];
+  int status;
+  int nut[kMaxRiccatiStages];           // reduced input dimensions of all stages (a global load per stage would sit on the critical path)
+};
+
+// D-layout of v_mfma_f64_16x16x4_f64: lane l, register r  <->  row (l / 16) + 4 r, column l % 16 of the 16x16 block.
+template <int LD>
+__device__ __forceinline__ v4d blk_load(const double* Mx, int r0, int c0, int l) {
+  v4d c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = Mx[(r0 + (l >> 4) + 4 * r) * LD + c0 + (l & 15)];
+  return c;
+}
+template <int LD>
+__device__ __forceinline__ void blk_store(double* Mx, int r0, int c0, int l, v4d c) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Mx[(r0 + (l >> 4) + 4 * r) * LD + c0 + (l & 15)] = c[r];
+}
+
+template <int NJ>
+__device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const RiccatiFastIO& io) {
+  using WS = RiccatiMfmaWorkspace<NJ>;
+  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccatiThreads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB;
+  constexpr int NXX = NX * NX, NXU = NX * NU;
+  constexpr int KS = (NX + 3) / 4;          // k-steps over the state dimension
+  constexpr int BC = NX + 1;                // first column of B~ / Pu / R~ in the packed layouts
+  static_assert(NX == NU, "packed layouts assume nx == nu");
+  static_assert(NX + 1 + NU <= kWave, "one lane per column of [H | G g]");
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int li = l & 15, lk = l >> 4;       // operand row/column index and k index of this lane
+  const int N = io.base.N;
+
+  const int k_top = (io.k_hi < N ? io.k_hi : N) - 1;
+  const bool resumed = io.k_hi < N;
+  {
+    double* z = &ws.S[0][0];
+    constexpr int total = (int)(sizeof(WS) / sizeof(double));
+    for (int idx = tid; idx < total - 1; idx += NT) z[idx] = 0.0;   // every matrix and its padding (status is set below)
+  }
+  __syncthreads();
+  if (tid == 0) ws.status = resumed ? (int)io.carry[NXX + NX] : 0;
+  if (resumed) {
+    for (int idx = tid; idx < NXX; idx += NT) ws.S[idx / NX][idx % NX] = io.carry[idx];
+    if (tid < NX) ws.S[tid][NX] = io.carry[NXX + tid];
+  }
+  for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) ws.nut[idx] = io.base.nut[idx];
+
+  // Prefetch registers of the loader waves (0..2): 16-byte loads, element pairs (2 t, 2 t + 1) and (2 (t + 192), ..).
+  constexpr int NLD = 3 * kWave;                       // loader threads
+  constexpr int NP2 = NXX / 2;                         // element pairs per matrix (nx is even)
+  static_assert(NXX % 2 == 0 && NP2 <= 2 * NLD, "two pairs per loader thread");
+  const bool loader = w < 3;
+  const bool second = loader && tid + NLD < NP2;
+  double2 pA[2], pB[2], pQ[2], pP[2], pR[2], pPx[2], pPu[2];
+  double pv[4];
+  const size_t o_top = (size_t)(k_top > 0 ? k_top : 0);
+  const int tp = loader ? tid : 0;
+  const double2 *gA = reinterpret_cast<const double2*>(io.base.At + o_top * NXX) + tp,
+                *gB = reinterpret_cast<const double2*>(io.base.Bt + o_top * NXX) + tp,
+                *gQ = reinterpret_cast<const double2*>(io.base.Qt + o_top * NXX) + tp,
+                *gP = reinterpret_cast<const double2*>(io.base.Pt + o_top * NXX) + tp,
+                *gR = reinterpret_cast<const double2*>(io.base.Rt + o_top * NXX) + tp,
+                *gPx = reinterpret_cast<const double2*>(io.base.Px + o_top * NXX) + tp,
+                *gPu = reinterpret_cast<const double2*>(io.base.Pu + o_top * NXX) + tp;
+  const int tv = tid < NX ? tid : 0;
+  const double *gb = io.base.bt + o_top * NX + tv, *gq = io.base.qt + o_top * NX + tv, *gr = io.base.rt + o_top * NU + tv,
+               *ge = io.base.Pe + o_top * NU + tv;
+  auto prefetch = [&]() {
+    if (!loader) return;
+    pA[0] = gA[0]; pB[0] = gB[0]; pQ[0] = gQ[0]; pP[0] = gP[0]; pR[0] = gR[0]; pPx[0] = gPx[0]; pPu[0] = gPu[0];
+    if (second) { pA[1] = gA[NLD]; pB[1] = gB[NLD]; pQ[1] = gQ[NLD]; pP[1] = gP[NLD]; pR[1] = gR[NLD]; pPx[1] = gPx[NLD]; pPu[1] = gPu[NLD]; }
+    if (tid < NX) { pv[0] = *gb; pv[1] = *gq; pv[2] = *gr; pv[3] = *ge; }
+    gA -= NP2; gB -= NP2; gQ -= NP2; gP -= NP2; gR -= NP2; gPx -= NP2; gPu -= NP2;
+    gb -= NX; gq -= NX; gr -= NU; ge -= NU;
+  };
+  if (k_top >= io.k_lo) prefetch();
+  __syncthreads();
+#ifdef BPMPC_RICCATI_PROFILE
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+#define RMPROF(slot) do { const long long tn_ = clock64(); tacc[slot] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define RMPROF(slot) ((void)0)
+#endif
+
+  // Deferred stores.  vmcnt retires in order, so a wait for the prefetched registers also waits for every store issued
+  // after the prefetch; stores issued at the end of a stage would put the HBM store latency on the critical path of the
+  // next one.  The outputs of stage k are therefore held in registers and stored right after the staging barrier of
+  // stage k-1, immediately before its prefetch: whatever the next wait covers is then a whole stage old.
+  v4d held_acl = {0.0, 0.0, 0.0, 0.0}, held_kf = {0.0, 0.0, 0.0, 0.0};
+  double held_m = 0.0;
+  int held_k = -1;
+  auto flush_held = [&]() {
+    if (held_k < 0) return;                            // uniform
+#if BPMPC_RICCATI_ABLATE != 2
+    const int r0 = 16 * (w >> 1), c0 = 16 * (w & 1);
+    double* Acl = io.Acl + (size_t)held_k * NXX;
+    double* Kf = io.Kfull + (size_t)held_k * NXU;
+    const int col = c0 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = r0 + lk + 4 * r;
+      if (rr < NX) {
+        if (col < NX) { Acl[rr * NX + col] = held_acl[r]; Kf[rr * NX + col] = held_kf[r]; }
+        else if (col == NX) { io.bcl[(size_t)held_k * NX + rr] = held_acl[r]; io.kff[(size_t)held_k * NU + rr] = held_kf[r]; }
+      }
+    }
+    if (w == 3 && l < NX) io.mvec[(size_t)held_k * NX + l] = held_m;
+    if (w == 3 && l == NX) io.mscal[held_k] = held_m;
+#endif
+  };
+
+  for (int k = k_top; k >= io.k_lo; --k) {
+    const int nt = ws.nut[k];        // max_nodes <= kMaxRiccatiStages is checked when the solver is created
+    const int ksn = (nt + 3) >> 2;                   // k-steps over the reduced input
+    const int nbc = (BC + nt + 15) >> 4;             // block columns of the packed width nx + 1 + nt
+    const int ntb = (nt + 15) >> 4;                  // block rows of the reduced input
+    // ---- P0: registers -> packed LDS layouts.  The projection kernel writes zeros beyond nt in B~, Pu, R~, P~, r~.
+    if (loader) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (e == 0 || second) {
+          const int idx = 2 * (tid + e * NLD);
+          const int i = idx / NX, j = idx % NX;              // j even: the pair stays inside row i
+          ws.W[i][j] = pA[e].x; ws.W[i][j + 1] = pA[e].y;
+          ws.W[i][BC + j] = pB[e].x; ws.W[i][BC + j + 1] = pB[e].y;
+          ws.Qq[i][j] = pQ[e].x; ws.Qq[i][j + 1] = pQ[e].y;
+          ws.PW[i][j] = pPx[e].x; ws.PW[i][j + 1] = pPx[e].y;
+          ws.PW[i][BC + j] = pPu[e].x; ws.PW[i][BC + j + 1] = pPu[e].y;
+          ws.M[i][j] = pP[e].x; ws.M[i][j + 1] = pP[e].y;
+          ws.M[i][BC + j] = pR[e].x; ws.M[i][BC + j + 1] = pR[e].y;
+        }
+      }
+      if (tid < NX) { ws.W[tid][NX] = pv[0]; ws.Qq[tid][NX] = pv[1]; ws.M[tid][NX] = pv[2]; ws.r[tid] = pv[2]; ws.PW[tid][NX] = pv[3]; }
+    }
+    lds_barrier();
+    RMPROF(0);
+    RMPROF(1);
+    // ---- P1: SW = sym(S) W, s added to the b column
+    for (int id = w; id < 2 * nbc; id += 4) {
+      const int r0 = 16 * (id / nbc), c0 = 16 * (id % nbc);
+      const int row = r0 + li;
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kk = 4 * ks + lk;
+        const double a = (row < NX && kk < NX) ? 0.5 * (ws.S[row][kk] + ws.S[kk][row]) : 0.0;
+        const double b = ws.W[kk][c0 + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+      if (c0 + li == NX) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int rr = r0 + lk + 4 * r; acc[r] += rr < NX ? ws.S[rr][NX] : 0.0; }
+      }
+      blk_store<LDW>(&ws.SW[0][0], r0, c0, l, acc);
+    }
+    lds_barrier();
+    RMPROF(2);
+    // ---- P2: [G | g | H] = [P | r | R] + B' SW
+    for (int id = w; id < ntb * nbc; id += 4) {
+      const int r0 = 16 * (id / nbc), c0 = 16 * (id % nbc);
+      v4d acc = blk_load<LDW>(&ws.M[0][0], r0, c0, l);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kk = 4 * ks + lk;
+        const double a = (kk < NX) ? ws.W[kk][BC + r0 + li] : 0.0;     // B'(i, kk); columns >= nt of B~ are zero
+        const double b = ws.SW[kk][c0 + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+      blk_store<LDW>(&ws.M[0][0], r0, c0, l, acc);
+      if (c0 < 32) blk_store<LDN>(&ws.G0[0][0], r0, c0, l, acc);
+    }
+    if (w == 3) flush_held();        // (wave 3 runs the elimination in P3, the other waves store and prefetch there)
+    lds_barrier();
+    RMPROF(3);
+    // ---- P3: wave 0: Y = H^-1 [G g] by Gauss-Jordan in registers; waves 1..3: [Sn | sn] = [Q | q] + A' SW(:, 0..nx)
+#if BPMPC_RICCATI_ABLATE == 1
+    if (false) {
+#else
+    if (w == 3) {
+#endif
+      const int col = l < nt ? BC + l : l - nt;
+      const bool used = l < nt + NX + 1;
+      bool ok;
+      if (nt <= 12) {
+        double v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = (used && i < nt) ? ws.M[i][col] : 0.0;
+        ok = gauss_jordan_wave<12>(v, nt);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) if (used && i < nt && l >= nt) ws.M[i][col] = v[i];
+      } else {
+        double v[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) v[i] = (used && i < nt) ? ws.M[i][col] : 0.0;
+        ok = gauss_jordan_wave<NU>(v, nt);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) if (used && i < nt && l >= nt) ws.M[i][col] = v[i];
+      }
+      if (l == 0 && !ok) ws.status = 1;
+    } else {
+      for (int id = w; id < 4; id += 3) {
+        const int r0 = 16 * (id >> 1), c0 = 16 * (id & 1);
+        v4d acc = blk_load<LDN>(&ws.Qq[0][0], r0, c0, l);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int kk = 4 * ks + lk;
+          const double a = (kk < NX && r0 + li < NX) ? ws.W[kk][r0 + li] : 0.0;   // A'(i, kk)
+          const double b = ws.SW[kk][c0 + li];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        blk_store<LDN>(&ws.Sn[0][0], r0, c0, l, acc);
+      }
+      // global memory traffic of the stage, off the critical path (the elimination on wave 3 is the long pole of P3):
+      // outputs of the previous stage, then the operands of the next one
+      flush_held();
+#if BPMPC_RICCATI_ABLATE != 3
+      if (k > io.k_lo) prefetch();     // never beyond the chunk: earlier stages may not be projected yet
+#endif
+    }
+    lds_barrier();
+    RMPROF(4);
+    // ---- P4: wave w owns block w of each result: [S | s] first (the next stage waits for it), then [Acl | bcl], [K | kff]
+    {
+      const int r0 = 16 * (w >> 1), c0 = 16 * (w & 1);
+      const int row = r0 + li;
+      v4d acc = blk_load<LDN>(&ws.Sn[0][0], r0, c0, l);
+      auto s_step = [&](int ks) {
+        const int kk = 4 * ks + lk;
+        const double a = row < NX ? -ws.G0[kk][row] : 0.0;           // -G'(i, kk); rows >= nt of G are zero
+        const double b = ws.M[kk][c0 + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      };
+      if (ksn == 2) { s_step(0); s_step(1); }
+      else if (ksn == 3) { s_step(0); s_step(1); s_step(2); }
+      else for (int ks = 0; ks < ksn; ++ks) s_step(ks);
+      blk_store<LDN>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, three barriers ago
+      v4d acl = blk_load<LDW>(&ws.W[0][0], r0, c0, l);
+      v4d kf = blk_load<LDW>(&ws.PW[0][0], r0, c0, l);
+      auto ak_step = [&](int ks) {
+        const int kk = 4 * ks + lk;
+        const double b = ws.M[kk][c0 + li];
+        const double a1 = row < NX ? -ws.W[row][BC + kk] : 0.0;      // -B(i, kk)
+        const double a2 = row < NX ? -ws.PW[row][BC + kk] : 0.0;     // -Pu(i, kk)
+        acl = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acl, 0, 0, 0);
+        kf = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, kf, 0, 0, 0);
+      };
+      if (ksn == 2) { ak_step(0); ak_step(1); }
+      else if (ksn == 3) { ak_step(0); ak_step(1); ak_step(2); }
+      else for (int ks = 0; ks < ksn; ++ks) ak_step(ks);
+      // m = q~ - Y' r~ (Kt = -Y), m0 = -r~' H^-1 g
+      double mt = 0.0;
+      if (BPMPC_RICCATI_ABLATE != 4 && w == 3 && l <= NX) {
+        mt = l < NX ? ws.Qq[l][NX] : 0.0;
+        if (nt <= 12) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) mt -= ws.M[i][l] * ws.r[i];     // rows >= nt of Y are zero
+        } else {
+          for (int i = 0; i < nt; ++i) mt -= ws.M[i][l] * ws.r[i];
+        }
+      }
+      // results of this stage stay in registers; they are stored after the staging barrier of the next stage (see there)
+      held_acl = acl; held_kf = kf; held_m = mt; held_k = k;
+    }
+    RMPROF(5);
+    lds_barrier();                   // the next stage overwrites W, PW, Qq, M
+    RMPROF(6);
+  }
+  flush_held();
+#ifdef BPMPC_RICCATI_PROFILE
+  if (io.prof && tid == 0)
+    for (int i = 0; i < 8; ++i) io.prof[i] = (double)tacc[i];
+#endif
+  __syncthreads();
+  if (io.k_lo > 0) {                                   // hand over to the launch that sweeps the earlier stages
+    for (int idx = tid; idx < NXX; idx += NT) io.carry[idx] = ws.S[idx / NX][idx % NX];
+    if (tid < NX) io.carry[NXX + tid] = ws.S[tid][NX];
+    if (tid == 0) io.carry[NXX + NX] = (double)ws.status;
+    return;
+  }
+  riccati_rollout<NJ>(ws.dx, ws.status, io);
+}
+
+}  // namespace bpmpc

@@ -29,6 +29,7 @@
 #include "kernels/project_lu4.h"
 #include "kernels/riccati.h"
 #include "kernels/riccati_fast.h"
+#include "kernels/riccati_mfma.h"
 #include "reference_gen.h"
 
 namespace bpmpc {
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati(Launch L) {
 template <int NJ>
 __global__ __launch_bounds__(kRiccatiThreads) void k_riccati_fast(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ RiccatiFastWorkspace<NJ> ws;
+  __shared__ RiccatiMfmaWorkspace<NJ> ws;
   const int b = blockIdx.x;
   if (!L.buf.active[b]) return;
   const size_t s0 = (size_t)b * L.N;
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati_fast(Launch L) {
   io.prof = L.buf.rprof ? L.buf.rprof + (size_t)b * 8 : nullptr;
   io.k_lo = L.k0;
   io.k_hi = L.k0 + L.klen;
-  io.carry = L.buf.ric_carry + (size_t)b * (NX * NX + NX + 1);
-  riccati_fast<NJ>(ws, io);
+  io.carry = L.buf.ric_carry + (size_t)b * (NX * NX + NX + 2);
+  riccati_mfma<NJ>(ws, io);
 }
 
 template <int NJ>
@@ -562,7 +563,7 @@ int translate(const std::exception& e) {
 void allocate(bpmpc_solver* s) {
   const size_t B = s->settings.max_batch, N = s->settings.max_nodes, NX = s->nx, NU = s->nu, S = B * N;
   Buffers& b = s->buf;
-  b.ric_carry = s->alloc<double>("ric_carry", B * (NX * NX + NX + 1));
+  b.ric_carry = s->alloc<double>("ric_carry", B * (NX * NX + NX + 2));   // S, s, status, scratch word
   b.g_kind = s->alloc<int>("g_kind", S, true); b.g_mode = s->alloc<int>("g_mode", S, true); b.g_nodes = s->alloc<int>("g_nodes", B, true);
   b.g_dt = s->alloc<double>("g_dt", S); b.g_start = s->alloc<double>("g_start", S);
   b.g_zref = s->alloc<double>("g_zref", S * 4); b.g_zdref = s->alloc<double>("g_zdref", S * 4);
@@ -713,6 +714,7 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
   if (!model || !settings || !out) { set_last_error("bpmpc_solver_create: null argument"); return BPMPC_ERR_INVALID_ARGUMENT; }
   *out = nullptr;
   if (settings->max_batch < 1 || settings->max_nodes < 1) { set_last_error("bpmpc_solver_create: max_batch and max_nodes must be positive"); return BPMPC_ERR_INVALID_ARGUMENT; }
+  if (settings->max_nodes > kMaxRiccatiStages) { set_last_error("bpmpc_solver_create: max_nodes exceeds 512"); return BPMPC_ERR_CAPACITY; }
   if ((long long)settings->max_batch * settings->max_nodes > 0x3fffffffLL) { set_last_error("bpmpc_solver_create: max_batch * max_nodes exceeds 2^30"); return BPMPC_ERR_CAPACITY; }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count < 1 || settings->device < 0 || settings->device >= count) {
