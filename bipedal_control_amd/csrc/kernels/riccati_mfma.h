@@ -188,13 +188,17 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
     RMPROF(1);
     // ---- P1: SW = sym(S) W, s added to the b column
     for (int id = w; id < 2 * nbc; id += 4) {
-      const int r0 = 16 * (id / nbc), c0 = 16 * (id % nbc);
+      const int bi = id >= nbc ? 1 : 0;
+      const int r0 = 16 * bi, c0 = 16 * (id - bi * nbc);
       const int row = r0 + li;
+      // unconditional operand loads (a predicated load compiles to a branch plus a full LDS wait per k-step): rows >= nx
+      // are switched off by the factor, k >= nx meets the zero rows of W
+      const double half = row < NX ? 0.5 : 0.0;
       v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
-        const double a = (row < NX && kk < NX) ? 0.5 * (ws.S[row][kk] + ws.S[kk][row]) : 0.0;
+        const double a = half * (ws.S[row][kk] + ws.S[kk][row]);
         const double b = ws.W[kk][c0 + li];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
       }
@@ -208,12 +212,13 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
     RMPROF(2);
     // ---- P2: [G | g | H] = [P | r | R] + B' SW
     for (int id = w; id < ntb * nbc; id += 4) {
-      const int r0 = 16 * (id / nbc), c0 = 16 * (id % nbc);
+      const int bi = id >= nbc ? 1 : 0;
+      const int r0 = 16 * bi, c0 = 16 * (id - bi * nbc);
       v4d acc = blk_load<LDW>(&ws.M[0][0], r0, c0, l);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
-        const double a = (kk < NX) ? ws.W[kk][BC + r0 + li] : 0.0;     // B'(i, kk); columns >= nt of B~ are zero
+        const double a = ws.W[kk][BC + r0 + li];                       // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
         const double b = ws.SW[kk][c0 + li];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
       }
@@ -232,30 +237,29 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
       const int col = l < nt ? BC + l : l - nt;
       const bool used = l < nt + NX + 1;
       bool ok;
-      if (nt <= 12) {
-        double v[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) v[i] = (used && i < nt) ? ws.M[i][col] : 0.0;
-        ok = gauss_jordan_wave<12>(v, nt);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) if (used && i < nt && l >= nt) ws.M[i][col] = v[i];
-      } else {
-        double v[NU];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) v[i] = (used && i < nt) ? ws.M[i][col] : 0.0;
-        ok = gauss_jordan_wave<NU>(v, nt);
-#pragma unroll
-        for (int i = 0; i < NU; ++i) if (used && i < nt && l >= nt) ws.M[i][col] = v[i];
+      // the elimination is the longest dependent chain of a stage: instantiate it for the actual number of rows
+#define BP_GJ_CASE(ROWS)                                                                      \
+      {                                                                                       \
+        double v[ROWS];                                                                       \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) v[i] = (used && i < nt) ? ws.M[i][col] : 0.0; \
+        ok = gauss_jordan_wave<ROWS>(v, nt);                                                  \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (used && i < nt && l >= nt) ws.M[i][col] = v[i]; \
       }
+      if (nt <= 8) BP_GJ_CASE(8)
+      else if (nt <= 10) BP_GJ_CASE(10)
+      else if (nt <= 12) BP_GJ_CASE(12)
+      else BP_GJ_CASE(NU)
+#undef BP_GJ_CASE
       if (l == 0 && !ok) ws.status = 1;
     } else {
       for (int id = w; id < 4; id += 3) {
         const int r0 = 16 * (id >> 1), c0 = 16 * (id & 1);
         v4d acc = blk_load<LDN>(&ws.Qq[0][0], r0, c0, l);
+        const int acol = r0 + li < NX ? r0 + li : LDW - 1;             // the last padding column of W is always zero
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int kk = 4 * ks + lk;
-          const double a = (kk < NX && r0 + li < NX) ? ws.W[kk][r0 + li] : 0.0;   // A'(i, kk)
+          const double a = ws.W[kk][acol];                             // A'(i, kk)
           const double b = ws.SW[kk][c0 + li];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
@@ -275,9 +279,10 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
       const int r0 = 16 * (w >> 1), c0 = 16 * (w & 1);
       const int row = r0 + li;
       v4d acc = blk_load<LDN>(&ws.Sn[0][0], r0, c0, l);
+      const int gcol = row < NX ? row : LDN - 1;                       // the last padding column of G0 is always zero
       auto s_step = [&](int ks) {
         const int kk = 4 * ks + lk;
-        const double a = row < NX ? -ws.G0[kk][row] : 0.0;           // -G'(i, kk); rows >= nt of G are zero
+        const double a = -ws.G0[kk][gcol];                           // -G'(i, kk); rows >= nt of G are zero
         const double b = ws.M[kk][c0 + li];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
       };
@@ -290,8 +295,8 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
       auto ak_step = [&](int ks) {
         const int kk = 4 * ks + lk;
         const double b = ws.M[kk][c0 + li];
-        const double a1 = row < NX ? -ws.W[row][BC + kk] : 0.0;      // -B(i, kk)
-        const double a2 = row < NX ? -ws.PW[row][BC + kk] : 0.0;     // -Pu(i, kk)
+        const double a1 = -ws.W[row][BC + kk];                       // -B(i, kk); rows >= nx of W and PW are zero
+        const double a2 = -ws.PW[row][BC + kk];                      // -Pu(i, kk)
         acl = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acl, 0, 0, 0);
         kf = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, kf, 0, 0, 0);
       };
