@@ -194,18 +194,21 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
       // unconditional operand loads (a predicated load compiles to a branch plus a full LDS wait per k-step): rows >= nx
       // are switched off by the factor, k >= nx meets the zero rows of W
       const double half = row < NX ? 0.5 : 0.0;
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      // all operands first, then the chain of dependent MFMAs back to back (interleaved, every k-step exposes an LDS round trip)
+      double a[KS], b[KS], sv[4];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
-        const double a = half * (ws.S[row][kk] + ws.S[kk][row]);
-        const double b = ws.W[kk][c0 + li];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        a[ks] = half * (ws.S[row][kk] + ws.S[kk][row]);
+        b[ks] = ws.W[kk][c0 + li];
       }
-      if (c0 + li == NX) {
+      const double smask = (c0 + li == NX) ? 1.0 : 0.0;              // s rides in the b column; rows >= nx of S are zero
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int rr = r0 + lk + 4 * r; acc[r] += rr < NX ? ws.S[rr][NX] : 0.0; }
-      }
+      for (int r = 0; r < 4; ++r) sv[r] = smask * ws.S[r0 + lk + 4 * r][NX];
+      __builtin_amdgcn_sched_barrier(0);
+      v4d acc = {sv[0], sv[1], sv[2], sv[3]};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
       blk_store<LDW>(&ws.SW[0][0], r0, c0, l, acc);
     }
     lds_barrier();
@@ -215,13 +218,16 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
       const int bi = id >= nbc ? 1 : 0;
       const int r0 = 16 * bi, c0 = 16 * (id - bi * nbc);
       v4d acc = blk_load<LDW>(&ws.M[0][0], r0, c0, l);
+      double a[KS], b[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
-        const double a = ws.W[kk][BC + r0 + li];                       // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
-        const double b = ws.SW[kk][c0 + li];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        a[ks] = ws.W[kk][BC + r0 + li];                                // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
+        b[ks] = ws.SW[kk][c0 + li];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
       blk_store<LDW>(&ws.M[0][0], r0, c0, l, acc);
       if (c0 < 32) blk_store<LDN>(&ws.G0[0][0], r0, c0, l, acc);
     }
@@ -256,13 +262,16 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
         const int r0 = 16 * (id >> 1), c0 = 16 * (id & 1);
         v4d acc = blk_load<LDN>(&ws.Qq[0][0], r0, c0, l);
         const int acol = r0 + li < NX ? r0 + li : LDW - 1;             // the last padding column of W is always zero
+        double a[KS], b[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int kk = 4 * ks + lk;
-          const double a = ws.W[kk][acol];                             // A'(i, kk)
-          const double b = ws.SW[kk][c0 + li];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          a[ks] = ws.W[kk][acol];                                      // A'(i, kk)
+          b[ks] = ws.SW[kk][c0 + li];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
         blk_store<LDN>(&ws.Sn[0][0], r0, c0, l, acc);
       }
       // global memory traffic of the stage, off the critical path (the elimination on wave 3 is the long pole of P3):
@@ -279,30 +288,41 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
       const int r0 = 16 * (w >> 1), c0 = 16 * (w & 1);
       const int row = r0 + li;
       v4d acc = blk_load<LDN>(&ws.Sn[0][0], r0, c0, l);
-      const int gcol = row < NX ? row : LDN - 1;                       // the last padding column of G0 is always zero
-      auto s_step = [&](int ks) {
-        const int kk = 4 * ks + lk;
-        const double a = -ws.G0[kk][gcol];                           // -G'(i, kk); rows >= nt of G are zero
-        const double b = ws.M[kk][c0 + li];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-      };
-      if (ksn == 2) { s_step(0); s_step(1); }
-      else if (ksn == 3) { s_step(0); s_step(1); s_step(2); }
-      else for (int ks = 0; ks < ksn; ++ks) s_step(ks);
-      blk_store<LDN>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, three barriers ago
       v4d acl = blk_load<LDW>(&ws.W[0][0], r0, c0, l);
       v4d kf = blk_load<LDW>(&ws.PW[0][0], r0, c0, l);
-      auto ak_step = [&](int ks) {
-        const int kk = 4 * ks + lk;
-        const double b = ws.M[kk][c0 + li];
-        const double a1 = -ws.W[row][BC + kk];                       // -B(i, kk); rows >= nx of W and PW are zero
-        const double a2 = -ws.PW[row][BC + kk];                      // -Pu(i, kk)
-        acl = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acl, 0, 0, 0);
-        kf = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, kf, 0, 0, 0);
-      };
-      if (ksn == 2) { ak_step(0); ak_step(1); }
-      else if (ksn == 3) { ak_step(0); ak_step(1); ak_step(2); }
-      else for (int ks = 0; ks < ksn; ++ks) ak_step(ks);
+      const int gcol = row < NX ? row : LDN - 1;                       // the last padding column of G0 is always zero
+      if (ksn <= 3) {
+        // up to 12 reduced inputs (every reference configuration): three k-steps, operands first, then the MFMAs of the
+        // three independent accumulators; the rows nt.. of Y and G are zero, so a surplus k-step adds nothing
+        double ag[3], ab[3], ap[3], yb[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const int kk = 4 * ks + lk;
+          yb[ks] = ws.M[kk][c0 + li];
+          ag[ks] = -ws.G0[kk][gcol];                                   // -G'(i, kk)
+          ab[ks] = -ws.W[row][BC + kk];                                // -B(i, kk); rows >= nx of W and PW are zero
+          ap[ks] = -ws.PW[row][BC + kk];                               // -Pu(i, kk)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int nks = ksn == 3 ? 3 : 2;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          if (ks < nks) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[ks], yb[ks], acc, 0, 0, 0);
+            acl = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[ks], yb[ks], acl, 0, 0, 0);
+            kf = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[ks], yb[ks], kf, 0, 0, 0);
+          }
+        }
+      } else {
+        for (int ks = 0; ks < ksn; ++ks) {
+          const int kk = 4 * ks + lk;
+          const double yv = ws.M[kk][c0 + li];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ws.G0[kk][gcol], yv, acc, 0, 0, 0);
+          acl = __builtin_amdgcn_mfma_f64_16x16x4f64(-ws.W[row][BC + kk], yv, acl, 0, 0, 0);
+          kf = __builtin_amdgcn_mfma_f64_16x16x4f64(-ws.PW[row][BC + kk], yv, kf, 0, 0, 0);
+        }
+      }
+      blk_store<LDN>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, three barriers ago
       // m = q~ - Y' r~ (Kt = -Y), m0 = -r~' H^-1 g
       double mt = 0.0;
       if (BPMPC_RICCATI_ABLATE != 4 && w == 3 && l <= NX) {
