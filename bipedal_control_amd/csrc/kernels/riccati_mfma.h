@@ -258,6 +258,12 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
 #undef BP_GJ_CASE
       if (l == 0 && !ok) ws.status = 1;
     } else {
+      // global memory traffic of the stage, off the critical path (the elimination on wave 3 is the long pole of P3) and
+      // as early as possible: outputs of the previous stage, then the operands of the next one
+      flush_held();
+#if BPMPC_RICCATI_ABLATE != 3
+      if (k > io.k_lo) prefetch();     // never beyond the chunk: earlier stages may not be projected yet
+#endif
       for (int id = w; id < 4; id += 3) {
         const int r0 = 16 * (id >> 1), c0 = 16 * (id & 1);
         v4d acc = blk_load<LDN>(&ws.Qq[0][0], r0, c0, l);
@@ -274,12 +280,6 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
         blk_store<LDN>(&ws.Sn[0][0], r0, c0, l, acc);
       }
-      // global memory traffic of the stage, off the critical path (the elimination on wave 3 is the long pole of P3):
-      // outputs of the previous stage, then the operands of the next one
-      flush_held();
-#if BPMPC_RICCATI_ABLATE != 3
-      if (k > io.k_lo) prefetch();     // never beyond the chunk: earlier stages may not be projected yet
-#endif
     }
     lds_barrier();
     RMPROF(4);

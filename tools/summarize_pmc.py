@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Aggregate the counter CSVs of two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM bytes per launch.
+
+usage: summarize_pmc.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json>
+Units and corrections as prescribed by /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KiB; on gfx950 FETCH_SIZE
+reports half of the streamed read bytes (doubled here), WRITE_SIZE is taken as reported."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_kernel(directory, counter):
+    acc = {}
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = row["Kernel_Name"].split("(")[0].replace("void bpmpc::", "")
+                e = acc.setdefault(name, [0.0, 0])
+                e[0] += float(row["Counter_Value"])
+                e[1] += 1
+    return acc
+
+
+def main(fetch_dir, write_dir, out):
+    fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for name in sorted(set(fetch) | set(write)):
+        if not name.startswith("k_"):
+            continue
+        f, nf = fetch.get(name, [0.0, 1])
+        w, nw = write.get(name, [0.0, 1])
+        kernels[name] = {"launches": nf, "FETCH_SIZE_KiB_per_launch": round(f / max(nf, 1), 1), "WRITE_SIZE_KiB_per_launch": round(w / max(nw, 1), 1),
+                         "hbm_bytes_per_launch": int(1024 * (2.0 * f / max(nf, 1) + w / max(nw, 1)))}
+    lin = next((k for k in kernels if k.startswith("k_linearize_fast")), None)
+    res = {"batch": 256, "intervals": 100, "kernel": lin,
+           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 3 --warmup 1 --cpu-sample 0",
+           "hbm_bytes_per_launch": kernels[lin]["hbm_bytes_per_launch"] if lin else None,
+           "note": "FETCH_SIZE doubled (gfx950 reports half of the streamed read bytes, MI355X_MICROARCH.md); WRITE_SIZE as reported.",
+           "all_kernels": kernels}
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
