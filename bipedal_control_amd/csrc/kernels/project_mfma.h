@@ -1,0 +1,207 @@
+// Constraint elimination, part two, on the FP64 matrix cores (HIP only): the change of input variables of one node
+//     du = Px dx + Pu dut + Pe     ([OCS2-upstream] multiple_shooting::projectTranscription / changeOfInputVariables;
+// reference body with a general cost cross term: project_node.h).  Px, Pu, Pe and nut come from project_lu4.h.
+//
+// One wavefront per node.  With the packed operand X = [Px | Pe | Pu] (nu x (nx + 1 + nut), zero padded) the whole
+// transformation is three products of 16x16 blocks accumulated with v_mfma_f64_16x16x4_f64:
+//     RX          = R X + [0 | r | 0]                 -> [R Px | r + R Pe | R Pu]
+//     [At|bt|Bt]  = [A | b | 0] + B X
+//     X' RX + [Q | q | 0 ; 0]                         -> Qt (rows < nx, cols < nx), qt (col nx), Pt, rt, Rt (rows > nx)
+// The operands R and B are used exactly once each, so they go from HBM straight into the A-operand registers (lane =
+// (row, k) of the 16x4 operand); the accumulator blocks are initialised from A, b, Q, q in the D layout and leave for HBM
+// in the same layout (16 consecutive doubles per row).  Only X and RX go through LDS.  The cost cross term P of the LQ
+// model is structurally zero for this problem and is not read (project_node.h handles a general P).
+// Everything beyond the reduced input dimension nut (columns of Bt, rows of Pt, rows/columns of Rt, rt) is written as
+// zero, as the Riccati sweep expects.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "project_node.h"
+#include "riccati_mfma.h"   // v4d, lds_wave_sync
+
+namespace bpmpc {
+
+template <int NJ>
+struct ProjectMfmaWorkspace {
+  static constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  static constexpr int KR = ((NX + 3) / 4) * 4;                  // rows used as the k index (nx rounded up to the k-step)
+  static constexpr int WC = NX + 1 + NU;
+  static constexpr int LDW = ((WC + 15) / 16) * 16 + 2;
+  alignas(16) double X[KR][LDW];        // [Px | Pe | Pu], zero padded
+  alignas(16) double RX[KR][LDW];       // R X + [0 | r | 0]
+};
+
+// The three products for a compile-time number of block columns NBC (packed width nx + 1 + nut <= 16 NBC).  Everything
+// that is read from HBM (operands, accumulator initial values) is loaded before the first output store: vmcnt retires in
+// order, a load issued behind a store would wait for that store to reach memory.
+template <int NJ, int NBC>
+__device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out) {
+  using WS = ProjectMfmaWorkspace<NJ>;
+  constexpr int NX = WS::NX, NU = WS::NU, KR = WS::KR, KS = KR / 4, BC = NX + 1;
+  const int l = threadIdx.x, li = l & 15, lk = l >> 4;
+  // A-operands from HBM: rows 16 bi + li of R and of B, k = 4 ks + lk (out-of-range lanes read element 0 and are masked)
+  double aR[2][KS], aB[2][KS];
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int row = 16 * bi + li, kk = 4 * ks + lk;
+      const bool ok = row < NU && kk < NU;
+      const int off = ok ? row * NU + kk : 0;
+      const double rv = in.R[off], bv = in.B[off];
+      aR[bi][ks] = ok ? rv : 0.0;
+      aB[bi][ks] = ok ? bv : 0.0;
+    }
+  // accumulator initial values in the D layout: [A | b | 0] (2 x NBC blocks), [Q | q | 0] (block row 0 and, for rows < nx, 1),
+  // r for the b column of R X
+  v4d cA[2][NBC], cQ[2][NBC], cR[2];
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 16 * bi + lk + 4 * r;
+      const bool rin = rr < NX;
+      const double rv = in.r[rin ? rr : 0];
+      cR[bi][r] = (li == NX - 16 && rin) ? rv : 0.0;             // column nx lives in block column 1 (nx in 16..31)
+#pragma unroll
+      for (int bj = 0; bj < NBC; ++bj) {
+        const int col = 16 * bj + li;
+        const bool in_m = rin && col < NX, in_v = rin && col == NX;
+        const double av = *(in_m ? in.A + rr * NX + col : (in_v ? in.b + rr : in.A));
+        const double qv = *(in_m ? in.Q + rr * NX + col : (in_v ? in.q + rr : in.Q));
+        cA[bi][bj][r] = (in_m || in_v) ? av : 0.0;
+        cQ[bi][bj][r] = (in_m || in_v) ? qv : 0.0;
+      }
+    }
+  }
+  static_assert(NX >= 16 && NX < 32, "column nx sits in block column 1");
+  lds_wave_sync();                                     // X is in LDS (written by the caller)
+
+  // ---- RX = R X + [0 | r | 0]
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < NBC; ++bj) {
+      double b[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) b[ks] = ws.X[4 * ks + lk][16 * bj + li];
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      if (bj == 1) acc = cR[bi];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[bi][ks], b[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * bi + lk + 4 * r;
+        if (rr < KR) ws.RX[rr][16 * bj + li] = acc[r];
+      }
+    }
+  // ---- [At | bt | Bt] = [A | b | 0] + B X   (kept in registers until every load is done)
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < NBC; ++bj) {
+      double b[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) b[ks] = ws.X[4 * ks + lk][16 * bj + li];
+      v4d acc = cA[bi][bj];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aB[bi][ks], b[ks], acc, 0, 0, 0);
+      cA[bi][bj] = acc;
+    }
+  lds_wave_sync();
+  // ---- X' RX + [Q | q | 0 ; 0]  ->  Qt, qt (rows < nx);  Pt, rt, Rt (rows > nx); stores follow directly
+#pragma unroll
+  for (int bi = 0; bi < NBC; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < NBC; ++bj) {
+      const int col = 16 * bj + li;
+      double a[KS], b[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a[ks] = ws.X[4 * ks + lk][16 * bi + li];         // X'(i, k)
+        b[ks] = ws.RX[4 * ks + lk][col];
+      }
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      if (bi < 2) acc = cQ[bi < 2 ? bi : 0][bj];         // rows >= nx of cQ are zero
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * bi + lk + 4 * r;             // row of the packed result: < nx: Px part, == nx: Pe, > nx: Pu part
+        const int ru = rr - BC, cu = col - BC;
+        const bool top = rr < NX, bot = rr > NX && ru < NU;
+        if (top) {
+          if (col < NX) out.Qt[rr * NX + col] = acc[r];
+          else if (col == NX) out.qt[rr] = acc[r];
+        } else if (bot) {
+          if (col < NX) out.Pt[ru * NX + col] = acc[r];
+          else if (col == NX) out.rt[ru] = acc[r];
+          else if (cu < NU) out.Rt[ru * NU + cu] = acc[r];
+        }
+      }
+    }
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < NBC; ++bj) {
+      const int col = 16 * bj + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * bi + lk + 4 * r;
+        if (rr < NX) {
+          if (col < NX) out.At[rr * NX + col] = cA[bi][bj][r];
+          else if (col == NX) out.bt[rr] = cA[bi][bj][r];
+          else if (col - BC < NU) out.Bt[rr * NU + (col - BC)] = cA[bi][bj][r];
+        }
+      }
+    }
+}
+
+template <int NJ>
+__device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out) {
+  using WS = ProjectMfmaWorkspace<NJ>;
+  constexpr int NX = WS::NX, NU = WS::NU, LDW = WS::LDW, KR = WS::KR, BC = NX + 1, WC = WS::WC;
+  static_assert(NX == NU, "packed layout assumes nx == nu");
+  const int l = threadIdx.x;
+
+  if (in.kind == 1) {  // event node: pass-through (same as the reference kernel; Px, Pu, Pe, nut were written by the LU kernel)
+    for (int idx = l; idx < NX * NX; idx += kWave) { out.At[idx] = in.A[idx]; out.Qt[idx] = in.Q[idx]; }
+    for (int idx = l; idx < NX * NU; idx += kWave) { out.Bt[idx] = 0.0; out.Pt[idx] = 0.0; }
+    for (int idx = l; idx < NU * NU; idx += kWave) out.Rt[idx] = 0.0;
+    if (l < NX) { out.bt[l] = in.b[l]; out.qt[l] = in.q[l]; }
+    if (l < NU) out.rt[l] = 0.0;
+    return;
+  }
+  const int nut = out.nut[0];
+  const int nbc = (BC + nut + 15) >> 4;                // block columns (and rows) of the packed width nx + 1 + nut
+  const int covered = 16 * nbc - BC;                   // reduced-input columns reached by the blocks (>= nut)
+
+  // ---- X to LDS (coalesced reads), padding zeroed; the workgroup is this one wave
+  for (int idx = l; idx < NU * NX; idx += kWave) {
+    const int i = idx / NX, j = idx % NX;
+    ws.X[i][j] = out.Px[idx];
+    ws.X[i][BC + j] = out.Pu[idx];
+  }
+  if (l < NU) ws.X[l][NX] = out.Pe[l];
+  for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
+  for (int idx = l; idx < NU * (LDW - WC); idx += kWave) ws.X[idx / (LDW - WC)][WC + idx % (LDW - WC)] = 0.0;   // columns beyond [Px Pe Pu]
+
+  if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out);
+  else if (nbc == 3) project_apply_blocks<NJ, 3>(ws, in, out);
+  else project_apply_blocks<NJ, (WC + 15) / 16>(ws, in, out);
+
+  // ---- zeros beyond the block-covered reduced inputs (the covered part beyond nut is zero through the zero columns of Pu)
+  const int cov = nbc <= 2 ? 32 - BC : covered;
+  if (cov < NU) {
+    const int nz = NU - cov;
+    for (int idx = l; idx < NX * nz; idx += kWave) out.Bt[(idx / nz) * NU + cov + idx % nz] = 0.0;
+    for (int idx = l; idx < nz * NX; idx += kWave) out.Pt[(cov + idx / NX) * NX + idx % NX] = 0.0;
+    for (int idx = l; idx < NU * NU; idx += kWave) {
+      const int i = idx / NU, j = idx % NU;
+      if (i >= cov || j >= cov) out.Rt[idx] = 0.0;
+    }
+    if (l < nz) out.rt[cov + l] = 0.0;
+  }
+}
+
+}  // namespace bpmpc

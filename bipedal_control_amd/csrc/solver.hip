@@ -30,6 +30,7 @@
 #include "kernels/riccati.h"
 #include "kernels/riccati_fast.h"
 #include "kernels/riccati_mfma.h"
+#include "kernels/project_mfma.h"
 #include "reference_gen.h"
 
 namespace bpmpc {
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kWave) void k_project_lu(Launch L) {
 template <int NJ>
 __global__ __launch_bounds__(kWave) void k_project_fast(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ ProjectFastWorkspace<NJ> ws;
+  __shared__ ProjectMfmaWorkspace<NJ> ws;
   const int b = blockIdx.x / L.klen, k = L.k0 + blockIdx.x % L.klen;
   if (!L.buf.active[b]) return;
   const int g = L.buf.p_grid[b];
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kWave) void k_project_fast(Launch L) {
   out.At = L.buf.At + s * NX * NX; out.Bt = L.buf.Bt + s * NX * NU; out.bt = L.buf.bt + s * NX;
   out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
   out.rt = L.buf.rt + s * NU;
-  project_fast<NJ>(ws, in, out, (b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr);
+  project_apply_mfma<NJ>(ws, in, out);
 }
 
 template <int NJ>
