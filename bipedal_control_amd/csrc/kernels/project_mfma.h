@@ -11,8 +11,10 @@
 // (row, k) of the 16x4 operand); the accumulator blocks are initialised from A, b, Q, q in the D layout and leave for HBM
 // in the same layout (16 consecutive doubles per row).  Only X and RX go through LDS.  The cost cross term P of the LQ
 // model is structurally zero for this problem and is not read (project_node.h handles a general P).
-// Everything beyond the reduced input dimension nut (columns of Bt, rows of Pt, rows/columns of Rt, rt) is written as
-// zero, as the Riccati sweep expects.
+// Everything beyond the reduced input dimension nut (columns of Bt, rows of Pt, rows/columns of Rt, rt) must read as zero
+// for the Riccati sweep.  The buffers start zero-filled and the blocks write exact zeros up to the block boundary; what
+// lies beyond is only rewritten when an earlier projection of the same node reached further (`extent`, one int per node),
+// so in the steady state no zero is stored twice.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -158,7 +160,7 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
 }
 
 template <int NJ>
-__device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out) {
+__device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, int* extent) {
   using WS = ProjectMfmaWorkspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, LDW = WS::LDW, KR = WS::KR, BC = NX + 1, WC = WS::WC;
   static_assert(NX == NU, "packed layout assumes nx == nu");
@@ -170,17 +172,28 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
     for (int idx = l; idx < NU * NU; idx += kWave) out.Rt[idx] = 0.0;
     if (l < NX) { out.bt[l] = in.b[l]; out.qt[l] = in.q[l]; }
     if (l < NU) out.rt[l] = 0.0;
+    if (l == 0) extent[0] = 0;
     return;
   }
   const int nut = out.nut[0];
   const int nbc = (BC + nut + 15) >> 4;                // block columns (and rows) of the packed width nx + 1 + nut
-  const int covered = 16 * nbc - BC;                   // reduced-input columns reached by the blocks (>= nut)
 
   // ---- X to LDS (coalesced reads), padding zeroed; the workgroup is this one wave
-  for (int idx = l; idx < NU * NX; idx += kWave) {
-    const int i = idx / NX, j = idx % NX;
-    ws.X[i][j] = out.Px[idx];
-    ws.X[i][BC + j] = out.Pu[idx];
+  {
+    constexpr int IT = (NU * NX + kWave - 1) / kWave;
+    double vx[IT], vu[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {                  // all loads in flight before the first LDS write
+      const int idx = l + it * kWave;
+      const bool ok = idx < NU * NX;
+      vx[it] = ok ? out.Px[idx] : 0.0;
+      vu[it] = (ok && idx % NX < nut) ? out.Pu[idx] : 0.0;     // columns >= nut of Pu are zero: not read
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = l + it * kWave;
+      if (idx < NU * NX) { ws.X[idx / NX][idx % NX] = vx[it]; ws.X[idx / NX][BC + idx % NX] = vu[it]; }
+    }
   }
   if (l < NU) ws.X[l][NX] = out.Pe[l];
   for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
@@ -190,18 +203,20 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   else if (nbc == 3) project_apply_blocks<NJ, 3>(ws, in, out);
   else project_apply_blocks<NJ, (WC + 15) / 16>(ws, in, out);
 
-  // ---- zeros beyond the block-covered reduced inputs (the covered part beyond nut is zero through the zero columns of Pu)
-  const int cov = nbc <= 2 ? 32 - BC : covered;
-  if (cov < NU) {
-    const int nz = NU - cov;
+  // ---- keep "beyond nut reads as zero": clear what an earlier, wider projection of this node left behind
+  const int cov = 16 * (nbc <= 2 ? 2 : nbc) - BC;      // reduced-input indices written by the blocks of this call
+  const int prev = extent[0];
+  if (prev > cov) {                                    // wave-uniform, rare (the mode of the node changed)
+    const int hi = prev < NU ? prev : NU, nz = hi - cov;
     for (int idx = l; idx < NX * nz; idx += kWave) out.Bt[(idx / nz) * NU + cov + idx % nz] = 0.0;
     for (int idx = l; idx < nz * NX; idx += kWave) out.Pt[(cov + idx / NX) * NX + idx % NX] = 0.0;
-    for (int idx = l; idx < NU * NU; idx += kWave) {
-      const int i = idx / NU, j = idx % NU;
-      if (i >= cov || j >= cov) out.Rt[idx] = 0.0;
+    for (int idx = l; idx < hi * hi; idx += kWave) {
+      const int i = idx / hi, j = idx % hi;
+      if (i >= cov || j >= cov) out.Rt[i * NU + j] = 0.0;
     }
     if (l < nz) out.rt[cov + l] = 0.0;
   }
+  if (l == 0) extent[0] = cov < NU ? cov : NU;
 }
 
 }  // namespace bpmpc

@@ -60,6 +60,7 @@ struct Buffers {
   // projection
   double *Px, *Pu, *Pe, *At, *Bt, *bt, *Qt, *Rt, *Pt, *qt, *rt;
   int* nut;
+  int* proj_extent;    // per node: reduced-input extent written by the last fast projection (see project_mfma.h)
   // riccati
   double *Kt, *kt, *dx, *du, *K, *summary, *dx0;
   double *Acl, *bcl, *kff, *mvec, *mscal, *rprof;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kWave) void k_project_fast(Launch L) {
   out.At = L.buf.At + s * NX * NX; out.Bt = L.buf.Bt + s * NX * NU; out.bt = L.buf.bt + s * NX;
   out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
   out.rt = L.buf.rt + s * NU;
-  project_apply_mfma<NJ>(ws, in, out);
+  project_apply_mfma<NJ>(ws, in, out, L.buf.proj_extent + s);
 }
 
 template <int NJ>
@@ -564,6 +565,7 @@ int translate(const std::exception& e) {
 void allocate(bpmpc_solver* s) {
   const size_t B = s->settings.max_batch, N = s->settings.max_nodes, NX = s->nx, NU = s->nu, S = B * N;
   Buffers& b = s->buf;
+  b.proj_extent = s->alloc<int>("proj_extent", S, true);
   b.ric_carry = s->alloc<double>("ric_carry", B * (NX * NX + NX + 2));   // S, s, status, scratch word
   b.g_kind = s->alloc<int>("g_kind", S, true); b.g_mode = s->alloc<int>("g_mode", S, true); b.g_nodes = s->alloc<int>("g_nodes", B, true);
   b.g_dt = s->alloc<double>("g_dt", S); b.g_start = s->alloc<double>("g_start", S);

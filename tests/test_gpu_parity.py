@@ -222,3 +222,18 @@ def test_pipelined_horizon_chunks_are_bit_identical(ctx):
     for r in results[1:]:
         assert np.array_equal(r[1], results[0][1]) and np.array_equal(r[2], results[0][2]) and np.array_equal(r[3], results[0][3])
         assert [s.step_size for s in r[4]] == [s.step_size for s in results[0][4]]
+
+
+def test_solver_reuse_across_gaits_matches_fresh_solver(ctx):
+    """A solver handle that has projected wider reduced inputs at a node before (double stance, nut = 10) must give the same
+    bits afterwards on a narrower problem (single support, nut = 9) as a fresh handle: the projection only clears the
+    stale part of its zero-padded outputs (project_mfma.h, `extent`)."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    trot = sc.trot_problem(itf, batch=4, n_intervals=60)
+    stance = sc.trot_problem(itf, batch=4, n_intervals=60, gait="stance")
+    reused = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=80, sqp_iterations=2, return_gains=True)
+    for prob in (trot, stance, trot):
+        last = reused.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    fresh = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=80, sqp_iterations=2, return_gains=True)
+    ref = fresh.run(trot["t0"], trot["x0"], trot["schedule"], trot["targets"], horizon=trot["horizon"])
+    assert np.array_equal(last[1], ref[1]) and np.array_equal(last[2], ref[2]) and np.array_equal(last[3], ref[3])
