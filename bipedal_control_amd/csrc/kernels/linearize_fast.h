@@ -52,7 +52,7 @@ __device__ __forceinline__ void load_shared_model(const DeviceModel& md, LinFast
   for (int i = tid; i < C::NB * NJ; i += nthreads) sh.path[i / NJ][i % NJ] = md.path[i / NJ][i % NJ];
 }
 
-template <int NJ>
+template <int NJ, bool FULL = true>   // FULL = false: value-only evaluation (line search trials), no parked columns
 struct LinFastNodeLds {
   using C = LinFastCfg<NJ>;
   // node inputs, staged once so that nothing is loaded from global memory after the first output store
@@ -70,9 +70,9 @@ struct LinFastNodeLds {
   double cpos[kNumContacts][3], cvel[kNumContacts][3];
   double cone[kNumContacts][13];
   // node-level results of the two stages: A_b^{-1} blocks, 1/m, contact points and com
-  double X12[2][9], X22[2][9], cps[2][kNumContacts][3], com[2][3];
+  double X12[FULL ? 2 : 1][FULL ? 9 : 1], X22[FULL ? 2 : 1][FULL ? 9 : 1], cps[FULL ? 2 : 1][FULL ? kNumContacts : 1][3], com[FULL ? 2 : 1][3];
   // parked stage-one columns: rows 3..11 of column 6+g and rows 6..11 of the joint-velocity column of lane g
-  double park[C::LPN][15];
+  double park[FULL ? C::LPN : 1][FULL ? 15 : 1];
 };
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -154,8 +154,8 @@ struct LaneKin {    // what the contact part needs from the evaluation
 #else
 #define EVPROF(slot) ((void)0)
 #endif
-template <int NJ, bool DERIV = true, bool TWIST = true>
-__device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ>& nl, int stage, const LaneBody& lb, const int* path, int g,
+template <int NJ, bool DERIV = true, bool TWIST = true, class NodeLds = LinFastNodeLds<NJ>>
+__device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastShared<NJ>& sh, NodeLds& nl, int stage, const LaneBody& lb, const int* path, int g,
                                           const double (&xh)[6], const double (&pb)[3], double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin,
                                           long long* evp = nullptr) {
 #ifdef BPMPC_EVAL_PROFILE
@@ -241,7 +241,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
       if (md.contact_body[i] == lb.body) {
         double t[3];
         mat3_vec(R, md.contact_off[i], t);
-        for (int a = 0; a < 3; ++a) { const double pv = o[a] + t[a]; nl.cpos[i][a] = pv; nl.cps[stage][i][a] = pv; }
+        for (int a = 0; a < 3; ++a) { const double pv = o[a] + t[a]; nl.cpos[i][a] = pv; if constexpr (DERIV) nl.cps[stage][i][a] = pv; }
       }
   }
   lds_wave_sync();
@@ -264,7 +264,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
   // whole-robot mass and com from lane 5 (the base body lane)
   const double Mtot = __shfl(Mc, 5, LPN);
   const double com[3] = {__shfl(Cc[0], 5, LPN), __shfl(Cc[1], 5, LPN), __shfl(Cc[2], 5, LPN)};
-  if (g == 0) for (int i = 0; i < 3; ++i) nl.com[stage][i] = com[i];
+  if constexpr (DERIV) { if (g == 0) for (int i = 0; i < 3; ++i) nl.com[stage][i] = com[i]; }
   EVPROF(3);
   // ---- centroidal momentum matrix column
   double Ac[6];
@@ -301,7 +301,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
     X22[6] = c02 * idet; X22[7] = (M[1] * M[6] - M[0] * M[7]) * idet; X22[8] = (M[0] * M[4] - M[1] * M[3]) * idet;
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) X12[3 * i + j] = -im * (A12[3 * i] * X22[j] + A12[3 * i + 1] * X22[3 + j] + A12[3 * i + 2] * X22[6 + j]);
-    if (g < 9) { nl.X12[stage][g] = X12[g]; nl.X22[stage][g] = X22[g]; }
+    if constexpr (DERIV) { if (g < 9) { nl.X12[stage][g] = X12[g]; nl.X22[stage][g] = X22[g]; } }
     mat3_vec(X22, &rhs[3], th);
     mat3_vec(X12, &rhs[3], pd);
     for (int i = 0; i < 3; ++i) pd[i] += im * rhs[i];
@@ -725,7 +725,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
 // Value-only metrics of x + alpha dx, u + alpha du at one node for the filter line search (same lane layout as
 // linearize_fast; reference version: trial_node in linesearch.h).
 template <int NJ>
-__device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ>& nl, bool valid,
+__device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ, false>& nl, bool valid,
                                            const NodeInputs& in, double alpha, const double* dx, const double* du, const double* dxn,
                                            double* perf, int g) {
   using C = LinFastCfg<NJ>;
@@ -767,7 +767,7 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
   LaneEval e1;
   LaneKin<NJ> kin;
-  eval_lane<NJ, false, true>(md, sh, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
+  eval_lane<NJ, false, true, LinFastNodeLds<NJ, false>>(md, sh, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
   if (g >= 5 && g < G)
     for (int i = 0; i < kNumContacts; ++i)
       if (md.contact_body[i] == lb.body) {
@@ -803,7 +803,7 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
     for (int i = 0; i < 3; ++i) pb2[i] = pb[i] + dt * kin.vb[i];
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
-    eval_lane<NJ, false, false>(md, sh, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
+    eval_lane<NJ, false, false, LinFastNodeLds<NJ, false>>(md, sh, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
   }
   double dyn_sse = 0.0;
   if (g < G) {

@@ -119,22 +119,23 @@ BP_DEVICE void linesearch_begin(double* partial /*kWave*3 LDS*/, const ProblemLS
   }
 }
 
-template <int NJ>
-BP_DEVICE void linesearch_decide(double* partial /*kWave*3 LDS + 2 flags*/, const ProblemLS& p, const LineSearchSettings& st) {
+// NL lanes work on one problem (64 in the lane emulation, 256 on the GPU: the accepted step touches (2N+1) nx doubles)
+template <int NJ, int NL = kWave>
+BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags*/, const ProblemLS& p, const LineSearchSettings& st) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   if (p.done[0]) return;
   const double alpha = p.alpha[0];
-  BP_LANES(tid, kWave) {
+  BP_LANES(tid, NL) {
     double a = 0.0, b = 0.0, c = 0.0;
-    for (int k = tid; k < p.n_nodes; k += kWave) { a += p.trial_perf[3 * k]; b += p.trial_perf[3 * k + 1]; c += p.trial_perf[3 * k + 2]; }
+    for (int k = tid; k < p.n_nodes; k += NL) { a += p.trial_perf[3 * k]; b += p.trial_perf[3 * k + 1]; c += p.trial_perf[3 * k + 2]; }
     if (tid < NX) { const double d = p.x0[tid] - (p.x[tid] + alpha * p.dx[tid]); b += d * d; }
-    partial[tid] = a; partial[kWave + tid] = b; partial[2 * kWave + tid] = c;
+    partial[tid] = a; partial[NL + tid] = b; partial[2 * NL + tid] = c;
   }
   BP_SYNC();
-  BP_LANES(tid, kWave) {
+  BP_LANES(tid, NL) {
     if (tid == 0) {
       double merit = 0.0, dyn = 0.0, eq = 0.0;
-      for (int i = 0; i < kWave; ++i) { merit += partial[i]; dyn += partial[kWave + i]; eq += partial[2 * kWave + i]; }
+      for (int i = 0; i < NL; ++i) { merit += partial[i]; dyn += partial[NL + i]; eq += partial[2 * NL + i]; }
       const double merit0 = p.base[0];
       const double viol0 = sqrt(p.base[1] + p.base[2]);
       const double viol = sqrt(dyn + eq);
@@ -151,8 +152,8 @@ BP_DEVICE void linesearch_decide(double* partial /*kWave*3 LDS + 2 flags*/, cons
       if (numerical) accepted = false;
       const double next_alpha = alpha * st.alpha_decay;
       const bool give_up = !accepted && (numerical || !(next_alpha >= st.alpha_min));
-      partial[3 * kWave] = accepted ? 1.0 : 0.0;
-      partial[3 * kWave + 1] = give_up ? 1.0 : 0.0;
+      partial[3 * NL] = accepted ? 1.0 : 0.0;
+      partial[3 * NL + 1] = give_up ? 1.0 : 0.0;
       if (accepted || give_up) {
         double* s = p.stats;
         const int it = p.iterations[0] + 1;
@@ -184,11 +185,11 @@ BP_DEVICE void linesearch_decide(double* partial /*kWave*3 LDS + 2 flags*/, cons
     }
   }
   BP_SYNC();
-  const bool accepted = partial[3 * kWave] != 0.0;
+  const bool accepted = partial[3 * NL] != 0.0;
   if (accepted) {
-    BP_LANES(tid, kWave) {
-      for (int idx = tid; idx < (p.n_nodes + 1) * NX; idx += kWave) p.x[idx] += alpha * p.dx[idx];
-      for (int idx = tid; idx < p.n_nodes * NU; idx += kWave) p.u[idx] += alpha * p.du[idx];
+    BP_LANES(tid, NL) {
+      for (int idx = tid; idx < (p.n_nodes + 1) * NX; idx += NL) p.x[idx] += alpha * p.dx[idx];
+      for (int idx = tid; idx < p.n_nodes * NU; idx += NL) p.u[idx] += alpha * p.du[idx];
     }
   }
 }

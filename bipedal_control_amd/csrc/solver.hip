@@ -329,7 +329,7 @@ template <int NJ>
 __global__ __launch_bounds__(kWave) void k_trial_fast(Launch L) {
   using C = LinFastCfg<NJ>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
-  __shared__ LinFastNodeLds<NJ> lds[NPW];
+  __shared__ LinFastNodeLds<NJ, false> lds[NPW];
   __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the wave
   load_shared_model<NJ>(*L.model, shared, threadIdx.x, kWave);
   __syncthreads();
@@ -344,10 +344,11 @@ __global__ __launch_bounds__(kWave) void k_trial_fast(Launch L) {
   trial_fast<NJ>(*L.model, shared, lds[sub], valid, in, L.buf.alpha[b], dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
 }
 
+constexpr int kDecideThreads = 256;
 template <int NJ>
-__global__ __launch_bounds__(kWave) void k_ls_decide(Launch L) {
-  __shared__ double partial[3 * kWave + 2];
-  linesearch_decide<NJ>(partial, problem_ls<NJ>(L, blockIdx.x), L.ls);
+__global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L) {
+  __shared__ double partial[3 * kDecideThreads + 2];
+  linesearch_decide<NJ, kDecideThreads>(partial, problem_ls<NJ>(L, blockIdx.x), L.ls);
 }
 
 // ------------------------------------------------------------------------------------------------ solver object
@@ -495,7 +496,7 @@ template <int NJ> void bpmpc_solver::stage_linesearch() {
       constexpr int NPW = LinFastCfg<NJ>::NPW;
       hipLaunchKernelGGL(k_trial_fast<NJ>, dim3((batch * settings.max_nodes + NPW - 1) / NPW), dim3(kWave), 0, stream, L);
     }
-    hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kWave), 0, stream, L);
+    hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L);
     HIP_CHECK(hipGetLastError());
     // one 4-byte read-back per trial round: stop as soon as every problem has accepted (or given up)
     HIP_CHECK(hipMemcpyAsync(h_remaining, buf.remaining, sizeof(int), hipMemcpyDeviceToHost, stream));
