@@ -65,7 +65,8 @@ struct LuLane {
   int cpos0, cpos1, size, nonzero;
   bool done0, done1, alive;
 };
-template <int K>
+// RM: rows RM.. are zero for every node of the launch (RM >= the largest row count), so the row loops stop there.
+template <int K, int RM>
 __device__ __forceinline__ void lu_step(LuLane& s, int j) {
   constexpr int R = kMaxEqRows, k = K;
   double (&vd0)[R] = s.vd0, (&vd1)[R] = s.vd1, (&vr0)[R] = s.vr0, (&vr1)[R] = s.vr1;
@@ -76,7 +77,7 @@ __device__ __forceinline__ void lu_step(LuLane& s, int j) {
     // ---- largest |a| of the trailing block
     double m0 = fabs(vd0[k]), m1 = fabs(vd1[k]);
 #pragma unroll
-    for (int r = k + 1; r < R; ++r) { m0 = fmax(m0, fabs(vd0[r])); m1 = fmax(m1, fabs(vd1[r])); }
+    for (int r = k + 1; r < RM; ++r) { m0 = fmax(m0, fabs(vd0[r])); m1 = fmax(m1, fabs(vd1[r])); }
     const bool stepping = alive && k < size;
     double cand = fmax(done0 ? -1.0 : m0, done1 ? -1.0 : m1);
     if (!stepping) cand = -1.0;
@@ -86,7 +87,7 @@ __device__ __forceinline__ void lu_step(LuLane& s, int j) {
     // ---- first occurrence in column-major order: smallest column position, then smallest row
     int row0 = 31, row1 = 31;
 #pragma unroll
-    for (int r = R - 1; r >= k; --r) {
+    for (int r = RM - 1; r >= k; --r) {
       row0 = (fabs(vd0[r]) == pivabs) ? r : row0;
       row1 = (fabs(vd1[r]) == pivabs) ? r : row1;
     }
@@ -100,7 +101,7 @@ __device__ __forceinline__ void lu_step(LuLane& s, int j) {
     {
       double n0 = vd0[k], n1 = vd1[k], n2 = vr0[k], n3 = vr1[k];
 #pragma unroll
-      for (int r = k + 1; r < R; ++r) {
+      for (int r = k + 1; r < RM; ++r) {
         const bool hit = pr == r;
         // opaque copies: without them the compiler folds the select chain into a dynamically indexed access, which
         // forces the column arrays into scratch memory
@@ -121,9 +122,9 @@ __device__ __forceinline__ void lu_step(LuLane& s, int j) {
     }
     // ---- elimination with the multipliers of the pivot column (broadcast from its lane)
     const double pivot = __shfl(ps ? vd1[k] : vd0[k], pl, kLuLanes);
-    const double inv = act ? 1.0 / pivot : 0.0;
+    const double inv = act ? fast_reciprocal(pivot) : 0.0;
 #pragma unroll
-    for (int r = k + 1; r < R; ++r) {
+    for (int r = k + 1; r < RM; ++r) {
       const double colv = __shfl(ps ? vd1[r] : vd0[r], pl, kLuLanes);
       const double f = act ? colv * inv : 0.0;
       vd0[r] -= f * vd0[k]; vd1[r] -= f * vd1[k]; vr0[r] -= f * vr0[k]; vr1[r] -= f * vr1[k];
@@ -132,7 +133,8 @@ __device__ __forceinline__ void lu_step(LuLane& s, int j) {
 }
 
 // `valid` false: the lanes run along with an empty problem (nc = 0) and write nothing.
-template <int NJ>
+// RM: upper bound of the row counts of the launch (12 double stance, 14 single support, 16 flight), known on the host.
+template <int NJ, int RM>
 __device__ __forceinline__ void project_lu4(ProjectLuLds<NJ>& nl, bool valid, int nc, const double* D, const double* C, const double* e, double* Px,
                                             double* Pu, double* Pe, int* nut_out, int sub, int j) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ, R = kMaxEqRows;
@@ -163,7 +165,7 @@ __device__ __forceinline__ void project_lu4(ProjectLuLds<NJ>& nl, bool valid, in
 #pragma unroll
   for (int r = 0; r < R; ++r) { st.vd0[r] = vd0[r]; st.vd1[r] = vd1[r]; st.vr0[r] = vr0[r]; st.vr1[r] = vr1[r]; }
   st.maxpiv = 0.0; st.cpos0 = cpos0; st.cpos1 = cpos1; st.size = size; st.nonzero = nonzero; st.done0 = done0; st.done1 = done1; st.alive = alive;
-#define BP_LU_STEP(K) if (K < smax) lu_step<K>(st, j);
+#define BP_LU_STEP(K) if (K < RM && K < smax) lu_step<K < RM ? K : 0, RM>(st, j);
   BP_LU_STEP(0) BP_LU_STEP(1) BP_LU_STEP(2) BP_LU_STEP(3) BP_LU_STEP(4) BP_LU_STEP(5) BP_LU_STEP(6) BP_LU_STEP(7)
   BP_LU_STEP(8) BP_LU_STEP(9) BP_LU_STEP(10) BP_LU_STEP(11) BP_LU_STEP(12) BP_LU_STEP(13) BP_LU_STEP(14) BP_LU_STEP(15)
 #undef BP_LU_STEP

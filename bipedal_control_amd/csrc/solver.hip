@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kWave) void k_project(Launch L) {
   project_node<NJ>(ws, in, out);
 }
 
-template <int NJ>
+template <int NJ, int RM>
 __global__ __launch_bounds__(kWave) void k_project_lu(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   __shared__ ProjectLuLds<NJ> lds[kLuNodes];
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kWave) void k_project_lu(Launch L) {
     if (j == 0) L.buf.nut[s] = 0;
     valid = false;
   }
-  project_lu4<NJ>(lds[sub], valid, L.buf.nc[s], L.buf.D + s * kMaxEqRows * NU, L.buf.C + s * kMaxEqRows * NX, L.buf.e + s * kMaxEqRows, Px, Pu, Pe,
+  project_lu4<NJ, RM>(lds[sub], valid, L.buf.nc[s], L.buf.D + s * kMaxEqRows * NU, L.buf.C + s * kMaxEqRows * NX, L.buf.e + s * kMaxEqRows, Px, Pu, Pe,
                   L.buf.nut + s, sub, j);
 }
 
@@ -369,6 +369,7 @@ struct bpmpc_solver {
   bpmpc_settings settings{};
   int nx = 0, nu = 0;
   int batch = 0, n_grids = 0, n_nodes_max = 0;
+  int max_rows = kMaxEqRows;                                // largest number of equality rows over the nodes of the current setup
   bool cold = true;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -471,7 +472,10 @@ template <int NJ> void bpmpc_solver::stage_project() {
   const Launch L = launch_params();
   if (settings.reference_kernels) TIMED_LAUNCH("project", k_project<NJ>, batch * settings.max_nodes, kWave, L);
   else {
-    TIMED_LAUNCH("project_lu", k_project_lu<NJ>, (batch * settings.max_nodes + kLuNodes - 1) / kLuNodes, kWave, L);
+    const int lu_grid = (batch * settings.max_nodes + kLuNodes - 1) / kLuNodes;
+    if (max_rows <= 12) TIMED_LAUNCH("project_lu", (k_project_lu<NJ, 12>), lu_grid, kWave, L);
+    else if (max_rows <= 14) TIMED_LAUNCH("project_lu", (k_project_lu<NJ, 14>), lu_grid, kWave, L);
+    else TIMED_LAUNCH("project_lu", (k_project_lu<NJ, 16>), lu_grid, kWave, L);
     TIMED_LAUNCH("project", k_project_fast<NJ>, batch * L.klen, kWave, L);
   }
 }
@@ -523,7 +527,9 @@ template <int NJ> void bpmpc_solver::pipelined_backward() {
     L.klen = hi - lo;
     const int nodes = batch * L.klen;
     TIMED_LAUNCH_ON(producer_stream, "linearize", k_linearize_fast<NJ>, (nodes + NPW - 1) / NPW, kWave, L);
-    TIMED_LAUNCH_ON(producer_stream, "project_lu", k_project_lu<NJ>, (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
+    if (max_rows <= 12) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 12>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
+    else if (max_rows <= 14) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 14>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
+    else TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 16>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
     TIMED_LAUNCH_ON(producer_stream, "project", k_project_fast<NJ>, nodes, kWave, L);
     HIP_CHECK(hipEventRecord(ev_chunk[c], producer_stream));
     HIP_CHECK(hipStreamWaitEvent(stream, ev_chunk[c], 0));
@@ -622,7 +628,7 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   std::vector<double> gdt(S, 0.0), gstart(S, 0.0), zref(S * 4, 0.0), zdref(S * 4, 0.0);
   s->node_times.assign((size_t)G * (N + 1), 0.0);
   SwingPlanner planner(s->rm.swing);
-  int nmax = 0;
+  int nmax = 0, rows_max = 12;
   for (int g = 0; g < G; ++g) {
     const bpmpc_mode_schedule& sc = schedules[g];
     if (sc.n_events < 0 || !sc.modes || (sc.n_events > 0 && !sc.event_times)) throw std::invalid_argument("invalid mode schedule");
@@ -638,6 +644,10 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
     for (int k = 0; k < tab.N; ++k) {
       const size_t i = (size_t)g * N + k;
       kind[i] = tab.kind[k]; mode[i] = tab.mode[k]; gdt[i] = tab.dt[k]; gstart[i] = tab.start[k];
+      if (tab.kind[k] == 0) {                            // rows per contact: 3 in stance, 4 in swing (two contact points per foot)
+        const int left = (tab.mode[k] == 1 || tab.mode[k] == 3) ? 3 : 4, right = (tab.mode[k] == 2 || tab.mode[k] == 3) ? 3 : 4;
+        rows_max = std::max(rows_max, 2 * left + 2 * right);
+      }
       for (int c = 0; c < 4; ++c) { zref[4 * i + c] = tab.zref[4 * k + c]; zdref[4 * i + c] = tab.zdref[4 * k + c]; }
     }
     std::copy(tab.node_time.begin(), tab.node_time.end(), s->node_times.begin() + (size_t)g * (N + 1));
@@ -653,6 +663,7 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
     std::copy(t.states, t.states + (size_t)t.n_points * NX, tgt_x.begin() + (size_t)b * kMaxTargetPoints * NX);
   }
   s->batch = batch; s->n_grids = G; s->n_nodes_max = nmax; s->cold = (warm_x == nullptr);
+  s->max_rows = rows_max;
   s->grid_nodes = nodes; s->grid_of_problem = pgrid;
   Buffers& bf = s->buf;
   upload(s, bf.g_kind, kind); upload(s, bf.g_mode, mode); upload(s, bf.g_nodes, nodes); upload(s, bf.g_dt, gdt); upload(s, bf.g_start, gstart);
