@@ -1,6 +1,6 @@
 // Riccati sweep on the FP64 matrix cores (HIP only; reference with the same mathematics: riccati.h).
 //
-// One 256-thread workgroup per problem, as in riccati_fast.h, whose prefetch, Gauss-Jordan and roll-out are reused.  The
+// One 256-thread workgroup per problem; Gauss-Jordan, barriers and roll-out come from riccati_fast.h.  The
 // products of a stage are 16x16 output blocks accumulated with v_mfma_f64_16x16x4_f64:
 //   * one wavefront per output block; an MFMA reads one A and one B element per lane (a 16x4 and a 4x16 operand), so a
 //     22x22x22 product costs 2 x 64-lane LDS reads per 1024 multiply-adds instead of two 16-byte reads per four - the

@@ -25,7 +25,6 @@
 #include "kernels/node_lq.h"
 #include "kernels/linearize_fast.h"
 #include "kernels/project_node.h"
-#include "kernels/project_fast.h"
 #include "kernels/project_lu4.h"
 #include "kernels/riccati.h"
 #include "kernels/riccati_fast.h"
