@@ -39,15 +39,18 @@ struct RiccatiMfmaWorkspace {
   static constexpr int WC = NX + 1 + NU;                         // packed width [A | b | B]
   static constexpr int LDW = ((WC + 15) / 16) * 16 + 2;
   static_assert(NX + 1 <= 32 && NU <= 32, "two block rows / columns");
+  // staged operands are double buffered when that fits in the 160 KB of LDS (nx = 22): stage k-1 is staged while the
+  // updates of stage k still read theirs, which saves a barrier per stage
+  static constexpr int NBUF = (8 * (4 * RB * LDN + RB * LDW + 2 * (RB * LDN + 3 * RB * LDW)) <= 150 * 1024) ? 2 : 1;
   alignas(16) double S[RB][LDN];        // [S | s], not symmetrised
-  alignas(16) double Qq[RB][LDN];       // [Q~ | q~]
+  alignas(16) double Qq[NBUF][RB][LDN];    // [Q~ | q~]
   alignas(16) double Sn[RB][LDN];       // [Sn | sn]
   alignas(16) double G0[RB][LDN];       // [G | g] before the elimination
-  alignas(16) double W[RB][LDW];        // [A~ | b~ | B~]
-  alignas(16) double PW[RB][LDW];       // [Px | Pe | Pu]
+  alignas(16) double W[NBUF][RB][LDW];     // [A~ | b~ | B~]
+  alignas(16) double PW[NBUF][RB][LDW];    // [Px | Pe | Pu]
   alignas(16) double SW[RB][LDW];       // sym(S) W
-  alignas(16) double M[RB][LDW];        // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
-  double r[NU];
+  alignas(16) double M[NBUF][RB][LDW];     // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
+  double r[NBUF][NU];
   alignas(16) double dx[2][NX];
   int status;
   int nut[kMaxRiccatiStages];           // reduced input dimensions of all stages (a global load per stage would sit on the critical path)
@@ -162,6 +165,12 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
 
   for (int k = k_top; k >= io.k_lo; --k) {
     const int nt = ws.nut[k];        // max_nodes <= kMaxRiccatiStages is checked when the solver is created
+    const int cur = WS::NBUF == 2 ? (k & 1) : 0;
+    double (*const W)[LDW] = ws.W[cur];
+    double (*const PW)[LDW] = ws.PW[cur];
+    double (*const Qq)[LDN] = ws.Qq[cur];
+    double (*const M)[LDW] = ws.M[cur];
+    double* const rvec = ws.r[cur];
     const int ksn = (nt + 3) >> 2;                   // k-steps over the reduced input
     const int nbc = (BC + nt + 15) >> 4;             // block columns of the packed width nx + 1 + nt
     const int ntb = (nt + 15) >> 4;                  // block rows of the reduced input
@@ -172,16 +181,16 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
         if (e == 0 || second) {
           const int idx = 2 * (tid + e * NLD);
           const int i = idx / NX, j = idx % NX;              // j even: the pair stays inside row i
-          ws.W[i][j] = pA[e].x; ws.W[i][j + 1] = pA[e].y;
-          ws.W[i][BC + j] = pB[e].x; ws.W[i][BC + j + 1] = pB[e].y;
-          ws.Qq[i][j] = pQ[e].x; ws.Qq[i][j + 1] = pQ[e].y;
-          ws.PW[i][j] = pPx[e].x; ws.PW[i][j + 1] = pPx[e].y;
-          ws.PW[i][BC + j] = pPu[e].x; ws.PW[i][BC + j + 1] = pPu[e].y;
-          ws.M[i][j] = pP[e].x; ws.M[i][j + 1] = pP[e].y;
-          ws.M[i][BC + j] = pR[e].x; ws.M[i][BC + j + 1] = pR[e].y;
+          W[i][j] = pA[e].x; W[i][j + 1] = pA[e].y;
+          W[i][BC + j] = pB[e].x; W[i][BC + j + 1] = pB[e].y;
+          Qq[i][j] = pQ[e].x; Qq[i][j + 1] = pQ[e].y;
+          PW[i][j] = pPx[e].x; PW[i][j + 1] = pPx[e].y;
+          PW[i][BC + j] = pPu[e].x; PW[i][BC + j + 1] = pPu[e].y;
+          M[i][j] = pP[e].x; M[i][j + 1] = pP[e].y;
+          M[i][BC + j] = pR[e].x; M[i][BC + j + 1] = pR[e].y;
         }
       }
-      if (tid < NX) { ws.W[tid][NX] = pv[0]; ws.Qq[tid][NX] = pv[1]; ws.M[tid][NX] = pv[2]; ws.r[tid] = pv[2]; ws.PW[tid][NX] = pv[3]; }
+      if (tid < NX) { W[tid][NX] = pv[0]; Qq[tid][NX] = pv[1]; M[tid][NX] = pv[2]; rvec[tid] = pv[2]; PW[tid][NX] = pv[3]; }
     }
     lds_barrier();
     RMPROF(0);
@@ -200,7 +209,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
         a[ks] = half * (ws.S[row][kk] + ws.S[kk][row]);
-        b[ks] = ws.W[kk][c0 + li];
+        b[ks] = W[kk][c0 + li];
       }
       const double smask = (c0 + li == NX) ? 1.0 : 0.0;              // s rides in the b column; rows >= nx of S are zero
 #pragma unroll
@@ -217,18 +226,18 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
     for (int id = w; id < ntb * nbc; id += 4) {
       const int bi = id >= nbc ? 1 : 0;
       const int r0 = 16 * bi, c0 = 16 * (id - bi * nbc);
-      v4d acc = blk_load<LDW>(&ws.M[0][0], r0, c0, l);
+      v4d acc = blk_load<LDW>(&M[0][0], r0, c0, l);
       double a[KS], b[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
-        a[ks] = ws.W[kk][BC + r0 + li];                                // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
+        a[ks] = W[kk][BC + r0 + li];                                // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
         b[ks] = ws.SW[kk][c0 + li];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-      blk_store<LDW>(&ws.M[0][0], r0, c0, l, acc);
+      blk_store<LDW>(&M[0][0], r0, c0, l, acc);
       if (c0 < 32) blk_store<LDN>(&ws.G0[0][0], r0, c0, l, acc);
     }
     if (w == 3) flush_held();        // (wave 3 runs the elimination in P3, the other waves store and prefetch there)
@@ -247,9 +256,9 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
 #define BP_GJ_CASE(ROWS)                                                                      \
       {                                                                                       \
         double v[ROWS];                                                                       \
-        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) v[i] = (used && i < nt) ? ws.M[i][col] : 0.0; \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) v[i] = (used && i < nt) ? M[i][col] : 0.0; \
         ok = gauss_jordan_wave<ROWS>(v, nt);                                                  \
-        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (used && i < nt && l >= nt) ws.M[i][col] = v[i]; \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (used && i < nt && l >= nt) M[i][col] = v[i]; \
       }
       if (nt <= 8) BP_GJ_CASE(8)
       else if (nt <= 10) BP_GJ_CASE(10)
@@ -266,13 +275,13 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
 #endif
       for (int id = w; id < 4; id += 3) {
         const int r0 = 16 * (id >> 1), c0 = 16 * (id & 1);
-        v4d acc = blk_load<LDN>(&ws.Qq[0][0], r0, c0, l);
+        v4d acc = blk_load<LDN>(&Qq[0][0], r0, c0, l);
         const int acol = r0 + li < NX ? r0 + li : LDW - 1;             // the last padding column of W is always zero
         double a[KS], b[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int kk = 4 * ks + lk;
-          a[ks] = ws.W[kk][acol];                                      // A'(i, kk)
+          a[ks] = W[kk][acol];                                      // A'(i, kk)
           b[ks] = ws.SW[kk][c0 + li];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -288,8 +297,8 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
       const int r0 = 16 * (w >> 1), c0 = 16 * (w & 1);
       const int row = r0 + li;
       v4d acc = blk_load<LDN>(&ws.Sn[0][0], r0, c0, l);
-      v4d acl = blk_load<LDW>(&ws.W[0][0], r0, c0, l);
-      v4d kf = blk_load<LDW>(&ws.PW[0][0], r0, c0, l);
+      v4d acl = blk_load<LDW>(&W[0][0], r0, c0, l);
+      v4d kf = blk_load<LDW>(&PW[0][0], r0, c0, l);
       const int gcol = row < NX ? row : LDN - 1;                       // the last padding column of G0 is always zero
       if (ksn <= 3) {
         // up to 12 reduced inputs (every reference configuration): three k-steps, operands first, then the MFMAs of the
@@ -298,10 +307,10 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
           const int kk = 4 * ks + lk;
-          yb[ks] = ws.M[kk][c0 + li];
+          yb[ks] = M[kk][c0 + li];
           ag[ks] = -ws.G0[kk][gcol];                                   // -G'(i, kk)
-          ab[ks] = -ws.W[row][BC + kk];                                // -B(i, kk); rows >= nx of W and PW are zero
-          ap[ks] = -ws.PW[row][BC + kk];                               // -Pu(i, kk)
+          ab[ks] = -W[row][BC + kk];                                // -B(i, kk); rows >= nx of W and PW are zero
+          ap[ks] = -PW[row][BC + kk];                               // -Pu(i, kk)
         }
         __builtin_amdgcn_sched_barrier(0);
         const int nks = ksn == 3 ? 3 : 2;
@@ -316,30 +325,30 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
       } else {
         for (int ks = 0; ks < ksn; ++ks) {
           const int kk = 4 * ks + lk;
-          const double yv = ws.M[kk][c0 + li];
+          const double yv = M[kk][c0 + li];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ws.G0[kk][gcol], yv, acc, 0, 0, 0);
-          acl = __builtin_amdgcn_mfma_f64_16x16x4f64(-ws.W[row][BC + kk], yv, acl, 0, 0, 0);
-          kf = __builtin_amdgcn_mfma_f64_16x16x4f64(-ws.PW[row][BC + kk], yv, kf, 0, 0, 0);
+          acl = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[row][BC + kk], yv, acl, 0, 0, 0);
+          kf = __builtin_amdgcn_mfma_f64_16x16x4f64(-PW[row][BC + kk], yv, kf, 0, 0, 0);
         }
       }
       blk_store<LDN>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, three barriers ago
       // m = q~ - Y' r~ (Kt = -Y), m0 = -r~' H^-1 g
       double mt = 0.0;
       if (BPMPC_RICCATI_ABLATE != 4 && w == 3 && l <= NX) {
-        mt = l < NX ? ws.Qq[l][NX] : 0.0;
+        mt = l < NX ? Qq[l][NX] : 0.0;
         if (nt <= 12) {
 #pragma unroll
-          for (int i = 0; i < 12; ++i) mt -= ws.M[i][l] * ws.r[i];     // rows >= nt of Y are zero
+          for (int i = 0; i < 12; ++i) mt -= M[i][l] * rvec[i];     // rows >= nt of Y are zero
         } else {
-          for (int i = 0; i < nt; ++i) mt -= ws.M[i][l] * ws.r[i];
+          for (int i = 0; i < nt; ++i) mt -= M[i][l] * rvec[i];
         }
       }
       // results of this stage stay in registers; they are stored after the staging barrier of the next stage (see there)
       held_acl = acl; held_kf = kf; held_m = mt; held_k = k;
     }
     RMPROF(5);
-    lds_barrier();                   // the next stage overwrites W, PW, Qq, M
-    RMPROF(6);
+    // double buffered: no barrier here, the next stage stages into the other buffer set and its staging barrier also orders S
+    if (WS::NBUF == 1) lds_barrier();
   }
   flush_held();
 #ifdef BPMPC_RICCATI_PROFILE
