@@ -260,6 +260,22 @@ class BatchedSqpMpc:
         self.batch = B
         return self.layout()
 
+    def setup_from_previous(self, t0, x0, modeSchedules, targetTrajectories, horizon=None):
+        """Receding-horizon step (MPC_BASE::run with mpc.coldStart false): new measured states / schedules / targets, initial
+        iterate shifted on the device from the previous solve of this handle (bpmpc_solver_setup_from_previous)."""
+        if horizon is None:
+            horizon = self.interface.mpcSettings()["timeHorizon"]
+        B, t0, x0, sched, ns, tg, _, _, keep = self._marshal(t0, x0, modeSchedules, targetTrajectories, None, None)
+        _check(load_library().bpmpc_solver_setup_from_previous(self._h, B, C.c_double(horizon), _d(t0), _d(x0), sched, ns, tg))
+        self.batch = B
+        return self.layout()
+
+    def advance(self, t0, x0, modeSchedules, targetTrajectories, horizon=None, gains=False):
+        """One MPC tick for the whole batch: warm start from the previous solution, solve, fetch."""
+        self.setup_from_previous(t0, x0, modeSchedules, targetTrajectories, horizon)
+        self.enqueue()
+        return self.fetch(gains=gains)
+
     def layout(self):
         b, n, g, nx, nu = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _check(load_library().bpmpc_solver_layout(self._h, C.byref(b), C.byref(n), C.byref(g), C.byref(nx), C.byref(nu)))

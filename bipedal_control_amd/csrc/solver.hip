@@ -63,6 +63,9 @@ struct Buffers {
   // riccati
   double *Kt, *kt, *dx, *du, *K, *summary, *dx0;
   double *Acl, *bcl, *kff, *mvec, *mscal, *rprof;
+  // previous solution, kept for the receding-horizon warm start (k_warm_shift)
+  double *x_prev, *u_prev, *K_prev, *tp_time;
+  int *tp_kind, *tp_nodes, *tp_grid;
   double* ric_carry;   // per problem NX*NX + NX + 1: value function and status handed from one horizon chunk to the next
   // line search
   double *trial_perf, *base, *alpha, *stats;
@@ -282,6 +285,76 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati_fast(Launch L) {
   riccati_mfma<NJ>(ws, io);
 }
 
+// Warm start of a receding-horizon solve from the previous solution, one wavefront per problem (sequential in the nodes:
+// the guess of x_{i+1} is either interpolated or a copy of x_i).  [OCS2-upstream, recalled]
+// SqpSolver::initializeStateInputTrajectories with a non-empty PrimalSolution: for an intermediate node with
+// intervalStart <= second-to-last and intervalEnd <= last time of the previous solution,
+//     u_i = uff(t) + K(t) x_i  (LinearController, sqp.useFeedbackPolicy true, task.info:80;  uff_j = u_j - K_j x_j, inputs and
+//           gains of pre-event nodes and of the terminal node repeat the previous one: multiple_shooting::toPrimalSolution),
+//     x_{i+1} = LinearInterpolation(intervalEnd, previous states);
+// otherwise BipedalRobotInitializer::compute (already written by k_prepare); event nodes copy the state.
+// Oracle: oracle/reference_py.py warm_start_from_previous.
+__device__ __forceinline__ void time_segment(const double* t, int n, double q, int* idx, double* alpha) {
+  if (q <= t[0]) { *idx = 0; *alpha = 1.0; return; }
+  if (q >= t[n - 1]) { *idx = n - 2; *alpha = 0.0; return; }
+  int lo = 0, hi = n;                       // lower_bound: first element >= q
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (t[mid] < q) lo = mid + 1; else hi = mid; }
+  int i = lo - 1;
+  i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+  *idx = i;
+  *alpha = (t[i + 1] - q) / (t[i + 1] - t[i]);
+}
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_warm_shift(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ double xi[NX];
+  const int b = blockIdx.x, l = threadIdx.x;
+  const int N = L.N;
+  const int g = L.buf.p_grid[b], n = L.buf.g_nodes[g];
+  const int gp = L.buf.tp_grid[b], np = L.buf.tp_nodes[gp];
+  if (np < 1) return;
+  const double* tp = L.buf.tp_time + (size_t)gp * (N + 1);
+  const int* kp = L.buf.tp_kind + (size_t)gp * N;
+  const double* xp = L.buf.x_prev + (size_t)b * (N + 1) * NX;
+  const double* up = L.buf.u_prev + (size_t)b * N * NU;
+  const double* Kp = L.buf.K_prev + (size_t)b * N * NU * NX;
+  double* x = L.buf.x + (size_t)b * (N + 1) * NX;
+  double* u = L.buf.u + (size_t)b * N * NU;
+  const double state_till = tp[np], input_till = tp[np - 1];
+  auto effective = [&](int j) { while (j > 0 && (j == np || kp[j] == 1)) --j; return j; };   // repeated input / gain
+  if (l < NX) { const double v = L.buf.p_x0[(size_t)b * NX + l]; xi[l] = v; x[l] = v; }
+  __syncthreads();
+  for (int i = 0; i < n; ++i) {
+    const size_t gs = (size_t)g * N + i;
+    double xn = l < NX ? xi[l] : 0.0;
+    if (L.buf.g_kind[gs] == 0) {
+      const double t = L.buf.g_start[gs], tn = t + L.buf.g_dt[gs];
+      if (!(t > input_till || tn > state_till)) {
+        int j, j2; double a, a2;
+        time_segment(tp, np + 1, t, &j, &a);
+        time_segment(tp, np + 1, tn, &j2, &a2);
+        if (l < NU) {
+          const int e0 = effective(j), e1 = effective(j + 1);
+          const double* K0 = Kp + ((size_t)e0 * NU + l) * NX;
+          const double* K1 = Kp + ((size_t)e1 * NU + l) * NX;
+          double uff0 = up[(size_t)e0 * NU + l], uff1 = up[(size_t)e1 * NU + l], kx = 0.0;
+          for (int c = 0; c < NX; ++c) {
+            const double k0 = K0[c], k1 = K1[c];
+            uff0 -= k0 * xp[(size_t)j * NX + c];
+            uff1 -= k1 * xp[(size_t)(j + 1) * NX + c];
+            kx += (a * k0 + (1.0 - a) * k1) * xi[c];
+          }
+          u[(size_t)i * NU + l] = a * uff0 + (1.0 - a) * uff1 + kx;
+        }
+        if (l < NX) xn = a2 * xp[(size_t)j2 * NX + l] + (1.0 - a2) * xp[(size_t)(j2 + 1) * NX + l];
+      }
+    }
+    __syncthreads();                        // everybody has read xi
+    if (l < NX) { xi[l] = xn; x[(size_t)(i + 1) * NX + l] = xn; }
+    __syncthreads();
+  }
+}
+
 template <int NJ>
 __device__ __forceinline__ ProblemLS problem_ls(const Launch& L, int b) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
@@ -368,6 +441,8 @@ struct bpmpc_solver {
   bpmpc_settings settings{};
   int nx = 0, nu = 0;
   int batch = 0, n_grids = 0, n_nodes_max = 0;
+  bool has_solution = false;                               // a solve has completed on the current setup
+  std::vector<int> grid_kind;                               // host copy of the node kinds of the current setup [n_grids][N]
   int max_rows = kMaxEqRows;                                // largest number of equality rows over the nodes of the current setup
   bool cold = true;
   hipStream_t stream = nullptr;
@@ -549,6 +624,7 @@ template <int NJ> void bpmpc_solver::run_iterations() {
     }
     stage_linesearch<NJ>();
   }
+  has_solution = true;
 }
 
 #define DISPATCH_NJ(self, call)                                        \
@@ -572,6 +648,10 @@ void allocate(bpmpc_solver* s) {
   const size_t B = s->settings.max_batch, N = s->settings.max_nodes, NX = s->nx, NU = s->nu, S = B * N;
   Buffers& b = s->buf;
   b.proj_extent = s->alloc<int>("proj_extent", S, true);
+  b.x_prev = s->alloc<double>("x_prev", B * (N + 1) * NX); b.u_prev = s->alloc<double>("u_prev", S * NU);
+  b.K_prev = s->alloc<double>("K_prev", S * NU * NX);
+  b.tp_time = s->alloc<double>("tp_time", B * (N + 1)); b.tp_kind = s->alloc<int>("tp_kind", S, true);
+  b.tp_nodes = s->alloc<int>("tp_nodes", B, true); b.tp_grid = s->alloc<int>("tp_grid", B, true);
   b.ric_carry = s->alloc<double>("ric_carry", B * (NX * NX + NX + 2));   // S, s, status, scratch word
   b.g_kind = s->alloc<int>("g_kind", S, true); b.g_mode = s->alloc<int>("g_mode", S, true); b.g_nodes = s->alloc<int>("g_nodes", B, true);
   b.g_dt = s->alloc<double>("g_dt", S); b.g_start = s->alloc<double>("g_start", S);
@@ -611,7 +691,7 @@ void upload(bpmpc_solver* s, T* dst, const std::vector<T>& src) {
 }
 
 void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
-           int n_schedules, const bpmpc_target* targets, const double* warm_x, const double* warm_u) {
+           int n_schedules, const bpmpc_target* targets, const double* warm_x, const double* warm_u, bool from_previous = false) {
   if (batch < 1 || batch > s->settings.max_batch) throw std::length_error("batch exceeds the solver's max_batch");
   if (!(horizon > 0) || !t0 || !x0 || !schedules || !targets) throw std::invalid_argument("solve: null or invalid argument");
   if (n_schedules != 1 && n_schedules != batch) throw std::invalid_argument("n_schedules must be 1 or batch");
@@ -622,6 +702,20 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   if (G == 1)
     for (int b = 1; b < batch; ++b)
       if (t0[b] != t0[0]) throw std::invalid_argument("a shared schedule needs identical t0 for all problems");
+  // receding-horizon warm start: keep the previous solution and its grid on the device before anything is overwritten
+  std::vector<double> prev_times;
+  std::vector<int> prev_kind, prev_nodes, prev_pgrid;
+  if (from_previous) {
+    if (warm_x) throw std::invalid_argument("warm start arrays and from_previous are exclusive");
+    if (!s->has_solution || batch != s->batch) throw std::invalid_argument("setup_from_previous needs a completed solve of the same batch");
+    Buffers& bp = s->buf;
+    if (!bp.K) throw std::invalid_argument("setup_from_previous needs the feedback gains (return_gains with reference kernels)");
+    HIP_CHECK(hipMemcpyAsync(bp.x_prev, bp.x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIP_CHECK(hipMemcpyAsync(bp.u_prev, bp.u, (size_t)batch * N * NU * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIP_CHECK(hipMemcpyAsync(bp.K_prev, bp.K, (size_t)batch * N * NU * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    prev_times = s->node_times; prev_kind = s->grid_kind; prev_nodes = s->grid_nodes; prev_pgrid = s->grid_of_problem;
+    upload(s, bp.tp_time, prev_times); upload(s, bp.tp_kind, prev_kind); upload(s, bp.tp_nodes, prev_nodes); upload(s, bp.tp_grid, prev_pgrid);
+  }
   const size_t S = (size_t)G * N;
   std::vector<int> kind(S, 0), mode(S, STANCE), nodes(G, 0), pgrid(batch, 0);
   std::vector<double> gdt(S, 0.0), gstart(S, 0.0), zref(S * 4, 0.0), zdref(S * 4, 0.0);
@@ -663,7 +757,7 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   }
   s->batch = batch; s->n_grids = G; s->n_nodes_max = nmax; s->cold = (warm_x == nullptr);
   s->max_rows = rows_max;
-  s->grid_nodes = nodes; s->grid_of_problem = pgrid;
+  s->grid_nodes = nodes; s->grid_of_problem = pgrid; s->grid_kind = kind; s->has_solution = false;
   Buffers& bf = s->buf;
   upload(s, bf.g_kind, kind); upload(s, bf.g_mode, mode); upload(s, bf.g_nodes, nodes); upload(s, bf.g_dt, gdt); upload(s, bf.g_start, gstart);
   upload(s, bf.g_zref, zref); upload(s, bf.g_zdref, zdref); upload(s, bf.p_grid, pgrid);
@@ -675,6 +769,12 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   }
   HIP_CHECK(hipStreamSynchronize(s->stream));  // the host staging vectors go out of scope
   DISPATCH_NJ(s, stage_prepare);
+  if (from_previous) {
+    const Launch L = s->launch_params();
+    if (s->rm.nj == 10) hipLaunchKernelGGL(k_warm_shift<10>, dim3(batch), dim3(kWave), 0, s->stream, L);
+    else hipLaunchKernelGGL(k_warm_shift<12>, dim3(batch), dim3(kWave), 0, s->stream, L);
+    HIP_CHECK(hipGetLastError());
+  }
   HIP_CHECK(hipMemcpyAsync(bf.x_init, bf.x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   HIP_CHECK(hipMemcpyAsync(bf.u_init, bf.u, (size_t)batch * N * NU * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   // activate
@@ -790,6 +890,10 @@ void bpmpc_solver_destroy(bpmpc_solver* s) {
 int bpmpc_solver_setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
                        int n_schedules, const bpmpc_target* targets, const double* warm_x, const double* warm_u) {
   API_GUARD(s, setup(s, batch, horizon, t0, x0, schedules, n_schedules, targets, warm_x, warm_u))
+}
+int bpmpc_solver_setup_from_previous(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0,
+                                     const bpmpc_mode_schedule* schedules, int n_schedules, const bpmpc_target* targets) {
+  API_GUARD(s, setup(s, batch, horizon, t0, x0, schedules, n_schedules, targets, nullptr, nullptr, true))
 }
 int bpmpc_solver_reset(bpmpc_solver* s) { API_GUARD(s, reset(s)) }
 int bpmpc_solver_run(bpmpc_solver* s) {

@@ -157,6 +157,13 @@ int bpmpc_solve_batch(bpmpc_solver* solver, int batch, double horizon, const dou
 int bpmpc_solver_setup(bpmpc_solver* solver, int batch, double horizon, const double* t0, const double* x0,
                        const bpmpc_mode_schedule* schedules, int n_schedules, const bpmpc_target* targets, const double* warm_x,
                        const double* warm_u);
+/* Receding-horizon step: like bpmpc_solver_setup, but the initial iterate is taken from the previous solve of this handle
+ * (same batch), entirely on the device: inside the time span of the previous solution u_k = uff(t_k) + K(t_k) x_k and x_{k+1} is
+ * interpolated, beyond it the initializer guess is used ([OCS2-upstream] SqpSolver::initializeStateInputTrajectories with
+ * mpc.coldStart false, task.info:173, and sqp.useFeedbackPolicy true, task.info:80 - the MPC loop of
+ * bipedal_controllers/src/BipedalController.cpp:332-350).  Needs a completed bpmpc_solver_run on the handle. */
+int bpmpc_solver_setup_from_previous(bpmpc_solver* solver, int batch, double horizon, const double* t0, const double* x0,
+                                     const bpmpc_mode_schedule* schedules, int n_schedules, const bpmpc_target* targets);
 int bpmpc_solver_reset(bpmpc_solver* solver);   /* restore the initial iterate of the last setup (device-side copy, async) */
 int bpmpc_solver_run(bpmpc_solver* solver);     /* enqueue the SQP iteration(s) on the solver's stream */
 int bpmpc_solver_sync(bpmpc_solver* solver);

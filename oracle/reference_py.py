@@ -332,3 +332,67 @@ def cold_start(model, nodes, x0):
         if nodes["kind"][k] == 0:
             u[k] = weight_compensating_input(model, int(nodes["mode"][k]))
     return x, u
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Warm start of a receding-horizon solve from the previous solution (SURVEY.md section 8(f) rank 1, A.5 "Initial guess").
+# [OCS2-upstream, recalled] SqpSolver::initializeStateInputTrajectories, multiple_shooting::toPrimalSolution,
+# multiple_shooting::initializeIntermediateNode(PrimalSolution&, ...), LinearController::computeInput,
+# LinearInterpolation::timeSegment.  Used with mpc.coldStart false (task.info:173) and sqp.useFeedbackPolicy true
+# (task.info:80).
+# ---------------------------------------------------------------------------------------------------------------
+def primal_solution_arrays(prev_nodes, x, u, K):
+    """[OCS2-upstream] multiple_shooting::toPrimalSolution: one entry per node time; the input (and gain) of a pre-event
+    node and of the terminal node repeat the previous one; uff = u - K x (LinearController bias)."""
+    N = int(prev_nodes["N"])
+    t = np.asarray(prev_nodes["times"], float)
+    nu, nx = u.shape[1], x.shape[1]
+    uu = np.zeros((N + 1, nu))
+    KK = np.zeros((N + 1, nu, nx))
+    for j in range(N + 1):
+        repeat = (j == N) or (prev_nodes["kind"][j] == 1 and j > 0)
+        if repeat and j > 0:
+            uu[j], KK[j] = uu[j - 1], KK[j - 1]
+        elif j < N:
+            uu[j], KK[j] = u[j], K[j]
+    uff = np.array([uu[j] - KK[j] @ x[j] for j in range(N + 1)])
+    return t, np.asarray(x, float), uff, KK
+
+
+def time_segment(times, t):
+    """[OCS2-upstream] LinearInterpolation::timeSegment: (index, alpha) with value = alpha v[i] + (1 - alpha) v[i + 1]."""
+    n = len(times)
+    if t <= times[0]:
+        return 0, 1.0
+    if t >= times[-1]:
+        return n - 2, 0.0
+    idx = int(np.searchsorted(times, t, side="left"))      # lower_bound
+    i = min(max(idx - 1, 0), n - 2)
+    return i, (times[i + 1] - t) / (times[i + 1] - times[i])
+
+
+def warm_start_from_previous(model, nodes, x_measured, prev_nodes, prev_x, prev_u, prev_K):
+    """Initial iterate (x[N+1], u[N]) of a new solve on `nodes` given the previous solve's result."""
+    N = int(nodes["N"])
+    nx, nu = model["nx"], model["nu"]
+    tp, xp, uff, KK = primal_solution_arrays(prev_nodes, prev_x, prev_u, prev_K)
+    state_till = tp[-1]
+    input_till = tp[-2] if len(tp) >= 2 else tp[0]
+    x = np.zeros((N + 1, nx))
+    u = np.zeros((N, nu))
+    x[0] = x_measured
+    for i in range(N):
+        if nodes["kind"][i] == 1:            # event node: identity jump map as the guess
+            x[i + 1] = x[i]
+            continue
+        t = nodes["ti"][i]
+        t_next = t + nodes["dt"][i]
+        if t > input_till or t_next > state_till:
+            u[i] = weight_compensating_input(model, int(nodes["mode"][i]))      # BipedalRobotInitializer::compute
+            x[i + 1] = x[i]
+        else:
+            j, a = time_segment(tp, t)
+            u[i] = a * uff[j] + (1.0 - a) * uff[j + 1] + (a * KK[j] + (1.0 - a) * KK[j + 1]) @ x[i]
+            j2, a2 = time_segment(tp, t_next)
+            x[i + 1] = a2 * xp[j2] + (1.0 - a2) * xp[j2 + 1]
+    return x, u

@@ -93,3 +93,50 @@ def test_bench_contract():
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-4
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["max_abs_x_diff_vs_gpu"] < 1e-8
     assert "workload" in d["config"] and d["value"] > 0
+
+
+def test_receding_horizon_loop_matches_oracle(ctx):
+    """the MPC loop (BipedalController.cpp:332-350) with warm starts shifted on the device
+    (bpmpc_solver_setup_from_previous) against the oracle's restatement of SqpSolver::initializeStateInputTrajectories
+    (oracle/reference_py.py warm_start_from_previous).  The tick period (0.02 s) is not a multiple of dt (0.015 s) and the
+    horizon contains gait events, so inputs, gains and states are all interpolated."""
+    import numpy as np
+    from oracle import reference_py as rp
+    bp, sc, ob, itf = ctx
+    B, NI, tick = 3, 40, 0.02
+    horizon = NI * sc.DT
+    x_meas = sc.perturbed_initial_states(itf, B)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=64, return_gains=True)
+    m, om = ob.model("h1"), ob.oracle("h1")
+    sq = m["sqp"]
+    prev = [None] * B
+    worst = 0.0
+    for it in range(4):
+        t0 = it * tick
+        sched = sc.gait_schedule(itf, "trot", t0, horizon)
+        targets = [itf.cmdVelToTargetTrajectories((0.3, 0.0, 0.0, 0.1), t0, x_meas[b], horizon) for b in range(B)]
+        prob = dict(t0=t0, x0=x_meas, schedule=sched, targets=targets, horizon=horizon)
+        if it == 0:
+            t, x, u, K, stats = mpc.run(t0, x_meas, sched, targets, horizon=horizon, gains=True)
+        else:
+            t, x, u, K, stats = mpc.advance(t0, x_meas, sched, targets, horizon=horizon, gains=True)
+        nxt = np.zeros_like(x_meas)
+        for b in range(B):
+            nodes = ob.oracle_nodes(prob, b)
+            if prev[b] is None:
+                xi, ui = rp.cold_start(m, nodes, x_meas[b])
+            else:
+                xi, ui = rp.warm_start_from_previous(m, nodes, x_meas[b], *prev[b])
+            xo, uo, Ko, st = om.solve(nodes, x_meas[b], xi, ui, iterations=1, g_max=sq["g_max"], g_min=sq["g_min"], delta_tol=sq["deltaTol"])
+            n = stats[b].n_nodes
+            assert n == nodes["N"]
+            ex = np.max(np.abs(x[b, :n + 1] - xo)) / max(1.0, np.max(np.abs(xo)))
+            eu = np.max(np.abs(u[b, :n] - uo)) / max(1.0, np.max(np.abs(uo)))
+            worst = max(worst, ex, eu)
+            assert ex < 1e-8 and eu < 1e-8, (it, b, ex, eu)
+            prev[b] = (nodes, xo, uo, Ko)
+            # "measurement" of the next tick: the planned state at t0 + tick plus a small deterministic disturbance
+            j, a = rp.time_segment(nodes["times"], t0 + tick)
+            nxt[b] = a * xo[j] + (1.0 - a) * xo[j + 1] + 1e-3 * np.sin(np.arange(xo.shape[1]) + b + it)
+        x_meas = nxt
+    assert worst < 1e-8

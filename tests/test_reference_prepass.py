@@ -120,3 +120,52 @@ def test_weight_compensation_known_answer(env):
     assert abs(rp.weight_compensating_input(m, 3)[2] - 126.6495525) < 1e-9
     u = rp.weight_compensating_input(m, 1)
     assert abs(u[2] - 253.299105) < 1e-9 and u[8] == 0 and np.all(u[12:] == 0)
+
+
+def test_time_segment_semantics():
+    """[OCS2-upstream] LinearInterpolation::timeSegment on a time array with a duplicated event time."""
+    t = [0.0, 1.0, 1.0, 2.0]
+    assert rp.time_segment(t, -1.0) == (0, 1.0) and rp.time_segment(t, 3.0) == (2, 0.0)
+    assert rp.time_segment(t, 0.25) == (0, 0.75)
+    i, a = rp.time_segment(t, 1.0)             # exactly on the event: the segment that ENDS at the pre-event node
+    assert (i, a) == (0, 0.0)
+    i, a = rp.time_segment(t, 1.0 + 1e-6)      # just behind it: the segment that STARTS at the post-event node
+    assert i == 2 and abs(a - (1.0 - 1e-6)) < 1e-12
+
+
+def test_warm_start_from_previous_properties():
+    """Restatement of SqpSolver::initializeStateInputTrajectories (warm branch): with an unchanged grid and the previous initial
+    state it reproduces the previous solution wherever that is defined; beyond its span it falls back to the initializer; a
+    shifted measurement enters through the feedback term of the first node only."""
+    from tests import oracle_bridge as ob
+    m, om = ob.model("h1"), ob.oracle("h1")
+    planner = rp.SwingTrajectoryPlanner(m["swing"])
+    ev, ms = [0.21, 0.9], [3, 1, 3]                                # stance, left-foot support (one event inside the horizons), stance
+    planner.update(ev, ms)
+    x0 = np.asarray(m["initial_state"], float)
+    tt, xs = np.array([0.0, 0.45]), np.vstack([x0, x0])
+    nodes = rp.node_arrays(m, 0.0, 0.45, 0.015, ev, ms, tt, xs, planner)
+    xi, ui = rp.cold_start(m, nodes, x0)
+    s = m["sqp"]
+    xo, uo, Ko, _ = om.solve(nodes, x0, xi, ui, iterations=1, g_max=s["g_max"], g_min=s["g_min"], delta_tol=s["deltaTol"])
+    N = nodes["N"]
+    xw, uw = rp.warm_start_from_previous(m, nodes, x0, nodes, xo, uo, Ko)
+    ev_node = int(np.nonzero(nodes["kind"] == 1)[0][0])            # the pre-event node; interval ends / starts next to it are nudged
+    near = {ev_node, ev_node + 1}                                  # by weakEpsilon = 1e-6, so the guess there is off by 1e-6 * slope
+    far = [k for k in range(N + 1) if k not in near]
+    assert np.allclose(xw[far], xo[far], atol=1e-12) and np.allclose(xw, xo, atol=5e-6)
+    inter = [k for k in range(N) if nodes["kind"][k] == 0]
+    assert np.allclose(uw[[k for k in inter if k not in near]], uo[[k for k in inter if k not in near]], atol=1e-9)
+    assert np.allclose(uw[inter], uo[inter], atol=1e-2)
+    last = N
+    # a new grid that starts later: nodes beyond the previous span get the initializer guess (constant state, nominal input)
+    nodes2 = rp.node_arrays(m, 0.30, 0.75, 0.015, ev, ms, tt + 0.3, xs, planner)
+    xw2, uw2 = rp.warm_start_from_previous(m, nodes2, xo[20], nodes, xo, uo, Ko)
+    beyond = [k for k in range(nodes2["N"]) if nodes2["ti"][k] > nodes["times"][-2]]
+    assert beyond and all(np.array_equal(xw2[k + 1], xw2[k]) for k in beyond)
+    assert all(np.array_equal(uw2[k], rp.weight_compensating_input(m, int(nodes2["mode"][k]))) for k in beyond)
+    # the measured state enters only through K (x_meas - x*) at the first node
+    dxm = 1e-3 * np.ones(m["nx"])
+    xw3, uw3 = rp.warm_start_from_previous(m, nodes, x0 + dxm, nodes, xo, uo, Ko)
+    assert np.allclose(uw3[0] - uw[0], Ko[0] @ dxm, atol=1e-10) and np.allclose(uw3[1:], uw[1:], atol=1e-12)
+    assert np.allclose(xw3[1:], xw[1:], atol=1e-12)
