@@ -698,10 +698,27 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   if ((warm_x == nullptr) != (warm_u == nullptr)) throw std::invalid_argument("warm_x and warm_u must be given together");
   const int N = s->settings.max_nodes, NX = s->nx, NU = s->nu;
   const double dt = s->settings.dt > 0 ? s->settings.dt : s->rm.sqp.dt;
-  const int G = n_schedules;
-  if (G == 1)
+  if (n_schedules == 1)
     for (int b = 1; b < batch; ++b)
       if (t0[b] != t0[0]) throw std::invalid_argument("a shared schedule needs identical t0 for all problems");
+  // One grid (time discretisation, modes, swing references) per DISTINCT (t0, mode schedule): a gait-library sweep hands over
+  // thousands of problems but only a handful of schedules, and the host pre-pass is per grid.
+  std::vector<int> grid_of(batch, 0), first_problem;       // first_problem[g]: a problem that owns grid g
+  {
+    std::map<std::string, int> seen;
+    for (int b = 0; b < batch; ++b) {
+      const bpmpc_mode_schedule& sc = schedules[n_schedules == 1 ? 0 : b];
+      if (sc.n_events < 0 || !sc.modes || (sc.n_events > 0 && !sc.event_times)) throw std::invalid_argument("invalid mode schedule");
+      std::string key(reinterpret_cast<const char*>(&t0[b]), sizeof(double));
+      key.append(reinterpret_cast<const char*>(sc.event_times), sizeof(double) * sc.n_events);
+      key.append(reinterpret_cast<const char*>(sc.modes), sizeof(int) * (sc.n_events + 1));
+      auto it = seen.find(key);
+      if (it == seen.end()) { it = seen.emplace(key, (int)first_problem.size()).first; first_problem.push_back(b); }
+      grid_of[b] = it->second;
+      if (n_schedules == 1) { std::fill(grid_of.begin(), grid_of.end(), 0); break; }
+    }
+  }
+  const int G = (int)first_problem.size();
   // receding-horizon warm start: keep the previous solution and its grid on the device before anything is overwritten
   std::vector<double> prev_times;
   std::vector<int> prev_kind, prev_nodes, prev_pgrid;
@@ -723,13 +740,12 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   SwingPlanner planner(s->rm.swing);
   int nmax = 0, rows_max = 12;
   for (int g = 0; g < G; ++g) {
-    const bpmpc_mode_schedule& sc = schedules[g];
-    if (sc.n_events < 0 || !sc.modes || (sc.n_events > 0 && !sc.event_times)) throw std::invalid_argument("invalid mode schedule");
+    const bpmpc_mode_schedule& sc = schedules[n_schedules == 1 ? 0 : first_problem[g]];
     ModeSchedule ms;
     ms.event_times.assign(sc.event_times, sc.event_times + sc.n_events);
     ms.modes.assign(sc.modes, sc.modes + sc.n_events + 1);
     planner.update(ms);
-    const double ts = t0[G == 1 ? 0 : g];
+    const double ts = t0[first_problem[g]];
     const NodeTable tab = build_node_table(s->rm, ts, ts + horizon, dt, ms, planner);
     if (tab.N > N) throw std::length_error("time grid has " + std::to_string(tab.N) + " intervals, solver max_nodes is " + std::to_string(N));
     nodes[g] = tab.N;
@@ -748,7 +764,7 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   std::vector<double> tgt_t((size_t)batch * kMaxTargetPoints, 0.0), tgt_x((size_t)batch * kMaxTargetPoints * NX, 0.0);
   std::vector<int> tgt_n(batch, 0);
   for (int b = 0; b < batch; ++b) {
-    pgrid[b] = (G == 1) ? 0 : b;
+    pgrid[b] = grid_of[b];
     const bpmpc_target& t = targets[b];
     if (t.n_points < 1 || t.n_points > kMaxTargetPoints || !t.times || !t.states) throw std::invalid_argument("target trajectories need 1..8 points");
     tgt_n[b] = t.n_points;
