@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
 }
 
 template <int NJ>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
+__global__ __launch_bounds__(kWave) void k_linearize_fast(Launch L) {
   using C = LinFastCfg<NJ>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
   __shared__ LinFastNodeLds<NJ> lds[NPW];
