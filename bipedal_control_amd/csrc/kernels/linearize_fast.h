@@ -72,7 +72,8 @@ struct LinFastNodeLds {
   // node-level results of the two stages: A_b^{-1} blocks, 1/m, contact points and com
   double X12[FULL ? 2 : 1][FULL ? 9 : 1], X22[FULL ? 2 : 1][FULL ? 9 : 1], cps[FULL ? 2 : 1][FULL ? kNumContacts : 1][3], com[FULL ? 2 : 1][3];
   // parked stage-one columns: rows 3..11 of column 6+g and rows 6..11 of the joint-velocity column of lane g
-  double park[FULL ? C::LPN : 1][FULL ? 15 : 1];
+  double park[FULL ? C::LPN : 1][FULL ? 9 : 1];      // rows 3..11 of column 6+g
+  double parkj[FULL ? NJ : 1][FULL ? 6 : 1];         // rows 6..11 of the joint-velocity column of joint g-6
 };
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -507,7 +508,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   LFPROF(1);
   // park the stage-one columns in LDS for the RK2 combination
   for (int rr = 0; rr < 9; ++rr) nl.park[g][rr] = e1.ar_q[rr];
-  for (int rr = 0; rr < 6; ++rr) nl.park[g][9 + rr] = e1.br_j[rr];
+  if (is_joint) for (int rr = 0; rr < 6; ++rr) nl.parkj[g - 6][rr] = e1.br_j[rr];
   const double f1h_g = lane_pick6(e1.fh, g), v1g = e1.vg;
 
   // =========================== contact part (first stage only) ===========================
@@ -614,7 +615,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     c1q[rr] = nl.park[g][rr];
     c1h[rr] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, g, rr);
     c1f[rr] = force_col(nl.cps[0], nl.com[0], imt, g, rr);
-    c1j[rr] = rr < 3 ? 0.0 : nl.park[g][9 + rr - 3];
+    c1j[rr] = (rr < 3 || !is_joint) ? 0.0 : nl.parkj[is_joint ? g - 6 : 0][rr - 3];
   }
   for (int r = 0; r < NX; ++r) {
     double aq, ah_, bf, bj;

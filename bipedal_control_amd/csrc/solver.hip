@@ -132,16 +132,17 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
   linearize_node<NJ>(*L.model, ws, in, out);
 }
 
+constexpr int kLinWaves = 3;   // wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS
 template <int NJ>
-__global__ __launch_bounds__(kWave) void k_linearize_fast(Launch L) {
+__global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
   using C = LinFastCfg<NJ>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
-  __shared__ LinFastNodeLds<NJ> lds[NPW];
-  __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the wave
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kWave);
+  __shared__ LinFastNodeLds<NJ> lds[kLinWaves * NPW];
+  __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
+  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kLinWaves * kWave);
   __syncthreads();
-  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
-  const int widx = blockIdx.x * NPW + sub;   // batch * max_nodes < 2^31 is checked at creation
+  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;       // sub: node slot of the workgroup
+  const int widx = blockIdx.x * (kLinWaves * NPW) + sub;          // batch * max_nodes < 2^31 is checked at creation
   bool valid = widx < L.batch * L.klen;
   const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
   valid = valid && L.buf.active[b] && k < L.buf.g_nodes[L.buf.p_grid[b]];
@@ -539,7 +540,7 @@ template <int NJ> void bpmpc_solver::stage_linearize() {
     TIMED_LAUNCH("linearize", k_linearize<NJ>, batch * settings.max_nodes, kWave, L);
   } else {
     constexpr int NPW = LinFastCfg<NJ>::NPW;
-    TIMED_LAUNCH("linearize", k_linearize_fast<NJ>, (batch * settings.max_nodes + NPW - 1) / NPW, kWave, L);
+    TIMED_LAUNCH("linearize", k_linearize_fast<NJ>, (batch * settings.max_nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW), kLinWaves * kWave, L);
   }
 }
 template <int NJ> void bpmpc_solver::stage_project() {
@@ -600,7 +601,7 @@ template <int NJ> void bpmpc_solver::pipelined_backward() {
     L.k0 = lo;
     L.klen = hi - lo;
     const int nodes = batch * L.klen;
-    TIMED_LAUNCH_ON(producer_stream, "linearize", k_linearize_fast<NJ>, (nodes + NPW - 1) / NPW, kWave, L);
+    TIMED_LAUNCH_ON(producer_stream, "linearize", k_linearize_fast<NJ>, (nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW), kLinWaves * kWave, L);
     if (max_rows <= 12) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 12>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
     else if (max_rows <= 14) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 14>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
     else TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 16>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
