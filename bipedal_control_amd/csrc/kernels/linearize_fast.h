@@ -441,9 +441,19 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
   EVPROF(7);
 }
 
+// Output views of the fast linearisation: wave-uniform base pointers of the whole batch plus the node slot of this lane
+// group.  Per-node pointers (14 x 64 bit per lane) would stay live across the whole kernel; the addresses are formed at
+// the point of use instead.
+struct LinFastOut {
+  double *A, *B, *b, *Q, *R, *q, *r, *c, *C, *D, *e, *perf;
+  int* nc;
+  double* prof;      // this node's debug slot or nullptr
+  size_t s;          // node slot (problem * max_nodes + node)
+};
+
 template <int NJ>
 __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ>& nl, bool valid,
-                                               const NodeInputs& in, const NodeLQOut& out, int g) {
+                                               const NodeInputs& in, const LinFastOut& o, int g) {
 #ifdef BPMPC_LINFAST_PROFILE
   long long lf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long lf_prev = clock64();
@@ -456,19 +466,19 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   if (!valid) return;
   if (in.kind == 1) {  // event node: identity jump map, no input, no cost (LPN lanes write the node)
     double d2 = 0.0;
-    for (int idx = g; idx < NX * NX; idx += LPN) { out.A[idx] = (idx / NX == idx % NX) ? 1.0 : 0.0; out.Q[idx] = 0.0; }
-    for (int idx = g; idx < NX * NU; idx += LPN) { out.B[idx] = 0.0; }
-    for (int idx = g; idx < NU * NU; idx += LPN) out.R[idx] = 0.0;
-    for (int idx = g; idx < kMaxEqRows * NX; idx += LPN) out.C[idx] = 0.0;
-    for (int idx = g; idx < kMaxEqRows * NU; idx += LPN) out.D[idx] = 0.0;
-    for (int idx = g; idx < kMaxEqRows; idx += LPN) out.e[idx] = 0.0;
+    for (int idx = g; idx < NX * NX; idx += LPN) { (o.A + o.s * (NX * NX))[idx] = (idx / NX == idx % NX) ? 1.0 : 0.0; (o.Q + o.s * (NX * NX))[idx] = 0.0; }
+    for (int idx = g; idx < NX * NU; idx += LPN) { (o.B + o.s * (NX * NU))[idx] = 0.0; }
+    for (int idx = g; idx < NU * NU; idx += LPN) (o.R + o.s * (NU * NU))[idx] = 0.0;
+    for (int idx = g; idx < kMaxEqRows * NX; idx += LPN) (o.C + o.s * (kMaxEqRows * NX))[idx] = 0.0;
+    for (int idx = g; idx < kMaxEqRows * NU; idx += LPN) (o.D + o.s * (kMaxEqRows * NU))[idx] = 0.0;
+    for (int idx = g; idx < kMaxEqRows; idx += LPN) (o.e + o.s * (kMaxEqRows))[idx] = 0.0;
     for (int idx = g; idx < NX; idx += LPN) {
       const double d = in.x[idx] - in.xnext[idx];
-      out.b[idx] = d; out.q[idx] = 0.0; out.r[idx] = 0.0;
+      (o.b + o.s * (NX))[idx] = d; (o.q + o.s * (NX))[idx] = 0.0; (o.r + o.s * (NU))[idx] = 0.0;
       d2 += d * d;
     }
     d2 = node_allreduce_add<LPN>(d2);
-    if (g == 0) { out.c[0] = 0.0; out.nc[0] = 0; out.perf[0] = 0.0; out.perf[1] = d2; out.perf[2] = 0.0; }
+    if (g == 0) { (o.c + o.s * (1))[0] = 0.0; (o.nc + o.s * (1))[0] = 0; (o.perf + o.s * (3))[0] = 0.0; (o.perf + o.s * (3))[1] = d2; (o.perf + o.s * (3))[2] = 0.0; }
     return;
   }
   const bool is_joint = g >= 6 && g < G;
@@ -573,22 +583,22 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
         if (type == 1) { if (md.pos_gain != 0.0 && a == 2) ev += md.pos_gain * cp_i[2]; }
         else { ev -= nl.zdref[i]; if (md.pos_gain != 0.0) ev += md.pos_gain * (cp_i[2] - nl.zref[i]); }
       }
-      if (g < G) out.C[row * NX + 6 + g] = vq;
-      if (g < 6) out.C[row * NX + g] = vh;
-      if (g < 12) out.D[row * NU + g] = vf;
-      if (is_joint) out.D[row * NU + 12 + g - 6] = vj;
-      if (g == 0) out.e[row] = ev;
+      if (g < G) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + g] = vq;
+      if (g < 6) (o.C + o.s * (kMaxEqRows * NX))[row * NX + g] = vh;
+      if (g < 12) (o.D + o.s * (kMaxEqRows * NU))[row * NU + g] = vf;
+      if (is_joint) (o.D + o.s * (kMaxEqRows * NU))[row * NU + 12 + g - 6] = vj;
+      if (g == 0) (o.e + o.s * (kMaxEqRows))[row] = ev;
       eq_sse += ev * ev;
       ++row;
     }
   }
   const int nc = row;
   for (; row < kMaxEqRows; ++row) {
-    if (g < G) out.C[row * NX + 6 + g] = 0.0;
-    if (g < 6) out.C[row * NX + g] = 0.0;
-    if (g < 12) out.D[row * NU + g] = 0.0;
-    if (is_joint) out.D[row * NU + 12 + g - 6] = 0.0;
-    if (g == 0) out.e[row] = 0.0;
+    if (g < G) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + g] = 0.0;
+    if (g < 6) (o.C + o.s * (kMaxEqRows * NX))[row * NX + g] = 0.0;
+    if (g < 12) (o.D + o.s * (kMaxEqRows * NU))[row * NU + g] = 0.0;
+    if (is_joint) (o.D + o.s * (kMaxEqRows * NU))[row * NU + 12 + g - 6] = 0.0;
+    if (g == 0) (o.e + o.s * (kMaxEqRows))[row] = 0.0;
   }
 
   LFPROF(2);
@@ -642,21 +652,21 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
       bf = hdt * (c1f[rr] + e2f + dt * sf);
       bj = hdt * (c1j[rr] + e2j + dt * sj);
     }
-    if (g < G) out.A[r * NX + 6 + g] = aq;
-    if (g < 6) out.A[r * NX + g] = ah_;
-    if (g < 12) out.B[r * NU + g] = bf;
-    if (is_joint) out.B[r * NU + 12 + g - 6] = bj;
+    if (g < G) (o.A + o.s * (NX * NX))[r * NX + 6 + g] = aq;
+    if (g < 6) (o.A + o.s * (NX * NX))[r * NX + g] = ah_;
+    if (g < 12) (o.B + o.s * (NX * NU))[r * NU + g] = bf;
+    if (is_joint) (o.B + o.s * (NX * NU))[r * NU + 12 + g - 6] = bj;
   }
   // b = x + dt/2 (f1 + f2) - x_next
   double dyn_sse = 0.0;
   if (g < G) {
     const double bb = qg + hdt * v1g + hdt * e2.vg - xn_q;
-    out.b[6 + g] = bb;
+    (o.b + o.s * (NX))[6 + g] = bb;
     dyn_sse += bb * bb;
   }
   if (g < 6) {
     const double bb = lane_pick6(xh, g) + hdt * f1h_g + hdt * lane_pick6(e2.fh, g) - xn_h;
-    out.b[g] = bb;
+    (o.b + o.s * (NX))[g] = bb;
     dyn_sse += bb * bb;
   }
   LFPROF(4);
@@ -677,8 +687,8 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     for (int r = 0; r < NX; ++r) {
       const double dxr = nl.dx[r], dur = nl.du[r];
       // gradient entries use row c of the weight (as the reference kernel), the written element is (r, c)
-      if (g < G) { accq += sh.Q[cq * NX + r] * dxr; out.Q[r * NX + cq] = dt * (sh.Q[r * NX + cq] + (r == cq ? shift : 0.0)); }
-      if (g < 6) { acch += sh.Q[ch * NX + r] * dxr; out.Q[r * NX + ch] = dt * (sh.Q[r * NX + ch] + (r == ch ? shift : 0.0)); }
+      if (g < G) { accq += sh.Q[cq * NX + r] * dxr; (o.Q + o.s * (NX * NX))[r * NX + cq] = dt * (sh.Q[r * NX + cq] + (r == cq ? shift : 0.0)); }
+      if (g < 6) { acch += sh.Q[ch * NX + r] * dxr; (o.Q + o.s * (NX * NX))[r * NX + ch] = dt * (sh.Q[r * NX + ch] + (r == ch ? shift : 0.0)); }
       if (g < 12) {
         accf += sh.R[cf * NU + r] * dur;
         double w = sh.R[r * NU + cf];
@@ -690,36 +700,36 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
           const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
           w += cn[3] * cn[4 + a] * cn[4 + b2] + cn[2] * cn[7 + sidx];
         }
-        out.R[r * NU + cf] = dt * w;
+        (o.R + o.s * (NU * NU))[r * NU + cf] = dt * w;
       }
-      if (is_joint) { accj += sh.R[cj * NU + r] * dur; out.R[r * NU + cj] = dt * (sh.R[r * NU + cj] + (r == cj ? shift : 0.0)); }
+      if (is_joint) { accj += sh.R[cj * NU + r] * dur; (o.R + o.s * (NU * NU))[r * NU + cj] = dt * (sh.R[r * NU + cj] + (r == cj ? shift : 0.0)); }
     }
-    if (g < G) { out.q[cq] = dt * accq; cost += 0.5 * nl.dx[cq] * accq; }
-    if (g < 6) { out.q[ch] = dt * acch; cost += 0.5 * nl.dx[ch] * acch; }
+    if (g < G) { (o.q + o.s * (NX))[cq] = dt * accq; cost += 0.5 * nl.dx[cq] * accq; }
+    if (g < 6) { (o.q + o.s * (NX))[ch] = dt * acch; cost += 0.5 * nl.dx[ch] * acch; }
     if (g < 12) {
       cost += 0.5 * nl.du[cf] * accf;
       if (stance_flag(mode, cf / 3)) accf += nl.cone[cf / 3][2] * nl.cone[cf / 3][4 + cf % 3];
-      out.r[cf] = dt * accf;
+      (o.r + o.s * (NU))[cf] = dt * accf;
     }
-    if (is_joint) { out.r[cj] = dt * accj; cost += 0.5 * nl.du[cj] * accj; }
+    if (is_joint) { (o.r + o.s * (NU))[cj] = dt * accj; cost += 0.5 * nl.du[cj] * accj; }
     if (g < kNumContacts && stance_flag(mode, g)) cost += nl.cone[g][1];
   }
   // P (cost cross term) is structurally zero for this problem: the buffer is zero-filled once at allocation and never written
   cost = node_allreduce_add<LPN>(cost);
   dyn_sse = node_allreduce_add<LPN>(dyn_sse);
   if (g == 0) {
-    out.c[0] = dt * cost;
-    out.nc[0] = nc;
-    out.perf[0] = dt * cost; out.perf[1] = dt * dyn_sse; out.perf[2] = dt * eq_sse;
+    (o.c + o.s * (1))[0] = dt * cost;
+    (o.nc + o.s * (1))[0] = nc;
+    (o.perf + o.s * (3))[0] = dt * cost; (o.perf + o.s * (3))[1] = dt * dyn_sse; (o.perf + o.s * (3))[2] = dt * eq_sse;
   }
   LFPROF(5);
 #ifdef BPMPC_LINFAST_PROFILE
-  if (out.prof && g == 0)
-    for (int i = 0; i < 8; ++i) out.prof[i] = (double)lf_t[i];
+  if (o.prof && g == 0)
+    for (int i = 0; i < 8; ++i) o.prof[i] = (double)lf_t[i];
 #endif
 #ifdef BPMPC_EVAL_PROFILE
-  if (out.prof && g == 0)
-    for (int i = 0; i < 8; ++i) out.prof[i] = (double)evacc[i];
+  if (o.prof && g == 0)
+    for (int i = 0; i < 8; ++i) o.prof[i] = (double)evacc[i];
 #endif
 }
 

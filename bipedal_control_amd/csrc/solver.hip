@@ -148,12 +148,10 @@ __global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_
   valid = valid && L.buf.active[b] && k < L.buf.g_nodes[L.buf.p_grid[b]];
   const size_t s = valid ? (size_t)b * L.N + k : 0;
   const NodeInputs in = node_inputs<NJ>(L, b, k);
-  NodeLQOut out;
-  out.A = L.buf.A + s * NX * NX; out.B = L.buf.B + s * NX * NU; out.b = L.buf.b + s * NX;
-  out.Q = L.buf.Q + s * NX * NX; out.R = L.buf.R + s * NU * NU; out.P = L.buf.P + s * NU * NX;
-  out.q = L.buf.q + s * NX; out.r = L.buf.r + s * NU; out.c = L.buf.c + s;
-  out.C = L.buf.C + s * kMaxEqRows * NX; out.D = L.buf.D + s * kMaxEqRows * NU; out.e = L.buf.e + s * kMaxEqRows;
-  out.nc = L.buf.nc + s; out.perf = L.buf.perf + s * 3;
+  LinFastOut out;
+  out.A = L.buf.A; out.B = L.buf.B; out.b = L.buf.b; out.Q = L.buf.Q; out.R = L.buf.R; out.q = L.buf.q; out.r = L.buf.r; out.c = L.buf.c;
+  out.C = L.buf.C; out.D = L.buf.D; out.e = L.buf.e; out.perf = L.buf.perf; out.nc = L.buf.nc;
+  out.s = s;
   out.prof = (valid && b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
   linearize_fast<NJ>(*L.model, shared, lds[sub], valid, in, out, g);
 }
