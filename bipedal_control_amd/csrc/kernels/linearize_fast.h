@@ -57,6 +57,7 @@ struct LinFastNodeLds {
   using C = LinFastCfg<NJ>;
   // node inputs, staged once so that nothing is loaded from global memory after the first output store
   double x[C::NX], u[C::NU], zref[kNumContacts], zdref[kNumContacts];
+  double xh2[6];                 // normalised momentum of the second RK2 stage (the first stage reads x[0..5])
   union {                        // chain tables (dead after the walks)  <->  second-stage block and cost vectors
     double T[NJ][12];            // joint-local transform of joint g-6: E (9) | pfix (3)
     struct { double a2[9][12]; double dx[C::NX], du[C::NU]; };   // rows 3..11, x columns 0..11 of the stage-two Jacobian
@@ -157,7 +158,7 @@ struct LaneKin {    // what the contact part needs from the evaluation
 #endif
 template <int NJ, bool DERIV = true, bool TWIST = true, class NodeLds = LinFastNodeLds<NJ>>
 __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastShared<NJ>& sh, NodeLds& nl, int stage, const LaneBody& lb, const int* path, int g,
-                                          const double (&xh)[6], const double (&pb)[3], double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin,
+                                          const double* xh /*LDS*/, const double (&pb)[3], double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin,
                                           long long* evp = nullptr) {
 #ifdef BPMPC_EVAL_PROFILE
   if (evp) evp[9] = clock64();
@@ -500,9 +501,9 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   }
   const int* path = sh.path[lb.body];
   lds_wave_sync();
-  double xh[6], pb[3];
-  for (int i = 0; i < 6; ++i) xh[i] = nl.x[i];
+  double pb[3];
   for (int i = 0; i < 3; ++i) pb[i] = nl.x[6 + i];
+  const double* xh = nl.x;             // normalised momentum, read from LDS where it is used
   const double qg = g < G ? nl.x[6 + g] : 0.0;
   const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
 
@@ -605,8 +606,9 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   // =========================== second RK2 stage ===========================
   LaneEval e2;
   {
-    double xh2[6], pb2[3];
-    for (int i = 0; i < 6; ++i) xh2[i] = xh[i] + dt * e1.fh[i];
+    double pb2[3];
+    if (g < 6) nl.xh2[g] = xh[g] + dt * lane_pick6(e1.fh, g);
+    const double* xh2 = nl.xh2;      // published by the lds_wave_sync at the top of eval_lane
     for (int i = 0; i < 3; ++i) pb2[i] = pb[i] + dt * kin.vb[i];
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
@@ -665,7 +667,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     dyn_sse += bb * bb;
   }
   if (g < 6) {
-    const double bb = lane_pick6(xh, g) + hdt * f1h_g + hdt * lane_pick6(e2.fh, g) - xn_h;
+    const double bb = (g < 6 ? xh[g] : 0.0) + hdt * f1h_g + hdt * lane_pick6(e2.fh, g) - xn_h;
     (o.b + o.s * (NX))[g] = bb;
     dyn_sse += bb * bb;
   }
@@ -673,7 +675,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   // =========================== cost ===========================
   lds_wave_sync();   // a2 is dead: its storage becomes dx / du
   if (g < G) nl.dx[6 + g] = qg - xr_q;
-  if (g < 6) nl.dx[g] = lane_pick6(xh, g) - xr_h;
+  if (g < 6) nl.dx[g] = (g < 6 ? xh[g] : 0.0) - xr_h;
   if (g < 12) nl.du[g] = nl.u[g] - nominal_input(md, mode, g);
   if (is_joint) nl.du[12 + g - 6] = ujg;
   lds_wave_sync();
@@ -771,9 +773,9 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   }
   const int* path = sh.path[lb.body];
   lds_wave_sync();
-  double xh[6], pb[3];
-  for (int i = 0; i < 6; ++i) xh[i] = nl.x[i];
+  double pb[3];
   for (int i = 0; i < 3; ++i) pb[i] = nl.x[6 + i];
+  const double* xh = nl.x;             // normalised momentum, read from LDS where it is used
   const double qg = g < G ? nl.x[6 + g] : 0.0;
   const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
   LaneEval e1;
@@ -809,8 +811,9 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   if (g < kNumContacts && stance_flag(mode, g)) cone_pen = nl.cone[g][1];
   LaneEval e2;
   {
-    double xh2[6], pb2[3];
-    for (int i = 0; i < 6; ++i) xh2[i] = xh[i] + dt * e1.fh[i];
+    double pb2[3];
+    if (g < 6) nl.xh2[g] = xh[g] + dt * lane_pick6(e1.fh, g);
+    const double* xh2 = nl.xh2;      // published by the lds_wave_sync at the top of eval_lane
     for (int i = 0; i < 3; ++i) pb2[i] = pb[i] + dt * kin.vb[i];
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
@@ -823,12 +826,12 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   }
   if (g < 6) {
     const double f1 = lane_pick6(e1.fh, g), f2 = lane_pick6(e2.fh, g);
-    const double bb = lane_pick6(xh, g) + hdt * f1 + hdt * f2 - xn_h;
+    const double bb = (g < 6 ? xh[g] : 0.0) + hdt * f1 + hdt * f2 - xn_h;
     dyn_sse += bb * bb;
   }
   lds_wave_sync();   // the chain tables are dead: their storage becomes dx / du
   if (g < G) nl.dx[6 + g] = qg - xr_q;
-  if (g < 6) nl.dx[g] = lane_pick6(xh, g) - xr_h;
+  if (g < 6) nl.dx[g] = (g < 6 ? xh[g] : 0.0) - xr_h;
   if (g < 12) nl.du[g] = nl.u[g] - nominal_input(md, mode, g);
   if (is_joint) nl.du[12 + g - 6] = ujg;
   lds_wave_sync();
