@@ -57,14 +57,15 @@ struct LinFastNodeLds {
   using C = LinFastCfg<NJ>;
   // node inputs, staged once so that nothing is loaded from global memory after the first output store
   double x[C::NX], u[C::NU], zref[kNumContacts], zdref[kNumContacts];
-  double xh2[6];                 // normalised momentum of the second RK2 stage (the first stage reads x[0..5])
-  union {                        // chain tables (dead after the walks)  <->  second-stage block and cost vectors
+  double xh2[9];                 // normalised momentum and base position of the second RK2 stage (the first stage reads x[0..8])
+  union {                        // chain tables (dead after the walks)  <->  second-stage block
     double T[NJ][12];            // joint-local transform of joint g-6: E (9) | pfix (3)
-    struct { double a2[9][12]; double dx[C::NX], du[C::NU]; };   // rows 3..11, x columns 0..11 of the stage-two Jacobian
+    double a2[9][12];            // rows 3..11, x columns 0..11 of the stage-two Jacobian
   };
   union {
     double comp[C::NB][10];      // per body mass / first moment / inertia about o0
     double hb[C::NB][6];         // per body momentum about o0
+    struct { double dx[C::NX], du[C::NU]; };   // cost vectors (both evaluations are done by then)
   };
   double og[C::G - 3][3];        // joint origins (coordinates 3..)
   double wv[C::G - 3][3];        // a_g * v_g
@@ -158,7 +159,7 @@ struct LaneKin {    // what the contact part needs from the evaluation
 #endif
 template <int NJ, bool DERIV = true, bool TWIST = true, class NodeLds = LinFastNodeLds<NJ>>
 __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastShared<NJ>& sh, NodeLds& nl, int stage, const LaneBody& lb, const int* path, int g,
-                                          const double* xh /*LDS*/, const double (&pb)[3], double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin,
+                                          const double* xh /*LDS: momentum [6], base position [3]*/, double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin,
                                           long long* evp = nullptr) {
 #ifdef BPMPC_EVAL_PROFILE
   if (evp) evp[9] = clock64();
@@ -167,6 +168,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
   constexpr int NB = C::NB, G = C::G, LPN = C::LPN;
   const bool is_joint = g >= 6 && g < G, is_body = g >= 5 && g < G;
   const double mass_total = md.robot_mass;
+  const double* pb = xh + 6;           // base position, read from LDS at every use (registers are the scarce resource here)
   // ---- sin/cos of the own angle; Euler sin/cos to everybody
   double sg = 0.0, cg = 1.0;
   if (g >= 3 && g < G) sincos(qg, &sg, &cg);
@@ -501,9 +503,8 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   }
   const int* path = sh.path[lb.body];
   lds_wave_sync();
-  double pb[3];
-  for (int i = 0; i < 3; ++i) pb[i] = nl.x[6 + i];
-  const double* xh = nl.x;             // normalised momentum, read from LDS where it is used
+  const double* xh = nl.x;             // normalised momentum and base position, read from LDS where they are used
+  const double* pb = nl.x + 6;
   const double qg = g < G ? nl.x[6 + g] : 0.0;
   const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
 
@@ -512,9 +513,9 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   LaneKin<NJ> kin;
 #ifdef BPMPC_EVAL_PROFILE
   long long evacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  eval_lane<NJ, true, true>(md, sh, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin, evacc);
+  eval_lane<NJ, true, true>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin, evacc);
 #else
-  eval_lane<NJ, true, true>(md, sh, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
+  eval_lane<NJ, true, true>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
 #endif
   LFPROF(1);
   // park the stage-one columns in LDS for the RK2 combination
@@ -606,13 +607,12 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   // =========================== second RK2 stage ===========================
   LaneEval e2;
   {
-    double pb2[3];
     if (g < 6) nl.xh2[g] = xh[g] + dt * lane_pick6(e1.fh, g);
+    if (g < 3) nl.xh2[6 + g] = pb[g] + dt * (g == 0 ? kin.vb[0] : (g == 1 ? kin.vb[1] : kin.vb[2]));
     const double* xh2 = nl.xh2;      // published by the lds_wave_sync at the top of eval_lane
-    for (int i = 0; i < 3; ++i) pb2[i] = pb[i] + dt * kin.vb[i];
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
-    eval_lane<NJ, true, true>(md, sh, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
+    eval_lane<NJ, true, true>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
   }
   LFPROF(3);
   // A2[rows 3..11][x columns 0..11] to LDS (a2 shares storage with the chain tables, dead now): columns 0..5 are the
@@ -773,14 +773,13 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   }
   const int* path = sh.path[lb.body];
   lds_wave_sync();
-  double pb[3];
-  for (int i = 0; i < 3; ++i) pb[i] = nl.x[6 + i];
-  const double* xh = nl.x;             // normalised momentum, read from LDS where it is used
+  const double* xh = nl.x;             // normalised momentum and base position, read from LDS where they are used
+  const double* pb = nl.x + 6;
   const double qg = g < G ? nl.x[6 + g] : 0.0;
   const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
   LaneEval e1;
   LaneKin<NJ> kin;
-  eval_lane<NJ, false, true, LinFastNodeLds<NJ, false>>(md, sh, nl, 0, lb, path, g, xh, pb, qg, ujg, e1, kin);
+  eval_lane<NJ, false, true, LinFastNodeLds<NJ, false>>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
   if (g >= 5 && g < G)
     for (int i = 0; i < kNumContacts; ++i)
       if (md.contact_body[i] == lb.body) {
@@ -811,13 +810,12 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   if (g < kNumContacts && stance_flag(mode, g)) cone_pen = nl.cone[g][1];
   LaneEval e2;
   {
-    double pb2[3];
     if (g < 6) nl.xh2[g] = xh[g] + dt * lane_pick6(e1.fh, g);
+    if (g < 3) nl.xh2[6 + g] = pb[g] + dt * (g == 0 ? kin.vb[0] : (g == 1 ? kin.vb[1] : kin.vb[2]));
     const double* xh2 = nl.xh2;      // published by the lds_wave_sync at the top of eval_lane
-    for (int i = 0; i < 3; ++i) pb2[i] = pb[i] + dt * kin.vb[i];
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
-    eval_lane<NJ, false, false, LinFastNodeLds<NJ, false>>(md, sh, nl, 1, lb, path, g, xh2, pb2, qg2, ujg, e2, kin2);
+    eval_lane<NJ, false, false, LinFastNodeLds<NJ, false>>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
   }
   double dyn_sse = 0.0;
   if (g < G) {
