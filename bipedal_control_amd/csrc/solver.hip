@@ -132,6 +132,7 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
   linearize_node<NJ>(*L.model, ws, in, out);
 }
 
+constexpr int kTrialWaves = 4; // same for the value-only trial kernel (smaller per-node LDS: four waves, 8 waves per CU)
 constexpr int kLinWaves = 3;   // wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS
 template <int NJ>
 __global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
@@ -397,15 +398,15 @@ __global__ __launch_bounds__(kWave) void k_trial(Launch L) {
 }
 
 template <int NJ>
-__global__ __launch_bounds__(kWave) void k_trial_fast(Launch L) {
+__global__ __launch_bounds__(kTrialWaves * kWave) void k_trial_fast(Launch L) {
   using C = LinFastCfg<NJ>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
-  __shared__ LinFastNodeLds<NJ, false> lds[NPW];
-  __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the wave
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kWave);
+  __shared__ LinFastNodeLds<NJ, false> lds[kTrialWaves * NPW];
+  __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
+  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
-  const int widx = blockIdx.x * NPW + sub;
+  const int widx = blockIdx.x * (kTrialWaves * NPW) + sub;
   bool valid = widx < L.batch * L.klen;
   const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
   valid = valid && !L.buf.done[b] && k < L.buf.g_nodes[L.buf.p_grid[b]];
@@ -571,7 +572,7 @@ template <int NJ> void bpmpc_solver::stage_linesearch() {
       hipLaunchKernelGGL(k_trial<NJ>, dim3(batch * settings.max_nodes), dim3(kWave), 0, stream, L);
     } else {
       constexpr int NPW = LinFastCfg<NJ>::NPW;
-      hipLaunchKernelGGL(k_trial_fast<NJ>, dim3((batch * settings.max_nodes + NPW - 1) / NPW), dim3(kWave), 0, stream, L);
+      hipLaunchKernelGGL(k_trial_fast<NJ>, dim3((batch * settings.max_nodes + kTrialWaves * NPW - 1) / (kTrialWaves * NPW)), dim3(kTrialWaves * kWave), 0, stream, L);
     }
     hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L);
     HIP_CHECK(hipGetLastError());
