@@ -73,9 +73,6 @@ struct LinFastNodeLds {
   double cone[kNumContacts][13];
   // node-level results of the two stages: A_b^{-1} blocks, 1/m, contact points and com
   double X12[FULL ? 2 : 1][FULL ? 9 : 1], X22[FULL ? 2 : 1][FULL ? 9 : 1], cps[FULL ? 2 : 1][FULL ? kNumContacts : 1][3], com[FULL ? 2 : 1][3];
-  // parked stage-one columns: rows 3..11 of column 6+g and rows 6..11 of the joint-velocity column of lane g
-  double park[FULL ? C::LPN : 1][FULL ? 9 : 1];      // rows 3..11 of column 6+g
-  double parkj[FULL ? NJ : 1][FULL ? 6 : 1];         // rows 6..11 of the joint-velocity column of joint g-6
 };
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -447,9 +444,14 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
 // Output views of the fast linearisation: wave-uniform base pointers of the whole batch plus the node slot of this lane
 // group.  Per-node pointers (14 x 64 bit per lane) would stay live across the whole kernel; the addresses are formed at
 // the point of use instead.
+// Stage-one columns parked in HBM scratch (not in LDS: 1.6 KB per node would cost a quarter of the occupancy): rows 3..11 of
+// column 6+g for 16 lanes, rows 6..11 of the joint-velocity column for the joints; layout [row][lane] (coalesced).  They are
+// written before the second evaluation and read after it, by when the stores have long retired.
+constexpr int kLinParkDoubles = 9 * 32 + 6 * 32;
 struct LinFastOut {
   double *A, *B, *b, *Q, *R, *q, *r, *c, *C, *D, *e, *perf;
   int* nc;
+  double* park;      // scratch, kLinParkDoubles per node: the stage-one Jacobian columns wait here for the RK2 combination
   double* prof;      // this node's debug slot or nullptr
   size_t s;          // node slot (problem * max_nodes + node)
 };
@@ -518,9 +520,12 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   eval_lane<NJ, true, true>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
 #endif
   LFPROF(1);
-  // park the stage-one columns in LDS for the RK2 combination
-  for (int rr = 0; rr < 9; ++rr) nl.park[g][rr] = e1.ar_q[rr];
-  if (is_joint) for (int rr = 0; rr < 6; ++rr) nl.parkj[g - 6][rr] = e1.br_j[rr];
+  // park the stage-one columns (HBM scratch) for the RK2 combination
+  {
+    double* pk = o.park + o.s * kLinParkDoubles;
+    for (int rr = 0; rr < 9; ++rr) pk[rr * LPN + g] = e1.ar_q[rr];
+    if (is_joint) for (int rr = 0; rr < 6; ++rr) pk[9 * LPN + rr * LPN + g] = e1.br_j[rr];
+  }
   const double f1h_g = lane_pick6(e1.fh, g), v1g = e1.vg;
 
   // =========================== contact part (first stage only) ===========================
@@ -623,11 +628,15 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   lds_wave_sync();
   // rows of A and B;  A = I + dt/2 (A1 + A2 + dt A2 A1),  B = dt/2 (B1 + B2 + dt A2 B1)
   double c1q[9], c1h[9], c1f[9], c1j[9];
+  {
+    const double* pk = o.park + o.s * kLinParkDoubles;
+    for (int rr = 0; rr < 9; ++rr) c1q[rr] = pk[rr * LPN + g];
+    for (int rr = 0; rr < 9; ++rr) c1j[rr] = 0.0;
+    if (is_joint) for (int rr = 3; rr < 9; ++rr) c1j[rr] = pk[9 * LPN + (rr - 3) * LPN + g];
+  }
   for (int rr = 0; rr < 9; ++rr) {
-    c1q[rr] = nl.park[g][rr];
     c1h[rr] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, g, rr);
     c1f[rr] = force_col(nl.cps[0], nl.com[0], imt, g, rr);
-    c1j[rr] = (rr < 3 || !is_joint) ? 0.0 : nl.parkj[is_joint ? g - 6 : 0][rr - 3];
   }
   for (int r = 0; r < NX; ++r) {
     double aq, ah_, bf, bj;

@@ -59,6 +59,7 @@ struct Buffers {
   // projection
   double *Px, *Pu, *Pe, *At, *Bt, *bt, *Qt, *Rt, *Pt, *qt, *rt;
   int* nut;
+  double* lin_park;    // per node kLinParkDoubles: scratch of the linearisation kernel
   int* proj_extent;    // per node: reduced-input extent written by the last fast projection (see project_mfma.h)
   // riccati
   double *Kt, *kt, *dx, *du, *K, *summary, *dx0;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
 }
 
 constexpr int kTrialWaves = 4; // same for the value-only trial kernel (smaller per-node LDS: four waves, 8 waves per CU)
-constexpr int kLinWaves = 3;   // wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS
+constexpr int kLinWaves = 4;   // wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS
 template <int NJ>
 __global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
   using C = LinFastCfg<NJ>;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_
   LinFastOut out;
   out.A = L.buf.A; out.B = L.buf.B; out.b = L.buf.b; out.Q = L.buf.Q; out.R = L.buf.R; out.q = L.buf.q; out.r = L.buf.r; out.c = L.buf.c;
   out.C = L.buf.C; out.D = L.buf.D; out.e = L.buf.e; out.perf = L.buf.perf; out.nc = L.buf.nc;
+  out.park = L.buf.lin_park;
   out.s = s;
   out.prof = (valid && b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
   linearize_fast<NJ>(*L.model, shared, lds[sub], valid, in, out, g);
@@ -648,6 +650,7 @@ void allocate(bpmpc_solver* s) {
   const size_t B = s->settings.max_batch, N = s->settings.max_nodes, NX = s->nx, NU = s->nu, S = B * N;
   Buffers& b = s->buf;
   b.proj_extent = s->alloc<int>("proj_extent", S, true);
+  b.lin_park = s->alloc<double>("lin_park", S * kLinParkDoubles);
   b.x_prev = s->alloc<double>("x_prev", B * (N + 1) * NX); b.u_prev = s->alloc<double>("u_prev", S * NU);
   b.K_prev = s->alloc<double>("K_prev", S * NU * NX);
   b.tp_time = s->alloc<double>("tp_time", B * (N + 1)); b.tp_kind = s->alloc<int>("tp_kind", S, true);
