@@ -261,6 +261,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
         _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (used && i < nt && l >= nt) M[i][col] = v[i]; \
       }
       if (nt <= 8) BP_GJ_CASE(8)
+      else if (nt == 9) BP_GJ_CASE(9)          // single support of this robot class: 14 rows of rank 13
       else if (nt <= 10) BP_GJ_CASE(10)
       else if (nt <= 12) BP_GJ_CASE(12)
       else BP_GJ_CASE(NU)
