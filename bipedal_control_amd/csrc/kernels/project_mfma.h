@@ -37,7 +37,8 @@ struct ProjectMfmaWorkspace {
 // that is read from HBM (operands, accumulator initial values) is loaded before the first output store: vmcnt retires in
 // order, a load issued behind a store would wait for that store to reach memory.
 template <int NJ, int NBC>
-__device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out) {
+__device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
+                                                     double dt_over_mass) {
   using WS = ProjectMfmaWorkspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, KR = WS::KR, KS = KR / 4, BC = NX + 1;
   const int l = threadIdx.x, li = l & 15, lk = l >> 4;
@@ -49,10 +50,14 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
     for (int ks = 0; ks < KS; ++ks) {
       const int row = 16 * bi + li, kk = 4 * ks + lk;
       const bool ok = row < NU && kk < NU;
-      const int off = ok ? row * NU + kk : 0;
-      const double rv = in.R[off], bv = in.B[off];
+      // Only the rows 3..11 of the discretised centroidal dynamics are dense (linearize_fast.h writes the others as
+      //   A: identity rows;   B rows 0..2: dt/m on the matching component of the four contact forces;   B rows 12..: dt on the
+      // joint velocity), so those are generated here instead of being read (a fifth of this kernel's HBM reads).
+      const bool dense = ok && row >= 3 && row < 12;
+      const double rv = in.R[ok ? row * NU + kk : 0], bv = in.B[dense ? row * NU + kk : 3 * NU];
       aR[bi][ks] = ok ? rv : 0.0;
-      aB[bi][ks] = ok ? bv : 0.0;
+      const double synth = row < 3 ? ((kk < 12 && kk % 3 == row) ? dt_over_mass : 0.0) : (kk == row ? dt : 0.0);
+      aB[bi][ks] = dense ? bv : (ok ? synth : 0.0);
     }
   // accumulator initial values in the D layout: [A | b | 0] (2 x NBC blocks), [Q | q | 0] (block row 0 and, for rows < nx, 1),
   // r for the b column of R X
@@ -69,7 +74,9 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
       for (int bj = 0; bj < NBC; ++bj) {
         const int col = 16 * bj + li;
         const bool in_m = rin && col < NX, in_v = rin && col == NX;
-        const double av = *(in_m ? in.A + rr * NX + col : (in_v ? in.b + rr : in.A));
+        const bool a_dense = in_m && rr >= 3 && rr < 12;
+        double av = *(a_dense ? in.A + rr * NX + col : (in_v ? in.b + rr : in.A + 3 * NX));
+        if (in_m && !a_dense) av = (rr == col) ? 1.0 : 0.0;          // identity rows of A
         const double qv = *(in_m ? in.Q + rr * NX + col : (in_v ? in.q + rr : in.Q));
         cA[bi][bj][r] = (in_m || in_v) ? av : 0.0;
         cQ[bi][bj][r] = (in_m || in_v) ? qv : 0.0;
@@ -160,7 +167,8 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
 }
 
 template <int NJ>
-__device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, int* extent) {
+__device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, int* extent, double dt,
+                                                   double dt_over_mass) {
   using WS = ProjectMfmaWorkspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, LDW = WS::LDW, KR = WS::KR, BC = NX + 1, WC = WS::WC;
   static_assert(NX == NU, "packed layout assumes nx == nu");
@@ -199,9 +207,9 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
   for (int idx = l; idx < NU * (LDW - WC); idx += kWave) ws.X[idx / (LDW - WC)][WC + idx % (LDW - WC)] = 0.0;   // columns beyond [Px Pe Pu]
 
-  if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out);
-  else if (nbc == 3) project_apply_blocks<NJ, 3>(ws, in, out);
-  else project_apply_blocks<NJ, (WC + 15) / 16>(ws, in, out);
+  if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass);
+  else if (nbc == 3) project_apply_blocks<NJ, 3>(ws, in, out, dt, dt_over_mass);
+  else project_apply_blocks<NJ, (WC + 15) / 16>(ws, in, out, dt, dt_over_mass);
 
   // ---- keep "beyond nut reads as zero": clear what an earlier, wider projection of this node left behind
   const int cov = 16 * (nbc <= 2 ? 2 : nbc) - BC;      // reduced-input indices written by the blocks of this call

@@ -226,7 +226,8 @@ __global__ __launch_bounds__(kWave) void k_project_fast(Launch L) {
   out.At = L.buf.At + s * NX * NX; out.Bt = L.buf.Bt + s * NX * NU; out.bt = L.buf.bt + s * NX;
   out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
   out.rt = L.buf.rt + s * NU;
-  project_apply_mfma<NJ>(ws, in, out, L.buf.proj_extent + s);
+  const double dt = L.buf.g_dt[(size_t)g * L.N + k];
+  project_apply_mfma<NJ>(ws, in, out, L.buf.proj_extent + s, dt, dt * (1.0 / L.model->robot_mass));   // as written by linearize_fast
 }
 
 template <int NJ>
