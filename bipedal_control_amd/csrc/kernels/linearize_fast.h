@@ -447,11 +447,11 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
 // Stage-one columns parked in HBM scratch (not in LDS: 1.6 KB per node would cost a quarter of the occupancy): rows 3..11 of
 // column 6+g for 16 lanes, rows 6..11 of the joint-velocity column for the joints; layout [row][lane] (coalesced).  They are
 // written before the second evaluation and read after it, by when the stores have long retired.
-constexpr int kLinParkDoubles = 9 * 32 + 6 * 32;
+constexpr int kLinParkDoublesPerLane = 15;   // times the lanes per node
 struct LinFastOut {
   double *A, *B, *b, *Q, *R, *q, *r, *c, *C, *D, *e, *perf;
   int* nc;
-  double* park;      // scratch, kLinParkDoubles per node: the stage-one Jacobian columns wait here for the RK2 combination
+  double* park;      // scratch, 15 * LPN doubles per node: the stage-one Jacobian columns wait here for the RK2 combination
   double* prof;      // this node's debug slot or nullptr
   size_t s;          // node slot (problem * max_nodes + node)
 };
@@ -522,9 +522,9 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   LFPROF(1);
   // park the stage-one columns (HBM scratch) for the RK2 combination
   {
-    double* pk = o.park + o.s * kLinParkDoubles;
+    double* pk = o.park + o.s * (15 * LPN);
     for (int rr = 0; rr < 9; ++rr) pk[rr * LPN + g] = e1.ar_q[rr];
-    if (is_joint) for (int rr = 0; rr < 6; ++rr) pk[9 * LPN + rr * LPN + g] = e1.br_j[rr];
+    for (int rr = 0; rr < 6; ++rr) pk[9 * LPN + rr * LPN + g] = is_joint ? e1.br_j[rr] : 0.0;   // whole 128-byte lines
   }
   const double f1h_g = lane_pick6(e1.fh, g), v1g = e1.vg;
 
@@ -629,7 +629,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   // rows of A and B;  A = I + dt/2 (A1 + A2 + dt A2 A1),  B = dt/2 (B1 + B2 + dt A2 B1)
   double c1q[9], c1h[9], c1f[9], c1j[9];
   {
-    const double* pk = o.park + o.s * kLinParkDoubles;
+    const double* pk = o.park + o.s * (15 * LPN);
     for (int rr = 0; rr < 9; ++rr) c1q[rr] = pk[rr * LPN + g];
     for (int rr = 0; rr < 9; ++rr) c1j[rr] = 0.0;
     if (is_joint) for (int rr = 3; rr < 9; ++rr) c1j[rr] = pk[9 * LPN + (rr - 3) * LPN + g];

@@ -59,7 +59,7 @@ struct Buffers {
   // projection
   double *Px, *Pu, *Pe, *At, *Bt, *bt, *Qt, *Rt, *Pt, *qt, *rt;
   int* nut;
-  double* lin_park;    // per node kLinParkDoubles: scratch of the linearisation kernel
+  double* lin_park;    // per node 15 doubles per lane: scratch of the linearisation kernel
   int* proj_extent;    // per node: reduced-input extent written by the last fast projection (see project_mfma.h)
   // riccati
   double *Kt, *kt, *dx, *du, *K, *summary, *dx0;
@@ -651,7 +651,7 @@ void allocate(bpmpc_solver* s) {
   const size_t B = s->settings.max_batch, N = s->settings.max_nodes, NX = s->nx, NU = s->nu, S = B * N;
   Buffers& b = s->buf;
   b.proj_extent = s->alloc<int>("proj_extent", S, true);
-  b.lin_park = s->alloc<double>("lin_park", S * kLinParkDoubles);
+  b.lin_park = s->alloc<double>("lin_park", S * kLinParkDoublesPerLane * (6 + s->rm.nj <= 16 ? 16 : 32));
   b.x_prev = s->alloc<double>("x_prev", B * (N + 1) * NX); b.u_prev = s->alloc<double>("u_prev", S * NU);
   b.K_prev = s->alloc<double>("K_prev", S * NU * NX);
   b.tp_time = s->alloc<double>("tp_time", B * (N + 1)); b.tp_kind = s->alloc<int>("tp_kind", S, true);
