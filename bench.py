@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 # cross term P (nu x nx, 3 872 B) is structurally zero for this problem and is no longer written by the kernel (the buffer
 # is zero-filled once at allocation), so it is not counted: 788 in + 21 784 out.
 BYTES_PER_NODE_H1 = 26444 - 3872
+BYTES_PER_NODE_24 = 30748 - 24 * 24 * 8      # nx = nu = 24 class, same rule
 HBM_PEAK_GBS = 8000.0              # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -33,6 +34,9 @@ def main():
     ap.add_argument("--intervals", type=int, default=100, help="horizon in shooting intervals of dt = 0.015 s")
     ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not wrap kernels in HIP events")
+    ap.add_argument("--robot", default="h1", choices=["h1", "openloong"],
+                    help="h1 = the headline workload (nx = nu = 22); openloong = the 24/24 class of BASELINE.json configs[3] (informational)")
+    ap.add_argument("--gait", default="trot", help="gait template of the workload (headline: trot)")
     ap.add_argument("--chunks", type=int, default=0, help="horizon chunks of the linearise/project || Riccati pipeline (0 = library default, 1 = off)")
     args = ap.parse_args()
 
@@ -58,9 +62,9 @@ def main():
     import bipedal_control_amd as bp
     from bipedal_control_amd import scenarios
 
-    itf = scenarios.h1_interface()
+    itf = scenarios.interface(args.robot)
     B, NI = args.batch, args.intervals
-    prob = scenarios.trot_problem(itf, batch=B, n_intervals=NI, offset=rank * B)
+    prob = scenarios.trot_problem(itf, batch=B, n_intervals=NI, offset=rank * B, gait=args.gait)
     max_nodes = NI + 16
     stream = torch.cuda.current_stream().cuda_stream
     mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=max_nodes, profile=not args.no_profile, device=local, stream=stream,
@@ -129,33 +133,36 @@ def main():
             # the horizon is linearised in `launches_per_step` chunk launches: an average launch covers that share of the nodes
             launches_per_step = lin_n / args.steps
             avg_s = 1e-3 * lin_ms / lin_n
-            alg_bytes = BYTES_PER_NODE_H1 * B * n_intermediate / launches_per_step
+            bytes_per_node = BYTES_PER_NODE_H1 if args.robot == "h1" else BYTES_PER_NODE_24
+            alg_bytes = bytes_per_node * B * n_intermediate / launches_per_step
             achieved = alg_bytes / avg_s / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "linearize_traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("batch") == B and tj.get("intervals") == NI:
+                    if tj.get("batch") == B and tj.get("intervals") == NI and (args.robot, args.gait) == ("h1", "trot"):
                         traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"kernel": "k_linearize_fast<10>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"kernel": "k_linearize_fast<%d>" % (10 if args.robot == "h1" else 12), "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_us": round(1e6 * avg_s, 2),
                         "algorithmic_bytes_per_launch": round(alg_bytes), "launches_per_step": launches_per_step,
                         "node_linearizations_per_s": round(B * n_intermediate / launches_per_step / avg_s, 1)}
-        out = {"metric": "MPC solves/s (H1, horizon=%d)" % NI, "value": round(value, 2), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+        out = {"metric": "MPC solves/s (%s, horizon=%d)" % ("H1" if args.robot == "h1" else args.robot, NI), "value": round(value, 2), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "Unitree H1 trot, horizon=%d intervals (dt 0.015), batch=%d perturbed initial states per GPU, "
-                                      "cold start, 1 SQP iteration (BASELINE.json configs[1])" % (NI, B),
+               "config": {"workload": "%s %s, horizon=%d intervals (dt 0.015), batch=%d perturbed initial states per GPU, "
+                                      "cold start, 1 SQP iteration (%s)" % ("Unitree H1" if args.robot == "h1" else "OpenLoong (nx = nu = 24)", args.gait, NI, B,
+                                                                             "BASELINE.json configs[1]" if (args.robot, args.gait) == ("h1", "trot")
+                                                                             else "not the headline workload"),
                           "global_batch": world * B, "shooting_nodes": n_nodes, "intermediate_nodes": n_intermediate, "nx": nx, "nu": nu,
                           "parallelism": "problem-sharded x%d, all-gather of trajectories overlapped with the next solve" % world, "accepted_steps": ok},
                "ms_per_solve": round(ms_per_step / B, 6),
                "kernel_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in ktimes.items()},
                "roofline": roofline}
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(prob, min(args.cpu_sample, B), x, u, stats)
+            out["cpu_baseline"] = cpu_baseline(prob, min(args.cpu_sample, B), x, u, stats, args.robot)
         print(json.dumps(out))
     if use_dist:
         # the gathered block of this rank must equal its local result
@@ -164,17 +171,17 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(prob, sample, x_gpu, u_gpu, stats):
+def cpu_baseline(prob, sample, x_gpu, u_gpu, stats, robot="h1"):
     """Single-thread C++ oracle (a port of the same SQP iteration; the reference itself cannot be built here) on the
     first `sample` problems of the same workload; doubles as an end-to-end parity check of the timed run."""
     import numpy as np
     from tests import oracle_bridge as ob
     from oracle import reference_py as rp
-    m, om = ob.h1_model(), ob.h1_oracle()
+    m, om = ob.model(robot), ob.oracle(robot)
     s = m["sqp"]
     pre = []
     for b in range(sample):
-        nodes = ob.oracle_nodes(prob, b)
+        nodes = ob.oracle_nodes(prob, b, robot=robot)
         xi, ui = rp.cold_start(m, nodes, prob["x0"][b])
         pre.append((nodes, xi, ui))
     worst = 0.0
@@ -190,7 +197,7 @@ def cpu_baseline(prob, sample, x_gpu, u_gpu, stats):
     except Exception:
         cpu_name = "unknown"
     return {"value": round(sample / dt, 3), "unit": "solves/s", "cores": 1, "kind": "port", "ms_per_solve": round(1e3 * dt / sample, 3),
-            "sample": "%d of the same H1 trot problems (horizon and SQP iteration count as on the GPU), solve only, "
+            "sample": "%d of the same problems (horizon and SQP iteration count as on the GPU), solve only, "
                       "reference pre-pass excluded" % sample,
             "host_cpu": cpu_name, "host_cores": os.cpu_count(), "max_abs_x_diff_vs_gpu": worst}
 
