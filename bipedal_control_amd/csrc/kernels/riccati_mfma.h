@@ -31,49 +31,63 @@ namespace bpmpc {
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kMaxRiccatiStages = 512;
 
-template <int NJ>
+// DB: the staged operands are double buffered (stage k-1 is staged while the updates of stage k still read theirs, which
+// saves a barrier per stage).  At nx = 22 that costs 98 KB of LDS (one workgroup per CU) against 66 KB single buffered (two
+// workgroups per CU): the solver double buffers when the batch does not exceed the number of CUs.
+template <int NJ, bool DB>
 struct RiccatiMfmaWorkspace {
   static constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  static constexpr int RB = 32;                                  // padded rows (two 16-row blocks)
+  static constexpr int ZR = NX;                                  // a row that is always zero: block rows >= nx are read there
+  // rows: two full 16-row blocks when double buffered (plain block loads / stores), otherwise nx + the zero row(s)
+  // (block rows >= nx are then read from the zero row and not stored)
+  static constexpr int RB = DB ? 32 : ((NX + 2 + 1) / 2) * 2;
+  static constexpr int RCL = DB ? 32 : NX;                       // block rows below this are read as they are
   static constexpr int LDN = 34;                                 // leading dimension of the [.. | vector] blocks (nx + 1 <= 32 columns)
   static constexpr int WC = NX + 1 + NU;                         // packed width [A | b | B]
   static constexpr int LDW = ((WC + 15) / 16) * 16 + 2;
-  static_assert(NX + 1 <= 32 && NU <= 32, "two block rows / columns");
-  // staged operands are double buffered when that fits in the 160 KB of LDS (nx = 22): stage k-1 is staged while the
-  // updates of stage k still read theirs, which saves a barrier per stage
-  static constexpr int NBUF = (8 * (4 * RB * LDN + RB * LDW + 2 * (RB * LDN + 3 * RB * LDW)) <= 150 * 1024) ? 2 : 1;
+  static_assert(NX + 1 <= 32 && NU <= 32 && ((NX + 3) / 4) * 4 <= RB, "two block rows / columns");
+  static constexpr int NBUF = DB ? 2 : 1;
   alignas(16) double S[RB][LDN];        // [S | s], not symmetrised
-  alignas(16) double Qq[NBUF][RB][LDN];    // [Q~ | q~]
+  alignas(16) double Qq[NBUF][RB][LDN]; // [Q~ | q~]
   alignas(16) double Sn[RB][LDN];       // [Sn | sn]
   alignas(16) double G0[RB][LDN];       // [G | g] before the elimination
-  alignas(16) double W[NBUF][RB][LDW];     // [A~ | b~ | B~]
-  alignas(16) double PW[NBUF][RB][LDW];    // [Px | Pe | Pu]
+  alignas(16) double W[NBUF][RB][LDW];  // [A~ | b~ | B~]
+  alignas(16) double PW[NBUF][RB][LDW]; // [Px | Pe | Pu]
   alignas(16) double SW[RB][LDW];       // sym(S) W
-  alignas(16) double M[NBUF][RB][LDW];     // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
+  alignas(16) double M[NBUF][RB][LDW];  // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
   double r[NBUF][NU];
   alignas(16) double dx[2][NX];
   int status;
-  int nut[kMaxRiccatiStages];           // reduced input dimensions of all stages (a global load per stage would sit on the critical path)
+  unsigned char nut[kMaxRiccatiStages]; // reduced input dimensions of all stages (a global load per stage would sit on the critical path)
 };
 
 // D-layout of v_mfma_f64_16x16x4_f64: lane l, register r  <->  row (l / 16) + 4 r, column l % 16 of the 16x16 block.
-template <int LD>
+// The LDS matrices hold RB < 32 rows: block rows >= NXR (all zero by construction) are read from the zero row ZR and not stored.
+template <int LD, int NXR, int ZR>
 __device__ __forceinline__ v4d blk_load(const double* Mx, int r0, int c0, int l) {
   v4d c;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) c[r] = Mx[(r0 + (l >> 4) + 4 * r) * LD + c0 + (l & 15)];
+  for (int r = 0; r < 4; ++r) {
+    const int row = r0 + (l >> 4) + 4 * r;
+    if constexpr (NXR >= 32) c[r] = Mx[row * LD + c0 + (l & 15)];
+    else c[r] = Mx[(row < NXR ? row : ZR) * LD + c0 + (l & 15)];
+  }
   return c;
 }
-template <int LD>
+template <int LD, int RBR>
 __device__ __forceinline__ void blk_store(double* Mx, int r0, int c0, int l, v4d c) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) Mx[(r0 + (l >> 4) + 4 * r) * LD + c0 + (l & 15)] = c[r];
+  for (int r = 0; r < 4; ++r) {
+    const int row = r0 + (l >> 4) + 4 * r;
+    if constexpr (RBR >= 32) Mx[row * LD + c0 + (l & 15)] = c[r];
+    else if (row < RBR) Mx[row * LD + c0 + (l & 15)] = c[r];
+  }
 }
 
-template <int NJ>
-__device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const RiccatiFastIO& io) {
-  using WS = RiccatiMfmaWorkspace<NJ>;
-  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccatiThreads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB;
+template <int NJ, bool DB>
+__device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, const RiccatiFastIO& io) {
+  using WS = RiccatiMfmaWorkspace<NJ, DB>;
+  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccatiThreads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, ZR = WS::ZR, RCL = WS::RCL;
   constexpr int NXX = NX * NX, NXU = NX * NU;
   constexpr int KS = (NX + 3) / 4;          // k-steps over the state dimension
   constexpr int BC = NX + 1;                // first column of B~ / Pu / R~ in the packed layouts
@@ -96,7 +110,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
     for (int idx = tid; idx < NXX; idx += NT) ws.S[idx / NX][idx % NX] = io.carry[idx];
     if (tid < NX) ws.S[tid][NX] = io.carry[NXX + tid];
   }
-  for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) ws.nut[idx] = io.base.nut[idx];
+  for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) ws.nut[idx] = (unsigned char)io.base.nut[idx];
 
   // Prefetch registers of the loader waves (0..2): 16-byte loads, element pairs (2 t, 2 t + 1) and (2 (t + 192), ..).
   constexpr int NLD = 3 * kWave;                       // loader threads
@@ -165,7 +179,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
 
   for (int k = k_top; k >= io.k_lo; --k) {
     const int nt = ws.nut[k];        // max_nodes <= kMaxRiccatiStages is checked when the solver is created
-    const int cur = WS::NBUF == 2 ? (k & 1) : 0;
+    const int cur = DB ? (k & 1) : 0;
     double (*const W)[LDW] = ws.W[cur];
     double (*const PW)[LDW] = ws.PW[cur];
     double (*const Qq)[LDN] = ws.Qq[cur];
@@ -203,22 +217,23 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
       // unconditional operand loads (a predicated load compiles to a branch plus a full LDS wait per k-step): rows >= nx
       // are switched off by the factor, k >= nx meets the zero rows of W
       const double half = row < NX ? 0.5 : 0.0;
+      const int rowc = RCL >= 32 ? row : (row < RCL ? row : ZR);
       // all operands first, then the chain of dependent MFMAs back to back (interleaved, every k-step exposes an LDS round trip)
       double a[KS], b[KS], sv[4];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
-        a[ks] = half * (ws.S[row][kk] + ws.S[kk][row]);
+        a[ks] = half * (ws.S[rowc][kk] + ws.S[kk][rowc]);
         b[ks] = W[kk][c0 + li];
       }
       const double smask = (c0 + li == NX) ? 1.0 : 0.0;              // s rides in the b column; rows >= nx of S are zero
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sv[r] = smask * ws.S[r0 + lk + 4 * r][NX];
+      for (int r = 0; r < 4; ++r) { const int rr = r0 + lk + 4 * r; sv[r] = smask * ws.S[RCL >= 32 ? rr : (rr < RCL ? rr : ZR)][NX]; }
       __builtin_amdgcn_sched_barrier(0);
       v4d acc = {sv[0], sv[1], sv[2], sv[3]};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-      blk_store<LDW>(&ws.SW[0][0], r0, c0, l, acc);
+      blk_store<LDW, RB>(&ws.SW[0][0], r0, c0, l, acc);
     }
     lds_barrier();
     RMPROF(2);
@@ -226,19 +241,21 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
     for (int id = w; id < ntb * nbc; id += 4) {
       const int bi = id >= nbc ? 1 : 0;
       const int r0 = 16 * bi, c0 = 16 * (id - bi * nbc);
-      v4d acc = blk_load<LDW>(&M[0][0], r0, c0, l);
+      v4d acc = blk_load<LDW, RCL, ZR>(&M[0][0], r0, c0, l);
+      // compact rows: input rows >= nu do not exist, read the (zero) last padding column of W instead
+      const int bcol = (RCL >= 32 || r0 + li < NU) ? BC + r0 + li : LDW - 1;
       double a[KS], b[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
-        a[ks] = W[kk][BC + r0 + li];                                // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
+        a[ks] = W[kk][bcol];                                       // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
         b[ks] = ws.SW[kk][c0 + li];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-      blk_store<LDW>(&M[0][0], r0, c0, l, acc);
-      if (c0 < 32) blk_store<LDN>(&ws.G0[0][0], r0, c0, l, acc);
+      blk_store<LDW, RB>(&M[0][0], r0, c0, l, acc);
+      if (c0 < 32) blk_store<LDN, RB>(&ws.G0[0][0], r0, c0, l, acc);
     }
     if (w == 3) flush_held();        // (wave 3 runs the elimination in P3, the other waves store and prefetch there)
     lds_barrier();
@@ -276,7 +293,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
 #endif
       for (int id = w; id < 4; id += 3) {
         const int r0 = 16 * (id >> 1), c0 = 16 * (id & 1);
-        v4d acc = blk_load<LDN>(&Qq[0][0], r0, c0, l);
+        v4d acc = blk_load<LDN, RCL, ZR>(&Qq[0][0], r0, c0, l);
         const int acol = r0 + li < NX ? r0 + li : LDW - 1;             // the last padding column of W is always zero
         double a[KS], b[KS];
 #pragma unroll
@@ -288,7 +305,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-        blk_store<LDN>(&ws.Sn[0][0], r0, c0, l, acc);
+        blk_store<LDN, RB>(&ws.Sn[0][0], r0, c0, l, acc);
       }
     }
     lds_barrier();
@@ -297,10 +314,11 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
     {
       const int r0 = 16 * (w >> 1), c0 = 16 * (w & 1);
       const int row = r0 + li;
-      v4d acc = blk_load<LDN>(&ws.Sn[0][0], r0, c0, l);
-      v4d acl = blk_load<LDW>(&W[0][0], r0, c0, l);
-      v4d kf = blk_load<LDW>(&PW[0][0], r0, c0, l);
+      v4d acc = blk_load<LDN, RCL, ZR>(&ws.Sn[0][0], r0, c0, l);
+      v4d acl = blk_load<LDW, RCL, ZR>(&W[0][0], r0, c0, l);
+      v4d kf = blk_load<LDW, RCL, ZR>(&PW[0][0], r0, c0, l);
       const int gcol = row < NX ? row : LDN - 1;                       // the last padding column of G0 is always zero
+      const int rowc = RCL >= 32 ? row : (row < RCL ? row : ZR);
       if (ksn <= 3) {
         // up to 12 reduced inputs (every reference configuration): three k-steps, operands first, then the MFMAs of the
         // three independent accumulators; the rows nt.. of Y and G are zero, so a surplus k-step adds nothing
@@ -310,8 +328,8 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
           const int kk = 4 * ks + lk;
           yb[ks] = M[kk][c0 + li];
           ag[ks] = -ws.G0[kk][gcol];                                   // -G'(i, kk)
-          ab[ks] = -W[row][BC + kk];                                // -B(i, kk); rows >= nx of W and PW are zero
-          ap[ks] = -PW[row][BC + kk];                               // -Pu(i, kk)
+          ab[ks] = -W[rowc][BC + kk];                               // -B(i, kk); rows >= nx of W and PW are zero
+          ap[ks] = -PW[rowc][BC + kk];                              // -Pu(i, kk)
         }
         __builtin_amdgcn_sched_barrier(0);
         const int nks = ksn == 3 ? 3 : 2;
@@ -328,11 +346,11 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
           const int kk = 4 * ks + lk;
           const double yv = M[kk][c0 + li];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ws.G0[kk][gcol], yv, acc, 0, 0, 0);
-          acl = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[row][BC + kk], yv, acl, 0, 0, 0);
-          kf = __builtin_amdgcn_mfma_f64_16x16x4f64(-PW[row][BC + kk], yv, kf, 0, 0, 0);
+          acl = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[rowc][BC + kk], yv, acl, 0, 0, 0);
+          kf = __builtin_amdgcn_mfma_f64_16x16x4f64(-PW[rowc][BC + kk], yv, kf, 0, 0, 0);
         }
       }
-      blk_store<LDN>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, three barriers ago
+      blk_store<LDN, RB>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, three barriers ago
       // m = q~ - Y' r~ (Kt = -Y), m0 = -r~' H^-1 g
       double mt = 0.0;
       if (BPMPC_RICCATI_ABLATE != 4 && w == 3 && l <= NX) {
@@ -349,7 +367,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ>& ws, const
     }
     RMPROF(5);
     // double buffered: no barrier here, the next stage stages into the other buffer set and its staging barrier also orders S
-    if (WS::NBUF == 1) lds_barrier();
+    if (!DB) lds_barrier();
   }
   flush_held();
 #ifdef BPMPC_RICCATI_PROFILE

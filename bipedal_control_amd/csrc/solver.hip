@@ -256,10 +256,11 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati(Launch L) {
   riccati_problem<NJ>(ws, io);
 }
 
-template <int NJ>
-__global__ __launch_bounds__(kRiccatiThreads) void k_riccati_fast(Launch L) {
+// The single-buffered variant is meant to run two workgroups per CU: cap its registers at 256 (VGPR + AGPR).
+template <int NJ, bool DB>
+__global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu((DB || NJ != 10) ? 1 : 2, (DB || NJ != 10) ? 8 : 2))) void k_riccati_fast(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ RiccatiMfmaWorkspace<NJ> ws;
+  __shared__ RiccatiMfmaWorkspace<NJ, DB> ws;
   const int b = blockIdx.x;
   if (!L.buf.active[b]) return;
   const size_t s0 = (size_t)b * L.N;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati_fast(Launch L) {
   io.k_lo = L.k0;
   io.k_hi = L.k0 + L.klen;
   io.carry = L.buf.ric_carry + (size_t)b * (NX * NX + NX + 2);
-  riccati_mfma<NJ>(ws, io);
+  riccati_mfma<NJ, DB>(ws, io);
 }
 
 // Warm start of a receding-horizon solve from the previous solution, one wavefront per problem (sequential in the nodes:
@@ -444,6 +445,10 @@ struct bpmpc_solver {
   bpmpc_settings settings{};
   int nx = 0, nu = 0;
   int batch = 0, n_grids = 0, n_nodes_max = 0;
+  int num_cus = 256;                                        // compute units of the device
+  // One Riccati workgroup per problem: double buffered staging (one workgroup per CU) while every problem gets its own CU,
+  // the leaner single-buffered variant (two workgroups per CU at nx = 22) for larger batches.
+  bool riccati_double_buffered() const { return batch <= num_cus || rm.nj != 10; }
   bool has_solution = false;                               // a solve has completed on the current setup
   std::vector<int> grid_kind;                               // host copy of the node kinds of the current setup [n_grids][N]
   int max_rows = kMaxEqRows;                                // largest number of equality rows over the nodes of the current setup
@@ -559,7 +564,8 @@ template <int NJ> void bpmpc_solver::stage_project() {
 template <int NJ> void bpmpc_solver::stage_riccati() {
   const Launch L = launch_params();
   if (settings.reference_kernels) TIMED_LAUNCH("riccati", k_riccati<NJ>, batch, kRiccatiThreads, L);
-  else TIMED_LAUNCH("riccati", k_riccati_fast<NJ>, batch, kRiccatiThreads, L);
+  else if (riccati_double_buffered()) TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, true>), batch, kRiccatiThreads, L);
+  else TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, false>), batch, kRiccatiThreads, L);
 }
 template <int NJ> void bpmpc_solver::stage_linesearch() {
   const Launch L = launch_params();
@@ -611,7 +617,8 @@ template <int NJ> void bpmpc_solver::pipelined_backward() {
     HIP_CHECK(hipEventRecord(ev_chunk[c], producer_stream));
     HIP_CHECK(hipStreamWaitEvent(stream, ev_chunk[c], 0));
     if (c == 0) { L.klen = settings.max_nodes - lo; }   // problems on longer grids than n_nodes_max do not exist; keep k_hi >= N
-    TIMED_LAUNCH("riccati", k_riccati_fast<NJ>, batch, kRiccatiThreads, L);
+    if (riccati_double_buffered()) TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, true>), batch, kRiccatiThreads, L);
+    else TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, false>), batch, kRiccatiThreads, L);
   }
 }
 
@@ -863,6 +870,7 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     s->settings = *settings;
     s->nx = s->rm.nx; s->nu = s->rm.nu;
     HIP_CHECK(hipSetDevice(settings->device));
+    { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, settings->device)); s->num_cus = prop.multiProcessorCount; }
     if (settings->stream) { s->stream = static_cast<hipStream_t>(settings->stream); }
     else { HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
     if (s->settings.pipeline_chunks <= 0) s->settings.pipeline_chunks = 1;
