@@ -322,7 +322,8 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
       ang[1] += r[2] * Fi[0] - r[0] * Fi[2];
       ang[2] += r[0] * Fi[1] - r[1] * Fi[0];
     }
-    for (int i = 0; i < 3; ++i) { ev.fh[i] = lin[i] / mass_total; ev.fh[3 + i] = ang[i] / mass_total; }
+    const double imt_c = 1.0 / mass_total;             // one division instead of six (an fp64 division is ~25 instructions)
+    for (int i = 0; i < 3; ++i) { ev.fh[i] = lin[i] * imt_c; ev.fh[3 + i] = ang[i] * imt_c; }
   }
   double om[3] = {0.0, 0.0, 0.0}, vo[3] = {pd[0], pd[1], pd[2]};
   if constexpr (TWIST) {
@@ -419,7 +420,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
       ev.br_j[3 + i] = -(X22[3 * i] * Ac[3] + X22[3 * i + 1] * Ac[4] + X22[3 * i + 2] * Ac[5]);
     }
     if (!is_joint) for (int i = 0; i < 6; ++i) ev.br_j[i] = 0.0;
-    const double jcm[3] = {Ac[0] / Mtot, Ac[1] / Mtot, Ac[2] / Mtot};
+    const double jcm[3] = {Ac[0] * im, Ac[1] * im, Ac[2] * im};
     double acc[3] = {0.0, 0.0, 0.0};
     for (int i = 0; i < kNumContacts; ++i) {
       double jcol[3] = {0.0, 0.0, 0.0};
