@@ -237,3 +237,25 @@ def test_solver_reuse_across_gaits_matches_fresh_solver(ctx):
     fresh = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=80, sqp_iterations=2, return_gains=True)
     ref = fresh.run(trot["t0"], trot["x0"], trot["schedule"], trot["targets"], horizon=trot["horizon"])
     assert np.array_equal(last[1], ref[1]) and np.array_equal(last[2], ref[2]) and np.array_equal(last[3], ref[3])
+
+
+@pytest.mark.parametrize("batch", [48, 300])      # 300 > number of CUs: the single-buffered Riccati variant (two workgroups per CU)
+def test_repeated_solves_are_bit_identical(ctx, batch):
+    """Races, stale LDS or stale HBM scratch would show up as run-to-run differences; also checks the larger-batch Riccati variant
+    against the oracle."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=batch, n_intervals=30, gait="flying_trot")
+    mpc = bp.BatchedSqpMpc(itf, max_batch=batch, max_nodes=48, sqp_iterations=2, return_gains=True)
+    mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    ref = None
+    for i in range(12):
+        mpc.reset(); mpc.enqueue()
+        t, x, u, K, st = mpc.fetch(gains=True)
+        if ref is None:
+            ref = (x.copy(), u.copy(), K.copy())
+        else:
+            assert np.array_equal(x, ref[0]) and np.array_equal(u, ref[1]) and np.array_equal(K, ref[2])
+    for b in (0, batch - 1):
+        xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
+        n = st[b].n_nodes
+        assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8 and _rel(K[b, :n], Ko) < 1e-7
