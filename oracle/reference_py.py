@@ -5,7 +5,7 @@ Each function cites the reference file:line it follows (paths relative to /root/
 marks behaviour of un-vendored OCS2 (`ocs2_core/misc/Lookup.h`, `ocs2_oc/oc_data/TimeDiscretization.cpp`,
 `ocs2_core/misc/LinearInterpolation.h`, `ocs2_core/reference/ModeSchedule.cpp`) restated from the published sources.
 Parity status: UNPINNED (no reference fixtures exist); pinned by the hand-derived known answers of SURVEY.md
-section 8(c)(4) in tests/test_reference_oracle.py.
+section 8(c)(4) in tests/test_reference_prepass.py.
 """
 import bisect
 import math
