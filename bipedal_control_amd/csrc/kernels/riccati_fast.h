@@ -1,6 +1,6 @@
 // Shared pieces of the fast Riccati sweep (HIP only; the sweep itself is riccati_mfma.h, the lane-emulated reference
 // version is riccati.h - same mathematics): the view of the per-stage data, LDS-only barriers, the Gauss-Jordan
-// elimination held in the registers of one wave, and the forward roll-out with the step norms.
+// elimination held in the registers of one wave, and the step norms after the roll-out (riccati_mfma.h).
 //   * the backward sweep stores the closed-loop quantities the roll-out needs
 //        Acl = A~ + B~ Kt, bcl = b~ + B~ kt, K = Px + Pu Kt, kff = Pe + Pu kt, m = q~ + Kt' r~, m0 = r~' kt
 //     so the roll-out is one mat-vec per stage (dx+ = Acl dx + bcl); du = K dx + kff is done afterwards for all
@@ -80,46 +80,14 @@ __device__ __forceinline__ bool gauss_jordan_wave(double (&v)[ROWS], int nt) {
   return ok;
 }
 
-// Forward roll-out dx_{k+1} = Acl_k dx_k + bcl_k (wave 0, one row per lane, next row prefetched), then
-// du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms.
+// du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms (dx is in HBM, workgroup-visible).
 template <int NJ>
-__device__ __forceinline__ void riccati_rollout(double (&wsdx)[2][12 + NJ], int status, const RiccatiFastIO& io) {
+__device__ __forceinline__ void riccati_step_norms(int status, const RiccatiFastIO& io) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ, NT = kRiccatiThreads;
   constexpr int NXX = NX * NX, NXU = NX * NU;
+  (void)NXX;
   const int tid = threadIdx.x;
   const int N = io.base.N;
-  // ---- forward roll-out: dx_{k+1} = Acl_k dx_k + bcl_k (wave 0, one row per lane, next row prefetched)
-  if (tid < NX) { const double v = io.base.dx0[tid]; wsdx[0][tid] = v; io.base.dx[tid] = v; }
-  __syncthreads();
-  if (tid < kWave) {
-    double row[NX], nrow[NX], bc = 0.0, nbc = 0.0;
-    if (tid < NX && N > 0) {
-#pragma unroll
-      for (int l = 0; l < NX; ++l) row[l] = io.Acl[(size_t)tid * NX + l];
-      bc = io.bcl[tid];
-    }
-    for (int k = 0; k < N; ++k) {
-      if (tid < NX && k + 1 < N) {
-        const double* nr = io.Acl + (size_t)(k + 1) * NXX + (size_t)tid * NX;
-#pragma unroll
-        for (int l = 0; l < NX; ++l) nrow[l] = nr[l];
-        nbc = io.bcl[(size_t)(k + 1) * NX + tid];
-      }
-      if (tid < NX) {
-        const double* cur = wsdx[k & 1];
-        double t = bc;
-#pragma unroll
-        for (int l = 0; l < NX; ++l) t += row[l] * cur[l];
-        wsdx[(k + 1) & 1][tid] = t;
-        io.base.dx[(size_t)(k + 1) * NX + tid] = t;
-#pragma unroll
-        for (int l = 0; l < NX; ++l) row[l] = nrow[l];
-        bc = nbc;
-      }
-      lds_wave_sync();
-    }
-  }
-  __syncthreads();
   // ---- du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms
   double acc_arm = 0.0, acc_x = 0.0, acc_u = 0.0;
   for (int idx = tid; idx < N * NU; idx += NT) {

@@ -84,6 +84,58 @@ __device__ __forceinline__ void blk_store(double* Mx, int r0, int c0, int l, v4d
   }
 }
 
+// Forward roll-out dx_{k+1} = Acl_k dx_k + bcl_k with the rows of three stages in flight (then du, Armijo metric and step
+// norms: riccati_step_norms).  The recurrence is one short mat-vec per stage, so whatever global-memory latency sits inside a
+// step dominates it:
+//   * wave 0 computes, one row of [Acl | bcl] per lane in registers, three register sets loaded three stages ahead; the loop
+//     body is straight-line code with unconditional loads, so the compiler can count how many younger loads may stay in flight
+//     when a set is consumed;
+//   * the state history stays in LDS (the workspace of the backward sweep is dead by now) and goes to HBM afterwards in one
+//     coalesced pass: inside the loop wave 0 issues no store, so no load ever waits for a store (vmcnt retires in order).
+template <int NJ>
+__device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 4) * nx doubles*/, int cap, int status, const RiccatiFastIO& io) {
+  constexpr int NX = 12 + NJ, NT = kRiccatiThreads, NXX = NX * NX;
+  const int tid = threadIdx.x;
+  const int N = io.base.N;
+  if (tid < NX) hist[tid] = io.base.dx0[tid];
+  if (tid >= kWave && tid < kWave + NX) io.base.dx[tid - kWave] = io.base.dx0[tid - kWave];
+  __syncthreads();
+  for (int k0 = 0; k0 < N; k0 += cap) {                 // one pass unless the horizon exceeds the LDS history
+    const int nk = N - k0 < cap ? N - k0 : cap;
+    if (tid < kWave) {
+      const int ri = tid < NX ? tid : 0;                // lanes >= nx shadow row 0 (keeps the loads unconditional)
+      double rA[NX], rB[NX], rC[NX], bA, bB, bC;
+      auto load = [&](double (&r)[NX], double& b, int k) {
+        const int kc = k < N ? k : N - 1;               // beyond the end: a valid, unused stage
+        const double* p = io.Acl + (size_t)kc * NXX + (size_t)ri * NX;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) r[l] = p[l];
+        b = io.bcl[(size_t)kc * NX + ri];
+      };
+      auto step = [&](const double (&r)[NX], double b, int j) {      // j: stage index inside this pass
+        const double* cur = hist + j * NX;
+        double t0 = b, t1 = 0.0;
+#pragma unroll
+        for (int l = 0; l < NX; l += 2) { t0 += r[l] * cur[l]; t1 += r[l + 1] * cur[l + 1]; }
+        if (tid < NX) hist[(j + 1) * NX + tid] = t0 + t1;
+        lds_wave_sync();
+      };
+      load(rA, bA, k0); load(rB, bB, k0 + 1); load(rC, bC, k0 + 2);
+      for (int j = 0; j < nk; j += 3) {                 // steps past nk write history rows that are never read
+        step(rA, bA, j);     load(rA, bA, k0 + j + 3);
+        step(rB, bB, j + 1); load(rB, bB, k0 + j + 4);
+        step(rC, bC, j + 2); load(rC, bC, k0 + j + 5);
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nk * NX; idx += NT) io.base.dx[(size_t)(k0 + 1) * NX + idx] = hist[NX + idx];
+    __syncthreads();
+    if (tid < NX) hist[tid] = hist[nk * NX + tid];      // input of the next pass
+    __syncthreads();
+  }
+  riccati_step_norms<NJ>(status, io);
+}
+
 template <int NJ, bool DB>
 __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, const RiccatiFastIO& io) {
   using WS = RiccatiMfmaWorkspace<NJ, DB>;
@@ -381,7 +433,13 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
     if (tid == 0) io.carry[NXX + NX] = (double)ws.status;
     return;
   }
-  riccati_rollout<NJ>(ws.dx, ws.status, io);
+  {
+    const int st = ws.status;
+    __syncthreads();                                   // the workspace is dead from here on: it holds the state history
+    constexpr int kHistCap = (int)(sizeof(WS) / sizeof(double)) / NX - 8;
+    static_assert(kHistCap >= 64, "roll-out history");
+    riccati_rollout_deep<NJ>(reinterpret_cast<double*>(&ws), kHistCap, st, io);
+  }
 }
 
 }  // namespace bpmpc
