@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -434,6 +436,21 @@ struct KernelTimer {
   int launches = 0;
 };
 
+// One launch instead of several driver copies / fills (each costs a dispatch gap of a few microseconds between kernels):
+// copies two pairs of double arrays and optionally re-arms the per-problem flags.
+__global__ __launch_bounds__(256) void k_copy_pairs(const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb,
+                                                     int* iterations, int* active, int batch) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  const double2* a2 = reinterpret_cast<const double2*>(a_src);
+  const double2* b2 = reinterpret_cast<const double2*>(b_src);
+  double2* ad = reinterpret_cast<double2*>(a_dst);
+  double2* bd = reinterpret_cast<double2*>(b_dst);
+  for (size_t i = i0; i < na / 2; i += stride) ad[i] = a2[i];
+  for (size_t i = i0; i < nb / 2; i += stride) bd[i] = b2[i];
+  if (i0 == 0) { if (na & 1) a_dst[na - 1] = a_src[na - 1]; if (nb & 1) b_dst[nb - 1] = b_src[nb - 1]; }
+  if (iterations) for (size_t i = i0; i < (size_t)batch; i += stride) { iterations[i] = 0; active[i] = 1; }
+}
+
 }  // namespace bpmpc
 
 using namespace bpmpc;
@@ -811,12 +828,17 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   HIP_CHECK(hipStreamSynchronize(s->stream));
 }
 
+void copy_pairs(bpmpc_solver* s, const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb, bool rearm) {
+  const size_t work = (na > nb ? na : nb) / 2;
+  const int grid = (int)std::min<size_t>((work + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_copy_pairs, dim3(grid > 0 ? grid : 1), dim3(256), 0, s->stream, a_src, a_dst, na, b_src, b_dst, nb,
+                     rearm ? s->buf.iterations : nullptr, s->buf.active, s->batch);
+  HIP_CHECK(hipGetLastError());
+}
+
 void reset(bpmpc_solver* s) {
   const size_t N = s->settings.max_nodes;
-  HIP_CHECK(hipMemcpyAsync(s->buf.x, s->buf.x_init, (size_t)s->batch * (N + 1) * s->nx * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  HIP_CHECK(hipMemcpyAsync(s->buf.u, s->buf.u_init, (size_t)s->batch * N * s->nu * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  HIP_CHECK(hipMemsetAsync(s->buf.iterations, 0, sizeof(int) * s->batch, s->stream));
-  HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)s->buf.active, 1, s->batch, s->stream));
+  copy_pairs(s, s->buf.x_init, s->buf.x, (size_t)s->batch * (N + 1) * s->nx, s->buf.u_init, s->buf.u, (size_t)s->batch * N * s->nu, true);
 }
 
 void fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double* out_K, bpmpc_stats* stats) {
@@ -993,8 +1015,12 @@ int bpmpc_solver_device_trajectories(bpmpc_solver* s, double** x_dev, double** u
 int bpmpc_solver_export_trajectories(bpmpc_solver* s, double* x_dst_dev, double* u_dst_dev) {
   API_GUARD(s, {
     const size_t N = s->settings.max_nodes;
-    if (x_dst_dev) HIP_CHECK(hipMemcpyAsync(x_dst_dev, s->buf.x, (size_t)s->batch * (N + 1) * s->nx * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    if (u_dst_dev) HIP_CHECK(hipMemcpyAsync(u_dst_dev, s->buf.u, (size_t)s->batch * N * s->nu * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    if (x_dst_dev && u_dst_dev && ((uintptr_t)x_dst_dev % 16 == 0) && ((uintptr_t)u_dst_dev % 16 == 0)) {
+      copy_pairs(s, s->buf.x, x_dst_dev, (size_t)s->batch * (N + 1) * s->nx, s->buf.u, u_dst_dev, (size_t)s->batch * N * s->nu, false);
+    } else {
+      if (x_dst_dev) HIP_CHECK(hipMemcpyAsync(x_dst_dev, s->buf.x, (size_t)s->batch * (N + 1) * s->nx * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+      if (u_dst_dev) HIP_CHECK(hipMemcpyAsync(u_dst_dev, s->buf.u, (size_t)s->batch * N * s->nu * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    }
   })
 }
 int bpmpc_solver_kernel_time(bpmpc_solver* s, const char* kernel, int reset_after, double* total_ms, int* launches) {
