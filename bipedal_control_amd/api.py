@@ -44,6 +44,10 @@ class _Schedule(C.Structure):
     _fields_ = [("n_events", C.c_int), ("event_times", _dp), ("modes", _ip)]
 
 
+class _GaitTemplate(C.Structure):
+    _fields_ = [("n_modes", C.c_int), ("switching_times", _dp), ("modes", _ip)]
+
+
 class _Target(C.Structure):
     _fields_ = [("n_points", C.c_int), ("times", _dp), ("states", _dp)]
 
@@ -267,6 +271,28 @@ class BatchedSqpMpc:
             horizon = self.interface.mpcSettings()["timeHorizon"]
         B, t0, x0, sched, ns, tg, _, _, keep = self._marshal(t0, x0, modeSchedules, targetTrajectories, None, None)
         _check(load_library().bpmpc_solver_setup_from_previous(self._h, B, C.c_double(horizon), _d(t0), _d(x0), sched, ns, tg))
+        self.batch = B
+        return self.layout()
+
+    def setup_commands(self, t0, x0, gaits, gait_of_problem, gait_start, cmd_vel, horizon=None, time_to_target=0.0, from_previous=False):
+        """The whole pre-pass on the device (bpmpc_solver_setup_commands): `gaits` is a list of ModeSequenceTemplate, problem b
+        follows gaits[gait_of_problem[b]] inserted at gait_start[b] (index < 0: initial schedule only) and tracks the velocity
+        command cmd_vel[b] = (vx, vy, vz, yaw rate)."""
+        if horizon is None:
+            horizon = self.interface.mpcSettings()["timeHorizon"]
+        x0 = _f64(x0).reshape(-1, self.nx)
+        B = x0.shape[0]
+        t0 = _f64(np.broadcast_to(np.asarray(t0, float), (B,)))
+        gop = np.ascontiguousarray(np.broadcast_to(np.asarray(gait_of_problem, np.int32), (B,)))
+        gst = _f64(np.broadcast_to(np.asarray(gait_start, float), (B,)))
+        cmd = _f64(np.broadcast_to(np.asarray(cmd_vel, float), (B, 4)))
+        keep, tm = [], (_GaitTemplate * max(1, len(gaits)))()
+        for i, g in enumerate(gaits):
+            sw, mo = _f64(g.switchingTimes), np.ascontiguousarray(g.modeSequence, np.int32)
+            keep += [sw, mo]
+            tm[i] = _GaitTemplate(len(mo), _d(sw), _i(mo))
+        _check(load_library().bpmpc_solver_setup_commands(self._h, B, C.c_double(horizon), _d(t0), _d(x0), tm, len(gaits), _i(gop), _d(gst), _d(cmd),
+                                                          C.c_double(time_to_target), int(bool(from_previous))))
         self.batch = B
         return self.layout()
 

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -33,6 +34,7 @@
 #include "kernels/riccati_mfma.h"
 #include "kernels/project_mfma.h"
 #include "reference_gen.h"
+#include "kernels/reference_device.h"
 
 namespace bpmpc {
 
@@ -69,6 +71,9 @@ struct Buffers {
   // previous solution, kept for the receding-horizon warm start (k_warm_shift)
   double *x_prev, *u_prev, *K_prev, *tp_time;
   int *tp_kind, *tp_nodes, *tp_grid;
+  // device-side reference generation (kernels/reference_device.h)
+  double *g_time, *rg_t0, *rg_start, *p_t0, *p_cmd, *lib_d;
+  int *rg_gait, *rg_status, *rg_rows, *lib_i;
   double* ric_carry;   // per problem NX*NX + NX + 1: value function and status handed from one horizon chunk to the next
   // line search
   double *trial_perf, *base, *alpha, *stats;
@@ -455,7 +460,13 @@ __global__ __launch_bounds__(256) void k_copy_pairs(const double* a_src, double*
 
 using namespace bpmpc;
 
+struct HostStaging {   // host-side images of the tables bpmpc_solver_setup uploads
+  std::vector<int> kind, mode, nodes, pgrid, tgt_n;
+  std::vector<double> gdt, gstart, zref, zdref, tgt_t, tgt_x;
+};
+
 struct bpmpc_solver {
+  HostStaging staging;
   RobotModel rm;
   DeviceModel dm;
   DeviceModel* d_model = nullptr;
@@ -681,6 +692,9 @@ void allocate(bpmpc_solver* s) {
   b.tp_time = s->alloc<double>("tp_time", B * (N + 1)); b.tp_kind = s->alloc<int>("tp_kind", S, true);
   b.tp_nodes = s->alloc<int>("tp_nodes", B, true); b.tp_grid = s->alloc<int>("tp_grid", B, true);
   b.ric_carry = s->alloc<double>("ric_carry", B * (NX * NX + NX + 2));   // S, s, status, scratch word
+  b.g_time = s->alloc<double>("g_time", B * (N + 1)); b.rg_t0 = s->alloc<double>(nullptr, B); b.rg_start = s->alloc<double>(nullptr, B);
+  b.p_t0 = s->alloc<double>(nullptr, B); b.p_cmd = s->alloc<double>(nullptr, B * 4); b.lib_d = s->alloc<double>(nullptr, kRefLibCapacity);
+  b.rg_gait = s->alloc<int>(nullptr, B); b.rg_status = s->alloc<int>(nullptr, B); b.rg_rows = s->alloc<int>(nullptr, B); b.lib_i = s->alloc<int>(nullptr, kRefLibCapacity);
   b.g_kind = s->alloc<int>("g_kind", S, true); b.g_mode = s->alloc<int>("g_mode", S, true); b.g_nodes = s->alloc<int>("g_nodes", B, true);
   b.g_dt = s->alloc<double>("g_dt", S); b.g_start = s->alloc<double>("g_start", S);
   b.g_zref = s->alloc<double>("g_zref", S * 4); b.g_zdref = s->alloc<double>("g_zdref", S * 4);
@@ -718,6 +732,47 @@ void upload(bpmpc_solver* s, T* dst, const std::vector<T>& src) {
   if (!src.empty()) HIP_CHECK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s->stream));
 }
 
+void copy_pairs(bpmpc_solver* s, const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb, bool rearm) {
+  const size_t work = (na > nb ? na : nb) / 2;
+  const int grid = (int)std::min<size_t>((work + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_copy_pairs, dim3(grid > 0 ? grid : 1), dim3(256), 0, s->stream, a_src, a_dst, na, b_src, b_dst, nb,
+                     rearm ? s->buf.iterations : nullptr, s->buf.active, s->batch);
+  HIP_CHECK(hipGetLastError());
+}
+
+// receding-horizon warm start: keep the previous solution and its grid on the device before anything is overwritten
+void preserve_previous(bpmpc_solver* s, int batch, bool warm_arrays) {
+  const int N = s->settings.max_nodes, NX = s->nx, NU = s->nu;
+  if (warm_arrays) throw std::invalid_argument("warm start arrays and from_previous are exclusive");
+  if (!s->has_solution || batch != s->batch) throw std::invalid_argument("setup_from_previous needs a completed solve of the same batch");
+  Buffers& bp = s->buf;
+  if (!bp.K) throw std::invalid_argument("setup_from_previous needs the feedback gains (return_gains with reference kernels)");
+  HIP_CHECK(hipMemcpyAsync(bp.x_prev, bp.x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(bp.u_prev, bp.u, (size_t)batch * N * NU * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(bp.K_prev, bp.K, (size_t)batch * N * NU * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  upload(s, bp.tp_time, s->node_times); upload(s, bp.tp_kind, s->grid_kind); upload(s, bp.tp_nodes, s->grid_nodes); upload(s, bp.tp_grid, s->grid_of_problem);
+  HIP_CHECK(hipStreamSynchronize(s->stream));   // the host vectors are replaced by the caller
+}
+
+// common tail of every setup flavour: initial iterate (initializer, warm arrays or shifted previous solution), activation
+void finish_setup(bpmpc_solver* s, int batch, const double* warm_x, const double* warm_u, bool from_previous) {
+  const int N = s->settings.max_nodes, NX = s->nx, NU = s->nu;
+  Buffers& bf = s->buf;
+  if (!s->cold) {
+    HIP_CHECK(hipMemcpyAsync(bf.x, warm_x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_CHECK(hipMemcpyAsync(bf.u, warm_u, (size_t)batch * N * NU * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  }
+  DISPATCH_NJ(s, stage_prepare);
+  if (from_previous) {
+    const Launch L = s->launch_params();
+    if (s->rm.nj == 10) hipLaunchKernelGGL(k_warm_shift<10>, dim3(batch), dim3(kWave), 0, s->stream, L);
+    else hipLaunchKernelGGL(k_warm_shift<12>, dim3(batch), dim3(kWave), 0, s->stream, L);
+    HIP_CHECK(hipGetLastError());
+  }
+  copy_pairs(s, bf.x, bf.x_init, (size_t)batch * (N + 1) * NX, bf.u, bf.u_init, (size_t)batch * N * NU, true);
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+}
+
 void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
            int n_schedules, const bpmpc_target* targets, const double* warm_x, const double* warm_u, bool from_previous = false) {
   if (batch < 1 || batch > s->settings.max_batch) throw std::length_error("batch exceeds the solver's max_batch");
@@ -747,23 +802,15 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
     }
   }
   const int G = (int)first_problem.size();
-  // receding-horizon warm start: keep the previous solution and its grid on the device before anything is overwritten
-  std::vector<double> prev_times;
-  std::vector<int> prev_kind, prev_nodes, prev_pgrid;
-  if (from_previous) {
-    if (warm_x) throw std::invalid_argument("warm start arrays and from_previous are exclusive");
-    if (!s->has_solution || batch != s->batch) throw std::invalid_argument("setup_from_previous needs a completed solve of the same batch");
-    Buffers& bp = s->buf;
-    if (!bp.K) throw std::invalid_argument("setup_from_previous needs the feedback gains (return_gains with reference kernels)");
-    HIP_CHECK(hipMemcpyAsync(bp.x_prev, bp.x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    HIP_CHECK(hipMemcpyAsync(bp.u_prev, bp.u, (size_t)batch * N * NU * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    HIP_CHECK(hipMemcpyAsync(bp.K_prev, bp.K, (size_t)batch * N * NU * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    prev_times = s->node_times; prev_kind = s->grid_kind; prev_nodes = s->grid_nodes; prev_pgrid = s->grid_of_problem;
-    upload(s, bp.tp_time, prev_times); upload(s, bp.tp_kind, prev_kind); upload(s, bp.tp_nodes, prev_nodes); upload(s, bp.tp_grid, prev_pgrid);
-  }
+  if (from_previous) preserve_previous(s, batch, warm_x != nullptr);
   const size_t S = (size_t)G * N;
-  std::vector<int> kind(S, 0), mode(S, STANCE), nodes(G, 0), pgrid(batch, 0);
-  std::vector<double> gdt(S, 0.0), gstart(S, 0.0), zref(S * 4, 0.0), zdref(S * 4, 0.0);
+  // staging vectors live in the solver: releasing megabytes of freshly DMA-ed pageable memory after every setup made the
+  // next solve stall for 10-30 ms on some boxes (tools/setup_time_probe.py)
+  HostStaging& hs = s->staging;
+  std::vector<int>&kind = hs.kind, &mode = hs.mode, &nodes = hs.nodes, &pgrid = hs.pgrid;
+  std::vector<double>&gdt = hs.gdt, &gstart = hs.gstart, &zref = hs.zref, &zdref = hs.zdref;
+  kind.assign(S, 0); mode.assign(S, STANCE); nodes.assign(G, 0); pgrid.assign(batch, 0);
+  gdt.assign(S, 0.0); gstart.assign(S, 0.0); zref.assign(S * 4, 0.0); zdref.assign(S * 4, 0.0);
   s->node_times.assign((size_t)G * (N + 1), 0.0);
   SwingPlanner planner(s->rm.swing);
   int nmax = 0, rows_max = 12;
@@ -789,8 +836,9 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
     }
     std::copy(tab.node_time.begin(), tab.node_time.end(), s->node_times.begin() + (size_t)g * (N + 1));
   }
-  std::vector<double> tgt_t((size_t)batch * kMaxTargetPoints, 0.0), tgt_x((size_t)batch * kMaxTargetPoints * NX, 0.0);
-  std::vector<int> tgt_n(batch, 0);
+  std::vector<double>&tgt_t = hs.tgt_t, &tgt_x = hs.tgt_x;
+  std::vector<int>& tgt_n = hs.tgt_n;
+  tgt_t.assign((size_t)batch * kMaxTargetPoints, 0.0); tgt_x.assign((size_t)batch * kMaxTargetPoints * NX, 0.0); tgt_n.assign(batch, 0);
   for (int b = 0; b < batch; ++b) {
     pgrid[b] = grid_of[b];
     const bpmpc_target& t = targets[b];
@@ -807,34 +855,106 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   upload(s, bf.g_zref, zref); upload(s, bf.g_zdref, zdref); upload(s, bf.p_grid, pgrid);
   upload(s, bf.p_tgt_t, tgt_t); upload(s, bf.p_tgt_x, tgt_x); upload(s, bf.p_tgt_n, tgt_n);
   HIP_CHECK(hipMemcpyAsync(bf.p_x0, x0, (size_t)batch * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  if (!s->cold) {
-    HIP_CHECK(hipMemcpyAsync(bf.x, warm_x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    HIP_CHECK(hipMemcpyAsync(bf.u, warm_u, (size_t)batch * N * NU * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  }
   HIP_CHECK(hipStreamSynchronize(s->stream));  // the host staging vectors go out of scope
-  DISPATCH_NJ(s, stage_prepare);
-  if (from_previous) {
-    const Launch L = s->launch_params();
-    if (s->rm.nj == 10) hipLaunchKernelGGL(k_warm_shift<10>, dim3(batch), dim3(kWave), 0, s->stream, L);
-    else hipLaunchKernelGGL(k_warm_shift<12>, dim3(batch), dim3(kWave), 0, s->stream, L);
-    HIP_CHECK(hipGetLastError());
-  }
-  HIP_CHECK(hipMemcpyAsync(bf.x_init, bf.x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  HIP_CHECK(hipMemcpyAsync(bf.u_init, bf.u, (size_t)batch * N * NU * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  // activate
-  std::vector<int> ones(batch, 1);
-  upload(s, bf.active, ones);
-  HIP_CHECK(hipMemsetAsync(bf.iterations, 0, sizeof(int) * batch, s->stream));
-  HIP_CHECK(hipStreamSynchronize(s->stream));
+  finish_setup(s, batch, warm_x, warm_u, from_previous);
 }
 
-void copy_pairs(bpmpc_solver* s, const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb, bool rearm) {
-  const size_t work = (na > nb ? na : nb) / 2;
-  const int grid = (int)std::min<size_t>((work + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_copy_pairs, dim3(grid > 0 ? grid : 1), dim3(256), 0, s->stream, a_src, a_dst, na, b_src, b_dst, nb,
-                     rearm ? s->buf.iterations : nullptr, s->buf.active, s->batch);
+// Device-side reference generation: the same tables as setup(), built on the GPU from gait
+// templates and velocity commands; the host only groups problems by (t0, gait, gait start) and reads the grid sizes back.
+void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_gait_template* gaits, int n_gaits,
+                    const int* gait_of_problem, const double* gait_start, const double* cmd_vel, double time_to_target, bool from_previous) {
+  if (batch < 1 || batch > s->settings.max_batch) throw std::length_error("batch exceeds the solver's max_batch");
+  if (!(horizon > 0) || !t0 || !x0 || !cmd_vel || n_gaits < 0 || (n_gaits > 0 && !gaits)) throw std::invalid_argument("setup_commands: null or invalid argument");
+  if (n_gaits > 0 && (!gait_of_problem || !gait_start)) throw std::invalid_argument("setup_commands: gait_of_problem and gait_start are needed with templates");
+  const int N = s->settings.max_nodes, NX = s->nx;
+  const double dt = s->settings.dt > 0 ? s->settings.dt : s->rm.sqp.dt;
+  std::vector<int> pgrid(batch), ggait;
+  std::vector<double> gt0, gstart;
+  {
+    std::map<std::tuple<double, int, double>, int> seen;
+    for (int b = 0; b < batch; ++b) {
+      const int gi = gait_of_problem ? gait_of_problem[b] : -1;
+      if (gi >= n_gaits) throw std::invalid_argument("gait_of_problem refers to a template that was not passed");
+      const double st = gi >= 0 ? gait_start[b] : 0.0;
+      auto key = std::make_tuple(t0[b], gi < 0 ? -1 : gi, st);
+      auto it = seen.find(key);
+      if (it == seen.end()) { it = seen.emplace(key, (int)gt0.size()).first; gt0.push_back(t0[b]); ggait.push_back(gi < 0 ? -1 : gi); gstart.push_back(st); }
+      pgrid[b] = it->second;
+    }
+  }
+  const int G = (int)gt0.size();
+  // gait library: the passed templates, then defaultModeSequenceTemplate; initialModeSchedule behind them
+  std::vector<double> lib_d;
+  std::vector<int> first_mode{0}, lib_modes;
+  auto add_template = [&](const double* sw, const int* modes, int n) {
+    if (n < 0 || (n > 0 && (!sw || !modes))) throw std::invalid_argument("invalid gait template");
+    lib_d.insert(lib_d.end(), sw, sw + (n > 0 ? n + 1 : 0));
+    if (n == 0) lib_d.push_back(0.0);
+    lib_modes.insert(lib_modes.end(), modes, modes + n);
+    first_mode.push_back((int)lib_modes.size());
+  };
+  for (int g = 0; g < n_gaits; ++g) add_template(gaits[g].switching_times, gaits[g].modes, gaits[g].n_modes);
+  const ModeTemplate& dflt = s->rm.default_template;
+  if (!dflt.modes.empty() && dflt.switching_times.size() != dflt.modes.size() + 1) throw std::invalid_argument("default gait template is malformed");
+  add_template(dflt.switching_times.data(), dflt.modes.data(), (int)dflt.modes.size());
+  const ModeSchedule& init = s->rm.initial_mode_schedule;
+  const size_t sw_count = lib_d.size(), mode_count = lib_modes.size();
+  lib_d.insert(lib_d.end(), init.event_times.begin(), init.event_times.end());
+  std::vector<int> lib_i = first_mode;
+  lib_i.insert(lib_i.end(), lib_modes.begin(), lib_modes.end());
+  lib_i.insert(lib_i.end(), init.modes.begin(), init.modes.end());
+  if (lib_d.size() > (size_t)kRefLibCapacity || lib_i.size() > (size_t)kRefLibCapacity) throw std::length_error("gait library exceeds the device capacity");
+  if (from_previous) preserve_previous(s, batch, false);
+  Buffers& bf = s->buf;
+  upload(s, bf.rg_t0, gt0); upload(s, bf.rg_gait, ggait); upload(s, bf.rg_start, gstart); upload(s, bf.lib_d, lib_d); upload(s, bf.lib_i, lib_i);
+  upload(s, bf.p_grid, pgrid);
+  HIP_CHECK(hipMemcpyAsync(bf.p_t0, t0, (size_t)batch * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(bf.p_cmd, cmd_vel, (size_t)batch * 4 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(bf.p_x0, x0, (size_t)batch * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  ReferenceGenArgs a{};
+  a.lib.switching = bf.lib_d; a.lib.first_mode = bf.lib_i; a.lib.modes = bf.lib_i + first_mode.size(); a.lib.n_templates = n_gaits + 1;
+  a.lib.init_events = bf.lib_d + sw_count; a.lib.init_modes = bf.lib_i + first_mode.size() + mode_count; a.lib.init_n_events = (int)init.event_times.size();
+  a.lib.transition_stance_time = s->rm.phase_transition_stance_time;
+  a.n_grids = G; a.N = N; a.horizon = horizon; a.dt = dt; a.dt_min = 1e-8;
+  a.t0 = bf.rg_t0; a.gait = bf.rg_gait; a.gait_start = bf.rg_start;
+  a.lift_off_velocity = s->rm.swing.lift_off_velocity; a.touch_down_velocity = s->rm.swing.touch_down_velocity;
+  a.swing_height = s->rm.swing.swing_height; a.swing_time_scale = s->rm.swing.swing_time_scale;
+  a.kind = bf.g_kind; a.mode = bf.g_mode; a.nodes = bf.g_nodes; a.status = bf.rg_status; a.rows = bf.rg_rows;
+  a.gdt = bf.g_dt; a.gstart = bf.g_start; a.zref = bf.g_zref; a.zdref = bf.g_zdref; a.node_time = bf.g_time;
+  hipLaunchKernelGGL(k_reference_grids, dim3(G), dim3(64), 0, s->stream, a);
   HIP_CHECK(hipGetLastError());
+  CommandTargetArgs c{};
+  c.batch = batch; c.nx = NX; c.nj = s->rm.nj; c.time_to_target = time_to_target > 0 ? time_to_target : horizon; c.com_height = s->rm.com_height;
+  for (int j = 0; j < s->rm.nj; ++j) c.default_joint_state[j] = s->rm.default_joint_state[j];
+  c.t0 = bf.p_t0; c.x0 = bf.p_x0; c.cmd_vel = bf.p_cmd; c.tgt_t = bf.p_tgt_t; c.tgt_x = bf.p_tgt_x; c.tgt_n = bf.p_tgt_n;
+  hipLaunchKernelGGL(k_command_targets, dim3((batch + 63) / 64), dim3(64), 0, s->stream, c);
+  HIP_CHECK(hipGetLastError());
+  std::vector<int> nodes(G), status(G), rows(G), kind((size_t)G * N);
+  s->node_times.assign((size_t)G * (N + 1), 0.0);
+  HIP_CHECK(hipMemcpyAsync(nodes.data(), bf.g_nodes, G * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipMemcpyAsync(status.data(), bf.rg_status, G * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipMemcpyAsync(rows.data(), bf.rg_rows, G * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipMemcpyAsync(kind.data(), bf.g_kind, kind.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipMemcpyAsync(s->node_times.data(), bf.g_time, s->node_times.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  s->has_solution = false;
+  s->batch = 0;                                           // stays unusable if a grid is rejected below
+  int nmax = 0, rows_max = 12;
+  for (int g = 0; g < G; ++g) {
+    const int st = status[g];
+    if (st == kRefTileOrder) throw std::runtime_error("The initial time for template-tiling is not greater than the last event time.");
+    if (st == kRefCapacity) throw std::length_error("mode schedule exceeds the device capacity of " + std::to_string(kRefMaxEvents) + " events");
+    if (st == kRefGridTooLong) throw std::length_error("time grid has " + std::to_string(nodes[g]) + " intervals, solver max_nodes is " + std::to_string(N));
+    if (st >= kRefNoTouchDown) throw std::runtime_error("The time of touch-down for the last swing of the EE with ID " + std::to_string(st - kRefNoTouchDown) + " is not defined.");
+    if (st >= kRefNoTakeOff) throw std::runtime_error("The time of take-off for the first swing of the EE with ID " + std::to_string(st - kRefNoTakeOff) + " is not defined.");
+    nmax = std::max(nmax, nodes[g]);
+    rows_max = std::max(rows_max, rows[g]);
+  }
+  s->batch = batch; s->n_grids = G; s->n_nodes_max = nmax; s->cold = true; s->max_rows = rows_max;
+  s->grid_nodes = nodes; s->grid_of_problem = pgrid; s->grid_kind = kind;
+  finish_setup(s, batch, nullptr, nullptr, from_previous);
 }
+
 
 void reset(bpmpc_solver* s) {
   const size_t N = s->settings.max_nodes;
@@ -952,6 +1072,11 @@ int bpmpc_solver_run(bpmpc_solver* s) {
 int bpmpc_solver_sync(bpmpc_solver* s) { API_GUARD(s, { HIP_CHECK(hipStreamSynchronize(s->stream)); s->collect_timers(); }) }
 int bpmpc_solver_fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double* out_K, bpmpc_stats* stats) {
   API_GUARD(s, fetch(s, out_t, out_x, out_u, out_K, stats))
+}
+int bpmpc_solver_setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_gait_template* gaits,
+                                int n_gaits, const int* gait_of_problem, const double* gait_start, const double* cmd_vel, double time_to_target,
+                                int from_previous) {
+  API_GUARD(s, { setup_commands(s, batch, horizon, t0, x0, gaits, n_gaits, gait_of_problem, gait_start, cmd_vel, time_to_target, from_previous != 0); })
 }
 int bpmpc_solve_batch(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
                       int n_schedules, const bpmpc_target* targets, const double* warm_x, const double* warm_u, double* out_t, double* out_x,

@@ -164,6 +164,23 @@ int bpmpc_solver_setup(bpmpc_solver* solver, int batch, double horizon, const do
  * bipedal_controllers/src/BipedalController.cpp:332-350).  Needs a completed bpmpc_solver_run on the handle. */
 int bpmpc_solver_setup_from_previous(bpmpc_solver* solver, int batch, double horizon, const double* t0, const double* x0,
                                      const bpmpc_mode_schedule* schedules, int n_schedules, const bpmpc_target* targets);
+/* Device-side reference generation: the whole pre-pass of a solve on the GPU.  Problem b follows
+ * gait template gaits[gait_of_problem[b]] (a ModeSequenceTemplate of gait.info; < 0 or n_gaits == 0: the initial schedule of
+ * reference.info only), inserted at gait_start[b] into GaitSchedule(initialModeSchedule, defaultModeSequenceTemplate) and asked for
+ * [t0 - horizon, t0 + 2 horizon] (GaitSchedule.cpp:40-137 as called from SwitchedModelReferenceManager.cpp:55-69); swing-height
+ * splines, shooting grid and node tables are derived from it per distinct (t0, gait, start), and the target trajectory is
+ * cmdVelToTargetTrajectories(cmd_vel[b], t0[b], x0[b]) reaching time_to_target (<= 0: horizon) ahead
+ * (TargetTrajectoriesPublisher.cpp:40-62).  Tables are bit-identical to those bpmpc_solver_setup builds on the host from the same
+ * schedule; errors (undefined take-off / touch-down, grid longer than max_nodes) are reported the same way.
+ * from_previous != 0: initial iterate shifted from the previous solve as in bpmpc_solver_setup_from_previous, else cold start. */
+typedef struct {
+  int n_modes;
+  const double* switching_times; /* n_modes + 1 */
+  const int* modes;              /* n_modes */
+} bpmpc_gait_template;
+int bpmpc_solver_setup_commands(bpmpc_solver* solver, int batch, double horizon, const double* t0, const double* x0,
+                                const bpmpc_gait_template* gaits, int n_gaits, const int* gait_of_problem, const double* gait_start,
+                                const double* cmd_vel /* [batch][4]: vx, vy, vz, yaw rate */, double time_to_target, int from_previous);
 int bpmpc_solver_reset(bpmpc_solver* solver);   /* restore the initial iterate of the last setup (device-side copy, async) */
 int bpmpc_solver_run(bpmpc_solver* solver);     /* enqueue the SQP iteration(s) on the solver's stream */
 int bpmpc_solver_sync(bpmpc_solver* solver);
