@@ -274,10 +274,10 @@ class BatchedSqpMpc:
         self.batch = B
         return self.layout()
 
-    def setup_commands(self, t0, x0, gaits, gait_of_problem, gait_start, cmd_vel, horizon=None, time_to_target=0.0, from_previous=False):
+    def setup_commands(self, t0, x0, gaits, gait_of_problem, gait_start, cmd_vel, horizon=None, time_to_target=0.0, from_previous=False, goal=False):
         """The whole pre-pass on the device (bpmpc_solver_setup_commands): `gaits` is a list of ModeSequenceTemplate, problem b
         follows gaits[gait_of_problem[b]] inserted at gait_start[b] (index < 0: initial schedule only) and tracks the velocity
-        command cmd_vel[b] = (vx, vy, vz, yaw rate)."""
+        command cmd_vel[b] = (vx, vy, vz, yaw rate), or with goal=True moves to the pose (x, y, -, yaw) like goalToTargetTrajectories."""
         if horizon is None:
             horizon = self.interface.mpcSettings()["timeHorizon"]
         x0 = _f64(x0).reshape(-1, self.nx)
@@ -292,7 +292,7 @@ class BatchedSqpMpc:
             keep += [sw, mo]
             tm[i] = _GaitTemplate(len(mo), _d(sw), _i(mo))
         _check(load_library().bpmpc_solver_setup_commands(self._h, B, C.c_double(horizon), _d(t0), _d(x0), tm, len(gaits), _i(gop), _d(gst), _d(cmd),
-                                                          C.c_double(time_to_target), int(bool(from_previous))))
+                                                          int(bool(goal)), C.c_double(time_to_target), int(bool(from_previous))))
         self.batch = B
         return self.layout()
 

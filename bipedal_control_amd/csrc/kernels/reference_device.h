@@ -238,7 +238,8 @@ __global__ __launch_bounds__(64) void k_reference_grids(ReferenceGenArgs a) {
 
 struct CommandTargetArgs {
   int batch, nx, nj;
-  double time_to_target, com_height;
+  int goal;                // 0: cmd = (vx, vy, vz, yaw rate) in the base frame; 1: cmd = goal pose (x, y, unused, yaw)
+  double time_to_target, com_height, displacement_velocity, rotation_velocity;
   double default_joint_state[kMaxJoints];
   const double* t0;        // per problem
   const double* x0;        // per problem [nx]
@@ -257,23 +258,31 @@ __global__ __launch_bounds__(64) void k_command_targets(CommandTargetArgs a) {
   const double* x = a.x0 + (size_t)b * nx;
   const double* cmd = a.cmd_vel + (size_t)b * 4;
   const double T = a.time_to_target, t_now = a.t0[b];
-  const double yz = x[9], yy = x[10], yx = x[11];
-  const double cz = cos(yz), sz = sin(yz), cy = cos(yy), sy = sin(yy), cx = cos(yx), sx = sin(yx);
-  const double R[9] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx, sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx, -sy, cy * sx, cy * cx};
-  double v[3];
-  for (int i = 0; i < 3; ++i) v[i] = R[3 * i] * cmd[0] + R[3 * i + 1] * cmd[1] + R[3 * i + 2] * cmd[2];
-  const double pose[6] = {x[6] + v[0] * T, x[7] + v[1] * T, a.com_height, x[9] + cmd[3] * T, 0.0, 0.0};
+  double v[3] = {0.0, 0.0, 0.0}, pose[6], t_reach;
+  if (a.goal) {            // goalToTargetTrajectories (TargetTrajectoriesPublisher.cpp:64-99 restated in reference_gen.cpp goal_to_targets)
+    pose[0] = cmd[0]; pose[1] = cmd[1]; pose[2] = a.com_height; pose[3] = cmd[3]; pose[4] = 0.0; pose[5] = 0.0;
+    const double dx = pose[0] - x[6], dy = pose[1] - x[7], dyaw = pose[3] - x[9];
+    const double tr = fabs(dyaw) / a.rotation_velocity, td = sqrt(dx * dx + dy * dy) / a.displacement_velocity;
+    t_reach = t_now + (tr < td ? td : tr);
+  } else {
+    const double yz = x[9], yy = x[10], yx = x[11];
+    const double cz = cos(yz), sz = sin(yz), cy = cos(yy), sy = sin(yy), cx = cos(yx), sx = sin(yx);
+    const double R[9] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx, sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx, -sy, cy * sx, cy * cx};
+    for (int i = 0; i < 3; ++i) v[i] = R[3 * i] * cmd[0] + R[3 * i + 1] * cmd[1] + R[3 * i + 2] * cmd[2];
+    pose[0] = x[6] + v[0] * T; pose[1] = x[7] + v[1] * T; pose[2] = a.com_height; pose[3] = x[9] + cmd[3] * T; pose[4] = 0.0; pose[5] = 0.0;
+    t_reach = t_now + T;
+  }
   double* ts = a.tgt_t + (size_t)b * kMaxTargetPoints;
   double* xs = a.tgt_x + (size_t)b * kMaxTargetPoints * nx;
   for (int i = 0; i < 2 * nx; ++i) xs[i] = 0.0;
   ts[0] = t_now;
-  ts[1] = t_now + T;
+  ts[1] = t_reach;
   for (int i = 0; i < 6; ++i) { xs[6 + i] = x[6 + i]; xs[nx + 6 + i] = pose[i]; }
   xs[6 + 2] = a.com_height;
   xs[6 + 4] = 0.0;
   xs[6 + 5] = 0.0;
   for (int j = 0; j < a.nj; ++j) xs[12 + j] = xs[nx + 12 + j] = a.default_joint_state[j];
-  for (int i = 0; i < 3; ++i) xs[i] = xs[nx + i] = v[i];
+  if (!a.goal) for (int i = 0; i < 3; ++i) xs[i] = xs[nx + i] = v[i];
   a.tgt_n[b] = 2;
 }
 

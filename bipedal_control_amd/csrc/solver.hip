@@ -862,9 +862,11 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
 // Device-side reference generation: the same tables as setup(), built on the GPU from gait
 // templates and velocity commands; the host only groups problems by (t0, gait, gait start) and reads the grid sizes back.
 void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_gait_template* gaits, int n_gaits,
-                    const int* gait_of_problem, const double* gait_start, const double* cmd_vel, double time_to_target, bool from_previous) {
+                    const int* gait_of_problem, const double* gait_start, const double* cmd_vel, int command_kind, double time_to_target,
+                    bool from_previous) {
   if (batch < 1 || batch > s->settings.max_batch) throw std::length_error("batch exceeds the solver's max_batch");
   if (!(horizon > 0) || !t0 || !x0 || !cmd_vel || n_gaits < 0 || (n_gaits > 0 && !gaits)) throw std::invalid_argument("setup_commands: null or invalid argument");
+  if (command_kind != 0 && command_kind != 1) throw std::invalid_argument("setup_commands: command_kind is 0 (velocity) or 1 (goal pose)");
   if (n_gaits > 0 && (!gait_of_problem || !gait_start)) throw std::invalid_argument("setup_commands: gait_of_problem and gait_start are needed with templates");
   const int N = s->settings.max_nodes, NX = s->nx;
   const double dt = s->settings.dt > 0 ? s->settings.dt : s->rm.sqp.dt;
@@ -925,6 +927,7 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
   HIP_CHECK(hipGetLastError());
   CommandTargetArgs c{};
   c.batch = batch; c.nx = NX; c.nj = s->rm.nj; c.time_to_target = time_to_target > 0 ? time_to_target : horizon; c.com_height = s->rm.com_height;
+  c.goal = command_kind; c.displacement_velocity = s->rm.target_displacement_velocity; c.rotation_velocity = s->rm.target_rotation_velocity;
   for (int j = 0; j < s->rm.nj; ++j) c.default_joint_state[j] = s->rm.default_joint_state[j];
   c.t0 = bf.p_t0; c.x0 = bf.p_x0; c.cmd_vel = bf.p_cmd; c.tgt_t = bf.p_tgt_t; c.tgt_x = bf.p_tgt_x; c.tgt_n = bf.p_tgt_n;
   hipLaunchKernelGGL(k_command_targets, dim3((batch + 63) / 64), dim3(64), 0, s->stream, c);
@@ -1074,9 +1077,9 @@ int bpmpc_solver_fetch(bpmpc_solver* s, double* out_t, double* out_x, double* ou
   API_GUARD(s, fetch(s, out_t, out_x, out_u, out_K, stats))
 }
 int bpmpc_solver_setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_gait_template* gaits,
-                                int n_gaits, const int* gait_of_problem, const double* gait_start, const double* cmd_vel, double time_to_target,
-                                int from_previous) {
-  API_GUARD(s, { setup_commands(s, batch, horizon, t0, x0, gaits, n_gaits, gait_of_problem, gait_start, cmd_vel, time_to_target, from_previous != 0); })
+                                int n_gaits, const int* gait_of_problem, const double* gait_start, const double* cmd_vel, int command_kind,
+                                double time_to_target, int from_previous) {
+  API_GUARD(s, { setup_commands(s, batch, horizon, t0, x0, gaits, n_gaits, gait_of_problem, gait_start, cmd_vel, command_kind, time_to_target, from_previous != 0); })
 }
 int bpmpc_solve_batch(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
                       int n_schedules, const bpmpc_target* targets, const double* warm_x, const double* warm_u, double* out_t, double* out_x,

@@ -170,7 +170,9 @@ int bpmpc_solver_setup_from_previous(bpmpc_solver* solver, int batch, double hor
  * [t0 - horizon, t0 + 2 horizon] (GaitSchedule.cpp:40-137 as called from SwitchedModelReferenceManager.cpp:55-69); swing-height
  * splines, shooting grid and node tables are derived from it per distinct (t0, gait, start), and the target trajectory is
  * cmdVelToTargetTrajectories(cmd_vel[b], t0[b], x0[b]) reaching time_to_target (<= 0: horizon) ahead
- * (TargetTrajectoriesPublisher.cpp:40-62).  Tables are bit-identical to those bpmpc_solver_setup builds on the host from the same
+ * (TargetTrajectoriesPublisher.cpp:40-62); with command_kind = 1 the four numbers are a goal pose (x, y, unused, yaw) and the
+ * target is goalToTargetTrajectories (TargetTrajectoriesPublisher.cpp:64-99, reach time from targetDisplacementVelocity /
+ * targetRotationVelocity of reference.info).  Tables are bit-identical to those bpmpc_solver_setup builds on the host from the same
  * schedule; errors (undefined take-off / touch-down, grid longer than max_nodes) are reported the same way.
  * from_previous != 0: initial iterate shifted from the previous solve as in bpmpc_solver_setup_from_previous, else cold start. */
 typedef struct {
@@ -180,7 +182,8 @@ typedef struct {
 } bpmpc_gait_template;
 int bpmpc_solver_setup_commands(bpmpc_solver* solver, int batch, double horizon, const double* t0, const double* x0,
                                 const bpmpc_gait_template* gaits, int n_gaits, const int* gait_of_problem, const double* gait_start,
-                                const double* cmd_vel /* [batch][4]: vx, vy, vz, yaw rate */, double time_to_target, int from_previous);
+                                const double* cmd_vel /* [batch][4]: vx, vy, vz, yaw rate */, int command_kind, double time_to_target,
+                                int from_previous);
 int bpmpc_solver_reset(bpmpc_solver* solver);   /* restore the initial iterate of the last setup (device-side copy, async) */
 int bpmpc_solver_run(bpmpc_solver* solver);     /* enqueue the SQP iteration(s) on the solver's stream */
 int bpmpc_solver_sync(bpmpc_solver* solver);

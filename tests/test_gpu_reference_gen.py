@@ -137,3 +137,24 @@ def test_errors_are_reported_like_the_host_path(ctx):
     mpc.enqueue()
     _, x, _, _, st = mpc.fetch()
     assert st[0].n_nodes == 10 and np.isfinite(x[:, :11]).all()
+
+
+def test_goal_pose_targets_match_host_path(ctx):
+    bp, sc, ob, itf, tm = ctx
+    nb, horizon = 5, 30 * sc.DT
+    x0 = sc.perturbed_initial_states(itf, nb)
+    goals = np.array([(1.0, 0.2, 0.0, 0.3), (-0.5, 0.0, 0.0, 0.0), (0.05, -0.4, 0.0, -1.0), (2.0, 2.0, 0.0, 0.1), (0.0, 0.0, 0.0, 0.0)])
+    sched = sc.gait_schedule(itf, "trot", 0.5, horizon)
+    targets = [itf.goalToTargetTrajectories(tuple(goals[b]), 0.5, x0[b]) for b in range(nb)]
+    host = bp.BatchedSqpMpc(itf, max_batch=nb, max_nodes=48)
+    dev = bp.BatchedSqpMpc(itf, max_batch=nb, max_nodes=48)
+    host.setup(0.5, x0, sched, targets, horizon=horizon)
+    dev.setup_commands(0.5, x0, tm, 0, sc.GAIT_START, goals, horizon=horizon, goal=True)
+    th, td = _tables(host, nb), _tables(dev, nb)
+    n = th["nodes"][0]
+    assert np.array_equal(th["nodes"], td["nodes"]) and np.array_equal(th["g_zref"], td["g_zref"])
+    assert np.abs(th["xref"][:, :n] - td["xref"][:, :n]).max() < 1e-13
+    host.enqueue(); dev.enqueue()
+    _, x1, u1, _, _ = host.fetch()
+    _, x2, u2, _, _ = dev.fetch()
+    assert np.abs(x1[:, :n + 1] - x2[:, :n + 1]).max() < 1e-9 and np.abs(u1[:, :n] - u2[:, :n]).max() < 1e-9 * max(1.0, np.abs(u1).max())
