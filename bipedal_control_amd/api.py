@@ -280,8 +280,11 @@ class BatchedSqpMpc:
         command cmd_vel[b] = (vx, vy, vz, yaw rate), or with goal=True moves to the pose (x, y, -, yaw) like goalToTargetTrajectories."""
         if horizon is None:
             horizon = self.interface.mpcSettings()["timeHorizon"]
-        x0 = _f64(x0).reshape(-1, self.nx)
-        B = x0.shape[0]
+        if x0 is None:                      # continue from the end states of the last rollout (device-resident)
+            B = self.batch
+        else:
+            x0 = _f64(x0).reshape(-1, self.nx)
+            B = x0.shape[0]
         t0 = _f64(np.broadcast_to(np.asarray(t0, float), (B,)))
         gop = np.ascontiguousarray(np.broadcast_to(np.asarray(gait_of_problem, np.int32), (B,)))
         gst = _f64(np.broadcast_to(np.asarray(gait_start, float), (B,)))
@@ -295,6 +298,15 @@ class BatchedSqpMpc:
                                                           int(bool(goal)), C.c_double(time_to_target), int(bool(from_previous))))
         self.batch = B
         return self.layout()
+
+    def rollout(self, duration, t_start=None, x_start=None):
+        """MRT_BASE::rolloutPolicy for the batch (bpmpc_solver_rollout): returns (x_end, u_end, steps[batch, 2])."""
+        B = self.batch
+        ts = None if t_start is None else _f64(np.broadcast_to(np.asarray(t_start, float), (B,)))
+        xs = None if x_start is None else _f64(x_start).reshape(B, self.nx)
+        x_end, u_end, steps = np.zeros((B, self.nx)), np.zeros((B, self.nu)), np.zeros((B, 2), np.int32)
+        _check(load_library().bpmpc_solver_rollout(self._h, _d(ts), _d(xs), C.c_double(duration), _d(x_end), _d(u_end), _i(steps)))
+        return x_end, u_end, steps
 
     def advance(self, t0, x0, modeSchedules, targetTrajectories, horizon=None, gains=False):
         """One MPC tick for the whole batch: warm start from the previous solution, solve, fetch."""

@@ -99,6 +99,7 @@ int bpmpc_model_get(const bpmpc_model* m, const char* name, double* out, int cap
     if (n == "contact_body") { std::vector<double> t(kNumContacts); for (int c = 0; c < kNumContacts; ++c) t[c] = r.contact_body[c]; return copy_out(t.data(), t.size(), out, capacity); }
     if (n == "cone") return list({r.friction_coefficient, r.cone_regularization, r.cone_gripper_force, r.cone_hessian_shift, r.barrier_mu, r.barrier_delta});
     if (n == "swing") return list({r.swing.lift_off_velocity, r.swing.touch_down_velocity, r.swing.swing_height, r.swing.swing_time_scale});
+    if (n == "rollout") return list({r.rollout.abs_tol, r.rollout.rel_tol, r.rollout.time_step, (double)r.rollout.max_steps_per_second, r.mrt_frequency, r.mpc_frequency});
     if (n == "sqp") return list({r.sqp.dt, (double)r.sqp.sqp_iteration, r.sqp.delta_tol, r.sqp.g_max, r.sqp.g_min});
     throw std::invalid_argument("bpmpc_model_get: unknown name " + n);
   });

@@ -1,0 +1,218 @@
+// MRT side of the MPC loop on the device: MRT_BASE::rolloutPolicy for a whole batch, i.e.
+// TimeTriggeredRollout::run over [t, t + duration] under the LinearController of the last solution,
+//   u(t, x) = uff(t) + K(t) x,  uff_j = u_j - K_j x_j,  linear interpolation in time (LinearController::computeInput),
+// integrated with the controlled Dormand-Prince 5(4) stepper of boost::numeric::odeint (integrate_adaptive, FSAL, error
+// norm |err_i| / (abs + rel (|x_i| + dt |dxdt_i|)), step factors 0.9 err^(-1/3) >= 0.2 on rejection, 0.9 max(err, 5^-5)^(-1/5) on
+// success when err < 0.5), restarted at every mode-schedule event inside the window with the begin time nudged by
+// weakEpsilon (RolloutBase::findActiveModesTimeInterval).  Used by MRT_ROS_Dummy_Loop
+// (ocs2_bipedal_robot_ros/src/BipedalRobotDummyNode.cpp:61,72-86) and BipedalController.cpp:322 with the rollout block of
+// task.info:158-167.  [OCS2-upstream / boost, recalled]; oracle: oracle/reference_py.py time_triggered_rollout.
+//
+// Mapping: as the line-search trial kernel - one lane per generalised coordinate, 16 (32) lanes per problem, the flow map is the
+// value-only eval_lane of linearize_fast.h.  Lane g < 6 carries normalised momentum g, lane g < 6 + NJ carries coordinate g.
+// Problems of one wavefront step in lock step (finished ones idle); everything else is per-problem state in registers.
+#pragma once
+#include "linearize_fast.h"
+
+namespace bpmpc {
+
+constexpr int kRolloutMaxEvents = 32;
+
+// [OCS2-upstream] LinearInterpolation::timeSegment: value(q) = alpha v[idx] + (1 - alpha) v[idx + 1]
+__device__ __forceinline__ void time_segment(const double* t, int n, double q, int* idx, double* alpha) {
+  if (q <= t[0]) { *idx = 0; *alpha = 1.0; return; }
+  if (q >= t[n - 1]) { *idx = n - 2; *alpha = 0.0; return; }
+  int lo = 0, hi = n;                       // lower_bound: first element >= q
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (t[mid] < q) lo = mid + 1; else hi = mid; }
+  int i = lo - 1;
+  i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+  *idx = i;
+  *alpha = (t[i + 1] - q) / (t[i + 1] - t[i]);
+}
+
+struct RolloutArgs {
+  int batch, N;                       // N = node stride of the solution arrays
+  const int* p_grid;                  // problem -> grid
+  const int* g_nodes;                 // per grid: number of intervals
+  const int* g_kind;                  // [grid][N]: 1 = pre-event node
+  const double* g_time;               // [grid][N + 1] node times
+  const double *x, *u, *K;            // solution: [batch][N + 1][NX], [batch][N][NU], [batch][N][NU][NX]
+  const double* t_start;              // [batch]
+  const double* x_start;              // [batch][NX]
+  double duration, abs_tol, rel_tol, time_step;
+  int max_steps;
+  double* x_end;                      // [batch][NX]
+  double* u_end;                      // [batch][NU]: controller at the final time and state
+  int* steps;                         // [batch][2]: accepted, rejected
+  int* status;                        // [batch]: 0 ok, 1 max steps, 2 no step size found, 3 too many events in the window
+};
+
+template <int NJ>
+struct RolloutLds {
+  using C = LinFastCfg<NJ>;
+  LinFastNodeLds<NJ, false> node[C::NPW];
+  LinFastShared<NJ> shared;
+  double event[C::NPW][kRolloutMaxEvents];
+  int n_events[C::NPW];
+};
+
+template <int LPN>
+__device__ __forceinline__ double node_allreduce_max(double x) {
+#pragma unroll
+  for (int m = 1; m < LPN; m <<= 1) x = fmax(x, __shfl_xor(x, m));
+  return x;
+}
+
+template <int NJ>
+__device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds<NJ>& w, const RolloutArgs& a) {
+  using C = LinFastCfg<NJ>;
+  constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN, NPW = C::NPW;
+  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
+  const int bq = blockIdx.x * NPW + sub;
+  const bool valid = bq < a.batch;
+  const int b = valid ? bq : 0;
+  LinFastNodeLds<NJ, false>& nl = w.node[sub];
+  const LinFastShared<NJ>& sh = w.shared;
+  const int N = a.N, grid = a.p_grid[b], n = a.g_nodes[grid];
+  const double* tp = a.g_time + (size_t)grid * (N + 1);
+  const int* kp = a.g_kind + (size_t)grid * N;
+  const double* xp = a.x + (size_t)b * (N + 1) * NX;
+  const double* up = a.u + (size_t)b * N * NU;
+  const double* Kp = a.K + (size_t)b * N * NU * NX;
+  const bool is_joint = g >= 6 && g < G;
+  LaneBody lb;
+  {
+    const int body = (g >= 5 && g < G) ? g - 5 : 0;
+    lb.body = body;
+    lb.depth = sh.depth[body];
+    lb.subtree = sh.subtree[body];
+  }
+  const int* path = sh.path[lb.body];
+  const double t0 = a.t_start[b], tf = t0 + a.duration;
+  // events of the window: the pre-event nodes of the solution grid with t0 < t <= tf (upper_bound on both ends)
+  if (g == 0) {
+    int cnt = 0;
+    for (int k = 0; k < n; ++k)
+      if (kp[k] == 1 && tp[k] > t0 && tp[k] <= tf) { if (cnt < kRolloutMaxEvents) w.event[sub][cnt] = tp[k]; ++cnt; }
+    w.n_events[sub] = cnt;
+  }
+  lds_wave_sync();
+  const int n_events = w.n_events[sub];
+  int status = n_events > kRolloutMaxEvents ? 3 : 0;
+
+  auto effective = [&](int j) { while (j > 0 && (j == n || kp[j] == 1)) --j; return j; };   // repeated input / gain (toPrimalSolution)
+  // publish a state for the other lanes of the problem
+  auto publish = [&](double vh, double vq) {
+    lds_wave_sync();
+    if (g < 6) nl.x[g] = vh;
+    if (g < G) nl.x[6 + g] = vq;
+    lds_wave_sync();
+  };
+  // LinearController::computeInput at time ts for the published state -> nl.u
+  auto controller = [&](double ts) {
+    int j;
+    double al;
+    time_segment(tp, n + 1, ts, &j, &al);
+    const int e0 = effective(j), e1 = effective(j + 1);
+    for (int r = g; r < NU; r += LPN) {
+      const double* K0 = Kp + ((size_t)e0 * NU + r) * NX;
+      const double* K1 = Kp + ((size_t)e1 * NU + r) * NX;
+      double s0 = up[(size_t)e0 * NU + r], s1 = up[(size_t)e1 * NU + r];
+      for (int c = 0; c < NX; ++c) {
+        const double xc = nl.x[c];
+        s0 += K0[c] * (xc - xp[(size_t)j * NX + c]);
+        s1 += K1[c] * (xc - xp[(size_t)(j + 1) * NX + c]);
+      }
+      nl.u[r] = al * s0 + (1.0 - al) * s1;
+    }
+    lds_wave_sync();
+  };
+  // dx/dt of the controlled system at (ts, state): this lane's momentum and coordinate rows
+  auto deriv = [&](double ts, double vh, double vq, double& kh, double& kq) {
+    publish(vh, vq);
+    controller(ts);
+    const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
+    LaneEval e;
+    LaneKin<NJ> kin;
+    eval_lane<NJ, false, false, LinFastNodeLds<NJ, false>>(md, sh, nl, 0, lb, path, g, nl.x, vq, ujg, e, kin);
+    kh = lane_pick6(e.fh, g);
+    kq = e.vg;
+  };
+
+  double xh = g < 6 ? a.x_start[(size_t)b * NX + g] : 0.0, xq = g < G ? a.x_start[(size_t)b * NX + 6 + g] : 0.0;
+  double k1h = 0.0, k1q = 0.0;
+  double t = t0, dt = a.time_step, seg_end = t0;
+  int seg = -1;                        // index of the current interval; -1: none opened yet
+  bool done = !valid || status != 0, have_k1 = false, fresh = true;
+  int accepted = 0, rejected = 0, failed_in_a_row = 0;
+  constexpr double kEps = 2.220446049250313e-16, kWeakEps = 1e-6;
+  for (;;) {
+    // ---- integrate_adaptive bookkeeping: open the next interval when the current one is exhausted
+    for (int guard = 0; guard < kRolloutMaxEvents + 2 && !done && !(seg >= 0 && seg_end - t > kEps); ++guard) {
+      if (seg == n_events) { done = true; break; }            // the interval ending at tf is finished
+      ++seg;
+      const double begin = seg == 0 ? t0 : w.event[sub][seg - 1];
+      seg_end = seg == n_events ? tf : w.event[sub][seg];
+      const double nudged = begin + kWeakEps;
+      t = nudged < seg_end ? nudged : seg_end;
+      dt = a.time_step;
+      have_k1 = false;                                          // a new controlled stepper: m_first_call
+      fresh = true;
+    }
+    if (!__any(!done)) break;
+    if (fresh && !done && (t + dt) - seg_end > kEps) dt = seg_end - t;
+    fresh = false;
+    // ---- try_step
+    if (__any(!done && !have_k1)) {
+      double fh, fq;
+      deriv(t, xh, xq, fh, fq);
+      if (!have_k1) { k1h = fh; k1q = fq; have_k1 = true; }
+    }
+    double k2h, k2q, k3h, k3q, k4h, k4q, k5h, k5q, k6h, k6q, k7h, k7q;
+    deriv(t + dt * (1.0 / 5.0), xh + dt * (1.0 / 5.0) * k1h, xq + dt * (1.0 / 5.0) * k1q, k2h, k2q);
+    deriv(t + dt * (3.0 / 10.0), xh + dt * (3.0 / 40.0 * k1h + 9.0 / 40.0 * k2h), xq + dt * (3.0 / 40.0 * k1q + 9.0 / 40.0 * k2q), k3h, k3q);
+    deriv(t + dt * (4.0 / 5.0), xh + dt * (44.0 / 45.0 * k1h - 56.0 / 15.0 * k2h + 32.0 / 9.0 * k3h),
+          xq + dt * (44.0 / 45.0 * k1q - 56.0 / 15.0 * k2q + 32.0 / 9.0 * k3q), k4h, k4q);
+    deriv(t + dt * (8.0 / 9.0), xh + dt * (19372.0 / 6561.0 * k1h - 25360.0 / 2187.0 * k2h + 64448.0 / 6561.0 * k3h - 212.0 / 729.0 * k4h),
+          xq + dt * (19372.0 / 6561.0 * k1q - 25360.0 / 2187.0 * k2q + 64448.0 / 6561.0 * k3q - 212.0 / 729.0 * k4q), k5h, k5q);
+    deriv(t + dt, xh + dt * (9017.0 / 3168.0 * k1h - 355.0 / 33.0 * k2h + 46732.0 / 5247.0 * k3h + 49.0 / 176.0 * k4h - 5103.0 / 18656.0 * k5h),
+          xq + dt * (9017.0 / 3168.0 * k1q - 355.0 / 33.0 * k2q + 46732.0 / 5247.0 * k3q + 49.0 / 176.0 * k4q - 5103.0 / 18656.0 * k5q), k6h, k6q);
+    const double nh = xh + dt * (35.0 / 384.0 * k1h + 500.0 / 1113.0 * k3h + 125.0 / 192.0 * k4h - 2187.0 / 6784.0 * k5h + 11.0 / 84.0 * k6h);
+    const double nq = xq + dt * (35.0 / 384.0 * k1q + 500.0 / 1113.0 * k3q + 125.0 / 192.0 * k4q - 2187.0 / 6784.0 * k5q + 11.0 / 84.0 * k6q);
+    deriv(t + dt, nh, nq, k7h, k7q);
+    constexpr double d1 = 35.0 / 384.0 - 5179.0 / 57600.0, d3 = 500.0 / 1113.0 - 7571.0 / 16695.0, d4 = 125.0 / 192.0 - 393.0 / 640.0,
+                     d5 = -2187.0 / 6784.0 + 92097.0 / 339200.0, d6 = 11.0 / 84.0 - 187.0 / 2100.0, d7 = -1.0 / 40.0;
+    const double eh = dt * (d1 * k1h + d3 * k3h + d4 * k4h + d5 * k5h + d6 * k6h + d7 * k7h);
+    const double eq = dt * (d1 * k1q + d3 * k3q + d4 * k4q + d5 * k5q + d6 * k6q + d7 * k7q);
+    double err = 0.0;
+    if (g < 6) err = fabs(eh) / (a.abs_tol + a.rel_tol * (fabs(xh) + fabs(dt) * fabs(k1h)));
+    if (g < G) err = fmax(err, fabs(eq) / (a.abs_tol + a.rel_tol * (fabs(xq) + fabs(dt) * fabs(k1q))));
+    err = node_allreduce_max<LPN>(err);
+    if (!done) {
+      if (err > 1.0) {                                          // reject: decrease_step (error order 4)
+        dt *= fmax(0.9 * pow(err, -1.0 / 3.0), 0.2);
+        ++rejected;
+        if (++failed_in_a_row > 500) { status = 2; done = true; }
+      } else {                                                  // accept: increase_step (stepper order 5)
+        t += dt;
+        xh = nh; xq = nq; k1h = k7h; k1q = k7q;
+        if (err < 0.5) dt *= 0.9 * pow(fmax(3.2e-4, err), -1.0 / 5.0);   // 5^-5 = 3.2e-4
+        ++accepted;
+        failed_in_a_row = 0;
+        fresh = true;
+        if (accepted > a.max_steps) { status = 1; done = true; }
+      }
+    }
+  }
+  // inputTrajectory.back() = computeInput(final time, final state)
+  publish(xh, xq);
+  controller(t);
+  if (valid) {
+    if (g < 6) a.x_end[(size_t)b * NX + g] = xh;
+    if (g < G) a.x_end[(size_t)b * NX + 6 + g] = xq;
+    for (int r = g; r < NU; r += LPN) a.u_end[(size_t)b * NU + r] = nl.u[r];
+    if (g == 0) { a.steps[2 * b] = accepted; a.steps[2 * b + 1] = rejected; a.status[b] = status; }
+  }
+}
+
+}  // namespace bpmpc

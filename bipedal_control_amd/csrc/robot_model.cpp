@@ -210,6 +210,12 @@ RobotModel load_robot_model(const std::string& urdf_path, const std::string& tas
   task->get("sqp.g_max", &m.sqp.g_max);
   task->get("sqp.g_min", &m.sqp.g_min);
   task->get("mpc.timeHorizon", &m.time_horizon);
+  task->get("mpc.mrtDesiredFrequency", &m.mrt_frequency);
+  task->get("mpc.mpcDesiredFrequency", &m.mpc_frequency);
+  task->get("rollout.AbsTolODE", &m.rollout.abs_tol);
+  task->get("rollout.RelTolODE", &m.rollout.rel_tol);
+  task->get("rollout.timeStep", &m.rollout.time_step);
+  task->get("rollout.maxNumStepsPerSecond", &m.rollout.max_steps_per_second);
 
   // cost weights: Q as given; R = blkdiag(R_task[forces], J^T R_task[feet] J) with J the contact-point Jacobians
   // w.r.t. the leg joints at initialState (BipedalRobotInterface.cpp:239-271)

@@ -30,6 +30,9 @@ struct SqpConfig { double dt = 0.015; int sqp_iteration = 1; double delta_tol = 
                    // [OCS2-upstream] sqp::Settings defaults not present in task.info
                    double alpha_decay = 0.5, alpha_min = 1e-4, gamma_c = 1e-6, armijo_factor = 1e-4, cost_tol = 1e-4; };
 
+// rollout block of task.info (TimeTriggeredRollout, ODE45)
+struct RolloutConfig { double abs_tol = 1e-5, rel_tol = 1e-3, time_step = 0.015; int max_steps_per_second = 10000; };
+
 struct RobotModel {
   int nj = 0, nx = 0, nu = 0;
   std::vector<std::string> joint_names, contact_names;
@@ -48,6 +51,8 @@ struct RobotModel {
   double time_horizon = 1.0;
   SwingConfig swing;
   SqpConfig sqp;
+  RolloutConfig rollout;
+  double mrt_frequency = 400, mpc_frequency = 50;
   ModeSchedule initial_mode_schedule;
   ModeTemplate default_template;
 };

@@ -35,6 +35,7 @@
 #include "kernels/project_mfma.h"
 #include "reference_gen.h"
 #include "kernels/reference_device.h"
+#include "kernels/rollout.h"
 
 namespace bpmpc {
 
@@ -71,6 +72,9 @@ struct Buffers {
   // previous solution, kept for the receding-horizon warm start (k_warm_shift)
   double *x_prev, *u_prev, *K_prev, *tp_time;
   int *tp_kind, *tp_nodes, *tp_grid;
+  // batched policy rollout (kernels/rollout.h)
+  double *roll_t, *roll_x0, *roll_x, *roll_u;
+  int *roll_steps, *roll_status;
   // device-side reference generation (kernels/reference_device.h)
   double *g_time, *rg_t0, *rg_start, *p_t0, *p_cmd, *lib_d;
   int *rg_gait, *rg_status, *rg_rows, *lib_i;
@@ -305,16 +309,6 @@ __global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu
 //     x_{i+1} = LinearInterpolation(intervalEnd, previous states);
 // otherwise BipedalRobotInitializer::compute (already written by k_prepare); event nodes copy the state.
 // Oracle: oracle/reference_py.py warm_start_from_previous.
-__device__ __forceinline__ void time_segment(const double* t, int n, double q, int* idx, double* alpha) {
-  if (q <= t[0]) { *idx = 0; *alpha = 1.0; return; }
-  if (q >= t[n - 1]) { *idx = n - 2; *alpha = 0.0; return; }
-  int lo = 0, hi = n;                       // lower_bound: first element >= q
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (t[mid] < q) lo = mid + 1; else hi = mid; }
-  int i = lo - 1;
-  i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
-  *idx = i;
-  *alpha = (t[i + 1] - q) / (t[i + 1] - t[i]);
-}
 template <int NJ>
 __global__ __launch_bounds__(kWave) void k_warm_shift(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
@@ -427,6 +421,14 @@ __global__ __launch_bounds__(kTrialWaves * kWave) void k_trial_fast(Launch L) {
   trial_fast<NJ>(*L.model, shared, lds[sub], valid, in, L.buf.alpha[b], dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
 }
 
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_rollout(const DeviceModel* model, RolloutArgs a) {
+  __shared__ RolloutLds<NJ> w;
+  load_shared_model<NJ>(*model, w.shared, threadIdx.x, kWave);
+  __syncthreads();
+  rollout_policy<NJ>(*model, w, a);
+}
+
 constexpr int kDecideThreads = 256;
 template <int NJ>
 __global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L) {
@@ -478,6 +480,7 @@ struct bpmpc_solver {
   // the leaner single-buffered variant (two workgroups per CU at nx = 22) for larger batches.
   bool riccati_double_buffered() const { return batch <= num_cus || rm.nj != 10; }
   bool has_solution = false;                               // a solve has completed on the current setup
+  bool has_rollout = false;                                // roll_x holds the end states of a rollout
   std::vector<int> grid_kind;                               // host copy of the node kinds of the current setup [n_grids][N]
   int max_rows = kMaxEqRows;                                // largest number of equality rows over the nodes of the current setup
   bool cold = true;
@@ -692,6 +695,8 @@ void allocate(bpmpc_solver* s) {
   b.tp_time = s->alloc<double>("tp_time", B * (N + 1)); b.tp_kind = s->alloc<int>("tp_kind", S, true);
   b.tp_nodes = s->alloc<int>("tp_nodes", B, true); b.tp_grid = s->alloc<int>("tp_grid", B, true);
   b.ric_carry = s->alloc<double>("ric_carry", B * (NX * NX + NX + 2));   // S, s, status, scratch word
+  b.roll_t = s->alloc<double>(nullptr, B); b.roll_x0 = s->alloc<double>(nullptr, B * NX); b.roll_x = s->alloc<double>("roll_x", B * NX);
+  b.roll_u = s->alloc<double>("roll_u", B * NU); b.roll_steps = s->alloc<int>(nullptr, B * 2); b.roll_status = s->alloc<int>(nullptr, B);
   b.g_time = s->alloc<double>("g_time", B * (N + 1)); b.rg_t0 = s->alloc<double>(nullptr, B); b.rg_start = s->alloc<double>(nullptr, B);
   b.p_t0 = s->alloc<double>(nullptr, B); b.p_cmd = s->alloc<double>(nullptr, B * 4); b.lib_d = s->alloc<double>(nullptr, kRefLibCapacity);
   b.rg_gait = s->alloc<int>(nullptr, B); b.rg_status = s->alloc<int>(nullptr, B); b.rg_rows = s->alloc<int>(nullptr, B); b.lib_i = s->alloc<int>(nullptr, kRefLibCapacity);
@@ -854,6 +859,7 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   upload(s, bf.g_kind, kind); upload(s, bf.g_mode, mode); upload(s, bf.g_nodes, nodes); upload(s, bf.g_dt, gdt); upload(s, bf.g_start, gstart);
   upload(s, bf.g_zref, zref); upload(s, bf.g_zdref, zdref); upload(s, bf.p_grid, pgrid);
   upload(s, bf.p_tgt_t, tgt_t); upload(s, bf.p_tgt_x, tgt_x); upload(s, bf.p_tgt_n, tgt_n);
+  upload(s, bf.g_time, s->node_times);
   HIP_CHECK(hipMemcpyAsync(bf.p_x0, x0, (size_t)batch * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
   HIP_CHECK(hipStreamSynchronize(s->stream));  // the host staging vectors go out of scope
   finish_setup(s, batch, warm_x, warm_u, from_previous);
@@ -865,7 +871,8 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
                     const int* gait_of_problem, const double* gait_start, const double* cmd_vel, int command_kind, double time_to_target,
                     bool from_previous) {
   if (batch < 1 || batch > s->settings.max_batch) throw std::length_error("batch exceeds the solver's max_batch");
-  if (!(horizon > 0) || !t0 || !x0 || !cmd_vel || n_gaits < 0 || (n_gaits > 0 && !gaits)) throw std::invalid_argument("setup_commands: null or invalid argument");
+  if (!(horizon > 0) || !t0 || !cmd_vel || n_gaits < 0 || (n_gaits > 0 && !gaits)) throw std::invalid_argument("setup_commands: null or invalid argument");
+  if (!x0 && (!s->has_rollout || batch != s->batch)) throw std::invalid_argument("setup_commands: x0 == NULL needs a rollout of the same batch on the handle");
   if (command_kind != 0 && command_kind != 1) throw std::invalid_argument("setup_commands: command_kind is 0 (velocity) or 1 (goal pose)");
   if (n_gaits > 0 && (!gait_of_problem || !gait_start)) throw std::invalid_argument("setup_commands: gait_of_problem and gait_start are needed with templates");
   const int N = s->settings.max_nodes, NX = s->nx;
@@ -912,7 +919,8 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
   upload(s, bf.p_grid, pgrid);
   HIP_CHECK(hipMemcpyAsync(bf.p_t0, t0, (size_t)batch * sizeof(double), hipMemcpyHostToDevice, s->stream));
   HIP_CHECK(hipMemcpyAsync(bf.p_cmd, cmd_vel, (size_t)batch * 4 * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  HIP_CHECK(hipMemcpyAsync(bf.p_x0, x0, (size_t)batch * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  if (x0) HIP_CHECK(hipMemcpyAsync(bf.p_x0, x0, (size_t)batch * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  else HIP_CHECK(hipMemcpyAsync(bf.p_x0, bf.roll_x, (size_t)batch * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));   // closed loop on the device
   ReferenceGenArgs a{};
   a.lib.switching = bf.lib_d; a.lib.first_mode = bf.lib_i; a.lib.modes = bf.lib_i + first_mode.size(); a.lib.n_templates = n_gaits + 1;
   a.lib.init_events = bf.lib_d + sw_count; a.lib.init_modes = bf.lib_i + first_mode.size() + mode_count; a.lib.init_n_events = (int)init.event_times.size();
@@ -958,6 +966,42 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
   finish_setup(s, batch, nullptr, nullptr, from_previous);
 }
 
+
+// MRT_BASE::rolloutPolicy for the whole batch (kernels/rollout.h): integrates every problem from (t_start, x_start) over `duration`
+// under the LinearController of the last solve.  NULL t_start / x_start: the initial time / measured state of that solve.
+void rollout(bpmpc_solver* s, const double* t_start, const double* x_start, double duration, double* x_end, double* u_end, int* steps) {
+  if (!s->has_solution) throw std::invalid_argument("bpmpc_solver_rollout needs a completed solve on the handle");
+  if (!(duration >= 0)) throw std::invalid_argument("bpmpc_solver_rollout: negative duration");
+  Buffers& bf = s->buf;
+  if (!bf.K) throw std::invalid_argument("bpmpc_solver_rollout needs the feedback gains (return_gains with reference kernels)");
+  const int B = s->batch, N = s->settings.max_nodes, NX = s->nx, NU = s->nu;
+  std::vector<double> ts(B);
+  for (int b = 0; b < B; ++b) ts[b] = t_start ? t_start[b] : s->node_times[(size_t)s->grid_of_problem[b] * (N + 1)];
+  upload(s, bf.roll_t, ts);
+  if (x_start) HIP_CHECK(hipMemcpyAsync(bf.roll_x0, x_start, (size_t)B * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  RolloutArgs a{};
+  a.batch = B; a.N = N; a.p_grid = bf.p_grid; a.g_nodes = bf.g_nodes; a.g_kind = bf.g_kind; a.g_time = bf.g_time;
+  a.x = bf.x; a.u = bf.u; a.K = bf.K; a.t_start = bf.roll_t; a.x_start = x_start ? bf.roll_x0 : bf.p_x0;
+  a.duration = duration; a.abs_tol = s->rm.rollout.abs_tol; a.rel_tol = s->rm.rollout.rel_tol; a.time_step = s->rm.rollout.time_step;
+  a.max_steps = (int)(s->rm.rollout.max_steps_per_second * std::max(1.0, duration));
+  a.x_end = bf.roll_x; a.u_end = bf.roll_u; a.steps = bf.roll_steps; a.status = bf.roll_status;
+  if (s->rm.nj == 10) hipLaunchKernelGGL(k_rollout<10>, dim3((B + LinFastCfg<10>::NPW - 1) / LinFastCfg<10>::NPW), dim3(kWave), 0, s->stream, s->d_model, a);
+  else hipLaunchKernelGGL(k_rollout<12>, dim3((B + LinFastCfg<12>::NPW - 1) / LinFastCfg<12>::NPW), dim3(kWave), 0, s->stream, s->d_model, a);
+  HIP_CHECK(hipGetLastError());
+  std::vector<int> status(B), st(2 * B);
+  HIP_CHECK(hipMemcpyAsync(status.data(), bf.roll_status, B * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipMemcpyAsync(st.data(), bf.roll_steps, 2 * B * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  if (x_end) HIP_CHECK(hipMemcpyAsync(x_end, bf.roll_x, (size_t)B * NX * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (u_end) HIP_CHECK(hipMemcpyAsync(u_end, bf.roll_u, (size_t)B * NU * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  if (steps) std::copy(st.begin(), st.end(), steps);
+  s->has_rollout = true;
+  for (int b = 0; b < B; ++b) {
+    if (status[b] == 1) throw std::runtime_error("rollout of problem " + std::to_string(b) + ": integration terminated, max number of steps reached");
+    if (status[b] == 2) throw std::runtime_error("rollout of problem " + std::to_string(b) + ": max number of iterations exceeded, a new step size was not found");
+    if (status[b] == 3) throw std::length_error("rollout of problem " + std::to_string(b) + ": more than " + std::to_string(kRolloutMaxEvents) + " events in the window");
+  }
+}
 
 void reset(bpmpc_solver* s) {
   const size_t N = s->settings.max_nodes;
@@ -1080,6 +1124,9 @@ int bpmpc_solver_setup_commands(bpmpc_solver* s, int batch, double horizon, cons
                                 int n_gaits, const int* gait_of_problem, const double* gait_start, const double* cmd_vel, int command_kind,
                                 double time_to_target, int from_previous) {
   API_GUARD(s, { setup_commands(s, batch, horizon, t0, x0, gaits, n_gaits, gait_of_problem, gait_start, cmd_vel, command_kind, time_to_target, from_previous != 0); })
+}
+int bpmpc_solver_rollout(bpmpc_solver* s, const double* t_start, const double* x_start, double duration, double* x_end, double* u_end, int* steps) {
+  API_GUARD(s, { rollout(s, t_start, x_start, duration, x_end, u_end, steps); })
 }
 int bpmpc_solve_batch(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
                       int n_schedules, const bpmpc_target* targets, const double* warm_x, const double* warm_u, double* out_t, double* out_x,

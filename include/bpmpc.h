@@ -174,6 +174,7 @@ int bpmpc_solver_setup_from_previous(bpmpc_solver* solver, int batch, double hor
  * target is goalToTargetTrajectories (TargetTrajectoriesPublisher.cpp:64-99, reach time from targetDisplacementVelocity /
  * targetRotationVelocity of reference.info).  Tables are bit-identical to those bpmpc_solver_setup builds on the host from the same
  * schedule; errors (undefined take-off / touch-down, grid longer than max_nodes) are reported the same way.
+ * x0 == NULL: the end states of the last bpmpc_solver_rollout on this handle (closed loop without leaving the device).
  * from_previous != 0: initial iterate shifted from the previous solve as in bpmpc_solver_setup_from_previous, else cold start. */
 typedef struct {
   int n_modes;
@@ -184,6 +185,15 @@ int bpmpc_solver_setup_commands(bpmpc_solver* solver, int batch, double horizon,
                                 const bpmpc_gait_template* gaits, int n_gaits, const int* gait_of_problem, const double* gait_start,
                                 const double* cmd_vel /* [batch][4]: vx, vy, vz, yaw rate */, int command_kind, double time_to_target,
                                 int from_previous);
+/* MRT side: MRT_BASE::rolloutPolicy for every problem of the batch - TimeTriggeredRollout::run from
+ * (t_start[b], x_start[b]) over `duration` under the LinearController of the last solve (u = uff(t) + K(t) x), ODE45 with the
+ * rollout block of task.info (AbsTolODE, RelTolODE, timeStep, maxNumStepsPerSecond), restarted at the mode-schedule events inside
+ * the window; what MRT_ROS_Dummy_Loop (ocs2_bipedal_robot_ros/src/BipedalRobotDummyNode.cpp:72-86) and BipedalController.cpp:322
+ * obtain through initRollout.  t_start / x_start NULL: initial time / measured state of the last solve.  Outputs (nullable):
+ * x_end[batch*nx], u_end[batch*nu] (the policy at the end point), steps[batch*2] (accepted, rejected integrator steps).  The end
+ * states also stay on the device: bpmpc_solver_setup_commands(x0 = NULL) starts the next solve from them. */
+int bpmpc_solver_rollout(bpmpc_solver* solver, const double* t_start, const double* x_start, double duration, double* x_end,
+                         double* u_end, int* steps);
 int bpmpc_solver_reset(bpmpc_solver* solver);   /* restore the initial iterate of the last setup (device-side copy, async) */
 int bpmpc_solver_run(bpmpc_solver* solver);     /* enqueue the SQP iteration(s) on the solver's stream */
 int bpmpc_solver_sync(bpmpc_solver* solver);

@@ -373,6 +373,8 @@ def build_model(urdf_path, task_path, reference_path):
     m["phase_transition_stance_time"] = float(info_get(task, "model_settings.phaseTransitionStanceTime"))
     m["swing"] = {k: float(info_get(task, "swing_trajectory_config." + k))
                   for k in ("liftOffVelocity", "touchDownVelocity", "swingHeight", "swingTimeScale")}
+    m["rollout"] = dict(AbsTolODE=float(info_get(task, "rollout.AbsTolODE", 1e-5)), RelTolODE=float(info_get(task, "rollout.RelTolODE", 1e-3)),
+                        timeStep=float(info_get(task, "rollout.timeStep", 0.015)), maxNumStepsPerSecond=int(info_get(task, "rollout.maxNumStepsPerSecond", 10000)))
     m["sqp"] = dict(dt=float(info_get(task, "sqp.dt")), sqpIteration=int(info_get(task, "sqp.sqpIteration")),
                     deltaTol=float(info_get(task, "sqp.deltaTol")), g_max=float(info_get(task, "sqp.g_max")),
                     g_min=float(info_get(task, "sqp.g_min")))

@@ -396,3 +396,110 @@ def warm_start_from_previous(model, nodes, x_measured, prev_nodes, prev_x, prev_
             j2, a2 = time_segment(tp, t_next)
             x[i + 1] = a2 * xp[j2] + (1.0 - a2) * xp[j2 + 1]
     return x, u
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MRT side: MRT_BASE::rolloutPolicy = TimeTriggeredRollout::run under the LinearController of
+# the last PrimalSolution, as used by MRT_ROS_Dummy_Loop (ocs2_bipedal_robot_ros/src/BipedalRobotDummyNode.cpp:61,72-86) and
+# BipedalController (bipedal_controllers/src/BipedalController.cpp:322).  rollout settings: task.info:158-167 (ODE45,
+# AbsTolODE 1e-5, RelTolODE 1e-3, timeStep 0.015).  [OCS2-upstream] RolloutBase::findActiveModesTimeInterval,
+# TimeTriggeredRollout::runImpl, LinearController::computeInput; [boost::numeric::odeint, un-vendored] integrate_adaptive with
+# make_controlled<runge_kutta_dopri5<...>>(abs, rel): controlled_runge_kutta (FSAL) try_step, default_error_checker,
+# default_step_adjuster.  Restated from the published sources as recalled; parity UNPINNED.
+# ---------------------------------------------------------------------------------------------------------------
+def linear_controller_input(tp, uff, KK, t, x):
+    j, a = time_segment(tp, t)
+    return a * uff[j] + (1.0 - a) * uff[j + 1] + (a * KK[j] + (1.0 - a) * KK[j + 1]) @ x
+
+
+DOPRI5_A = ((1.0 / 5.0,),
+            (3.0 / 40.0, 9.0 / 40.0),
+            (44.0 / 45.0, -56.0 / 15.0, 32.0 / 9.0),
+            (19372.0 / 6561.0, -25360.0 / 2187.0, 64448.0 / 6561.0, -212.0 / 729.0),
+            (9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0))
+DOPRI5_C = (1.0 / 5.0, 3.0 / 10.0, 4.0 / 5.0, 8.0 / 9.0, 1.0)
+DOPRI5_B = (35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0)
+DOPRI5_DB = (35.0 / 384.0 - 5179.0 / 57600.0, 0.0, 500.0 / 1113.0 - 7571.0 / 16695.0, 125.0 / 192.0 - 393.0 / 640.0,
+             -2187.0 / 6784.0 - (-92097.0 / 339200.0), 11.0 / 84.0 - 187.0 / 2100.0, -1.0 / 40.0)
+
+
+def dopri5_step(f, x, dxdt, t, dt):
+    """runge_kutta_dopri5::do_step_impl (FSAL): returns x_new, dxdt_new, x_err."""
+    k = [dxdt]
+    for s in range(5):
+        xs = x + dt * sum(a * kk for a, kk in zip(DOPRI5_A[s], k))
+        k.append(f(t + dt * DOPRI5_C[s], xs))
+    x_new = x + dt * sum(b * kk for b, kk in zip(DOPRI5_B, k))
+    k.append(f(t + dt, x_new))
+    x_err = dt * sum(d * kk for d, kk in zip(DOPRI5_DB, k))
+    return x_new, k[6], x_err
+
+
+def integrate_adaptive_dopri5(f, x, t0, t1, dt, abs_tol, rel_tol, observer, max_steps=10 ** 6):
+    """odeint integrate_adaptive(controlled_stepper_tag) with a fresh controlled dopri5 stepper.  Returns (x, t, accepted, rejected)."""
+    eps = np.finfo(float).eps
+    t = t0
+    dxdt = None
+    accepted = rejected = 0
+    while t1 - t > eps:                                   # less_with_sign(start_time, end_time, dt)
+        observer(x, t)
+        if (t + dt) - t1 > eps:                           # less_with_sign(end_time, start_time + dt, dt)
+            dt = t1 - t
+        while True:
+            if dxdt is None:                              # m_first_call: initialize the FSAL derivative
+                dxdt = f(t, x)
+            x_new, dxdt_new, x_err = dopri5_step(f, x, dxdt, t, dt)
+            err = float(np.max(np.abs(x_err) / (abs_tol + rel_tol * (np.abs(x) + abs(dt) * np.abs(dxdt)))))
+            if err > 1.0:                                 # decrease_step, error_order 4
+                dt *= max(0.9 * err ** (-1.0 / 3.0), 0.2)
+                rejected += 1
+                if rejected > 500:                        # failed_step_checker (500 consecutive failures) is never reached in the tests
+                    raise RuntimeError("Max number of iterations exceeded (500). A new step size was not found.")
+                continue
+            t = t + dt
+            x, dxdt = x_new, dxdt_new
+            if err < 0.5:                                 # increase_step, stepper_order 5
+                e = max(5.0 ** -5, err)
+                dt *= 0.9 * e ** (-1.0 / 5.0)
+            accepted += 1
+            break
+        if accepted > max_steps:
+            raise RuntimeError("integration terminated: max number of steps reached")
+    observer(x, t)
+    return x, t, accepted, rejected
+
+
+def find_active_modes_time_interval(t0, tf, event_times):
+    """[OCS2-upstream] RolloutBase::findActiveModesTimeInterval: split at the events in (t0, tf]; every begin time is nudged by
+    weakEpsilon (never past its end)."""
+    first = bisect.bisect_right(event_times, t0)
+    last = bisect.bisect_right(event_times, tf)
+    sw = [t0] + list(event_times[first:last]) + [tf]
+    return [(min(sw[i] + WEAK_EPS, sw[i + 1]), sw[i + 1]) for i in range(len(sw) - 1)]
+
+
+def time_triggered_rollout(flow_map, controller, t0, x0, tf, event_times, settings):
+    """[OCS2-upstream] TimeTriggeredRollout::runImpl.  flow_map(x, u) -> dx/dt, controller(t, x) -> u.
+    Returns dict(times, states, inputs, post_event_indices, accepted, rejected)."""
+    intervals = find_active_modes_time_interval(t0, tf, event_times)
+    max_steps = int(settings["maxNumStepsPerSecond"] * max(1.0, intervals[-1][1] - intervals[0][0]))
+    times, states, inputs, post = [], [], [], []
+
+    def observer(x, t):
+        states.append(np.array(x, float))
+        times.append(float(t))
+
+    def f(t, x):
+        return flow_map(x, controller(t, x))
+
+    x = np.array(x0, float)
+    acc = rej = 0
+    for i, (tb, te) in enumerate(intervals):
+        x, _, a, r = integrate_adaptive_dopri5(f, x, tb, te, settings["timeStep"], settings["AbsTolODE"], settings["RelTolODE"], observer, max_steps)
+        acc += a
+        rej += r
+        while len(inputs) < len(times):
+            inputs.append(controller(times[len(inputs)], states[len(inputs)]))
+        if i < len(intervals) - 1:
+            post.append(len(states))                      # identity jump map: the next segment starts from the same state
+    return dict(times=np.array(times), states=np.array(states), inputs=np.array(inputs), post_event_indices=post, accepted=acc, rejected=rej)
