@@ -1,5 +1,6 @@
 """Host pre-pass (rows a10, a11, a12 + time grid + targets): product C++ (C ABI) vs the oracle's pure-Python
 restatement, and the hand-derived known answers of SURVEY.md section 8(c)(4)."""
+import math
 import os
 
 import numpy as np
@@ -169,3 +170,50 @@ def test_warm_start_from_previous_properties():
     xw3, uw3 = rp.warm_start_from_previous(m, nodes, x0 + dxm, nodes, xo, uo, Ko)
     assert np.allclose(uw3[0] - uw[0], Ko[0] @ dxm, atol=1e-10) and np.allclose(uw3[1:], uw[1:], atol=1e-12)
     assert np.allclose(xw3[1:], xw[1:], atol=1e-12)
+
+
+# ---- MRT side restatement (oracle/reference_py.py): hand-checkable properties
+def test_dopri5_controlled_stepper_known_answers():
+    from oracle import reference_py as rp
+    # order conditions of the tableau: rows of A sum to c, b sums to 1, the embedded weights sum to 0
+    for row, c in zip(rp.DOPRI5_A, rp.DOPRI5_C):
+        assert abs(sum(row) - c) < 1e-15
+    assert abs(sum(rp.DOPRI5_B) - 1.0) < 1e-15 and abs(sum(rp.DOPRI5_DB)) < 1e-15
+    # one step on dx/dt = -x: 5th order solution, error estimate of the size of the true error of the 4th order companion
+    x = np.array([1.0])
+    xn, dn, err = rp.dopri5_step(lambda t, y: -y, x, -x, 0.0, 0.1)
+    assert abs(xn[0] - math.exp(-0.1)) < 2e-9 and abs(dn[0] + xn[0]) < 1e-15 and 0 < abs(err[0]) < 1e-6
+    # adaptive integration: tolerance respected, the last step lands exactly on the end time, every accepted point is observed
+    seen = []
+    xe, te, acc, rej = rp.integrate_adaptive_dopri5(lambda t, y: np.array([y[1], -y[0]]), np.array([1.0, 0.0]), 0.0, 2.0, 0.015, 1e-8, 1e-6,
+                                                     lambda y, t: seen.append(t))
+    assert te == 2.0 and len(seen) == acc + 1 and seen[0] == 0.0 and seen[-1] == 2.0 and all(b > a for a, b in zip(seen, seen[1:]))
+    assert abs(xe[0] - math.cos(2.0)) < 1e-5 and abs(xe[1] + math.sin(2.0)) < 1e-5
+    assert acc < 40                       # the step grows from the initial 0.015 (factor <= 5 per accepted step)
+    # a zero-length interval records its single point and takes no step
+    seen = []
+    _, _, acc, _ = rp.integrate_adaptive_dopri5(lambda t, y: -y, np.array([1.0]), 0.3, 0.3, 0.015, 1e-5, 1e-3, lambda y, t: seen.append(t))
+    assert acc == 0 and seen == [0.3]
+
+
+def test_rollout_intervals_and_linear_controller():
+    from oracle import reference_py as rp
+    ev = [0.1, 0.35, 0.7]
+    iv = rp.find_active_modes_time_interval(0.1, 0.7, ev)                  # events in (t0, tf]: 0.35 and 0.7 (upper_bound on both ends)
+    assert [e for _, e in iv] == [0.35, 0.7, 0.7]
+    assert iv[0][0] == 0.1 + 1e-6 and iv[1][0] == 0.35 + 1e-6 and iv[2] == (0.7, 0.7)   # begin nudged, never past the end
+    assert rp.find_active_modes_time_interval(0.4, 0.45, ev) == [(0.4 + 1e-6, 0.45)]
+    # LinearController: bias and gain interpolated with the same (index, alpha), clamped outside the time stamps
+    tp = np.array([0.0, 1.0, 1.0, 2.0])                                      # an event at t = 1 (pre / post pair)
+    uff = np.array([[0.0], [1.0], [10.0], [12.0]])
+    KK = np.array([[[1.0]], [[1.0]], [[2.0]], [[2.0]]])
+    x = np.array([3.0])
+    assert rp.linear_controller_input(tp, uff, KK, 0.25, x)[0] == 0.25 + 3.0
+    assert rp.linear_controller_input(tp, uff, KK, 1.5, x)[0] == 11.0 + 6.0
+    assert rp.linear_controller_input(tp, uff, KK, 1.0, x)[0] == 1.0 + 3.0    # exactly on the event: the pre-event entry
+    assert rp.linear_controller_input(tp, uff, KK, 5.0, x)[0] == 12.0 + 6.0
+    # a rollout under u = -x of dx/dt = u across an event restarts the integrator but keeps the state
+    r = rp.time_triggered_rollout(lambda xx, uu: uu, lambda t, xx: -xx, 0.0, np.array([1.0]), 0.5, [0.2], dict(AbsTolODE=1e-9, RelTolODE=1e-7, timeStep=0.015, maxNumStepsPerSecond=10000))
+    assert r["post_event_indices"] and r["times"][r["post_event_indices"][0]] == 0.2 + 1e-6
+    assert np.array_equal(r["states"][r["post_event_indices"][0]], r["states"][r["post_event_indices"][0] - 1])
+    assert abs(r["states"][-1][0] - math.exp(-0.5 + 2e-6)) < 1e-7 and len(r["inputs"]) == len(r["times"])
