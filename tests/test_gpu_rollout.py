@@ -18,9 +18,9 @@ def ctx():
     return bp, scenarios, ob, rp, scenarios.h1_interface()
 
 
-def _oracle_rollout(ob, rp, prob, b, x, u, K, n, t_start, x_start, duration):
-    m, om = ob.model("h1"), ob.oracle("h1")
-    nodes = ob.oracle_nodes(prob, b)
+def _oracle_rollout(ob, rp, prob, b, x, u, K, n, t_start, x_start, duration, robot="h1"):
+    m, om = ob.model(robot), ob.oracle(robot)
+    nodes = ob.oracle_nodes(prob, b, robot=robot)
     assert nodes["N"] == n
     tp, xp, uff, KK = rp.primal_solution_arrays(nodes, x[b, :n + 1], u[b, :n], K[b, :n])
     sched = prob["schedule"][b] if isinstance(prob["schedule"], list) else prob["schedule"]
@@ -94,3 +94,33 @@ def test_rollout_needs_a_solution(ctx):
         mpc.rollout(0.02)
     with pytest.raises(bp.BpmpcError):
         mpc.setup_commands(0.0, None, [], -1, 0.0, (0, 0, 0, 0), horizon=prob["horizon"])   # no rollout yet
+
+
+def test_openloong_device_prepass_and_rollout(ctx):
+    """nx = nu = 24: 32 lanes per problem in the rollout kernel; device-side reference generation on the other model files."""
+    bp, sc, ob, rp, _ = ctx
+    itf = sc.interface("openloong")
+    B, NI = 3, 30
+    horizon = NI * sc.DT
+    x0 = sc.perturbed_initial_states(itf, B)
+    tm = [bp.loadModeSequenceTemplate(sc.OPENLOONG["gait"], "standing_trot")]
+    cmd = (0.2, 0.0, 0.0, 0.1)
+    sched = sc.gait_schedule(itf, "standing_trot", 0.0, horizon)
+    targets = [itf.cmdVelToTargetTrajectories(cmd, 0.0, x0[b], horizon) for b in range(B)]
+    prob = dict(t0=0.0, x0=x0, schedule=sched, targets=targets, horizon=horizon)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=48, return_gains=True)
+    mpc.setup_commands(0.0, x0, tm, 0, sc.GAIT_START, cmd, horizon=horizon)
+    mpc.enqueue()
+    t, x, u, K, st = mpc.fetch(gains=True)
+    n = st[0].n_nodes
+    for b in range(B):
+        xo, uo, _, _ = ob.oracle_solve_like(prob, b, robot="openloong")
+        assert np.abs(x[b, :n + 1] - xo).max() / max(1.0, np.abs(xo).max()) < 1e-8
+    for duration in (0.02, 0.2):
+        xs = x0 + 1e-3
+        x_end, u_end, steps = mpc.rollout(duration, t_start=0.0, x_start=xs)
+        for b in range(B):
+            r = _oracle_rollout(ob, rp, prob, b, x, u, K, n, 0.0, xs[b], duration, robot="openloong")
+            assert (int(steps[b, 0]), int(steps[b, 1])) == (r["accepted"], r["rejected"])
+            assert np.abs(x_end[b] - r["states"][-1]).max() < 1e-9
+            assert np.abs(u_end[b] - r["inputs"][-1]).max() / max(1.0, np.abs(r["inputs"][-1]).max()) < 1e-8
