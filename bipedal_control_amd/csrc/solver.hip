@@ -300,22 +300,26 @@ __global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu
   riccati_mfma<NJ, DB>(ws, io);
 }
 
-// Warm start of a receding-horizon solve from the previous solution, one wavefront per problem (sequential in the nodes:
-// the guess of x_{i+1} is either interpolated or a copy of x_i).  [OCS2-upstream, recalled]
+// Warm start of a receding-horizon solve from the previous solution, one wavefront per (problem, node).  [OCS2-upstream, recalled]
 // SqpSolver::initializeStateInputTrajectories with a non-empty PrimalSolution: for an intermediate node with
 // intervalStart <= second-to-last and intervalEnd <= last time of the previous solution,
 //     u_i = uff(t) + K(t) x_i  (LinearController, sqp.useFeedbackPolicy true, task.info:80;  uff_j = u_j - K_j x_j, inputs and
 //           gains of pre-event nodes and of the terminal node repeat the previous one: multiple_shooting::toPrimalSolution),
 //     x_{i+1} = LinearInterpolation(intervalEnd, previous states);
-// otherwise BipedalRobotInitializer::compute (already written by k_prepare); event nodes copy the state.
+// otherwise BipedalRobotInitializer::compute (already written by k_prepare) and x_{i+1} = x_i; event nodes copy the state.
+// The state guess of node i is therefore the interpolation at the end of the last interpolating node before it (or the measured
+// state), which every node finds on its own - no sequential sweep (the first version, one wavefront per problem walking the
+// horizon, took 0.53 ms at batch 256 and was the longest kernel of a closed-loop tick).
 // Oracle: oracle/reference_py.py warm_start_from_previous.
 template <int NJ>
 __global__ __launch_bounds__(kWave) void k_warm_shift(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   __shared__ double xi[NX];
-  const int b = blockIdx.x, l = threadIdx.x;
+  __shared__ double Ks[2][NU * NX];
+  const int b = blockIdx.x / L.N, i = blockIdx.x % L.N, l = threadIdx.x;
   const int N = L.N;
   const int g = L.buf.p_grid[b], n = L.buf.g_nodes[g];
+  if (i >= n) return;
   const int gp = L.buf.tp_grid[b], np = L.buf.tp_nodes[gp];
   if (np < 1) return;
   const double* tp = L.buf.tp_time + (size_t)gp * (N + 1);
@@ -327,36 +331,47 @@ __global__ __launch_bounds__(kWave) void k_warm_shift(Launch L) {
   double* u = L.buf.u + (size_t)b * N * NU;
   const double state_till = tp[np], input_till = tp[np - 1];
   auto effective = [&](int j) { while (j > 0 && (j == np || kp[j] == 1)) --j; return j; };   // repeated input / gain
-  if (l < NX) { const double v = L.buf.p_x0[(size_t)b * NX + l]; xi[l] = v; x[l] = v; }
+  auto interpolates = [&](int k) {
+    const size_t gs = (size_t)g * N + k;
+    if (L.buf.g_kind[gs] != 0) return false;
+    const double t = L.buf.g_start[gs], tn = t + L.buf.g_dt[gs];
+    return !(t > input_till || tn > state_till);
+  };
+  auto state_after = [&](int k, int c) {            // component c of the guess of x_{k+1} for an interpolating node k
+    const size_t gs = (size_t)g * N + k;
+    int j2;
+    double a2;
+    time_segment(tp, np + 1, L.buf.g_start[gs] + L.buf.g_dt[gs], &j2, &a2);
+    return a2 * xp[(size_t)j2 * NX + c] + (1.0 - a2) * xp[(size_t)(j2 + 1) * NX + c];
+  };
+  int src = i - 1;
+  while (src >= 0 && !interpolates(src)) --src;
+  const bool mine = interpolates(i);
+  if (l < NX) {
+    const double v = src < 0 ? L.buf.p_x0[(size_t)b * NX + l] : state_after(src, l);
+    xi[l] = v;
+    if (i == 0) x[l] = v;
+    x[(size_t)(i + 1) * NX + l] = mine ? state_after(i, l) : v;
+  }
+  if (!mine) return;
+  int j;
+  double a;
+  time_segment(tp, np + 1, L.buf.g_start[(size_t)g * N + i], &j, &a);
+  const int e0 = effective(j), e1 = effective(j + 1);
+  for (int idx = l; idx < NU * NX; idx += kWave) {
+    Ks[0][idx] = Kp[(size_t)e0 * NU * NX + idx];
+    Ks[1][idx] = Kp[(size_t)e1 * NU * NX + idx];
+  }
   __syncthreads();
-  for (int i = 0; i < n; ++i) {
-    const size_t gs = (size_t)g * N + i;
-    double xn = l < NX ? xi[l] : 0.0;
-    if (L.buf.g_kind[gs] == 0) {
-      const double t = L.buf.g_start[gs], tn = t + L.buf.g_dt[gs];
-      if (!(t > input_till || tn > state_till)) {
-        int j, j2; double a, a2;
-        time_segment(tp, np + 1, t, &j, &a);
-        time_segment(tp, np + 1, tn, &j2, &a2);
-        if (l < NU) {
-          const int e0 = effective(j), e1 = effective(j + 1);
-          const double* K0 = Kp + ((size_t)e0 * NU + l) * NX;
-          const double* K1 = Kp + ((size_t)e1 * NU + l) * NX;
-          double uff0 = up[(size_t)e0 * NU + l], uff1 = up[(size_t)e1 * NU + l], kx = 0.0;
-          for (int c = 0; c < NX; ++c) {
-            const double k0 = K0[c], k1 = K1[c];
-            uff0 -= k0 * xp[(size_t)j * NX + c];
-            uff1 -= k1 * xp[(size_t)(j + 1) * NX + c];
-            kx += (a * k0 + (1.0 - a) * k1) * xi[c];
-          }
-          u[(size_t)i * NU + l] = a * uff0 + (1.0 - a) * uff1 + kx;
-        }
-        if (l < NX) xn = a2 * xp[(size_t)j2 * NX + l] + (1.0 - a2) * xp[(size_t)(j2 + 1) * NX + l];
-      }
+  if (l < NU) {
+    double uff0 = up[(size_t)e0 * NU + l], uff1 = up[(size_t)e1 * NU + l], kx = 0.0;
+    for (int c = 0; c < NX; ++c) {
+      const double k0 = Ks[0][l * NX + c], k1 = Ks[1][l * NX + c];
+      uff0 -= k0 * xp[(size_t)j * NX + c];
+      uff1 -= k1 * xp[(size_t)(j + 1) * NX + c];
+      kx += (a * k0 + (1.0 - a) * k1) * xi[c];
     }
-    __syncthreads();                        // everybody has read xi
-    if (l < NX) { xi[l] = xn; x[(size_t)(i + 1) * NX + l] = xn; }
-    __syncthreads();
+    u[(size_t)i * NU + l] = a * uff0 + (1.0 - a) * uff1 + kx;
   }
 }
 
@@ -770,8 +785,8 @@ void finish_setup(bpmpc_solver* s, int batch, const double* warm_x, const double
   DISPATCH_NJ(s, stage_prepare);
   if (from_previous) {
     const Launch L = s->launch_params();
-    if (s->rm.nj == 10) hipLaunchKernelGGL(k_warm_shift<10>, dim3(batch), dim3(kWave), 0, s->stream, L);
-    else hipLaunchKernelGGL(k_warm_shift<12>, dim3(batch), dim3(kWave), 0, s->stream, L);
+    if (s->rm.nj == 10) hipLaunchKernelGGL(k_warm_shift<10>, dim3(batch * L.N), dim3(kWave), 0, s->stream, L);
+    else hipLaunchKernelGGL(k_warm_shift<12>, dim3(batch * L.N), dim3(kWave), 0, s->stream, L);
     HIP_CHECK(hipGetLastError());
   }
   copy_pairs(s, bf.x, bf.x_init, (size_t)batch * (N + 1) * NX, bf.u, bf.u_init, (size_t)batch * N * NU, true);
