@@ -451,6 +451,45 @@ __global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L) {
   linesearch_decide<NJ, kDecideThreads>(partial, problem_ls<NJ>(L, blockIdx.x), L.ls);
 }
 
+// Back-tracking rounds after the first one, entirely on the device: a workgroup per problem that has not accepted yet (normally
+// none: the block exits at once) evaluates its own trial nodes, sixteen at a time, and decides, until the problem accepts or gives
+// up.  The host never reads a flag back inside a solve, so consecutive solves queue without a gap.
+template <int NJ>
+__global__ __launch_bounds__(kDecideThreads) void k_ls_tail(Launch L, int max_trials) {
+  using C = LinFastCfg<NJ>;
+  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW, CHUNK = (kDecideThreads / kWave) * NPW;
+  const int b = blockIdx.x;
+  if (L.buf.done[b]) return;
+  __shared__ LinFastNodeLds<NJ, false> lds[CHUNK];
+  __shared__ LinFastShared<NJ> shared;
+  __shared__ double partial[3 * kDecideThreads + 2];
+  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kDecideThreads);
+  __syncthreads();
+  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
+  const int n = L.buf.g_nodes[L.buf.p_grid[b]];
+  const ProblemLS p = problem_ls<NJ>(L, b);
+  volatile const int* done = L.buf.done + b;
+  volatile const double* alpha = L.buf.alpha + b;
+  for (int round = 1; round < max_trials; ++round) {
+    const double al = *alpha;
+    for (int k0 = 0; k0 < n; k0 += CHUNK) {
+      const int k = k0 + sub;
+      const bool valid = k < n;
+      const int kk = valid ? k : 0;
+      const size_t s = (size_t)b * L.N + kk;
+      const NodeInputs in = node_inputs<NJ>(L, b, kk);
+      const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + kk) * NX;
+      trial_fast<NJ>(*L.model, shared, lds[sub], valid, in, al, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
+    }
+    __threadfence();
+    __syncthreads();
+    linesearch_decide<NJ, kDecideThreads>(partial, p, L.ls);
+    __threadfence();
+    __syncthreads();
+    if (*done) break;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ solver object
 struct KernelTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -622,13 +661,18 @@ template <int NJ> void bpmpc_solver::stage_linesearch() {
   // alpha = 1, 1/2, ... >= alpha_min  ([OCS2-upstream] SqpSolver::takeStep do-while)
   int max_trials = 0;
   for (double a = 1.0; a >= ls.alpha_min; a *= ls.alpha_decay) ++max_trials;
+  if (!settings.reference_kernels) {
+    // first round for everybody, later rounds per problem on the device (k_ls_tail): no read-back inside a solve
+    constexpr int NPW = LinFastCfg<NJ>::NPW;
+    hipLaunchKernelGGL(k_trial_fast<NJ>, dim3((batch * settings.max_nodes + kTrialWaves * NPW - 1) / (kTrialWaves * NPW)), dim3(kTrialWaves * kWave), 0, stream, L);
+    hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L);
+    hipLaunchKernelGGL(k_ls_tail<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L, max_trials);
+    HIP_CHECK(hipGetLastError());
+    time_end("linesearch", ev_a, ev_b);
+    return;
+  }
   for (int t = 0; t < max_trials; ++t) {
-    if (settings.reference_kernels) {
-      hipLaunchKernelGGL(k_trial<NJ>, dim3(batch * settings.max_nodes), dim3(kWave), 0, stream, L);
-    } else {
-      constexpr int NPW = LinFastCfg<NJ>::NPW;
-      hipLaunchKernelGGL(k_trial_fast<NJ>, dim3((batch * settings.max_nodes + kTrialWaves * NPW - 1) / (kTrialWaves * NPW)), dim3(kTrialWaves * kWave), 0, stream, L);
-    }
+    hipLaunchKernelGGL(k_trial<NJ>, dim3(batch * settings.max_nodes), dim3(kWave), 0, stream, L);
     hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L);
     HIP_CHECK(hipGetLastError());
     // one 4-byte read-back per trial round: stop as soon as every problem has accepted (or given up)
