@@ -140,3 +140,26 @@ def test_receding_horizon_loop_matches_oracle(ctx):
             nxt[b] = a * xo[j] + (1.0 - a) * xo[j + 1] + 1e-3 * np.sin(np.arange(xo.shape[1]) + b + it)
         x_meas = nxt
     assert worst < 1e-8
+
+
+def test_backtracking_rounds_on_device_match_oracle(ctx):
+    """Several back-tracking rounds of the filter line search (alpha = 1/2, 1/4, ...): after the first trial they run inside k_ls_tail,
+    one workgroup per problem, without the host.  A converged iterate re-used as the warm start for a far-away measured state makes
+    the full step unacceptable; step sizes, merit and the accepted iterate must equal the oracle's."""
+    bp, sc, ob, itf = ctx
+    B = 6
+    prob = sc.trot_problem(itf, batch=B, n_intervals=40)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=64)
+    t, x, u, _, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    n = st[0].n_nodes
+    seen = set()
+    for d in (0.5, 1.0):
+        x0b = prob["x0"] + d * np.sin(np.arange(prob["x0"].size).reshape(prob["x0"].shape))
+        t2, x2, u2, _, st2 = mpc.run(prob["t0"], x0b, prob["schedule"], prob["targets"], horizon=prob["horizon"], warm_x=x, warm_u=u)
+        p2 = dict(prob, x0=x0b)
+        for b in range(B):
+            xo, uo, _, sto = ob.oracle_solve_like(p2, b, x_init=x[b, :n + 1], u_init=u[b, :n])
+            assert st2[b].step_size == sto[0][3], (d, b, st2[b].step_size, sto[0][3])
+            assert _rel(x2[b, :n + 1], xo) < 1e-8 and _rel(u2[b, :n], uo) < 1e-8
+            seen.add(st2[b].step_size)
+    assert min(seen) <= 0.25 and len(seen) >= 2, seen      # the device-side rounds were really exercised
