@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kWave) void k_project(Launch L) {
 }
 
 template <int NJ, int RM>
-__global__ __launch_bounds__(kWave) void k_project_lu(Launch L) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_project_lu(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   __shared__ ProjectLuLds<NJ> lds[kLuNodes];
   const int sub = threadIdx.x / kLuLanes, j = threadIdx.x % kLuLanes;
