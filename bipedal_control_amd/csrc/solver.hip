@@ -804,18 +804,22 @@ void copy_pairs(bpmpc_solver* s, const double* a_src, double* a_dst, size_t na, 
   HIP_CHECK(hipGetLastError());
 }
 
-// receding-horizon warm start: keep the previous solution and its grid on the device before anything is overwritten
+// receding-horizon warm start: keep the previous solution and its grid on the device before anything is overwritten.  The
+// solution buffers trade places with the "previous" ones (x and u are rewritten by k_prepare, K by the Riccati sweep for every node
+// of the new grid), the grid tables are copied device to device; nothing waits on the host.
 void preserve_previous(bpmpc_solver* s, int batch, bool warm_arrays) {
-  const int N = s->settings.max_nodes, NX = s->nx, NU = s->nu;
+  const size_t N = s->settings.max_nodes, B = batch;
   if (warm_arrays) throw std::invalid_argument("warm start arrays and from_previous are exclusive");
   if (!s->has_solution || batch != s->batch) throw std::invalid_argument("setup_from_previous needs a completed solve of the same batch");
   Buffers& bp = s->buf;
   if (!bp.K) throw std::invalid_argument("setup_from_previous needs the feedback gains (return_gains with reference kernels)");
-  HIP_CHECK(hipMemcpyAsync(bp.x_prev, bp.x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  HIP_CHECK(hipMemcpyAsync(bp.u_prev, bp.u, (size_t)batch * N * NU * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  HIP_CHECK(hipMemcpyAsync(bp.K_prev, bp.K, (size_t)batch * N * NU * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  upload(s, bp.tp_time, s->node_times); upload(s, bp.tp_kind, s->grid_kind); upload(s, bp.tp_nodes, s->grid_nodes); upload(s, bp.tp_grid, s->grid_of_problem);
-  HIP_CHECK(hipStreamSynchronize(s->stream));   // the host vectors are replaced by the caller
+  std::swap(bp.x, bp.x_prev); std::swap(bp.u, bp.u_prev); std::swap(bp.K, bp.K_prev);
+  s->named["x"].first = bp.x; s->named["u"].first = bp.u; s->named["K"].first = bp.K;
+  s->named["x_prev"].first = bp.x_prev; s->named["u_prev"].first = bp.u_prev; s->named["K_prev"].first = bp.K_prev;
+  HIP_CHECK(hipMemcpyAsync(bp.tp_time, bp.g_time, B * (N + 1) * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(bp.tp_kind, bp.g_kind, B * N * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(bp.tp_nodes, bp.g_nodes, B * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(bp.tp_grid, bp.p_grid, B * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
 }
 
 // common tail of every setup flavour: initial iterate (initializer, warm arrays or shifted previous solution), activation

@@ -206,7 +206,8 @@ int bpmpc_solver_stage(bpmpc_solver* solver, const char* stage);
  * double.  Returns the element count or a negative status. */
 int bpmpc_solver_read(bpmpc_solver* solver, const char* name, double* out, long capacity);
 /* Device pointers of the iterate, for zero-copy hand-off (e.g. an RCCL gather through torch.distributed):
- * x: batch*(max_nodes+1)*nx doubles, u: batch*max_nodes*nu doubles. */
+ * x: batch*(max_nodes+1)*nx doubles, u: batch*max_nodes*nu doubles.  Valid until the next setup with a warm start from the previous
+ * solve (the solution buffers then trade places with the kept copy); query again after such a setup. */
 int bpmpc_solver_device_trajectories(bpmpc_solver* solver, double** x_dev, double** u_dev);
 /* Asynchronous device-to-device copy of the iterate into caller-owned device buffers (same shapes as above) on the
  * solver's stream - e.g. torch tensors that are then all-gathered over RCCL. */
