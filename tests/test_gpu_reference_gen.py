@@ -158,3 +158,49 @@ def test_goal_pose_targets_match_host_path(ctx):
     _, x1, u1, _, _ = host.fetch()
     _, x2, u2, _, _ = dev.fetch()
     assert np.abs(x1[:, :n + 1] - x2[:, :n + 1]).max() < 1e-9 and np.abs(u1[:, :n] - u2[:, :n]).max() < 1e-9 * max(1.0, np.abs(u1).max())
+
+
+def test_config5_gait_library_sweep_full_size(ctx):
+    """BASELINE.json configs[4] per-GPU shape: 512 problems, horizon 150, the reference's 4 gaits + 4 synthetic trot variants
+    (periods 0.5 / 0.6 / 0.9 / 1.0 s), commands on a v_x x omega_z grid - generated on the device.
+    Full-size properties (every problem solves, solutions do not depend on batch neighbours) and the oracle on a sample."""
+    bp, sc, ob, itf, tm = ctx
+    trot = tm[0]
+    variants = [bp.ModeSequenceTemplate(np.asarray(trot.switchingTimes) * (T / 0.7), np.asarray(trot.modeSequence)) for T in (0.5, 0.6, 0.9, 1.0)]
+    stance = bp.loadModeSequenceTemplate(sc.H1["gait"], "stance")
+    lib = [stance] + list(tm) + variants                                   # 8 templates
+    cmds = [(vx, 0.0, 0.0, wz) for vx in np.linspace(-0.5, 0.5, 8) for wz in np.linspace(-0.3, 0.3, 8)]      # 64 commands per gait
+    NI = 150
+    horizon = NI * sc.DT
+    B = len(lib) * len(cmds)
+    assert B == 512
+    gop = np.repeat(np.arange(len(lib)), len(cmds)).astype(np.int32)
+    cmd = np.array(cmds * len(lib))
+    x0 = sc.perturbed_initial_states(itf, B)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=200)
+    lay = mpc.setup_commands(0.0, x0, lib, gop, sc.GAIT_START, cmd, horizon=horizon)
+    assert lay["n_grids"] == len(lib) and lay["n_nodes_max"] <= 200
+    mpc.enqueue()
+    t, x, u, _, st = mpc.fetch()
+    assert all(s.status == 0 and s.step_size > 0 for s in st)
+    viol = np.array([np.sqrt(s.dynamics_sse_after + s.equality_sse_after) for s in st])
+    viol0 = np.array([np.sqrt(s.dynamics_sse_before + s.equality_sse_before) for s in st])
+    assert np.all(viol < viol0) and np.isfinite(x[:, :NI]).all()
+    # a sub-batch in another order gives bit-identical solutions
+    sub = [511, 130, 64, 7]
+    mpc2 = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=200)
+    mpc2.setup_commands(0.0, x0[sub], lib, gop[sub], sc.GAIT_START, cmd[sub], horizon=horizon)
+    mpc2.enqueue()
+    _, x2, u2, _, _ = mpc2.fetch()
+    for j, i in enumerate(sub):
+        assert np.array_equal(x2[j], x[i]) and np.array_equal(u2[j], u[i])
+    # oracle on one problem per synthetic variant: schedule from the host GaitSchedule fed with the same scaled template
+    for i in (4 * 64 + 5, 7 * 64 + 63):
+        gs = bp.GaitSchedule(itf)
+        gs.insertModeSequenceTemplate(lib[gop[i]], sc.GAIT_START, 2 * horizon)
+        sched = gs.getModeSchedule(-horizon, 2 * horizon)
+        prob = dict(t0=0.0, x0=x0[i:i + 1], schedule=sched, targets=[itf.cmdVelToTargetTrajectories(tuple(cmd[i]), 0.0, x0[i], horizon)], horizon=horizon)
+        xo, uo, _, _ = ob.oracle_solve_like(prob, 0)
+        n = st[i].n_nodes
+        assert xo.shape[0] == n + 1
+        assert np.abs(x[i, :n + 1] - xo).max() / max(1.0, np.abs(xo).max()) < 1e-8 and np.abs(u[i, :n] - uo).max() / max(1.0, np.abs(uo).max()) < 1e-8
