@@ -91,7 +91,7 @@ struct ProblemLS {
 };
 
 template <int NJ>
-BP_DEVICE void linesearch_begin(double* partial /*kWave*3 LDS*/, const ProblemLS& p) {
+BP_DEVICE void linesearch_begin(double* partial /*kWave*3 + 5 LDS*/, const ProblemLS& p) {
   constexpr int NX = 12 + NJ;
   BP_LANES(tid, kWave) {
     double a = 0.0, b = 0.0, c = 0.0;
@@ -100,10 +100,18 @@ BP_DEVICE void linesearch_begin(double* partial /*kWave*3 LDS*/, const ProblemLS
     partial[tid] = a; partial[kWave + tid] = b; partial[2 * kWave + tid] = c;
   }
   BP_SYNC();
+  // the three sums in lane order, one lane each (same numbers as one lane doing all three, a third of the time)
+  BP_LANES(tid, kWave) {
+    if (tid < 3) {
+      double s = 0.0;
+      for (int i = 0; i < kWave; ++i) s += partial[tid * kWave + i];
+      partial[3 * kWave + 2 + tid] = s;
+    }
+  }
+  BP_SYNC();
   BP_LANES(tid, kWave) {
     if (tid == 0) {
-      double a = 0.0, b = 0.0, c = 0.0;
-      for (int i = 0; i < kWave; ++i) { a += partial[i]; b += partial[kWave + i]; c += partial[2 * kWave + i]; }
+      const double a = partial[3 * kWave + 2], b = partial[3 * kWave + 3], c = partial[3 * kWave + 4];
       p.base[0] = a; p.base[1] = b; p.base[2] = c;
       p.alpha[0] = 1.0;
       const bool run = p.active[0] != 0;
@@ -121,7 +129,7 @@ BP_DEVICE void linesearch_begin(double* partial /*kWave*3 LDS*/, const ProblemLS
 
 // NL lanes work on one problem (64 in the lane emulation, 256 on the GPU: the accepted step touches (2N+1) nx doubles)
 template <int NJ, int NL = kWave>
-BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags*/, const ProblemLS& p, const LineSearchSettings& st) {
+BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags + 3 sums*/, const ProblemLS& p, const LineSearchSettings& st) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   if (p.done[0]) return;
   const double alpha = p.alpha[0];
@@ -132,10 +140,21 @@ BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags*/, const P
     partial[tid] = a; partial[NL + tid] = b; partial[2 * NL + tid] = c;
   }
   BP_SYNC();
+  // the three sums in lane order, one lane each; lanes beyond the nodes (and beyond the nx mismatch terms) hold exact zeros and are
+  // skipped - the numbers equal those of one lane adding all NL entries
+  BP_LANES(tid, NL) {
+    if (tid < 3) {
+      int lim = p.n_nodes > NX ? p.n_nodes : NX;
+      if (lim > NL) lim = NL;
+      double s = 0.0;
+      for (int i = 0; i < lim; ++i) s += partial[tid * NL + i];
+      partial[3 * NL + 2 + tid] = s;
+    }
+  }
+  BP_SYNC();
   BP_LANES(tid, NL) {
     if (tid == 0) {
-      double merit = 0.0, dyn = 0.0, eq = 0.0;
-      for (int i = 0; i < NL; ++i) { merit += partial[i]; dyn += partial[NL + i]; eq += partial[2 * NL + i]; }
+      const double merit = partial[3 * NL + 2], dyn = partial[3 * NL + 3], eq = partial[3 * NL + 4];
       const double merit0 = p.base[0];
       const double viol0 = sqrt(p.base[1] + p.base[2]);
       const double viol = sqrt(dyn + eq);

@@ -401,7 +401,7 @@ __device__ __forceinline__ ProblemLS problem_ls(const Launch& L, int b) {
 
 template <int NJ>
 __global__ __launch_bounds__(kWave) void k_ls_begin(Launch L) {
-  __shared__ double partial[3 * kWave + 2];
+  __shared__ double partial[3 * kWave + 5];
   linesearch_begin<NJ>(partial, problem_ls<NJ>(L, blockIdx.x));
 }
 
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kWave) void k_rollout(const DeviceModel* model, Rol
 constexpr int kDecideThreads = 256;
 template <int NJ>
 __global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L) {
-  __shared__ double partial[3 * kDecideThreads + 2];
+  __shared__ double partial[3 * kDecideThreads + 5];
   linesearch_decide<NJ, kDecideThreads>(partial, problem_ls<NJ>(L, blockIdx.x), L.ls);
 }
 
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kDecideThreads) void k_ls_tail(Launch L, int max_tr
   if (L.buf.done[b]) return;
   __shared__ LinFastNodeLds<NJ, false> lds[CHUNK];
   __shared__ LinFastShared<NJ> shared;
-  __shared__ double partial[3 * kDecideThreads + 2];
+  __shared__ double partial[3 * kDecideThreads + 5];
   load_shared_model<NJ>(*L.model, shared, threadIdx.x, kDecideThreads);
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
