@@ -449,10 +449,17 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastSh
 // column 6+g for 16 lanes, rows 6..11 of the joint-velocity column for the joints; layout [row][lane] (coalesced).  They are
 // written before the second evaluation and read after it, by when the stores have long retired.
 constexpr int kLinParkDoublesPerLane = 15;   // times the lanes per node
+// Q and R of a node are dt x (constant weight) except for the Hessian shift on their diagonals and the four 3x3 force blocks of R
+// (cone Hessians).  Besides the full matrices the lineariser leaves exactly that part in a compact record: [shift, block entries
+// (column-major inside the block row: 3 * column + row % 3)], so that the change of variables need not read 7.7 KB of mostly
+// constant numbers per node.
+constexpr int kQrdStride = 40;
+
 struct LinFastOut {
   double *A, *B, *b, *Q, *R, *q, *r, *c, *C, *D, *e, *perf;
   int* nc;
   double* park;      // scratch, 15 * LPN doubles per node: the stage-one Jacobian columns wait here for the RK2 combination
+  double* qrd;       // kQrdStride doubles per node: the node-dependent part of Q and R in compact form (read by project_mfma.h)
   double* prof;      // this node's debug slot or nullptr
   size_t s;          // node slot (problem * max_nodes + node)
 };
@@ -713,6 +720,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
           w += cn[3] * cn[4 + a] * cn[4 + b2] + cn[2] * cn[7 + sidx];
         }
         (o.R + o.s * (NU * NU))[r * NU + cf] = dt * w;
+        if (r < 12 && r / 3 == cf / 3) (o.qrd + o.s * kQrdStride)[1 + 3 * cf + r % 3] = dt * w;
       }
       if (is_joint) { accj += sh.R[cj * NU + r] * dur; (o.R + o.s * (NU * NU))[r * NU + cj] = dt * (sh.R[r * NU + cj] + (r == cj ? shift : 0.0)); }
     }
@@ -730,6 +738,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   cost = node_allreduce_add<LPN>(cost);
   dyn_sse = node_allreduce_add<LPN>(dyn_sse);
   if (g == 0) {
+    (o.qrd + o.s * kQrdStride)[0] = shift;
     (o.c + o.s * (1))[0] = dt * cost;
     (o.nc + o.s * (1))[0] = nc;
     (o.perf + o.s * (3))[0] = dt * cost; (o.perf + o.s * (3))[1] = dt * dyn_sse; (o.perf + o.s * (3))[2] = dt * eq_sse;

@@ -38,10 +38,11 @@ struct ProjectMfmaWorkspace {
 // order, a load issued behind a store would wait for that store to reach memory.
 template <int NJ, int NBC>
 __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
-                                                     double dt_over_mass) {
+                                                     double dt_over_mass, const double* Qc, const double* Rc) {
   using WS = ProjectMfmaWorkspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, KR = WS::KR, KS = KR / 4, BC = NX + 1;
   const int l = threadIdx.x, li = l & 15, lk = l >> 4;
+  const double shift = in.qrd[0];
   // A-operands from HBM: rows 16 bi + li of R and of B, k = 4 ks + lk (out-of-range lanes read element 0 and are masked)
   double aR[2][KS], aB[2][KS];
 #pragma unroll
@@ -54,8 +55,14 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
       //   A: identity rows;   B rows 0..2: dt/m on the matching component of the four contact forces;   B rows 12..: dt on the
       // joint velocity), so those are generated here instead of being read (a fifth of this kernel's HBM reads).
       const bool dense = ok && row >= 3 && row < 12;
-      const double rv = in.R[ok ? row * NU + kk : 0], bv = in.B[dense ? row * NU + kk : 3 * NU];
-      aR[bi][ks] = ok ? rv : 0.0;
+      // R and Q of the node are dt x (constant weight) except on the diagonal (Hessian shift of the relaxed barriers) and in the
+      // four 3x3 force blocks of R (cone Hessians), linearize_fast.h: those come from the node's compact record (320 B), the
+      // rest is regenerated from the model constants (cache resident) with the lineariser's own expressions - 7 KB less HBM
+      // read per node than fetching Q and R
+      const bool r_block = ok && row < 12 && kk < 12 && row / 3 == kk / 3;
+      const double rv = *(r_block ? in.qrd + 1 + 3 * kk + row % 3 : Rc + (ok ? row * NU + kk : 0));
+      const double bv = in.B[dense ? row * NU + kk : 3 * NU];
+      aR[bi][ks] = ok ? (r_block ? rv : dt * (row == kk ? rv + shift : rv)) : 0.0;
       const double synth = row < 3 ? ((kk < 12 && kk % 3 == row) ? dt_over_mass : 0.0) : (kk == row ? dt : 0.0);
       aB[bi][ks] = dense ? bv : (ok ? synth : 0.0);
     }
@@ -77,7 +84,8 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
         const bool a_dense = in_m && rr >= 3 && rr < 12;
         double av = *(a_dense ? in.A + rr * NX + col : (in_v ? in.b + rr : in.A + 3 * NX));
         if (in_m && !a_dense) av = (rr == col) ? 1.0 : 0.0;          // identity rows of A
-        const double qv = *(in_m ? in.Q + rr * NX + col : (in_v ? in.q + rr : in.Q));
+        double qv = *(in_m ? Qc + rr * NX + col : (in_v ? in.q + rr : in.q));
+        if (in_m) qv = dt * (rr == col ? qv + shift : qv);
         cA[bi][bj][r] = (in_m || in_v) ? av : 0.0;
         cQ[bi][bj][r] = (in_m || in_v) ? qv : 0.0;
       }
@@ -168,7 +176,7 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
 
 template <int NJ>
 __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, int* extent, double dt,
-                                                   double dt_over_mass) {
+                                                   double dt_over_mass, const double* Qc, const double* Rc) {
   using WS = ProjectMfmaWorkspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, LDW = WS::LDW, KR = WS::KR, BC = NX + 1, WC = WS::WC;
   static_assert(NX == NU, "packed layout assumes nx == nu");
@@ -207,9 +215,9 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
   for (int idx = l; idx < NU * (LDW - WC); idx += kWave) ws.X[idx / (LDW - WC)][WC + idx % (LDW - WC)] = 0.0;   // columns beyond [Px Pe Pu]
 
-  if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass);
-  else if (nbc == 3) project_apply_blocks<NJ, 3>(ws, in, out, dt, dt_over_mass);
-  else project_apply_blocks<NJ, (WC + 15) / 16>(ws, in, out, dt, dt_over_mass);
+  if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass, Qc, Rc);
+  else if (nbc == 3) project_apply_blocks<NJ, 3>(ws, in, out, dt, dt_over_mass, Qc, Rc);
+  else project_apply_blocks<NJ, (WC + 15) / 16>(ws, in, out, dt, dt_over_mass, Qc, Rc);
 
   // ---- keep "beyond nut reads as zero": clear what an earlier, wider projection of this node left behind
   const int cov = 16 * (nbc <= 2 ? 2 : nbc) - BC;      // reduced-input indices written by the blocks of this call

@@ -19,6 +19,7 @@ struct ProjectIn {
   int nc;
   const double *C, *D, *e;        // 16*NX, 16*NU, 16
   const double *A, *B, *b, *Q, *R, *P, *q, *r;
+  const double* qrd = nullptr;    // compact node-dependent part of Q, R (linearize_fast.h kQrdStride), fast kernels only
 };
 struct ProjectOut {
   double *Px, *Pu, *Pe;           // NU*NX, NU*NU (first nut columns), NU

@@ -65,6 +65,7 @@ struct Buffers {
   double *Px, *Pu, *Pe, *At, *Bt, *bt, *Qt, *Rt, *Pt, *qt, *rt;
   int* nut;
   double* lin_park;    // per node 15 doubles per lane: scratch of the linearisation kernel
+  double* qrd;         // per node kQrdStride doubles: node-dependent part of Q, R in compact form (linearize_fast.h)
   int* proj_extent;    // per node: reduced-input extent written by the last fast projection (see project_mfma.h)
   // riccati
   double *Kt, *kt, *dx, *du, *K, *summary, *dx0;
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_
   out.A = L.buf.A; out.B = L.buf.B; out.b = L.buf.b; out.Q = L.buf.Q; out.R = L.buf.R; out.q = L.buf.q; out.r = L.buf.r; out.c = L.buf.c;
   out.C = L.buf.C; out.D = L.buf.D; out.e = L.buf.e; out.perf = L.buf.perf; out.nc = L.buf.nc;
   out.park = L.buf.lin_park;
+  out.qrd = L.buf.qrd;
   out.s = s;
   out.prof = (valid && b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
   linearize_fast<NJ>(*L.model, shared, lds[sub], valid, in, out, g);
@@ -237,8 +239,9 @@ __global__ __launch_bounds__(kWave) void k_project_fast(Launch L) {
   out.At = L.buf.At + s * NX * NX; out.Bt = L.buf.Bt + s * NX * NU; out.bt = L.buf.bt + s * NX;
   out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
   out.rt = L.buf.rt + s * NU;
+  in.qrd = L.buf.qrd + s * kQrdStride;
   const double dt = L.buf.g_dt[(size_t)g * L.N + k];
-  project_apply_mfma<NJ>(ws, in, out, L.buf.proj_extent + s, dt, dt * (1.0 / L.model->robot_mass));   // as written by linearize_fast
+  project_apply_mfma<NJ>(ws, in, out, L.buf.proj_extent + s, dt, dt * (1.0 / L.model->robot_mass), L.model->Q, L.model->R);   // as written by linearize_fast
 }
 
 template <int NJ>
@@ -748,6 +751,7 @@ void allocate(bpmpc_solver* s) {
   const size_t B = s->settings.max_batch, N = s->settings.max_nodes, NX = s->nx, NU = s->nu, S = B * N;
   Buffers& b = s->buf;
   b.proj_extent = s->alloc<int>("proj_extent", S, true);
+  b.qrd = s->alloc<double>("qrd", S * kQrdStride);
   b.lin_park = s->alloc<double>("lin_park", S * kLinParkDoublesPerLane * (6 + s->rm.nj <= 16 ? 16 : 32));
   b.x_prev = s->alloc<double>("x_prev", B * (N + 1) * NX); b.u_prev = s->alloc<double>("u_prev", S * NU);
   b.K_prev = s->alloc<double>("K_prev", S * NU * NX);
