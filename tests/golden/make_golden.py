@@ -48,6 +48,32 @@ def main():
         for k in ("A", "B", "b", "Q", "R", "q", "r", "c", "C", "D", "e", "nc", "perf"):
             out["out%d_%s" % (mode, k)] = np.asarray(o[k])
     np.savez_compressed(os.path.join(HERE, "h1_node_lq_modes.npz"), **out)
+    # 4. the loop around the solve: solve -> policy rollout over one MPC period and over a
+    #    window with a gait event -> next solve warm-started from the shifted previous solution at the rolled-out state
+    prob = scenarios.trot_problem(itf, batch=1, n_intervals=30)
+    nodes = ob.oracle_nodes(prob, 0)
+    xi, ui = rp.cold_start(m, nodes, prob["x0"][0])
+    sq = m["sqp"]
+    x1, u1, K1, _ = om.solve(nodes, prob["x0"][0], xi, ui, iterations=1, g_max=sq["g_max"], g_min=sq["g_min"], delta_tol=sq["deltaTol"])
+    tp, xp, uff, KK = rp.primal_solution_arrays(nodes, x1, u1, K1)
+    ev = [float(e) for e in prob["schedule"].eventTimes]
+    ctrl = lambda t, xx: rp.linear_controller_input(tp, uff, KK, t, xx)   # noqa: E731
+    fm = lambda xx, uu: om.flow_map(xx, uu)                               # noqa: E731
+    x_start = prob["x0"][0] + 1e-3 * np.cos(np.arange(22))
+    r_short = rp.time_triggered_rollout(fm, ctrl, 0.0, x_start, 0.02, ev, m["rollout"])
+    r_long = rp.time_triggered_rollout(fm, ctrl, 0.0, x_start, 0.25, ev, m["rollout"])
+    horizon = prob["horizon"]
+    sched2 = scenarios.gait_schedule(itf, "trot", 0.02, horizon)
+    x_meas = r_short["states"][-1]
+    tgt2 = itf.cmdVelToTargetTrajectories((0.3, 0.0, 0.0, 0.0), 0.02, x_meas, horizon)
+    prob2 = dict(t0=0.02, x0=x_meas[None, :], schedule=sched2, targets=[tgt2], horizon=horizon)
+    nodes2 = ob.oracle_nodes(prob2, 0)
+    xw, uw = rp.warm_start_from_previous(m, nodes2, x_meas, nodes, x1, u1, K1)
+    x2, u2, _, s2 = om.solve(nodes2, x_meas, xw, uw, iterations=1, g_max=sq["g_max"], g_min=sq["g_min"], delta_tol=sq["deltaTol"])
+    np.savez_compressed(os.path.join(HERE, "h1_loop_rollout.npz"), x_start=x_start, short_end=r_short["states"][-1], short_u=r_short["inputs"][-1],
+                        short_steps=np.array([r_short["accepted"], r_short["rejected"]]), long_end=r_long["states"][-1], long_times=r_long["times"],
+                        long_steps=np.array([r_long["accepted"], r_long["rejected"]]), long_post=np.array(r_long["post_event_indices"]),
+                        x_second=x2, u_second=u2, step_second=np.array([s2[0][3]]))
     print("golden fixtures written to", HERE)
 
 
