@@ -122,6 +122,15 @@ def main():
 
     t, x, u, _, stats = mpc.fetch()
     ok = sum(1 for s in stats if s.status == 0)
+    # whole-job report: one 32-byte all-reduce of {merit, dynamics SSE, equality SSE, failures}, outside the timed region
+    report = [sum(s.merit_after for s in stats), sum(s.dynamics_sse_after for s in stats), sum(s.equality_sse_after for s in stats), float(len(stats) - ok)]
+    if use_dist:
+        rep = torch.tensor(report, dtype=torch.float64, device="cuda")
+        dist.all_reduce(rep, op=dist.ReduceOp.SUM)
+        report = [float(v) for v in rep.tolist()]
+        gathered_ok = bool(torch.equal(x_all[rank * B:(rank + 1) * B], x_loc))     # the gathered block of this rank is its own result
+    else:
+        gathered_ok = True
     ktimes = {k: mpc.kernel_time(k, reset=False) for k in ("linearize", "project_lu", "project", "riccati", "linesearch")}
 
     if rank == 0:
@@ -157,7 +166,8 @@ def main():
                                                                              "BASELINE.json configs[1]" if (args.robot, args.gait) == ("h1", "trot")
                                                                              else "not the headline workload"),
                           "global_batch": world * B, "shooting_nodes": n_nodes, "intermediate_nodes": n_intermediate, "nx": nx, "nu": nu,
-                          "parallelism": "problem-sharded x%d, all-gather of trajectories overlapped with the next solve" % world, "accepted_steps": ok},
+                          "parallelism": "problem-sharded x%d, all-gather of trajectories overlapped with the next solve" % world, "accepted_steps": ok, "job_report": {"merit_sum": report[0], "dynamics_sse_sum": report[1], "equality_sse_sum": report[2], "failures": int(report[3]),
+                                                                "gather_consistent": gathered_ok}},
                "ms_per_solve": round(ms_per_step / B, 6),
                "kernel_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in ktimes.items()},
                "roofline": roofline}
