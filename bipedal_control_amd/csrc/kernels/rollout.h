@@ -54,6 +54,8 @@ struct RolloutLds {
   LinFastShared<NJ> shared;
   double event[C::NPW][kRolloutMaxEvents];
   int n_events[C::NPW];
+  // controller data of the time segment the integrator is in: K and u of the two (effective) nodes, the two planned states
+  double Kc[C::NPW][2][C::NU * C::NX], uc[C::NPW][2][C::NU], xc[C::NPW][2][C::NX];
 };
 
 template <int LPN>
@@ -108,20 +110,41 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
     if (g < G) nl.x[6 + g] = vq;
     lds_wave_sync();
   };
-  // LinearController::computeInput at time ts for the published state -> nl.u
+  // LinearController::computeInput at time ts for the published state -> nl.u.  The seven stages of a step nearly always fall into
+  // the same segment of the solution's time grid, so its index, the two node times and the controller data (K, u, planned x of both
+  // ends) are kept - the segment test below is LinearInterpolation::timeSegment's own (t_j < t <= t_{j+1}, clamped at the ends).
+  int seg_j = -1;
+  double seg_lo = 0.0, seg_hi = 0.0;
+  const double t_first = tp[0], t_last = tp[n];
   auto controller = [&](double ts) {
-    int j;
-    double al;
-    time_segment(tp, n + 1, ts, &j, &al);
-    const int e0 = effective(j), e1 = effective(j + 1);
+    const bool hit = seg_j >= 0 && ((ts > seg_lo && ts <= seg_hi) || (seg_j == 0 && ts <= seg_lo) || (seg_j == n - 1 && ts >= seg_hi));
+    if (!hit) {
+      int j;
+      double unused;
+      time_segment(tp, n + 1, ts, &j, &unused);
+      seg_j = j; seg_lo = tp[j]; seg_hi = tp[j + 1];
+      const int e0 = effective(j), e1 = effective(j + 1);
+      lds_wave_sync();                                  // earlier readers of the cached rows are done
+      for (int idx = g; idx < NU * NX; idx += LPN) {
+        w.Kc[sub][0][idx] = Kp[(size_t)e0 * NU * NX + idx];
+        w.Kc[sub][1][idx] = Kp[(size_t)e1 * NU * NX + idx];
+      }
+      for (int idx = g; idx < NU; idx += LPN) { w.uc[sub][0][idx] = up[(size_t)e0 * NU + idx]; w.uc[sub][1][idx] = up[(size_t)e1 * NU + idx]; }
+      for (int idx = g; idx < NX; idx += LPN) { w.xc[sub][0][idx] = xp[(size_t)j * NX + idx]; w.xc[sub][1][idx] = xp[(size_t)(j + 1) * NX + idx]; }
+    }
+    lds_wave_sync();
+    double al;                                          // as time_segment: clamped outside the grid
+    if (ts <= t_first) al = 1.0;
+    else if (ts >= t_last) al = 0.0;
+    else al = (seg_hi - ts) / (seg_hi - seg_lo);
     for (int r = g; r < NU; r += LPN) {
-      const double* K0 = Kp + ((size_t)e0 * NU + r) * NX;
-      const double* K1 = Kp + ((size_t)e1 * NU + r) * NX;
-      double s0 = up[(size_t)e0 * NU + r], s1 = up[(size_t)e1 * NU + r];
+      const double* K0 = w.Kc[sub][0] + r * NX;
+      const double* K1 = w.Kc[sub][1] + r * NX;
+      double s0 = w.uc[sub][0][r], s1 = w.uc[sub][1][r];
       for (int c = 0; c < NX; ++c) {
         const double xc = nl.x[c];
-        s0 += K0[c] * (xc - xp[(size_t)j * NX + c]);
-        s1 += K1[c] * (xc - xp[(size_t)(j + 1) * NX + c]);
+        s0 += K0[c] * (xc - w.xc[sub][0][c]);
+        s1 += K1[c] * (xc - w.xc[sub][1][c]);
       }
       nl.u[r] = al * s0 + (1.0 - al) * s1;
     }
