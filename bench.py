@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--intervals", type=int, default=100, help="horizon in shooting intervals of dt = 0.015 s")
     ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not wrap kernels in HIP events")
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel class inside the timed region (default: the linearisation kernel only)")
     ap.add_argument("--robot", default="h1", choices=["h1", "openloong"],
                     help="h1 = the headline workload (nx = nu = 22); openloong = the 24/24 class of BASELINE.json configs[3] (informational)")
     ap.add_argument("--gait", default="trot", help="gait template of the workload (headline: trot)")
@@ -67,7 +68,7 @@ def main():
     prob = scenarios.trot_problem(itf, batch=B, n_intervals=NI, offset=rank * B, gait=args.gait)
     max_nodes = NI + 16
     stream = torch.cuda.current_stream().cuda_stream
-    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=max_nodes, profile=not args.no_profile, device=local, stream=stream,
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=max_nodes, profile=(0 if args.no_profile else (1 if args.profile_all else 2)), device=local, stream=stream,
                            pipeline_chunks=args.chunks)
     lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
     n_nodes = lay["n_nodes_max"]
@@ -122,6 +123,19 @@ def main():
 
     t, x, u, _, stats = mpc.fetch()
     ok = sum(1 for s in stats if s.status == 0)
+    lin_timed = mpc.kernel_time("linearize", reset=False)         # HIP events on the launch stream, over exactly the timed steps
+    kt_steps = args.steps
+    if not args.no_profile and not args.profile_all:
+        # per-kernel breakdown from a short extra pass with every kernel class timed (each event pair costs 1-2 us of stream time,
+        # so the timed region itself only carries the pair around the roofline kernel)
+        mpc.set_profile(1)
+        for k in ("linearize", "project_lu", "project", "riccati", "linesearch"):
+            mpc.kernel_time(k, reset=True)
+        extra = kt_steps = max(3, min(args.steps, 10))
+        for _ in range(extra):
+            step()
+        fence()
+        mpc.synchronize()
     # whole-job report: one 32-byte all-reduce of {merit, dynamics SSE, equality SSE, failures}, outside the timed region
     report = [sum(s.merit_after for s in stats), sum(s.dynamics_sse_after for s in stats), sum(s.equality_sse_after for s in stats), float(len(stats) - ok)]
     if use_dist:
@@ -136,7 +150,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
-        lin_ms, lin_n = ktimes["linearize"]
+        lin_ms, lin_n = lin_timed
         roofline = None
         if lin_n > 0:
             # the horizon is linearised in `launches_per_step` chunk launches: an average launch covers that share of the nodes
@@ -169,7 +183,7 @@ def main():
                           "parallelism": "problem-sharded x%d, all-gather of trajectories overlapped with the next solve" % world, "accepted_steps": ok, "job_report": {"merit_sum": report[0], "dynamics_sse_sum": report[1], "equality_sse_sum": report[2], "failures": int(report[3]),
                                                                 "gather_consistent": gathered_ok}},
                "ms_per_solve": round(ms_per_step / B, 6),
-               "kernel_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in ktimes.items()},
+               "kernel_ms_per_step": {k: round(v[0] / max(1, kt_steps), 4) for k, v in ktimes.items()},
                "roofline": roofline}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(prob, min(args.cpu_sample, B), x, u, stats, args.robot)

@@ -217,7 +217,7 @@ class BatchedSqpMpc:
         self.max_batch, self.max_nodes = int(max_batch), int(max_nodes)
         self.nx, self.nu = interface.stateDim, interface.inputDim
         self.return_gains = bool(return_gains)
-        st = _Settings(int(device), self.max_batch, self.max_nodes, int(sqp_iterations), float(dt), int(bool(return_gains)), int(bool(profile)),
+        st = _Settings(int(device), self.max_batch, self.max_nodes, int(sqp_iterations), float(dt), int(bool(return_gains)), int(profile),
                        C.c_void_p(stream) if stream else None, int(bool(reference_kernels)), int(pipeline_chunks))
         self._h = C.c_void_p()
         _check(lib.bpmpc_solver_create(interface.handle, C.byref(st), C.byref(self._h)))
@@ -372,6 +372,10 @@ class BatchedSqpMpc:
         out = np.zeros(cap)
         n = _check(lib.bpmpc_solver_read(self._h, name.encode(), _d(out), C.c_long(cap)))
         return out[:n].copy()
+
+    def set_profile(self, level):
+        """0 off, 1 every kernel class, 2 the linearisation kernel only."""
+        _check(load_library().bpmpc_solver_set_profile(self._h, int(level)))
 
     def kernel_time(self, kernel, reset=True):
         ms, n = C.c_double(), C.c_int()

@@ -103,7 +103,7 @@ typedef struct {
   int sqp_iterations;   /* <= 0: sqp.sqpIteration of task.info */
   double dt;            /* <= 0: sqp.dt of task.info */
   int return_gains;     /* allocate and compute the feedback gains K (sqp.useFeedbackPolicy) */
-  int profile;          /* time every kernel class with HIP events (bpmpc_solver_kernel_time) */
+  int profile;          /* HIP-event timing (bpmpc_solver_kernel_time): 0 off, 1 every kernel class, 2 the linearisation kernel only */
   void* stream;         /* hipStream_t to run on; NULL = a stream owned by the solver */
   int reference_kernels; /* != 0: run the lane-emulation-verified reference kernel bodies instead of the fast variants (debugging) */
   int pipeline_chunks;  /* > 1: sweep the horizon in that many chunks, the Riccati sweep of one chunk overlapping with the
@@ -212,6 +212,8 @@ int bpmpc_solver_device_trajectories(bpmpc_solver* solver, double** x_dev, doubl
 /* Asynchronous device-to-device copy of the iterate into caller-owned device buffers (same shapes as above) on the
  * solver's stream - e.g. torch tensors that are then all-gathered over RCCL. */
 int bpmpc_solver_export_trajectories(bpmpc_solver* solver, double* x_dst_dev, double* u_dst_dev);
+/* Change settings.profile of a live solver (0 / 1 / 2 as above). */
+int bpmpc_solver_set_profile(bpmpc_solver* solver, int level);
 /* Accumulated HIP-event time of one kernel class since the last call with reset != 0 (needs settings.profile):
  * "prepare","linearize","project","riccati","linesearch". */
 int bpmpc_solver_kernel_time(bpmpc_solver* solver, const char* kernel, int reset, double* total_ms, int* launches);
