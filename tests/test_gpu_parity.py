@@ -259,3 +259,35 @@ def test_repeated_solves_are_bit_identical(ctx, batch):
         xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
         n = st[b].n_nodes
         assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8 and _rel(K[b, :n], Ko) < 1e-7
+
+
+@pytest.mark.parametrize("n_intervals,max_nodes", [(1, 8), (2, 8), (3, 8), (450, 512)])
+def test_shortest_and_longest_horizons(ctx, n_intervals, max_nodes):
+    """One to three intervals, and a horizon that fills the solver's maximum of 512 stages (482 nodes with the gait events)."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=2, n_intervals=n_intervals)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=2, max_nodes=max_nodes, return_gains=True)
+    t, x, u, K, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    n = st[0].n_nodes
+    assert n >= n_intervals and all(s.status == 0 for s in st)
+    xo, uo, Ko, so = ob.oracle_solve_like(prob, 1)
+    assert xo.shape[0] == n + 1 and st[1].step_size == so[0][3]
+    assert _rel(x[1, :n + 1], xo) < 1e-8 and _rel(u[1, :n], uo) < 1e-8 and _rel(K[1, :n], Ko) < 1e-7
+
+
+@pytest.mark.parametrize("t0", [0.175, 0.175 - 30 * 0.015])
+def test_gait_event_on_the_window_boundaries(ctx, t0):
+    """A mode switch exactly at the initial time resp. exactly at the final time of the horizon (events at -1.225 + 0.35 k)."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    horizon = 30 * sc.DT
+    sched = sc.gait_schedule(itf, "trot", t0, horizon)
+    ev = np.asarray(sched.eventTimes)
+    assert np.any(np.abs(ev - t0) < 1e-12) or np.any(np.abs(ev - (t0 + horizon)) < 1e-12)
+    x0 = sc.perturbed_initial_states(itf, 1)
+    tg = [itf.cmdVelToTargetTrajectories((0.3, 0.0, 0.0, 0.0), t0, x0[0], horizon)]
+    prob = dict(t0=t0, x0=x0, schedule=sched, targets=tg, horizon=horizon)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=1, max_nodes=48)
+    t, x, u, _, st = mpc.run(t0, x0, sched, tg, horizon=horizon)
+    n = st[0].n_nodes
+    xo, uo, _, _ = ob.oracle_solve_like(prob, 0)
+    assert xo.shape[0] == n + 1 and _rel(x[0, :n + 1], xo) < 1e-8 and _rel(u[0, :n], uo) < 1e-8
