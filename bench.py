@@ -77,11 +77,13 @@ def main():
     nx, nu = itf.stateDim, itf.inputDim
 
     # result buffers owned by torch so that RCCL can gather them
-    x_loc = torch.empty((B, max_nodes + 1, nx), dtype=torch.float64, device="cuda")
-    u_loc = torch.empty((B, max_nodes, nu), dtype=torch.float64, device="cuda")
+    # (one flat block per rank, [x | u], so that a step needs a single collective)
+    n_x, n_u = B * (max_nodes + 1) * nx, B * max_nodes * nu
+    xu_loc = torch.empty(n_x + n_u, dtype=torch.float64, device="cuda")
+    x_loc = xu_loc[:n_x].view(B, max_nodes + 1, nx)
+    u_loc = xu_loc[n_x:].view(B, max_nodes, nu)
     if use_dist:
-        x_all = torch.empty((world * B, max_nodes + 1, nx), dtype=torch.float64, device="cuda")
-        u_all = torch.empty((world * B, max_nodes, nu), dtype=torch.float64, device="cuda")
+        xu_all = torch.empty(world * (n_x + n_u), dtype=torch.float64, device="cuda")
 
     pending = []           # the all-gather of step i runs on RCCL's stream while step i + 1 is being solved
 
@@ -95,8 +97,7 @@ def main():
         drain()
         mpc.export_trajectories(x_loc.data_ptr(), u_loc.data_ptr())
         if use_dist:
-            pending.append(dist.all_gather_into_tensor(x_all, x_loc, async_op=True))
-            pending.append(dist.all_gather_into_tensor(u_all, u_loc, async_op=True))
+            pending.append(dist.all_gather_into_tensor(xu_all, xu_loc, async_op=True))
 
     def fence():
         drain()
@@ -142,7 +143,7 @@ def main():
         rep = torch.tensor(report, dtype=torch.float64, device="cuda")
         dist.all_reduce(rep, op=dist.ReduceOp.SUM)
         report = [float(v) for v in rep.tolist()]
-        gathered_ok = bool(torch.equal(x_all[rank * B:(rank + 1) * B], x_loc))     # the gathered block of this rank is its own result
+        gathered_ok = bool(torch.equal(xu_all[rank * (n_x + n_u):(rank + 1) * (n_x + n_u)], xu_loc))     # the gathered block of this rank is its own result
     else:
         gathered_ok = True
     ktimes = {k: mpc.kernel_time(k, reset=False) for k in ("linearize", "project_lu", "project", "riccati", "linesearch")}
@@ -190,7 +191,7 @@ def main():
         print(json.dumps(out))
     if use_dist:
         # the gathered block of this rank must equal its local result
-        assert torch.equal(x_all[rank * B:(rank + 1) * B], x_loc) and torch.equal(u_all[rank * B:(rank + 1) * B], u_loc)
+        assert torch.equal(xu_all[rank * (n_x + n_u):(rank + 1) * (n_x + n_u)], xu_loc)
         dist.barrier()
         dist.destroy_process_group()
 
