@@ -53,6 +53,7 @@ struct DevSchedule {
   double* ev;
   int* ms;
   int ne, nm, cap, status;
+  double keep_from;      // events more than one phase in front of this time are never looked at again (GaitSchedule::getModeSchedule drops them)
 };
 
 #define BPMPC_EXACT_FP _Pragma("clang fp contract(off)")   // first statement of a body: no fused multiply-add, as on the host
@@ -63,8 +64,20 @@ __device__ inline int ref_lower_bound(const double* a, int n, double t) {   // f
   return lo;
 }
 __device__ inline bool ref_contact(int mode, int c) { return c < 2 ? (mode == 1 || mode == 3) : (mode == 2 || mode == 3); }
-__device__ inline void ref_push_ev(DevSchedule& s, double t) { if (s.ne < s.cap) s.ev[s.ne++] = t; else s.status = kRefCapacity; }
-__device__ inline void ref_push_ms(DevSchedule& s, int m) { if (s.nm < s.cap + 1) s.ms[s.nm++] = m; else s.status = kRefCapacity; }
+// A long-running gait is tiled from its insertion time, so the schedule grows with t0; what lies more than one phase in front of the
+// window is dropped on the way (exactly what getModeSchedule would erase at the end), the event times themselves are the same
+// repeated additions.
+__device__ inline bool ref_compact(DevSchedule& s) {
+  const int drop = ref_lower_bound(s.ev, s.ne, s.keep_from) - 1;
+  if (drop <= 0) { s.status = kRefCapacity; return false; }
+  for (int i = 0; i + drop < s.ne; ++i) s.ev[i] = s.ev[i + drop];
+  for (int i = 0; i + drop < s.nm; ++i) s.ms[i] = s.ms[i + drop];
+  s.ne -= drop;
+  s.nm -= drop;
+  return true;
+}
+__device__ inline void ref_push_ev(DevSchedule& s, double t) { if (s.ne < s.cap || ref_compact(s)) s.ev[s.ne++] = t; }
+__device__ inline void ref_push_ms(DevSchedule& s, int m) { if (s.nm < s.cap + 1 || ref_compact(s)) s.ms[s.nm++] = m; }
 
 __device__ inline void ref_tile(DevSchedule& s, const double* sw, const int* modes, int phases, double start, double final_time) {
   BPMPC_EXACT_FP
@@ -83,7 +96,7 @@ __device__ inline void ref_tile(DevSchedule& s, const double* sw, const int* mod
 // mode_schedule(t0 - H, t0 + 2 H): what SwitchedModelReferenceManager::modifyReferences asks for at solve time.
 __device__ inline void ref_build_schedule(RefGenLds& w, const GaitLibraryView& lib, int gait, double start, double t0, double horizon) {
   BPMPC_EXACT_FP
-  DevSchedule s{w.ev, w.ms, 0, 0, kRefMaxEvents, kRefOk};
+  DevSchedule s{w.ev, w.ms, 0, 0, kRefMaxEvents, kRefOk, t0 - horizon};
   for (int i = 0; i < lib.init_n_events; ++i) ref_push_ev(s, lib.init_events[i]);
   for (int i = 0; i <= lib.init_n_events; ++i) ref_push_ms(s, lib.init_modes[i]);
   int tmpl = lib.n_templates - 1;

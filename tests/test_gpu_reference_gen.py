@@ -204,3 +204,24 @@ def test_config5_gait_library_sweep_full_size(ctx):
         n = st[i].n_nodes
         assert xo.shape[0] == n + 1
         assert np.abs(x[i, :n + 1] - xo).max() / max(1.0, np.abs(xo).max()) < 1e-8 and np.abs(u[i, :n] - uo).max() / max(1.0, np.abs(uo).max()) < 1e-8
+
+
+def test_long_running_gait_is_tiled_without_growing(ctx):
+    """t0 = 512.3 s: the trot has been tiled for ~1470 events since its insertion, far more than the device keeps (448); what lies in
+    front of the window is dropped while tiling, the tables still equal the host pre-pass bit for bit."""
+    bp, sc, ob, itf, tm = ctx
+    prob = _problem(sc, itf, [512.3], ["trot", "flying_trot"], [(0.3, 0.0, 0.0, 0.1)], 40)
+    nb = len(prob["t0"])
+    assert len(prob["schedule"][0].eventTimes) < 30          # the host keeps only the window, too
+    host = bp.BatchedSqpMpc(itf, max_batch=nb, max_nodes=64)
+    dev = bp.BatchedSqpMpc(itf, max_batch=nb, max_nodes=64)
+    host.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    dev.setup_commands(prob["t0"], prob["x0"], tm, prob["gait_of_problem"], prob["gait_start"], prob["cmd_vel"], horizon=prob["horizon"])
+    th, td = _tables(host, nb), _tables(dev, nb)
+    for name in ("g_kind", "g_mode", "g_dt", "g_start", "g_zref", "g_zdref", "nodes"):
+        assert np.array_equal(th[name], td[name]), name
+    host.enqueue(); dev.enqueue()
+    _, x1, u1, _, s1 = host.fetch()
+    _, x2, u2, _, s2 = dev.fetch()
+    n = s1[0].n_nodes
+    assert np.abs(x1[:, :n + 1] - x2[:, :n + 1]).max() < 1e-9 and all(s.status == 0 for s in s2)
