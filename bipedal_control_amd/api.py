@@ -299,11 +299,15 @@ class BatchedSqpMpc:
         self.batch = B
         return self.layout()
 
-    def rollout(self, duration, t_start=None, x_start=None):
-        """MRT_BASE::rolloutPolicy for the batch (bpmpc_solver_rollout): returns (x_end, u_end, steps[batch, 2])."""
+    def rollout(self, duration, t_start=None, x_start=None, fetch=True):
+        """MRT_BASE::rolloutPolicy for the batch (bpmpc_solver_rollout): returns (x_end, u_end, steps[batch, 2]); fetch=False only
+        enqueues (the end states stay on the device for setup_commands(x0=None))."""
         B = self.batch
         ts = None if t_start is None else _f64(np.broadcast_to(np.asarray(t_start, float), (B,)))
         xs = None if x_start is None else _f64(x_start).reshape(B, self.nx)
+        if not fetch:
+            _check(load_library().bpmpc_solver_rollout(self._h, _d(ts), _d(xs), C.c_double(duration), None, None, None))
+            return None
         x_end, u_end, steps = np.zeros((B, self.nx)), np.zeros((B, self.nu)), np.zeros((B, 2), np.int32)
         _check(load_library().bpmpc_solver_rollout(self._h, _d(ts), _d(xs), C.c_double(duration), _d(x_end), _d(u_end), _i(steps)))
         return x_end, u_end, steps

@@ -538,6 +538,7 @@ struct bpmpc_solver {
   bool riccati_double_buffered() const { return batch <= num_cus || rm.nj != 10; }
   bool has_solution = false;                               // a solve has completed on the current setup
   bool has_rollout = false;                                // roll_x holds the end states of a rollout
+  bool rollout_unchecked = false;                          // ... whose status flags have not been read back yet
   std::vector<int> grid_kind;                               // host copy of the node kinds of the current setup [n_grids][N]
   int max_rows = kMaxEqRows;                                // largest number of equality rows over the nodes of the current setup
   bool cold = true;
@@ -935,6 +936,8 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   finish_setup(s, batch, warm_x, warm_u, from_previous);
 }
 
+void check_rollout_status(bpmpc_solver* s, int* steps);
+
 // Device-side reference generation: the same tables as setup(), built on the GPU from gait
 // templates and velocity commands; the host only groups problems by (t0, gait, gait start) and reads the grid sizes back.
 void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_gait_template* gaits, int n_gaits,
@@ -943,6 +946,7 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
   if (batch < 1 || batch > s->settings.max_batch) throw std::length_error("batch exceeds the solver's max_batch");
   if (!(horizon > 0) || !t0 || !cmd_vel || n_gaits < 0 || (n_gaits > 0 && !gaits)) throw std::invalid_argument("setup_commands: null or invalid argument");
   if (!x0 && (!s->has_rollout || batch != s->batch)) throw std::invalid_argument("setup_commands: x0 == NULL needs a rollout of the same batch on the handle");
+  if (!x0 && s->rollout_unchecked) check_rollout_status(s, nullptr);
   if (command_kind != 0 && command_kind != 1) throw std::invalid_argument("setup_commands: command_kind is 0 (velocity) or 1 (goal pose)");
   if (n_gaits > 0 && (!gait_of_problem || !gait_start)) throw std::invalid_argument("setup_commands: gait_of_problem and gait_start are needed with templates");
   const int N = s->settings.max_nodes, NX = s->nx;
@@ -1037,6 +1041,22 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
 }
 
 
+// reads the per-problem flags of the last rollout back (synchronises) and reports failures like the reference's integrator does
+void check_rollout_status(bpmpc_solver* s, int* steps) {
+  const int B = s->batch;
+  std::vector<int> status(B), st(2 * B);
+  HIP_CHECK(hipMemcpyAsync(status.data(), s->buf.roll_status, B * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipMemcpyAsync(st.data(), s->buf.roll_steps, 2 * B * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  s->rollout_unchecked = false;
+  if (steps) std::copy(st.begin(), st.end(), steps);
+  for (int b = 0; b < B; ++b) {
+    if (status[b] == 1) throw std::runtime_error("rollout of problem " + std::to_string(b) + ": integration terminated, max number of steps reached");
+    if (status[b] == 2) throw std::runtime_error("rollout of problem " + std::to_string(b) + ": max number of iterations exceeded, a new step size was not found");
+    if (status[b] == 3) throw std::length_error("rollout of problem " + std::to_string(b) + ": more than " + std::to_string(kRolloutMaxEvents) + " events in the window");
+  }
+}
+
 // MRT_BASE::rolloutPolicy for the whole batch (kernels/rollout.h): integrates every problem from (t_start, x_start) over `duration`
 // under the LinearController of the last solve.  NULL t_start / x_start: the initial time / measured state of that solve.
 void rollout(bpmpc_solver* s, const double* t_start, const double* x_start, double duration, double* x_end, double* u_end, int* steps) {
@@ -1058,19 +1078,14 @@ void rollout(bpmpc_solver* s, const double* t_start, const double* x_start, doub
   if (s->rm.nj == 10) hipLaunchKernelGGL(k_rollout<10>, dim3((B + LinFastCfg<10>::NPW - 1) / LinFastCfg<10>::NPW), dim3(kWave), 0, s->stream, s->d_model, a);
   else hipLaunchKernelGGL(k_rollout<12>, dim3((B + LinFastCfg<12>::NPW - 1) / LinFastCfg<12>::NPW), dim3(kWave), 0, s->stream, s->d_model, a);
   HIP_CHECK(hipGetLastError());
-  std::vector<int> status(B), st(2 * B);
-  HIP_CHECK(hipMemcpyAsync(status.data(), bf.roll_status, B * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-  HIP_CHECK(hipMemcpyAsync(st.data(), bf.roll_steps, 2 * B * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-  if (x_end) HIP_CHECK(hipMemcpyAsync(x_end, bf.roll_x, (size_t)B * NX * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  if (u_end) HIP_CHECK(hipMemcpyAsync(u_end, bf.roll_u, (size_t)B * NU * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  HIP_CHECK(hipStreamSynchronize(s->stream));
-  if (steps) std::copy(st.begin(), st.end(), steps);
   s->has_rollout = true;
-  for (int b = 0; b < B; ++b) {
-    if (status[b] == 1) throw std::runtime_error("rollout of problem " + std::to_string(b) + ": integration terminated, max number of steps reached");
-    if (status[b] == 2) throw std::runtime_error("rollout of problem " + std::to_string(b) + ": max number of iterations exceeded, a new step size was not found");
-    if (status[b] == 3) throw std::length_error("rollout of problem " + std::to_string(b) + ": more than " + std::to_string(kRolloutMaxEvents) + " events in the window");
+  if (!x_end && !u_end && !steps) {                 // nothing to hand back: stay asynchronous; the status is looked at by the next
+    s->rollout_unchecked = true;                    // setup_commands(x0 = NULL), which reads its own flags back anyway
+    return;
   }
+  check_rollout_status(s, steps);
+  if (x_end) HIP_CHECK(hipMemcpy(x_end, bf.roll_x, (size_t)B * NX * sizeof(double), hipMemcpyDeviceToHost));
+  if (u_end) HIP_CHECK(hipMemcpy(u_end, bf.roll_u, (size_t)B * NU * sizeof(double), hipMemcpyDeviceToHost));
 }
 
 void reset(bpmpc_solver* s) {

@@ -191,7 +191,8 @@ int bpmpc_solver_setup_commands(bpmpc_solver* solver, int batch, double horizon,
  * the window; what MRT_ROS_Dummy_Loop (ocs2_bipedal_robot_ros/src/BipedalRobotDummyNode.cpp:72-86) and BipedalController.cpp:322
  * obtain through initRollout.  t_start / x_start NULL: initial time / measured state of the last solve.  Outputs (nullable):
  * x_end[batch*nx], u_end[batch*nu] (the policy at the end point), steps[batch*2] (accepted, rejected integrator steps).  The end
- * states also stay on the device: bpmpc_solver_setup_commands(x0 = NULL) starts the next solve from them. */
+ * states also stay on the device: bpmpc_solver_setup_commands(x0 = NULL) starts the next solve from them; with all three outputs
+ * NULL the call only enqueues and integrator failures are reported by that next setup. */
 int bpmpc_solver_rollout(bpmpc_solver* solver, const double* t_start, const double* x_start, double duration, double* x_end,
                          double* u_end, int* steps);
 int bpmpc_solver_reset(bpmpc_solver* solver);   /* restore the initial iterate of the last setup (device-side copy, async) */

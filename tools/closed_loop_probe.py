@@ -23,7 +23,8 @@ tt = dict(setup=0.0, solve=0.0, rollout=0.0)
 mpc.setup_commands(0.0, x0, tm, gop, sc.GAIT_START, cmd, horizon=horizon)
 for k in range(ticks):
     t = time.perf_counter(); mpc.enqueue(); mpc.synchronize(); tt["solve"] += time.perf_counter() - t
-    t = time.perf_counter(); xe, ue, st = mpc.rollout(period); tt["rollout"] += time.perf_counter() - t
+    t = time.perf_counter(); out = mpc.rollout(period, fetch=(k == ticks - 1)); tt["rollout"] += time.perf_counter() - t
+    if out is not None: xe, ue, st = out
     t = time.perf_counter(); mpc.setup_commands((k + 1) * period, None, tm, gop, sc.GAIT_START, cmd, horizon=horizon, from_previous=True); tt["setup"] += time.perf_counter() - t
 tot = sum(tt.values())
 print("closed loop, %d robots x %d ticks of %.0f ms: %.2f ms per tick (setup %.2f, solve %.2f, rollout %.2f) = %.0f robot-ticks/s; base height %.3f..%.3f m, forward speed mean %.2f m/s"
