@@ -28,19 +28,20 @@ struct LinFastCfg {
 // Model constants that the lanes index by their own coordinate, staged once per workgroup.  Reading them from global
 // memory inside the node would put vector loads behind the node's output stores (vmcnt retires in order on this
 // architecture), i.e. every such load would wait for the stores in flight.
-template <int NJ>
+template <int NJ, bool COST = true>   // COST = false: without the cost weights (the value-only kernels read them from global memory)
 struct LinFastShared {
   using C = LinFastCfg<NJ>;
-  double Q[C::NX * C::NX], R[C::NU * C::NU];
+  double Q[COST ? C::NX * C::NX : 1], R[COST ? C::NU * C::NU : 1];
   double Rfix[C::NB][9], pfix[C::NB][3], axis[C::NB][3], com[C::NB][3], inertia[C::NB][6], mass[C::NB];
   int depth[C::NB];
   unsigned subtree[C::NB];
   int path[C::NB][NJ];
 };
-template <int NJ>
-__device__ __forceinline__ void load_shared_model(const DeviceModel& md, LinFastShared<NJ>& sh, int tid, int nthreads) {
+template <int NJ, bool COST>
+__device__ __forceinline__ void load_shared_model(const DeviceModel& md, LinFastShared<NJ, COST>& sh, int tid, int nthreads) {
   using C = LinFastCfg<NJ>;
-  for (int i = tid; i < C::NX * C::NX; i += nthreads) { sh.Q[i] = md.Q[i]; sh.R[i] = md.R[i]; }
+  if constexpr (COST)
+    for (int i = tid; i < C::NX * C::NX; i += nthreads) { sh.Q[i] = md.Q[i]; sh.R[i] = md.R[i]; }
   for (int i = tid; i < C::NB * 9; i += nthreads) sh.Rfix[i / 9][i % 9] = md.Rfix[i / 9][i % 9];
   for (int i = tid; i < C::NB * 6; i += nthreads) sh.inertia[i / 6][i % 6] = md.inertia[i / 6][i % 6];
   for (int i = tid; i < C::NB * 3; i += nthreads) {
@@ -56,7 +57,7 @@ template <int NJ, bool FULL = true>   // FULL = false: value-only evaluation (li
 struct LinFastNodeLds {
   using C = LinFastCfg<NJ>;
   // node inputs, staged once so that nothing is loaded from global memory after the first output store
-  double x[C::NX], u[C::NU], zref[kNumContacts], zdref[kNumContacts];
+  double x[C::NX], u[C::NU], zref[FULL ? kNumContacts : 1], zdref[FULL ? kNumContacts : 1];   // value-only: swing references straight from HBM
   double xh2[9];                 // normalised momentum and base position of the second RK2 stage (the first stage reads x[0..8])
   union {                        // chain tables (dead after the walks)  <->  second-stage block
     double T[NJ][12];            // joint-local transform of joint g-6: E (9) | pfix (3)
@@ -70,7 +71,7 @@ struct LinFastNodeLds {
   double og[C::G - 3][3];        // joint origins (coordinates 3..)
   double wv[C::G - 3][3];        // a_g * v_g
   double cpos[kNumContacts][3], cvel[kNumContacts][3];
-  double cone[kNumContacts][13];
+  double cone[FULL ? kNumContacts : 1][FULL ? 13 : 1];   // value-only: the barrier value stays in the lane that computes it
   // node-level results of the two stages: A_b^{-1} blocks, 1/m, contact points and com
   double X12[FULL ? 2 : 1][FULL ? 9 : 1], X22[FULL ? 2 : 1][FULL ? 9 : 1], cps[FULL ? 2 : 1][FULL ? kNumContacts : 1][3], com[FULL ? 2 : 1][3];
 };
@@ -154,8 +155,8 @@ struct LaneKin {    // what the contact part needs from the evaluation
 #else
 #define EVPROF(slot) ((void)0)
 #endif
-template <int NJ, bool DERIV = true, bool TWIST = true, class NodeLds = LinFastNodeLds<NJ>>
-__device__ __forceinline__ void eval_lane(const DeviceModel& md, const LinFastShared<NJ>& sh, NodeLds& nl, int stage, const LaneBody& lb, const int* path, int g,
+template <int NJ, bool DERIV = true, bool TWIST = true, class NodeLds = LinFastNodeLds<NJ>, class Shared = LinFastShared<NJ>>
+__device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& sh, NodeLds& nl, int stage, const LaneBody& lb, const int* path, int g,
                                           const double* xh /*LDS: momentum [6], base position [3]*/, double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin,
                                           long long* evp = nullptr) {
 #ifdef BPMPC_EVAL_PROFILE
@@ -757,7 +758,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
 // Value-only metrics of x + alpha dx, u + alpha du at one node for the filter line search (same lane layout as
 // linearize_fast; reference version: trial_node in linesearch.h).
 template <int NJ>
-__device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ, false>& nl, bool valid,
+__device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastShared<NJ, false>& sh, LinFastNodeLds<NJ, false>& nl, bool valid,
                                            const NodeInputs& in, double alpha, const double* dx, const double* du, const double* dxn,
                                            double* perf, int g) {
   using C = LinFastCfg<NJ>;
@@ -782,7 +783,6 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   }
   const double xn_q = g < G ? in.xnext[6 + g] + alpha * dxn[6 + g] : 0.0, xn_h = g < 6 ? in.xnext[g] + alpha * dxn[g] : 0.0;
   const double xr_q = g < G ? in.xref[6 + g] : 0.0, xr_h = g < 6 ? in.xref[g] : 0.0;
-  if (g < kNumContacts) { nl.zref[g] = in.zref[g]; nl.zdref[g] = in.zdref[g]; }
   LaneBody lb;
   {
     const int body = (g >= 5 && g < G) ? g - 5 : 0;
@@ -807,7 +807,8 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
         cross3(kin.omg, r, t);
         for (int a = 0; a < 3; ++a) nl.cvel[i][a] = kin.vog[a] + t[a];
       }
-  if (g < kNumContacts && stance_flag(mode, g)) cone_terms(md, &nl.u[3 * g], false, nl.cone[g]);
+  double cone_own[4] = {0.0, 0.0, 0.0, 0.0};          // h, barrier value, first and second derivative of this lane's contact
+  if (g < kNumContacts && stance_flag(mode, g)) cone_terms(md, &nl.u[3 * g], false, cone_own);
   lds_wave_sync();
   double eq_sse = 0.0;
   for (int i = 0; i < kNumContacts; ++i) {
@@ -820,13 +821,13 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
       }
     } else {
       for (int a = 0; a < 3; ++a) { const double ev = nl.u[3 * i + a]; eq_sse += ev * ev; }
-      double ev = nl.cvel[i][2] - nl.zdref[i];
-      if (md.pos_gain != 0.0) ev += md.pos_gain * (cz - nl.zref[i]);
+      double ev = nl.cvel[i][2] - in.zdref[i];
+      if (md.pos_gain != 0.0) ev += md.pos_gain * (cz - in.zref[i]);
       eq_sse += ev * ev;
     }
   }
   double cone_pen = 0.0;
-  if (g < kNumContacts && stance_flag(mode, g)) cone_pen = nl.cone[g][1];
+  if (g < kNumContacts && stance_flag(mode, g)) cone_pen = cone_own[1];
   LaneEval e2;
   {
     if (g < 6) nl.xh2[g] = xh[g] + dt * lane_pick6(e1.fh, g);
@@ -858,10 +859,10 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
     double accq = 0.0, acch = 0.0, accf = 0.0, accj = 0.0;
     for (int r = 0; r < NX; ++r) {
       const double dxr = nl.dx[r], dur = nl.du[r];
-      if (g < G) accq += sh.Q[cq * NX + r] * dxr;
-      if (g < 6) acch += sh.Q[ch * NX + r] * dxr;
-      if (g < 12) accf += sh.R[cf * NU + r] * dur;
-      if (is_joint) accj += sh.R[cj * NU + r] * dur;
+      if (g < G) accq += md.Q[cq * NX + r] * dxr;       // cost weights from global memory (cache resident): this kernel stores next to nothing,
+      if (g < 6) acch += md.Q[ch * NX + r] * dxr;       // so the loads never queue behind stores, and the LDS they would take buys a third
+      if (g < 12) accf += md.R[cf * NU + r] * dur;      // workgroup per CU
+      if (is_joint) accj += md.R[cj * NU + r] * dur;
     }
     if (g < G) cost += 0.5 * nl.dx[cq] * accq;
     if (g < 6) cost += 0.5 * nl.dx[ch] * acch;

@@ -51,7 +51,7 @@ template <int NJ>
 struct RolloutLds {
   using C = LinFastCfg<NJ>;
   LinFastNodeLds<NJ, false> node[C::NPW];
-  LinFastShared<NJ> shared;
+  LinFastShared<NJ, false> shared;
   double event[C::NPW][kRolloutMaxEvents];
   int n_events[C::NPW];
   // controller data of the time segment the integrator is in: K and u of the two (effective) nodes, the two planned states
@@ -74,7 +74,7 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
   const bool valid = bq < a.batch;
   const int b = valid ? bq : 0;
   LinFastNodeLds<NJ, false>& nl = w.node[sub];
-  const LinFastShared<NJ>& sh = w.shared;
+  const LinFastShared<NJ, false>& sh = w.shared;
   const int N = a.N, grid = a.p_grid[b], n = a.g_nodes[grid];
   const double* tp = a.g_time + (size_t)grid * (N + 1);
   const int* kp = a.g_kind + (size_t)grid * N;

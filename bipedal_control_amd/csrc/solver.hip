@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kTrialWaves * kWave) void k_trial_fast(Launch L) {
   using C = LinFastCfg<NJ>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
   __shared__ LinFastNodeLds<NJ, false> lds[kTrialWaves * NPW];
-  __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
+  __shared__ LinFastShared<NJ, false> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
   load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(kDecideThreads) void k_ls_tail(Launch L, int max_tr
   const int b = blockIdx.x;
   if (L.buf.done[b]) return;
   __shared__ LinFastNodeLds<NJ, false> lds[CHUNK];
-  __shared__ LinFastShared<NJ> shared;
+  __shared__ LinFastShared<NJ, false> shared;
   __shared__ double partial[3 * kDecideThreads + 5];
   load_shared_model<NJ>(*L.model, shared, threadIdx.x, kDecideThreads);
   __syncthreads();
