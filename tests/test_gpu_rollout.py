@@ -127,3 +127,23 @@ def test_openloong_device_prepass_and_rollout(ctx):
             assert (int(steps[b, 0]), int(steps[b, 1])) == (r["accepted"], r["rejected"])
             assert np.abs(x_end[b] - r["states"][-1]).max() < 1e-9
             assert np.abs(u_end[b] - r["inputs"][-1]).max() / max(1.0, np.abs(r["inputs"][-1]).max()) < 1e-8
+
+
+def test_rollout_degenerate_windows(ctx):
+    """Zero duration returns the start state without a step; a negative duration is an argument error; a window that reaches past
+    the end of the solution keeps using the last segment of the controller (clamped interpolation), like the oracle."""
+    bp, sc, ob, rp, itf = ctx
+    prob = sc.trot_problem(itf, batch=2, n_intervals=20)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=2, max_nodes=32, return_gains=True)
+    t, x, u, K, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    n = st[0].n_nodes
+    xe, ue, steps = mpc.rollout(0.0)
+    assert np.array_equal(xe, prob["x0"]) and not steps.any()
+    with pytest.raises(bp.BpmpcError):
+        mpc.rollout(-0.01)
+    xs = prob["x0"] + 1e-3
+    t_start = prob["horizon"] - 0.01                              # 10 ms before the end of the solution, 30 ms window
+    xe, ue, steps = mpc.rollout(0.03, t_start=t_start, x_start=xs)
+    for b in range(2):
+        r = _oracle_rollout(ob, rp, prob, b, x, u, K, n, t_start, xs[b], 0.03)
+        assert (int(steps[b, 0]), int(steps[b, 1])) == (r["accepted"], r["rejected"]) and np.abs(xe[b] - r["states"][-1]).max() < 1e-9
