@@ -30,7 +30,7 @@ struct ProjectMfmaWorkspace {
   static constexpr int WC = NX + 1 + NU;
   static constexpr int LDW = ((WC + 15) / 16) * 16 + 2;
   alignas(16) double X[KR][LDW];        // [Px | Pe | Pu], zero padded
-  alignas(16) double RX[KR][LDW];       // R X + [0 | r | 0]
+  alignas(16) double RX[KR][16 + 2];    // one block column of R X + [0 | r | 0] at a time (13 KB of LDS per wave in total: 12 waves per CU)
 };
 
 // The three products for a compile-time number of block columns NBC (packed width nx + 1 + nut <= 16 NBC).  Everything
@@ -94,25 +94,8 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
   static_assert(NX >= 16 && NX < 32, "column nx sits in block column 1");
   lds_wave_sync();                                     // X is in LDS (written by the caller)
 
-  // ---- RX = R X + [0 | r | 0]
-#pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-    for (int bj = 0; bj < NBC; ++bj) {
-      double b[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) b[ks] = ws.X[4 * ks + lk][16 * bj + li];
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
-      if (bj == 1) acc = cR[bi];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[bi][ks], b[ks], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 16 * bi + lk + 4 * r;
-        if (rr < KR) ws.RX[rr][16 * bj + li] = acc[r];
-      }
-    }
-  // ---- [At | bt | Bt] = [A | b | 0] + B X   (kept in registers until every load is done)
+  // Every HBM load of this node has been issued by now, so results may leave as soon as they exist.
+  // ---- [At | bt | Bt] = [A | b | 0] + B X, stored at once (frees the B operands and these accumulators)
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
@@ -123,21 +106,48 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
       v4d acc = cA[bi][bj];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aB[bi][ks], b[ks], acc, 0, 0, 0);
-      cA[bi][bj] = acc;
-    }
-  lds_wave_sync();
-  // ---- X' RX + [Q | q | 0 ; 0]  ->  Qt, qt (rows < nx);  Pt, rt, Rt (rows > nx); stores follow directly
-#pragma unroll
-  for (int bi = 0; bi < NBC; ++bi)
-#pragma unroll
-    for (int bj = 0; bj < NBC; ++bj) {
       const int col = 16 * bj + li;
-      double a[KS], b[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        a[ks] = ws.X[4 * ks + lk][16 * bi + li];         // X'(i, k)
-        b[ks] = ws.RX[4 * ks + lk][col];
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * bi + lk + 4 * r;
+        if (rr < NX) {
+          if (col < NX) out.At[rr * NX + col] = acc[r];
+          else if (col == NX) out.bt[rr] = acc[r];
+          else if (col - BC < NU) out.Bt[rr * NU + (col - BC)] = acc[r];
+        }
       }
+    }
+  // ---- per block column bj:  RX(:, bj) = R X(:, bj) + [0 | r | 0]  ->  LDS,  then  X' RX(:, bj) + [Q | q | 0 ; 0](:, bj)
+  //      -> Qt, qt (rows < nx);  Pt, rt, Rt (rows > nx)
+#pragma unroll
+  for (int bj = 0; bj < NBC; ++bj) {
+    const int col = 16 * bj + li;
+    {
+      double b[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) b[ks] = ws.X[4 * ks + lk][col];
+#pragma unroll
+      for (int bi = 0; bi < 2; ++bi) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        if (bj == 1) acc = cR[bi];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[bi][ks], b[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 16 * bi + lk + 4 * r;
+          if (rr < KR) ws.RX[rr][li] = acc[r];
+        }
+      }
+    }
+    lds_wave_sync();
+    double b[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) b[ks] = ws.RX[4 * ks + lk][li];
+#pragma unroll
+    for (int bi = 0; bi < NBC; ++bi) {
+      double a[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[ks] = ws.X[4 * ks + lk][16 * bi + li];         // X'(i, k)
       v4d acc = {0.0, 0.0, 0.0, 0.0};
       if (bi < 2) acc = cQ[bi < 2 ? bi : 0][bj];         // rows >= nx of cQ are zero
 #pragma unroll
@@ -157,21 +167,8 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
         }
       }
     }
-#pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-    for (int bj = 0; bj < NBC; ++bj) {
-      const int col = 16 * bj + li;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 16 * bi + lk + 4 * r;
-        if (rr < NX) {
-          if (col < NX) out.At[rr * NX + col] = cA[bi][bj][r];
-          else if (col == NX) out.bt[rr] = cA[bi][bj][r];
-          else if (col - BC < NU) out.Bt[rr * NU + (col - BC)] = cA[bi][bj][r];
-        }
-      }
-    }
+    lds_wave_sync();                                     // the block column buffer is rewritten by the next bj
+  }
 }
 
 template <int NJ>
