@@ -150,7 +150,7 @@ constexpr int kLinWaves = 4;   // wavefronts per workgroup of the linearisation 
 template <int NJ>
 __global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
   using C = LinFastCfg<NJ>;
-  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
+  constexpr int LPN = C::LPN, NPW = C::NPW;
   __shared__ LinFastNodeLds<NJ> lds[kLinWaves * NPW];
   __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
   load_shared_model<NJ>(*L.model, shared, threadIdx.x, kLinWaves * kWave);
@@ -603,8 +603,8 @@ struct bpmpc_solver {
         HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
         kv.second.total_ms += ms;
         kv.second.launches += 1;
-        hipEventDestroy(pr.first);
-        hipEventDestroy(pr.second);
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
       }
       kv.second.pending.clear();
     }
@@ -855,7 +855,7 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   if (!(horizon > 0) || !t0 || !x0 || !schedules || !targets) throw std::invalid_argument("solve: null or invalid argument");
   if (n_schedules != 1 && n_schedules != batch) throw std::invalid_argument("n_schedules must be 1 or batch");
   if ((warm_x == nullptr) != (warm_u == nullptr)) throw std::invalid_argument("warm_x and warm_u must be given together");
-  const int N = s->settings.max_nodes, NX = s->nx, NU = s->nu;
+  const int N = s->settings.max_nodes, NX = s->nx;
   const double dt = s->settings.dt > 0 ? s->settings.dt : s->rm.sqp.dt;
   if (n_schedules == 1)
     for (int b = 1; b < batch; ++b)
@@ -1172,14 +1172,15 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
 
 void bpmpc_solver_destroy(bpmpc_solver* s) {
   if (!s) return;
-  if (s->stream) hipStreamSynchronize(s->stream);
-  if (s->producer_stream) { hipStreamSynchronize(s->producer_stream); hipStreamDestroy(s->producer_stream); }
-  if (s->ev_go) hipEventDestroy(s->ev_go);
-  for (hipEvent_t e : s->ev_chunk) if (e) hipEventDestroy(e);
-  for (void* p : s->allocations) hipFree(p);
-  if (s->d_model) hipFree(s->d_model);
-  if (s->h_remaining) hipHostFree(s->h_remaining);
-  if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
+  // teardown: nothing useful can be done with an error here
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->producer_stream) { (void)hipStreamSynchronize(s->producer_stream); (void)hipStreamDestroy(s->producer_stream); }
+  if (s->ev_go) (void)hipEventDestroy(s->ev_go);
+  for (hipEvent_t e : s->ev_chunk) if (e) (void)hipEventDestroy(e);
+  for (void* p : s->allocations) (void)hipFree(p);
+  if (s->d_model) (void)hipFree(s->d_model);
+  if (s->h_remaining) (void)hipHostFree(s->h_remaining);
+  if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
 
