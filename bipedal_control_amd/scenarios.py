@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from .api import BipedalRobotInterface, GaitSchedule, ModeSchedule, loadModeSequenceTemplate
+from .api import BipedalRobotInterface, GaitSchedule, loadModeSequenceTemplate
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H1 = dict(task=os.path.join(ROOT, "assets/h1/task.info"), urdf=os.path.join(ROOT, "assets/h1/h1_mpc.urdf"),

@@ -1,7 +1,6 @@
 # Diagnostic: which scenarios make the filter line search back-track more than once?
 import numpy as np, bipedal_control_amd as bp
 from bipedal_control_amd import scenarios as sc
-from tests import oracle_bridge as ob
 itf = sc.h1_interface()
 for gait in ("trot", "flying_trot", "standing_trot"):
     for its in (1, 2, 3, 5):

@@ -1,5 +1,5 @@
 # Experiment: does replaying one solve as a hipGraph shorten the step (launch gaps)?  Captures reset + solve + export on the solver's stream.
-import ctypes as C, time, numpy as np, torch, bipedal_control_amd as bp
+import ctypes as C, time, torch, bipedal_control_amd as bp
 from bipedal_control_amd import scenarios as sc
 hip = C.CDLL("libamdhip64.so")
 itf = sc.h1_interface()
