@@ -163,3 +163,23 @@ def test_backtracking_rounds_on_device_match_oracle(ctx):
             assert _rel(x2[b, :n + 1], xo) < 1e-8 and _rel(u2[b, :n], uo) < 1e-8
             seen.add(st2[b].step_size)
     assert min(seen) <= 0.25 and len(seen) >= 2, seen      # the device-side rounds were really exercised
+
+
+def test_profile_levels(ctx):
+    """settings.profile: 0 nothing is timed, 1 every kernel class, 2 the linearisation kernel only; switchable on a live solver."""
+    bp, sc, ob, itf = ctx
+    prob = sc.trot_problem(itf, batch=4, n_intervals=20)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=32, profile=2)
+    mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    mpc.enqueue(); mpc.synchronize()
+    assert mpc.kernel_time("linearize")[1] == 1 and mpc.kernel_time("riccati")[1] == 0
+    mpc.set_profile(1)
+    mpc.reset(); mpc.enqueue(); mpc.synchronize()
+    t_lin, n_lin = mpc.kernel_time("linearize")
+    t_ric, n_ric = mpc.kernel_time("riccati")
+    assert n_lin == 1 and n_ric == 1 and 0.0 < t_lin < 50.0 and 0.0 < t_ric < 50.0
+    mpc.set_profile(0)
+    mpc.reset(); mpc.enqueue(); mpc.synchronize()
+    assert mpc.kernel_time("linearize")[1] == 0
+    with pytest.raises(bp.BpmpcError):
+        mpc.set_profile(7)
