@@ -3,14 +3,24 @@
 
 One "step" = one MPC solve (task.info: 1 SQP iteration = linearise every shooting node, eliminate the equality
 constraints, Riccati sweep, filter line search, step) of a batch of independent problems per GPU, inputs already resident
-in HBM.  Ranks own disjoint problem slices (weak scaling: 256 problems per GPU); the only collective is the final
-all-gather of the optimal trajectories over RCCL, which is inside the timed step for N > 1.
+in HBM.  Ranks own disjoint problem slices; the only collective is the all-gather of the optimal trajectories over RCCL
+(bipedal_control_amd.distributed.TrajectoryGather), which is inside the timed step for N > 1 and overlaps with the next solve.
+
+  python bench.py                      N = 1, configs[1]: H1 trot, horizon 100, batch 256
+  python bench.py --gpus 8             spawns 8 ranks itself (one per GPU, torch.distributed.run on 127.0.0.1); weak scaling, 256 per GPU
+  python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8     the same, launched from outside
+  python bench.py --gpus 8 --scaling strong --global-batch 4096                configs[2]: 4096 problems split into contiguous slices
+  python bench.py --gpus 8 --workload gait-sweep                               configs[4]: 8 gaits x 512 commands, horizon 150, gaits split over ranks
+  python bench.py --robot g1 --gait standing_trot --batch 1024                 configs[3]: G1 walk (self-defined configuration)
+
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (linearisation sweep) and, at N = 1,
 `cpu_baseline` (the single-thread C++ oracle timed on this box's host cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,23 +33,51 @@ sys.path.insert(0, ROOT)
 BYTES_PER_NODE_H1 = 26444 - 3872
 BYTES_PER_NODE_24 = 30748 - 24 * 24 * 8      # nx = nu = 24 class, same rule
 HBM_PEAK_GBS = 8000.0              # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ROBOT_LABEL = {"h1": "Unitree H1", "openloong": "OpenLoong (nx = nu = 24)", "g1": "Unitree G1 (nx = nu = 24; self-defined configuration, not reference parity)"}
+KERNEL_CLASSES = ("linearize", "project_lu", "project", "riccati", "linesearch")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="problems per GPU")
-    ap.add_argument("--intervals", type=int, default=100, help="horizon in shooting intervals of dt = 0.015 s")
+    ap.add_argument("--batch", type=int, default=256, help="problems per GPU (weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="strong: --global-batch problems split over the ranks")
+    ap.add_argument("--global-batch", type=int, default=4096, help="total problems with --scaling strong (BASELINE.json configs[2])")
+    ap.add_argument("--workload", default="trot", choices=["trot", "gait-sweep"],
+                    help="trot: perturbed initial states on one gait (configs[1..3]); gait-sweep: 8 gaits x 512 velocity commands, "
+                         "horizon 150, generated on the device, gaits split over the ranks (configs[4])")
+    ap.add_argument("--intervals", type=int, default=None, help="horizon in shooting intervals of dt = 0.015 s (default 100; gait-sweep 150)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not wrap kernels in HIP events")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class inside the timed region (default: the linearisation kernel only)")
-    ap.add_argument("--robot", default="h1", choices=["h1", "openloong"],
-                    help="h1 = the headline workload (nx = nu = 22); openloong = the 24/24 class of BASELINE.json configs[3] (informational)")
-    ap.add_argument("--gait", default="trot", help="gait template of the workload (headline: trot)")
+    ap.add_argument("--robot", default="h1", choices=["h1", "openloong", "g1"],
+                    help="h1 = the headline workload (nx = nu = 22); g1 = BASELINE.json configs[3] (nx = nu = 24, self-defined configuration); "
+                         "openloong = the reference's own 12-joint robot")
+    ap.add_argument("--gait", default=None, help="gait template of the trot workload (default: trot; g1: standing_trot = \"walk\")")
     ap.add_argument("--chunks", type=int, default=0, help="horizon chunks of the linearise/project || Riccati pipeline (0 = library default, 1 = off)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1.  Rank 0's JSON line passes through on stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
 
     import numpy as np
     import torch
@@ -49,151 +87,211 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local)
+    # BPMPC_BENCH_ONE_DEVICE=1: every rank on device 0 (a 1-GPU box exercising the N > 1 code path; RCCL refuses two ranks on one
+    # device, so that mode gathers over gloo - the transport differs, sharding / stream ordering / overlap logic are the same)
+    one_device = os.environ.get("BPMPC_BENCH_ONE_DEVICE") == "1"
+    device = 0 if one_device else local
+    torch.cuda.set_device(device)
     use_dist = world > 1 or os.environ.get("BPMPC_BENCH_FORCE_DIST") == "1"   # the latter exercises RCCL with one rank
+    backend = os.environ.get("BPMPC_BENCH_BACKEND", "gloo" if (one_device and world > 1) else "nccl")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import bipedal_control_amd as bp
-    from bipedal_control_amd import scenarios
+    from bipedal_control_amd import distributed as bd, scenarios
 
     itf = scenarios.interface(args.robot)
-    B, NI = args.batch, args.intervals
-    prob = scenarios.trot_problem(itf, batch=B, n_intervals=NI, offset=rank * B, gait=args.gait)
-    max_nodes = NI + 16
-    stream = torch.cuda.current_stream().cuda_stream
-    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=max_nodes, profile=(0 if args.no_profile else (1 if args.profile_all else 2)), device=local, stream=stream,
-                           pipeline_chunks=args.chunks)
-    lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
-    n_nodes = lay["n_nodes_max"]
-    kinds = mpc.read("g_kind")[:n_nodes]
-    n_intermediate = int((kinds == 0).sum())
     nx, nu = itf.stateDim, itf.inputDim
+    gait = args.gait or ("standing_trot" if args.robot == "g1" else "trot")
+    sweep = args.workload == "gait-sweep"
+    NI = args.intervals or (150 if sweep else 100)
+    # ---- which problems does this rank own?
+    if sweep:
+        names, lib = scenarios.gait_library(itf)
+        glo, ghi = bd.shard_range(len(lib), world, rank)          # one gait per GPU at N = 8
+        cp = scenarios.gait_sweep_commands(itf, list(range(glo, ghi)), n_intervals=NI)
+        per_gait = len(cp["cmd_vel"]) // max(1, ghi - glo) if ghi > glo else 512
+        B = len(cp["x0"])
+        total = len(lib) * per_gait
+        capacity = bd.shard_capacity(len(lib), world) * per_gait
+        scaling = "strong"
+        max_nodes = NI + 2 * int(NI * scenarios.DT / 0.25 + 2) + 16     # shortest period of the library is 0.5 s: two events per 0.25 s at most
+    else:
+        if args.scaling == "strong":
+            total = args.global_batch
+            lo, hi = bd.shard_range(total, world, rank)
+            capacity = bd.shard_capacity(total, world)
+        else:
+            total = world * args.batch
+            lo, hi = rank * args.batch, (rank + 1) * args.batch
+            capacity = args.batch
+        B = hi - lo
+        scaling = args.scaling
+        prob = scenarios.trot_problem(itf, batch=B, n_intervals=NI, offset=lo, gait=gait)
+        max_nodes = NI + 16
+    if B < 1:
+        raise SystemExit("rank %d owns no problems (more ranks than work units)" % rank)
 
-    # result buffers owned by torch so that RCCL can gather them
-    # (one flat block per rank, [x | u], so that a step needs a single collective)
-    n_x, n_u = B * (max_nodes + 1) * nx, B * max_nodes * nu
-    xu_loc = torch.empty(n_x + n_u, dtype=torch.float64, device="cuda")
-    x_loc = xu_loc[:n_x].view(B, max_nodes + 1, nx)
-    u_loc = xu_loc[n_x:].view(B, max_nodes, nu)
-    if use_dist:
-        xu_all = torch.empty(world * (n_x + n_u), dtype=torch.float64, device="cuda")
+    # The solver runs on an explicit torch stream: torch.distributed orders a collective only against torch's CURRENT stream, so
+    # solve -> export -> all-gather -> next export are ordered by running everything under `with torch.cuda.stream(s)`.
+    s = torch.cuda.Stream(device=device)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=max_nodes, profile=(0 if args.no_profile else (1 if args.profile_all else 2)), device=device,
+                           stream=s.cuda_stream, pipeline_chunks=args.chunks)
+    if sweep:
+        lay = mpc.setup_commands(cp["t0"], cp["x0"], cp["gaits"], cp["gait_of_problem"], cp["gait_start"], cp["cmd_vel"], horizon=cp["horizon"])
+    else:
+        lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    n_nodes = lay["n_nodes_max"]
+    # intermediate (= linearised) nodes of this rank: per grid, times the problems on it
+    kinds = mpc.read("g_kind").reshape(B, max_nodes)          # [grid][node]; grid index < n_grids <= B
+    g_nodes = mpc.read("g_nodes")[:lay["n_grids"]].astype(int)
+    p_grid = mpc.read("p_grid")[:B].astype(int)
+    inter_of_grid = np.array([int((kinds[g, :g_nodes[g]] == 0).sum()) for g in range(lay["n_grids"])])
+    n_intermediate_total = int(inter_of_grid[p_grid].sum())     # node linearisations per launch on this rank
 
-    pending = []           # the all-gather of step i runs on RCCL's stream while step i + 1 is being solved
-
-    def drain():
-        while pending:
-            pending.pop().wait()      # the compute stream waits for the collective (x_loc / u_loc may be overwritten afterwards)
+    with torch.cuda.stream(s):
+        gather = bd.TrajectoryGather(capacity, max_nodes, nx, nu, torch.device("cuda", device))
+    if capacity != B:       # a short shard exports into the head of its block: x and u sub-blocks of B problems are contiguous only together with
+        x_dst = torch.zeros(B * (max_nodes + 1) * nx, dtype=torch.float64, device="cuda")   # the padding, so go through a staging copy
+        u_dst = torch.zeros(B * max_nodes * nu, dtype=torch.float64, device="cuda")
 
     def step():
         mpc.reset()        # device-side restore of the cold-start iterate: every step solves the same problems
         mpc.enqueue()      # 1 SQP iteration per problem, all on the GPU
-        drain()
-        mpc.export_trajectories(x_loc.data_ptr(), u_loc.data_ptr())
-        if use_dist:
-            pending.append(dist.all_gather_into_tensor(xu_all, xu_loc, async_op=True))
+        gather.drain()     # the previous all-gather has read the block
+        if capacity == B:
+            mpc.export_trajectories(gather.x_local.data_ptr(), gather.u_local.data_ptr())
+        else:
+            mpc.export_trajectories(x_dst.data_ptr(), u_dst.data_ptr())
+            gather.x_local[:B].copy_(x_dst.view(B, max_nodes + 1, nx))
+            gather.u_local[:B].copy_(u_dst.view(B, max_nodes, nu))
+        gather.launch()
 
     def fence():
-        drain()
+        gather.drain()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    mpc.synchronize()
-    for k in ("prepare", "linearize", "project_lu", "project", "riccati", "linesearch"):
-        mpc.kernel_time(k, reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    mpc.synchronize()
-
-    t, x, u, _, stats = mpc.fetch()
-    ok = sum(1 for s in stats if s.status == 0)
-    lin_timed = mpc.kernel_time("linearize", reset=False)         # HIP events on the launch stream, over exactly the timed steps
-    kt_steps = args.steps
-    if not args.no_profile and not args.profile_all:
-        # per-kernel breakdown from a short extra pass with every kernel class timed (each event pair costs 1-2 us of stream time,
-        # so the timed region itself only carries the pair around the roofline kernel)
-        mpc.set_profile(1)
-        for k in ("linearize", "project_lu", "project", "riccati", "linesearch"):
-            mpc.kernel_time(k, reset=True)
-        extra = kt_steps = max(3, min(args.steps, 10))
-        for _ in range(extra):
+    with torch.cuda.stream(s):
+        for _ in range(args.warmup):
             step()
         fence()
         mpc.synchronize()
-    # whole-job report: one 32-byte all-reduce of {merit, dynamics SSE, equality SSE, failures}, outside the timed region
-    report = [sum(s.merit_after for s in stats), sum(s.dynamics_sse_after for s in stats), sum(s.equality_sse_after for s in stats), float(len(stats) - ok)]
-    if use_dist:
-        rep = torch.tensor(report, dtype=torch.float64, device="cuda")
-        dist.all_reduce(rep, op=dist.ReduceOp.SUM)
-        report = [float(v) for v in rep.tolist()]
-        gathered_ok = bool(torch.equal(xu_all[rank * (n_x + n_u):(rank + 1) * (n_x + n_u)], xu_loc))     # the gathered block of this rank is its own result
-    else:
-        gathered_ok = True
-    ktimes = {k: mpc.kernel_time(k, reset=False) for k in ("linearize", "project_lu", "project", "riccati", "linesearch")}
+        for k in ("prepare",) + KERNEL_CLASSES:
+            mpc.kernel_time(k, reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            elapsed = float(bd.reduce_stats([elapsed], op="max")[0])
+        mpc.synchronize()
+
+        t, x, u, _, stats = mpc.fetch()
+        ok = sum(1 for st in stats if st.status == 0)
+        lin_timed = mpc.kernel_time("linearize", reset=False)         # HIP events on the launch stream, over exactly the timed steps
+        kt_steps = args.steps
+        if not args.no_profile and not args.profile_all:
+            # per-kernel breakdown from a short extra pass with every kernel class timed (each event pair costs 1-2 us of stream time,
+            # so the timed region itself only carries the pair around the roofline kernel)
+            mpc.set_profile(1)
+            for k in KERNEL_CLASSES:
+                mpc.kernel_time(k, reset=True)
+            extra = kt_steps = max(3, min(args.steps, 10))
+            for _ in range(extra):
+                step()
+            fence()
+            mpc.synchronize()
+        # whole-job report: one 40-byte all-reduce of {merit, dynamics SSE, equality SSE, failures, node
+        # linearisations}, outside the timed region
+        report = [sum(st.merit_after for st in stats), sum(st.dynamics_sse_after for st in stats), sum(st.equality_sse_after for st in stats),
+                  float(len(stats) - ok), float(n_intermediate_total)]
+        gathered_ok = gather.own_block_consistent()
+        if use_dist:
+            report = [float(v) for v in bd.reduce_stats(report).tolist()]
+            # every rank holds everybody's result: rank 0's copy of the last rank's block must be what that rank computed
+            probe = torch.zeros(2, dtype=torch.float64)
+            xb, ub = gather.block(world - 1)
+            if rank == world - 1:
+                probe = torch.tensor([float(gather.x_local.sum()), float(gather.u_local.sum())], dtype=torch.float64)
+            probe = bd.reduce_stats(probe.tolist())
+            gathered_ok = gathered_ok and float(xb.sum()) == float(probe[0]) and float(ub.sum()) == float(probe[1])
+        ktimes = {k: mpc.kernel_time(k, reset=False) for k in KERNEL_CLASSES}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * B * args.steps / elapsed
+        value = total * args.steps / elapsed
         lin_ms, lin_n = lin_timed
         roofline = None
         if lin_n > 0:
             # the horizon is linearised in `launches_per_step` chunk launches: an average launch covers that share of the nodes
             launches_per_step = lin_n / args.steps
             avg_s = 1e-3 * lin_ms / lin_n
-            bytes_per_node = BYTES_PER_NODE_H1 if args.robot == "h1" else BYTES_PER_NODE_24
-            alg_bytes = bytes_per_node * B * n_intermediate / launches_per_step
+            bytes_per_node = BYTES_PER_NODE_H1 if nx == 22 else BYTES_PER_NODE_24
+            alg_bytes = bytes_per_node * n_intermediate_total / launches_per_step
             achieved = alg_bytes / avg_s / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "linearize_traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("batch") == B and tj.get("intervals") == NI and (args.robot, args.gait) == ("h1", "trot"):
+                    if tj.get("batch") == B and tj.get("intervals") == NI and (args.robot, gait, sweep) == ("h1", "trot", False):
                         traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"kernel": "k_linearize_fast<%d>" % (10 if args.robot == "h1" else 12), "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"kernel": "k_linearize_fast<%d>" % (nx - 12), "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_us": round(1e6 * avg_s, 2),
                         "algorithmic_bytes_per_launch": round(alg_bytes), "launches_per_step": launches_per_step,
-                        "node_linearizations_per_s": round(B * n_intermediate / launches_per_step / avg_s, 1)}
-        out = {"metric": "MPC solves/s (%s, horizon=%d)" % ("H1" if args.robot == "h1" else args.robot, NI), "value": round(value, 2), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                        "node_linearizations_per_s": round(n_intermediate_total / launches_per_step / avg_s, 1), "measured_on": "rank 0"}
+        headline = (args.robot, gait, sweep, NI) == ("h1", "trot", False, 100)
+        if sweep:
+            wl = "%s gait-library sweep: %d gaits (%s) x %d velocity commands, horizon=%d intervals (dt 0.015), generated on the device, " \
+                 "gaits split over the ranks, cold start, 1 SQP iteration (BASELINE.json configs[4])" % (ROBOT_LABEL[args.robot], len(lib), ", ".join(names), per_gait, NI)
+        else:
+            wl = "%s %s, horizon=%d intervals (dt 0.015), %s perturbed initial states, cold start, 1 SQP iteration (%s)" % (
+                ROBOT_LABEL[args.robot], gait, NI, ("batch=%d per GPU" % args.batch) if scaling == "weak" else ("global batch %d in contiguous slices" % total),
+                "BASELINE.json configs[1]" if headline and scaling == "weak" and args.batch == 256 else
+                "BASELINE.json configs[2]" if headline and scaling == "strong" and total == 4096 else
+                "BASELINE.json configs[3]" if (args.robot, gait, NI) == ("g1", "standing_trot", 100) else "not the headline workload")
+        out = {"metric": "MPC solves/s (%s, horizon=%d)" % ({"h1": "H1", "g1": "G1"}.get(args.robot, args.robot), NI), "value": round(value, 2), "unit": "solves/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "%s %s, horizon=%d intervals (dt 0.015), batch=%d perturbed initial states per GPU, "
-                                      "cold start, 1 SQP iteration (%s)" % ("Unitree H1" if args.robot == "h1" else "OpenLoong (nx = nu = 24)", args.gait, NI, B,
-                                                                             "BASELINE.json configs[1]" if (args.robot, args.gait) == ("h1", "trot")
-                                                                             else "not the headline workload"),
-                          "global_batch": world * B, "shooting_nodes": n_nodes, "intermediate_nodes": n_intermediate, "nx": nx, "nu": nu,
-                          "parallelism": "problem-sharded x%d, all-gather of trajectories overlapped with the next solve" % world, "accepted_steps": ok, "job_report": {"merit_sum": report[0], "dynamics_sse_sum": report[1], "equality_sse_sum": report[2], "failures": int(report[3]),
-                                                                "gather_consistent": gathered_ok}},
-               "ms_per_solve": round(ms_per_step / B, 6),
+               "config": {"workload": wl, "global_batch": total, "problems_on_rank0": B, "shooting_nodes": n_nodes,
+                          "node_linearizations_per_step": int(report[4]), "nx": nx, "nu": nu,
+                          "parallelism": "problem-sharded x%d, one all-gather of trajectories per solve (%s), overlapped with the next solve" % (world, backend if use_dist else "none at N = 1"),
+                          "accepted_steps_rank0": ok,
+                          "job_report": {"merit_sum": report[0], "dynamics_sse_sum": report[1], "equality_sse_sum": report[2], "failures": int(report[3]),
+                                         "gather_consistent": bool(gathered_ok)}},
+               "ms_per_solve": round(ms_per_step / max(1, total // world), 6),
                "kernel_ms_per_step": {k: round(v[0] / max(1, kt_steps), 4) for k, v in ktimes.items()},
                "roofline": roofline}
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(prob, min(args.cpu_sample, B), x, u, stats, args.robot)
-        print(json.dumps(out))
+            if sweep:
+                out["cpu_baseline"] = cpu_baseline_sweep(itf, cp, min(args.cpu_sample, 16), x, stats, args.robot)
+            else:
+                out["cpu_baseline"] = cpu_baseline(prob, min(args.cpu_sample, B), x, u, stats, args.robot)
+        print(json.dumps(out), flush=True)
     if use_dist:
-        # the gathered block of this rank must equal its local result
-        assert torch.equal(xu_all[rank * (n_x + n_u):(rank + 1) * (n_x + n_u)], xu_loc)
+        assert gathered_ok, "gathered trajectories differ from the local result"
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _host_cpu():
+    try:
+        return [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        return "unknown"
 
 
 def cpu_baseline(prob, sample, x_gpu, u_gpu, stats, robot="h1"):
@@ -228,14 +326,33 @@ def cpu_baseline(prob, sample, x_gpu, u_gpu, stats, robot="h1"):
             list(pool.map(lambda it: om.solve(it[1][0], prob["x0"][it[0]], it[1][1], it[1][2], iterations=1, g_max=s["g_max"], g_min=s["g_min"],
                                               delta_tol=s["deltaTol"]), enumerate(sub)))
             threads3 = round(len(sub) / (time.perf_counter() - t1), 3)
-    try:
-        cpu_name = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-    except Exception:
-        cpu_name = "unknown"
     return {"value": round(sample / dt, 3), "unit": "solves/s", "cores": 1, "kind": "port", "ms_per_solve": round(1e3 * dt / sample, 3),
             "sample": "%d of the same problems (horizon and SQP iteration count as on the GPU), solve only, "
                       "reference pre-pass excluded" % sample,
-            "host_cpu": cpu_name, "host_cores": os.cpu_count(), "max_abs_x_diff_vs_gpu": worst, "value_3_threads": threads3}
+            "note": "the port differentiates with 44-direction dual numbers where the reference runs CppAD-generated sparse code: likely 2-4x slower than "
+                    "the reference's own LQ approximation; a large GPU/CPU ratio says nothing about kernel quality",
+            "host_cpu": _host_cpu(), "host_cores": os.cpu_count(), "max_abs_x_diff_vs_gpu": worst, "value_3_threads": threads3}
+
+
+def cpu_baseline_sweep(itf, cp, sample, x_gpu, stats, robot):
+    """The same for the gait-library sweep: `sample` problems spread over the rank's gaits, rebuilt on the host through the product's
+    GaitSchedule / cmdVelToTargetTrajectories mirror and solved by the single-thread oracle."""
+    import numpy as np
+    from bipedal_control_amd import scenarios
+    from tests import oracle_bridge as ob
+    B = len(cp["x0"])
+    picks = [int(i) for i in np.linspace(0, B - 1, sample)]
+    worst, spent = 0.0, 0.0
+    for b in picks:
+        hp = scenarios.commands_problem_on_host(itf, cp, b)
+        t0 = time.perf_counter()
+        xo, uo, _, _ = ob.oracle_solve_like(hp, 0, robot=robot)
+        spent += time.perf_counter() - t0
+        n = stats[b].n_nodes
+        worst = max(worst, float(np.abs(x_gpu[b, :n + 1] - xo).max()))
+    return {"value": round(len(picks) / spent, 3), "unit": "solves/s", "cores": 1, "kind": "port", "ms_per_solve": round(1e3 * spent / len(picks), 3),
+            "sample": "%d problems spread over the gaits of the sweep (same horizon, 1 SQP iteration), oracle pre-pass included" % len(picks),
+            "host_cpu": _host_cpu(), "host_cores": os.cpu_count(), "max_abs_x_diff_vs_gpu": worst}
 
 
 if __name__ == "__main__":

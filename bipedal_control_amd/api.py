@@ -217,8 +217,12 @@ class BatchedSqpMpc:
         self.max_batch, self.max_nodes = int(max_batch), int(max_nodes)
         self.nx, self.nu = interface.stateDim, interface.inputDim
         self.return_gains = bool(return_gains)
+        if stream is not None and int(stream) == 0:
+            # the C ABI reads a NULL stream as "create your own": the legacy default stream cannot be passed.  Work that must be
+            # ordered against torch has to run on an explicit stream (torch.cuda.Stream().cuda_stream), see bench.py.
+            raise ValueError("stream=0 (the default stream) cannot be handed over; pass an explicit stream handle or None for a solver-owned stream")
         st = _Settings(int(device), self.max_batch, self.max_nodes, int(sqp_iterations), float(dt), int(bool(return_gains)), int(profile),
-                       C.c_void_p(stream) if stream else None, int(bool(reference_kernels)), int(pipeline_chunks))
+                       C.c_void_p(int(stream)) if stream is not None else None, int(bool(reference_kernels)), int(pipeline_chunks))
         self._h = C.c_void_p()
         _check(lib.bpmpc_solver_create(interface.handle, C.byref(st), C.byref(self._h)))
         self._keep = None
@@ -238,6 +242,10 @@ class BatchedSqpMpc:
             modeSchedules = [modeSchedules]
         if isinstance(targetTrajectories, TargetTrajectories):
             targetTrajectories = [targetTrajectories] * B
+        if len(targetTrajectories) != B:
+            raise ValueError("%d target trajectories for %d problems (pass one per problem, or a single TargetTrajectories to share)" % (len(targetTrajectories), B))
+        if len(modeSchedules) not in (1, B):
+            raise ValueError("%d mode schedules for %d problems (pass one to share, or one per problem)" % (len(modeSchedules), B))
         keep = [t0, x0]
         sched = (_Schedule * len(modeSchedules))()
         for i, ms in enumerate(modeSchedules):
@@ -251,8 +259,12 @@ class BatchedSqpMpc:
             tg[i] = _Target(len(ts), _d(ts), _d(xs))
         wx = wu = None
         if warm_x is not None:
+            if warm_u is None:
+                raise ValueError("warm_x and warm_u must be given together")
             wx, wu = _f64(warm_x), _f64(warm_u)
-            assert wx.size == B * (self.max_nodes + 1) * self.nx and wu.size == B * self.max_nodes * self.nu
+            if wx.size != B * (self.max_nodes + 1) * self.nx or wu.size != B * self.max_nodes * self.nu:
+                raise ValueError("warm start arrays must have the solver's strides: x [%d, %d, %d], u [%d, %d, %d]"
+                                 % (B, self.max_nodes + 1, self.nx, B, self.max_nodes, self.nu))
             keep += [wx, wu]
         return B, t0, x0, sched, len(modeSchedules), tg, wx, wu, keep
 
@@ -371,11 +383,10 @@ class BatchedSqpMpc:
     def read(self, name):
         """Named device buffer as a flat float64 array (tests / debugging)."""
         lib = load_library()
-        N, B, nx, nu = self.max_nodes, self.max_batch, self.nx, self.nu
-        cap = B * (N + 1) * max(nx * nx, 16 * nx) + 64
+        cap = _check(lib.bpmpc_solver_read(self._h, name.encode(), None, C.c_long(0)))
         out = np.zeros(cap)
         n = _check(lib.bpmpc_solver_read(self._h, name.encode(), _d(out), C.c_long(cap)))
-        return out[:n].copy()
+        return out[:n]
 
     def set_profile(self, level):
         """0 off, 1 every kernel class, 2 the linearisation kernel only."""

@@ -170,7 +170,10 @@ BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags + 3 sums*/
       const bool numerical = p.summary[3] != 0.0;
       if (numerical) accepted = false;
       const double next_alpha = alpha * st.alpha_decay;
-      const bool give_up = !accepted && (numerical || !(next_alpha >= st.alpha_min));
+      // [OCS2-upstream] SqpSolver::takeStep: back-tracking also stops (no step taken) once the next trial step would be shorter than
+      // deltaTol in both the state and the input norm
+      const bool tiny = next_alpha * sqrt(p.summary[1]) < st.delta_tol && next_alpha * sqrt(p.summary[2]) < st.delta_tol;
+      const bool give_up = !accepted && (numerical || tiny || !(next_alpha >= st.alpha_min));
       partial[3 * NL] = accepted ? 1.0 : 0.0;
       partial[3 * NL + 1] = give_up ? 1.0 : 0.0;
       if (accepted || give_up) {

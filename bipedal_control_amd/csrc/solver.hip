@@ -586,14 +586,15 @@ struct bpmpc_solver {
   void time_begin(const char* cls, hipEvent_t* a, hipEvent_t* b, hipStream_t on = nullptr) {
     if (!timed(cls)) return;
     HIP_CHECK(hipEventCreate(a));
-    HIP_CHECK(hipEventCreate(b));
-    HIP_CHECK(hipEventRecord(*a, on ? on : stream));
-    (void)cls;
+    if (hipEventCreate(b) != hipSuccess) { (void)hipEventDestroy(*a); throw DeviceError("hipEventCreate failed"); }
+    if (hipEventRecord(*a, on ? on : stream) != hipSuccess) { (void)hipEventDestroy(*a); (void)hipEventDestroy(*b); throw DeviceError("hipEventRecord failed"); }
   }
   void time_end(const char* cls, hipEvent_t a, hipEvent_t b, hipStream_t on = nullptr) {
     if (!timed(cls)) return;
     HIP_CHECK(hipEventRecord(b, on ? on : stream));
-    timers[cls].pending.emplace_back(a, b);
+    KernelTimer& t = timers[cls];
+    t.pending.emplace_back(a, b);
+    if (t.pending.size() > 4096) collect_timers();   // a profiled loop that never asks for the times must not grow without bound
   }
   void collect_timers() {
     for (auto& kv : timers) {
@@ -624,8 +625,8 @@ struct bpmpc_solver {
     hipEvent_t ev_a_, ev_b_;                                                        \
     time_begin(cls, &ev_a_, &ev_b_, on);                                            \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, on, L);                  \
-    HIP_CHECK(hipGetLastError());                                                   \
     time_end(cls, ev_a_, ev_b_, on);                                                \
+    HIP_CHECK(hipGetLastError());                                                   \
   } while (0)
 #define TIMED_LAUNCH(cls, kernel, grid, block, L) TIMED_LAUNCH_ON(stream, cls, kernel, grid, block, L)
 
@@ -878,7 +879,6 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
     }
   }
   const int G = (int)first_problem.size();
-  if (from_previous) preserve_previous(s, batch, warm_x != nullptr);
   const size_t S = (size_t)G * N;
   // staging vectors live in the solver: releasing megabytes of freshly DMA-ed pageable memory after every setup made the
   // next solve stall for 10-30 ms on some boxes (tools/setup_time_probe.py)
@@ -923,6 +923,9 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
     std::copy(t.times, t.times + t.n_points, tgt_t.begin() + (size_t)b * kMaxTargetPoints);
     std::copy(t.states, t.states + (size_t)t.n_points * NX, tgt_x.begin() + (size_t)b * kMaxTargetPoints * NX);
   }
+  // every host-side check (grids, targets) has passed: only now do the solution buffers trade places with the kept copy, so a
+  // rejected call leaves the handle exactly as it was
+  if (from_previous) preserve_previous(s, batch, warm_x != nullptr);
   s->batch = batch; s->n_grids = G; s->n_nodes_max = nmax; s->cold = (warm_x == nullptr);
   s->max_rows = rows_max;
   s->grid_nodes = nodes; s->grid_of_problem = pgrid; s->grid_kind = kind; s->has_solution = false;
@@ -1119,6 +1122,7 @@ void fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double*
       st.step_size = r[9]; st.armijo_descent = r[10]; st.dx_norm = r[11]; st.du_norm = r[12];
     }
   }
+  s->collect_timers();   // the stream is idle here; a closed loop of advance() calls never reaches bpmpc_solver_sync
 }
 
 }  // namespace
@@ -1243,8 +1247,14 @@ int bpmpc_solver_stage(bpmpc_solver* s, const char* stage) {
   })
 }
 int bpmpc_solver_read(bpmpc_solver* s, const char* name, double* out, long capacity) {
-  if (!s || !name || !out) { set_last_error("bpmpc_solver_read: null argument"); return BPMPC_ERR_INVALID_ARGUMENT; }
+  if (!s || !name) { set_last_error("bpmpc_solver_read: null argument"); return BPMPC_ERR_INVALID_ARGUMENT; }
   try {
+    if (!out) {                                             // size query
+      auto q = s->named.find(name);
+      if (q == s->named.end()) throw std::invalid_argument(std::string("unknown buffer ") + name);
+      if (q->second.second > 0x7fffffffu) throw std::length_error("bpmpc_solver_read: buffer exceeds 2^31 elements");
+      return (int)q->second.second;
+    }
     HIP_CHECK(hipSetDevice(s->settings.device));
 #if defined(BPMPC_EVAL_PROFILE)
     if (std::string(name) == "evprof") {
@@ -1261,6 +1271,7 @@ int bpmpc_solver_read(bpmpc_solver* s, const char* name, double* out, long capac
     if (it == s->named.end()) throw std::invalid_argument(std::string("unknown buffer ") + name);
     const size_t n = it->second.second;
     if ((long)n > capacity) throw std::length_error("bpmpc_solver_read: capacity too small");
+    if (n > 0x7fffffffu) throw std::length_error("bpmpc_solver_read: buffer exceeds 2^31 elements");
     HIP_CHECK(hipStreamSynchronize(s->stream));
     if (s->is_int[name]) {
       std::vector<int> tmp(n);

@@ -1,5 +1,8 @@
 """Multi-GPU sharding of independent MPC problems: contiguous slices per rank, no data-path
-collective during the solve, one all-gather of the optimal trajectories at the end (RCCL on GPUs, gloo in CPU tests)."""
+collective during the solve, one all-gather of the optimal trajectories per solve (RCCL on GPUs, gloo in CPU tests).
+
+`TrajectoryGather` is the one collective path of the job: bench.py drives it on RCCL with the HIP solver writing into its
+local block, tests/test_distributed_gloo.py drives the same object on gloo."""
 import torch
 import torch.distributed as dist
 
@@ -11,25 +14,80 @@ def shard_range(total, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_trajectories(x_local, u_local, group=None):
-    """All-gather equally sized local trajectory blocks [b, N+1, nx] / [b, N, nu] into [world*b, ...] on every rank.
-    On an 8-GPU MI355X node the 18 MB per-rank shard crosses each xGMI link once (direct all-gather)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
-        return x_local, u_local
-    x_all = torch.empty((world * x_local.shape[0],) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
-    u_all = torch.empty((world * u_local.shape[0],) + tuple(u_local.shape[1:]), dtype=u_local.dtype, device=u_local.device)
-    dist.all_gather_into_tensor(x_all, x_local.contiguous(), group=group)
-    dist.all_gather_into_tensor(u_all, u_local.contiguous(), group=group)
-    return x_all, u_all
+def shard_capacity(total, world):
+    """Largest slice of shard_range(total, world, .): the per-rank block size of the gather (smaller slices are zero padded)."""
+    return (total + world - 1) // world
 
 
-def reduce_stats(values, group=None):
-    """Sum-reduce a small float64 vector of per-rank statistics (cost, SSEs, failure counts)."""
+class TrajectoryGather:
+    """One flat block [x | u] per rank and ONE all-gather per solve, asynchronous: the collective of solve i runs on the backend's
+    own stream while solve i + 1 is being computed and is waited for (`drain`) before the local block is overwritten again.
+
+    x block: capacity x (nodes + 1) x nx, u block: capacity x nodes x nu (doubles), `capacity` problems per rank (a rank that owns
+    fewer leaves the tail zero).  On an 8-GPU MI355X node a 512-problem H1 block is 18 MB and crosses each xGMI link once.
+
+    Stream contract (GPU): every method must be called with the solver's stream as torch's current stream
+    (`with torch.cuda.stream(s)`), so that the collective is ordered after the export that fills the block and the next export is
+    ordered after `drain()` - torch.distributed orders a collective only against the CURRENT stream."""
+
+    def __init__(self, capacity, nodes, nx, nu, device, group=None, dtype=torch.float64):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.capacity, self.nodes, self.nx, self.nu = int(capacity), int(nodes), int(nx), int(nu)
+        self.n_x = self.capacity * (self.nodes + 1) * self.nx
+        self.n_u = self.capacity * self.nodes * self.nu
+        self.local = torch.zeros(self.n_x + self.n_u, dtype=dtype, device=device)
+        self.gathered = torch.zeros(self.world * (self.n_x + self.n_u), dtype=dtype, device=device) if self.world > 1 or dist.is_initialized() else self.local
+        self.pending = []
+
+    # views of this rank's block (the solver exports straight into them)
+    @property
+    def x_local(self):
+        return self.local[:self.n_x].view(self.capacity, self.nodes + 1, self.nx)
+
+    @property
+    def u_local(self):
+        return self.local[self.n_x:].view(self.capacity, self.nodes, self.nu)
+
+    def launch(self):
+        """Start the all-gather of the local block (no-op without a process group)."""
+        if dist.is_initialized():
+            self.pending.append(dist.all_gather_into_tensor(self.gathered, self.local, group=self.group, async_op=True))
+
+    def drain(self):
+        """Make the current stream (GPU) / the caller (CPU) wait for every collective in flight: afterwards the local block may be
+        overwritten and `gathered` may be read."""
+        while self.pending:
+            self.pending.pop().wait()
+
+    def block(self, rank):
+        """(x, u) views of the gathered block of `rank`."""
+        base = rank * (self.n_x + self.n_u)
+        flat = self.gathered[base:base + self.n_x + self.n_u]
+        return flat[:self.n_x].view(self.capacity, self.nodes + 1, self.nx), flat[self.n_x:].view(self.capacity, self.nodes, self.nu)
+
+    def assemble(self, total):
+        """All `total` problems in global order (drops the padding of short shards): x [total, nodes+1, nx], u [total, nodes, nu]."""
+        xs, us = [], []
+        for r in range(self.world):
+            lo, hi = shard_range(total, self.world, r)
+            x, u = self.block(r)
+            xs.append(x[:hi - lo]); us.append(u[:hi - lo])
+        return torch.cat(xs), torch.cat(us)
+
+    def own_block_consistent(self):
+        """The gathered copy of this rank's block equals what it sent."""
+        base = self.rank * (self.n_x + self.n_u)
+        return bool(torch.equal(self.gathered[base:base + self.n_x + self.n_u], self.local))
+
+
+def reduce_stats(values, group=None, op="sum"):
+    """Reduce a small float64 vector of per-rank statistics (cost, SSEs, failure counts; elapsed time with op="max")."""
     t = torch.as_tensor(values, dtype=torch.float64)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
         t = t.to(dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=group)
         t = t.cpu()
     return t

@@ -9,11 +9,14 @@ from .api import BipedalRobotInterface, GaitSchedule, loadModeSequenceTemplate
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H1 = dict(task=os.path.join(ROOT, "assets/h1/task.info"), urdf=os.path.join(ROOT, "assets/h1/h1_mpc.urdf"),
           reference=os.path.join(ROOT, "assets/h1/reference.info"), gait=os.path.join(ROOT, "assets/h1/gait.info"))
-# the reference's own 12-leg-joint robot (nx = nu = 24): stands in for BASELINE.json configs[3] ("G1 ... different DoF"),
-# for which the reference ships no OCS2 configuration
+# the reference's own 12-leg-joint robot (nx = nu = 24)
 OPENLOONG = dict(task=os.path.join(ROOT, "assets/openloong/task.info"), urdf=os.path.join(ROOT, "assets/openloong/openloong_mpc.urdf"),
                  reference=os.path.join(ROOT, "assets/openloong/reference.info"), gait=os.path.join(ROOT, "assets/openloong/gait.info"))
-ROBOTS = {"h1": H1, "openloong": OPENLOONG}
+# Unitree G1 (BASELINE.json configs[3]): the reference ships only g1.urdf - sole frames and the INFO files are authored by
+# tools/make_assets.py (see assets/ATTRIBUTION.md); results on it are self-defined, not reference parity
+G1 = dict(task=os.path.join(ROOT, "assets/g1/task.info"), urdf=os.path.join(ROOT, "assets/g1/g1_mpc.urdf"),
+          reference=os.path.join(ROOT, "assets/g1/reference.info"), gait=os.path.join(ROOT, "assets/g1/gait.info"))
+ROBOTS = {"h1": H1, "openloong": OPENLOONG, "g1": G1}
 DT = 0.015
 SEED = 20241008
 # phase offset of the steady-state gait: the template starts 3.5 periods-halves before t = 0 so that t0 = 0 is mid-swing
@@ -88,3 +91,52 @@ def gait_sweep_problem(itf, gaits, commands, n_intervals=150, seed=SEED):
             schedules.append(sched)
             targets.append(itf.cmdVelToTargetTrajectories((vx, 0.0, 0.0, wz), 0.0, x0[b], horizon))
     return dict(t0=np.zeros(nb), x0=x0, schedule=schedules, targets=targets, horizon=horizon)
+
+
+# ---- BASELINE.json configs[4]: gait-library sweep (SURVEY.md section 8d "Config 5")
+SYNTHETIC_TROT_PERIODS = (0.5, 0.6, 0.9, 1.0)
+
+
+def gait_library(itf, gait_file=None):
+    """The 8 gait modes of the sweep: the reference's four templates (gait.info:1-7: stance, trot, standing_trot, flying_trot) and four
+    synthetic variants - the trot template scaled to periods 0.5 / 0.6 / 0.9 / 1.0 s (the reference defines only four gaits).
+    Returns (names, templates)."""
+    from .api import ModeSequenceTemplate
+    gf = gait_file or getattr(itf, "gaitFile", H1["gait"])
+    names = ["stance", "trot", "standing_trot", "flying_trot"]
+    lib = [loadModeSequenceTemplate(gf, n) for n in names]
+    trot = lib[1]
+    period = float(trot.switchingTimes[-1])
+    for T in SYNTHETIC_TROT_PERIODS:
+        names.append("trot_%.1fs" % T)
+        lib.append(ModeSequenceTemplate(np.asarray(trot.switchingTimes) * (T / period), np.asarray(trot.modeSequence)))
+    return names, lib
+
+
+def command_grid(n_vx=32, n_wz=16, vx_max=0.5, wz_max=0.3):
+    """512 velocity commands (v_x, 0, 0, omega_z): v_x in [-0.5, 0.5] (32) x omega_z in [-0.3, 0.3] (16), limits from reference.info:1-2."""
+    return np.array([(vx, 0.0, 0.0, wz) for vx in np.linspace(-vx_max, vx_max, n_vx) for wz in np.linspace(-wz_max, wz_max, n_wz)])
+
+
+def gait_sweep_commands(itf, gait_indices, n_intervals=150, n_vx=32, n_wz=16, seed=SEED):
+    """Inputs of bpmpc_solver_setup_commands for the gaits `gait_indices` of the library (one block of n_vx * n_wz problems per gait,
+    problem index = gait * 512 + command, so that any sharding by gait reproduces the same problems)."""
+    names, lib = gait_library(itf)
+    cmds = command_grid(n_vx, n_wz)
+    per = len(cmds)
+    x0_all = perturbed_initial_states(itf, len(lib) * per, seed)
+    gop = np.repeat(np.asarray(gait_indices, np.int32), per)
+    x0 = np.concatenate([x0_all[g * per:(g + 1) * per] for g in gait_indices]) if len(gait_indices) else x0_all[:0]
+    cmd = np.tile(cmds, (len(gait_indices), 1))
+    return dict(t0=0.0, x0=x0, gaits=lib, gait_names=names, gait_of_problem=gop, gait_start=GAIT_START, cmd_vel=cmd, horizon=n_intervals * DT)
+
+
+def commands_problem_on_host(itf, cp, b):
+    """Problem b of a gait_sweep_commands() set as a host-side scenario (schedule from GaitSchedule, target from cmdVelToTargetTrajectories):
+    what the oracle-side checker of bench.py / the tests solves."""
+    gs = GaitSchedule(itf)
+    g = int(cp["gait_of_problem"][b])
+    gs.insertModeSequenceTemplate(cp["gaits"][g], cp["gait_start"], cp["t0"] + 2 * cp["horizon"])
+    sched = gs.getModeSchedule(cp["t0"] - cp["horizon"], cp["t0"] + 2 * cp["horizon"])
+    tg = itf.cmdVelToTargetTrajectories(tuple(cp["cmd_vel"][b]), cp["t0"], cp["x0"][b], cp["horizon"])
+    return dict(t0=cp["t0"], x0=cp["x0"][b:b + 1], schedule=sched, targets=[tg], horizon=cp["horizon"])

@@ -204,7 +204,7 @@ int bpmpc_solver_fetch(bpmpc_solver* solver, double* out_t, double* out_x, doubl
 int bpmpc_solver_stage(bpmpc_solver* solver, const char* stage);
 /* Copy a named device buffer to the host (tests): "x","u","xref","A","B","b","Q","R","P","q","r","c","C","D","e","nc","perf",
  * "Px","Pu","Pe","nut","At","Bt","bt","Qt","Rt","Pt","qt","rt","dx","du","K","summary".  Integer buffers are converted to
- * double.  Returns the element count or a negative status. */
+ * double.  Returns the element count or a negative status; out == NULL only queries the element count. */
 int bpmpc_solver_read(bpmpc_solver* solver, const char* name, double* out, long capacity);
 /* Device pointers of the iterate, for zero-copy hand-off (e.g. an RCCL gather through torch.distributed):
  * x: batch*(max_nodes+1)*nx doubles, u: batch*max_nodes*nu doubles.  Valid until the next setup with a warm start from the previous

@@ -1014,6 +1014,9 @@ int oracle_solve(const oracle_model* om, int N, const int* kind, const double* d
       }
       if (accepted) break;
       alpha *= alpha_decay;
+      // [OCS2-upstream] SqpSolver::takeStep: "detect too small step size during back-tracking to escape early" - once the
+      // next trial step would be below deltaTol in both norms the search stops and no step is taken
+      if (alpha * dun < delta_tol && alpha * dxn < delta_tol) break;
     } while (alpha >= alpha_min);
     st[10] = trials;
     if (K_out) std::memcpy(K_out, so.K.data(), sizeof(double) * so.K.size());

@@ -1,5 +1,8 @@
-"""N > 1 path on CPU: two gloo ranks own disjoint problem slices, solve them independently (here with the oracle, the
-GPU is not available in this tier) and all-gather the trajectories with the same helper bench.py's RCCL path uses."""
+"""N > 1 path on CPU: two (three) gloo ranks own contiguous problem slices and exchange their optimal trajectories through
+bipedal_control_amd.distributed.TrajectoryGather - the SAME object bench.py drives over RCCL (one flat [x | u] block per rank, one
+asynchronous all-gather per solve, drained before the block is overwritten).  There is no GPU in this tier, so the local blocks are
+filled with the oracle's solutions; the HIP solver in front of the same gather is covered on the GPU tier by
+tests/test_gpu_multi_rank.py (two ranks on one device)."""
 import os
 import socket
 
@@ -27,37 +30,65 @@ def _worker(rank, world, port, total, n_intervals, out_dir):
     itf = scenarios.h1_interface()
     lo, hi = bd.shard_range(total, world, rank)
     prob = scenarios.trot_problem(itf, batch=hi - lo, n_intervals=n_intervals, offset=lo)
-    xs, us = [], []
-    for b in range(hi - lo):
-        xo, uo, _, _ = ob.oracle_solve_like(prob, b)
-        xs.append(xo); us.append(uo)
-    x_all, u_all = bd.gather_trajectories(torch.from_numpy(np.stack(xs)), torch.from_numpy(np.stack(us)))
-    stats = bd.reduce_stats([float(hi - lo), float(np.stack(xs).sum())])
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x_all.numpy(), u=u_all.numpy(), stats=stats.numpy())
+    sols = [ob.oracle_solve_like(prob, b) for b in range(hi - lo)]
+    nodes = sols[0][0].shape[0] - 1
+    g = bd.TrajectoryGather(bd.shard_capacity(total, world), nodes, itf.stateDim, itf.inputDim, torch.device("cpu"))
+    # two "solves" in a row, as the timed loop of bench.py issues them: launch, (next solve), drain, overwrite, launch
+    for scale in (2.0, 1.0):
+        g.drain()
+        for b, (xo, uo, _, _) in enumerate(sols):
+            g.x_local[b] = torch.from_numpy(xo) * scale
+            g.u_local[b] = torch.from_numpy(uo) * scale
+        g.launch()
+    g.drain()
+    assert g.own_block_consistent()
+    x_all, u_all = g.assemble(total)
+    stats = bd.reduce_stats([float(hi - lo), float(sum(s[0].sum() for s in sols))])
+    tmax = bd.reduce_stats([float(rank)], op="max")
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x_all.numpy(), u=u_all.numpy(), stats=stats.numpy(), tmax=tmax.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_shard_range():
-    from bipedal_control_amd.distributed import shard_range
+    from bipedal_control_amd.distributed import shard_capacity, shard_range
     assert [shard_range(4096, 8, r) for r in (0, 7)] == [(0, 512), (3584, 4096)]
     cover = [shard_range(10, 4, r) for r in range(4)]
     assert cover == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_capacity(10, 4) == 3 and shard_capacity(4096, 8) == 512 and shard_capacity(8, 3) == 3
+    # gait-library sweep: 8 gaits over 1 / 2 / 4 / 8 ranks
+    assert [shard_range(8, 8, r) for r in range(8)] == [(r, r + 1) for r in range(8)]
+    assert [shard_range(8, 2, r) for r in range(2)] == [(0, 4), (4, 8)]
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_gather(tmp_path):
-    total, n_int = 4, 6
+@pytest.mark.parametrize("world,total", [(2, 4), (3, 5)])       # equal shards; shards of 2 + 2 + 1 (the short one is zero padded)
+def test_ranks_gather_trajectories(tmp_path, world, total):
+    n_int = 6
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, total, n_int, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert np.array_equal(r0["x"], r1["x"]) and np.array_equal(r0["u"], r1["u"])
-    # equals the single-process solve of all four problems in order
+    mp.spawn(_worker, args=(world, port, total, n_int, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    for r in res[1:]:
+        assert np.array_equal(r["x"], res[0]["x"]) and np.array_equal(r["u"], res[0]["u"])
+    # equals the single-process solve of all problems in order
     from bipedal_control_amd import scenarios
     from tests import oracle_bridge as ob
     itf = scenarios.h1_interface()
     prob = scenarios.trot_problem(itf, batch=total, n_intervals=n_int)
+    assert res[0]["x"].shape[0] == total
     for b in range(total):
         xo, uo, _, _ = ob.oracle_solve_like(prob, b)
-        assert np.array_equal(r0["x"][b], xo) and np.array_equal(r0["u"][b], uo)
-    assert r0["stats"][0] == total
+        assert np.array_equal(res[0]["x"][b], xo) and np.array_equal(res[0]["u"][b], uo)
+    assert res[0]["stats"][0] == total and res[0]["tmax"][0] == world - 1
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` re-executes itself under torch.distributed.run on 127.0.0.1 (the driver starts it without a launcher)."""
+    import bench
+    import unittest.mock as um
+    args = type("A", (), {"gpus": 4})()
+    with um.patch("subprocess.call", return_value=0) as call, um.patch("sys.argv", ["bench.py", "--gpus", "4", "--steps", "2"]):
+        assert bench.self_launch(args) == 0
+    cmd = call.call_args[0][0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]

@@ -1,0 +1,142 @@
+"""BASELINE.json configs[3]: Unitree G1 (nx = nu = 24, hip pitch / roll / yaw, knee, ankle pitch / roll - a different joint order and
+tilted hip / knee / ankle joint frames compared with H1 and OpenLoong) walking, i.e. following `standing_trot` (SURVEY.md section 8d
+"Config 4").  The reference ships no OCS2 configuration for G1: sole frames and INFO files are authored by tools/make_assets.py, so
+these results are SELF-DEFINED, NOT REFERENCE PARITY - they check the HIP path against the oracle on that configuration.
+Tolerances as for H1: LQ model 1e-11, QP step 1e-9, solve outputs 1e-8 (relative to max(1, |oracle|_max))."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROBOT = "g1"
+WALK = "standing_trot"
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import bipedal_control_amd as bp
+    from bipedal_control_amd import scenarios
+    from tests import oracle_bridge as ob
+    itf = scenarios.interface(ROBOT)
+    assert itf.stateDim == 24 and itf.jointNames()[0] == "left_hip_pitch_joint"
+    return dict(bp=bp, sc=scenarios, ob=ob, itf=itf)
+
+
+@pytest.mark.parametrize("gait", [WALK, "trot", "flying_trot"])
+def test_g1_linearize_matches_oracle(ctx, gait):
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    B, NN = 3, 56
+    prob = sc.trot_problem(itf, batch=B, n_intervals=36, gait=gait)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN)
+    lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    mpc.enqueue(); mpc.synchronize()          # one accepted step: a generic iterate
+    mpc.stage("linearize"); mpc.synchronize()
+    nx = nu = 24
+    x = mpc.read("x").reshape(B, NN + 1, nx); u = mpc.read("u").reshape(B, NN, nu)
+    shapes = dict(A=(nx, nx), B=(nx, nu), b=(nx,), Q=(nx, nx), R=(nu, nu), P=(nu, nx), q=(nx,), r=(nu,), c=(), C=(16, nx), D=(16, nu), e=(16,), perf=(3,))
+    dev = {k: mpc.read(k).reshape(B, NN, *s) for k, s in shapes.items()}
+    nc = mpc.read("nc").reshape(B, NN)
+    om = ob.oracle(ROBOT)
+    worst = {}
+    modes = set()
+    for b in range(B):
+        nodes = ob.oracle_nodes(prob, b, robot=ROBOT)
+        assert nodes["N"] == lay["n_nodes_max"]
+        for k in range(nodes["N"]):
+            o = om.node_lq(nodes["kind"][k], nodes["dt"][k], x[b, k], u[b, k], x[b, k + 1], nodes["xref"][k], nodes["mode"][k], nodes["zref"][k], nodes["zdref"][k])
+            assert int(nc[b, k]) == o["nc"]
+            modes.add(int(nodes["mode"][k]))
+            for name in shapes:
+                worst[name] = max(worst.get(name, 0.0), _rel(dev[name][b, k], o[name]))
+    assert len(modes) >= 3
+    assert max(worst.values()) < 1e-11, worst
+
+
+def test_g1_qp_step_matches_oracle(ctx):
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    B, NN = 2, 64
+    prob = sc.trot_problem(itf, batch=B, n_intervals=40, gait=WALK)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN, return_gains=True)
+    mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    mpc.enqueue(); mpc.synchronize()
+    for st in ("linearize", "project", "riccati"):
+        mpc.stage(st)
+    mpc.synchronize()
+    nx = nu = 24
+    x = mpc.read("x").reshape(B, NN + 1, nx); u = mpc.read("u").reshape(B, NN, nu)
+    dx = mpc.read("dx").reshape(B, NN + 1, nx); du = mpc.read("du").reshape(B, NN, nu); K = mpc.read("K").reshape(B, NN, nu, nx)
+    om = ob.oracle(ROBOT)
+    for b in range(B):
+        nodes = ob.oracle_nodes(prob, b, robot=ROBOT)
+        N = nodes["N"]
+        odx, odu, oK = om.qp_step(nodes, prob["x0"][b], x[b, :N + 1], u[b, :N])
+        assert _rel(dx[b, :N + 1], odx) < 1e-9 and _rel(du[b, :N], odu) < 1e-9 and _rel(K[b, :N], oK) < 1e-9
+
+
+@pytest.mark.parametrize("gait,iterations", [(WALK, 1), (WALK, 3), ("trot", 2)])
+def test_g1_solve_matches_oracle(ctx, gait, iterations):
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    B = 4
+    prob = sc.trot_problem(itf, batch=B, n_intervals=50, gait=gait)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=72, sqp_iterations=iterations, return_gains=True)
+    t, x, u, K, stats = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    for b in range(B):
+        xo, uo, Ko, st = ob.oracle_solve_like(prob, b, iterations=iterations, robot=ROBOT)
+        n = stats[b].n_nodes
+        its = int(sum(1 for r in st if r[10] > 0))
+        assert stats[b].iterations == its and stats[b].step_size == st[its - 1][3]
+        assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8 and _rel(K[b, :n], Ko) < 1e-7
+    # reference kernel bodies (lane-emulation verified on the CPU tier) agree with the fast ones
+    ref = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=72, sqp_iterations=iterations, reference_kernels=True)
+    t2, x2, u2, _, _ = ref.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    assert _rel(x2, x) < 1e-9 and _rel(u2, u) < 1e-9
+
+
+def test_g1_full_size_properties(ctx):
+    """configs[3] at its full size (batch 1024, horizon 100, walk), through size-independent properties: the QP step satisfies the
+    linearised dynamics and the eliminated equality rows, three SQP iterations bring the violation down for every problem, a
+    problem's solution is bitwise independent of its batch neighbours, and a sample of problems matches the oracle."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    B, N, NN = 1024, 100, 120
+    prob = sc.trot_problem(itf, batch=B, n_intervals=N, gait=WALK)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN, sqp_iterations=3)
+    mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    for st in ("linearize", "project", "riccati"):
+        mpc.stage(st)
+    mpc.synchronize()
+    nx = nu = 24
+    n = mpc.layout()["n_nodes_max"]
+    S = slice(0, 256)                        # the dense checks read a quarter of the batch back (the LQ model of all 1024 is 4 GB)
+    dx = mpc.read("dx").reshape(B, NN + 1, nx)[S]; du = mpc.read("du").reshape(B, NN, nu)[S]
+    A = mpc.read("A").reshape(B, NN, nx, nx)[S]; Bm = mpc.read("B").reshape(B, NN, nx, nu)[S]; bv = mpc.read("b").reshape(B, NN, nx)[S]
+    res_dyn = np.einsum("bkij,bkj->bki", A[:, :n], dx[:, :n]) + np.einsum("bkij,bkj->bki", Bm[:, :n], du[:, :n]) + bv[:, :n] - dx[:, 1:n + 1]
+    assert np.abs(res_dyn).max() < 1e-9
+    del A, Bm
+    C = mpc.read("C").reshape(B, NN, 16, nx)[S]; D = mpc.read("D").reshape(B, NN, 16, nu)[S]; e = mpc.read("e").reshape(B, NN, 16)[S]
+    kind = mpc.read("g_kind")[:n]
+    inter = kind == 0
+    res_eq = np.einsum("bkij,bkj->bki", C[:, :n], dx[:, :n]) + np.einsum("bkij,bkj->bki", D[:, :n], du[:, :n]) + e[:, :n]
+    nc = mpc.read("nc").reshape(B, NN)[S, :n]
+    nut = mpc.read("nut").reshape(B, NN)[S, :n]
+    violated = (np.abs(res_eq) > 1e-8).sum(axis=2)
+    dropped = nc - (nu - nut)
+    assert np.all(violated[:, inter] <= dropped[:, inter]) and dropped[:, inter].max() <= 2
+    mpc.reset(); mpc.enqueue(); mpc.synchronize()
+    t, x, u, K, stats = mpc.fetch()
+    assert all(s.status == 0 for s in stats)
+    viol0 = np.array([np.sqrt(s.dynamics_sse_before + s.equality_sse_before) for s in stats])
+    viol1 = np.array([np.sqrt(s.dynamics_sse_after + s.equality_sse_after) for s in stats])
+    assert np.all(viol1 < 5e-2) and np.median(viol1) < 5e-3 and np.all(viol1 <= viol0 + 1e-12)
+    sub = [1000, 3, 517]
+    prob2 = dict(prob, x0=prob["x0"][sub], targets=[prob["targets"][i] for i in sub])
+    mpc2 = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=NN, sqp_iterations=3)
+    t2, x2, u2, _, st2 = mpc2.run(prob2["t0"], prob2["x0"], prob2["schedule"], prob2["targets"], horizon=prob2["horizon"])
+    for j, i in enumerate(sub):
+        assert np.array_equal(x2[j], x[i]) and np.array_equal(u2[j], u[i])
+    xo, uo, _, _ = ob.oracle_solve_like(prob2, 1, iterations=3, robot=ROBOT)
+    nn = st2[1].n_nodes
+    assert _rel(x2[1, :nn + 1], xo) < 1e-8 and _rel(u2[1, :nn], uo) < 1e-8
