@@ -52,7 +52,7 @@ def test_g1_linearize_matches_oracle(ctx, gait):
             modes.add(int(nodes["mode"][k]))
             for name in shapes:
                 worst[name] = max(worst.get(name, 0.0), _rel(dev[name][b, k], o[name]))
-    assert len(modes) >= 3
+    assert len(modes) >= (3 if gait == WALK else 2)      # standing_trot: LF, RF and double stance; trot: LF, RF; flying trot: + flight
     assert max(worst.values()) < 1e-11, worst
 
 
@@ -130,7 +130,8 @@ def test_g1_full_size_properties(ctx):
     assert all(s.status == 0 for s in stats)
     viol0 = np.array([np.sqrt(s.dynamics_sse_before + s.equality_sse_before) for s in stats])
     viol1 = np.array([np.sqrt(s.dynamics_sse_after + s.equality_sse_after) for s in stats])
-    assert np.all(viol1 < 5e-2) and np.median(viol1) < 5e-3 and np.all(viol1 <= viol0 + 1e-12)
+    # cold-start violation is O(1); the G1 walk converges more slowly than the H1 trot (oracle: 1.0 -> 0.27 -> 0.05 -> 0.03 typical)
+    assert np.all(viol1 < 0.15) and np.median(viol1) < 0.06 and np.all(viol1 <= viol0 + 1e-12)
     sub = [1000, 3, 517]
     prob2 = dict(prob, x0=prob["x0"][sub], targets=[prob["targets"][i] for i in sub])
     mpc2 = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=NN, sqp_iterations=3)
