@@ -56,6 +56,7 @@ def parse_args():
                     help="h1 = the headline workload (nx = nu = 22); g1 = BASELINE.json configs[3] (nx = nu = 24, self-defined configuration); "
                          "openloong = the reference's own 12-joint robot")
     ap.add_argument("--gait", default=None, help="gait template of the trot workload (default: trot; g1: standing_trot = \"walk\")")
+    ap.add_argument("--no-fused", action="store_true", help="skip the second timed region (fused solve mode)")
     ap.add_argument("--chunks", type=int, default=0, help="horizon chunks of the linearise/project || Riccati pipeline (0 = library default, 1 = off)")
     return ap.parse_args()
 
@@ -143,8 +144,12 @@ def main():
     # The solver runs on an explicit torch stream: torch.distributed orders a collective only against torch's CURRENT stream, so
     # solve -> export -> all-gather -> next export are ordered by running everything under `with torch.cuda.stream(s)`.
     s = torch.cuda.Stream(device=device)
+    # The timed region runs the MATERIALISED formulation (the lineariser writes the reference's complete per-node LQ model): that is the
+    # sweep the north-star asks to profile and the one the roofline unit (algorithmic bytes per node linearisation) is defined on.
+    # The engine's default, fused solve mode (the lineariser leaves only what the solve reads; identical solution bits) is timed in a
+    # second region of the same length and reported as `fused` ("report both").
     mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=max_nodes, profile=(0 if args.no_profile else (1 if args.profile_all else 2)), device=device,
-                           stream=s.cuda_stream, pipeline_chunks=args.chunks)
+                           stream=s.cuda_stream, pipeline_chunks=args.chunks, materialize_lq=True)
     if sweep:
         lay = mpc.setup_commands(cp["t0"], cp["x0"], cp["gaits"], cp["gait_of_problem"], cp["gait_start"], cp["cmd_vel"], horizon=cp["horizon"])
     else:
@@ -227,6 +232,27 @@ def main():
             probe = bd.reduce_stats(probe.tolist())
             gathered_ok = gathered_ok and float(xb.sum()) == float(probe[0]) and float(ub.sum()) == float(probe[1])
         ktimes = {k: mpc.kernel_time(k, reset=False) for k in KERNEL_CLASSES}
+        # ---- second timed region: the fused solve mode, same problems, same number of steps, no kernel carries an event pair
+        fused = None
+        if not args.no_fused:
+            mpc.set_materialize(False)
+            mpc.set_profile(0)
+            for _ in range(max(1, args.warmup)):
+                step()
+            fence()
+            tf0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            f_elapsed = time.perf_counter() - tf0
+            if use_dist:
+                f_elapsed = float(bd.reduce_stats([f_elapsed], op="max")[0])
+            _, xf, uf, _, _ = mpc.fetch()
+            same = bool(np.array_equal(xf, x) and np.array_equal(uf, u))
+            if use_dist:
+                same = bool(bd.reduce_stats([0.0 if same else 1.0])[0] == 0.0)
+            fused = {"value": round(total * args.steps / f_elapsed, 2), "unit": "solves/s", "ms_per_step": round(1e3 * f_elapsed / args.steps, 4),
+                     "solution_bits_equal_materialised": same, "hbm_bytes_per_step": None}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -241,12 +267,15 @@ def main():
             alg_bytes = bytes_per_node * n_intermediate_total / launches_per_step
             achieved = alg_bytes / avg_s / 1e9
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "linearize_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "linearize_traffic.json")       # PMC passes of the same command (tools/collect_profiles.sh)
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     if tj.get("batch") == B and tj.get("intervals") == NI and (args.robot, gait, sweep) == ("h1", "trot", False):
                         traffic = tj.get("hbm_bytes_per_launch")
+                        if fused is not None:
+                            fused["hbm_bytes_per_step"] = tj.get("fused_hbm_bytes_per_step")
+                            fused["materialised_hbm_bytes_per_step"] = tj.get("materialised_hbm_bytes_per_step")
                 except Exception:
                     traffic = None
             roofline = {"kernel": "k_linearize_fast<%d>" % (nx - 12), "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -274,7 +303,7 @@ def main():
                                          "gather_consistent": bool(gathered_ok)}},
                "ms_per_solve": round(ms_per_step / max(1, total // world), 6),
                "kernel_ms_per_step": {k: round(v[0] / max(1, kt_steps), 4) for k, v in ktimes.items()},
-               "roofline": roofline}
+               "roofline": roofline, "fused": fused}
         if world == 1 and args.cpu_sample > 0:
             if sweep:
                 out["cpu_baseline"] = cpu_baseline_sweep(itf, cp, min(args.cpu_sample, 16), x, stats, args.robot)

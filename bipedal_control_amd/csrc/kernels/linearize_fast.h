@@ -465,7 +465,12 @@ struct LinFastOut {
   size_t s;          // node slot (problem * max_nodes + node)
 };
 
-template <int NJ>
+// MAT = true: the complete per-node LQ model of the reference (A, B, b, Q, R, q, r, c, C, D, e zero padded to 16 rows) is written -
+// the materialised formulation the parity stages read and the roofline unit is defined on.  MAT = false ("fused" solve mode): only
+// what the rest of the solve reads leaves the kernel - rows 3..11 of A and B (the others are structural and regenerated by the change
+// of variables), b, q, r, the nc rows of C, D, e, the 320-byte record of the node-dependent part of Q and R; 9.6 instead of 21.8 KB per
+// node.  The numbers that are written are the same bits in both modes.
+template <int NJ, bool MAT = true>
 __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ>& nl, bool valid,
                                                const NodeInputs& in, const LinFastOut& o, int g) {
 #ifdef BPMPC_LINFAST_PROFILE
@@ -480,19 +485,22 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   if (!valid) return;
   if (in.kind == 1) {  // event node: identity jump map, no input, no cost (LPN lanes write the node)
     double d2 = 0.0;
-    for (int idx = g; idx < NX * NX; idx += LPN) { (o.A + o.s * (NX * NX))[idx] = (idx / NX == idx % NX) ? 1.0 : 0.0; (o.Q + o.s * (NX * NX))[idx] = 0.0; }
-    for (int idx = g; idx < NX * NU; idx += LPN) { (o.B + o.s * (NX * NU))[idx] = 0.0; }
-    for (int idx = g; idx < NU * NU; idx += LPN) (o.R + o.s * (NU * NU))[idx] = 0.0;
-    for (int idx = g; idx < kMaxEqRows * NX; idx += LPN) (o.C + o.s * (kMaxEqRows * NX))[idx] = 0.0;
-    for (int idx = g; idx < kMaxEqRows * NU; idx += LPN) (o.D + o.s * (kMaxEqRows * NU))[idx] = 0.0;
-    for (int idx = g; idx < kMaxEqRows; idx += LPN) (o.e + o.s * (kMaxEqRows))[idx] = 0.0;
+    if constexpr (MAT) {      // fused mode: the change of variables generates the identity jump map and the zero cost of an event node itself
+      for (int idx = g; idx < NX * NX; idx += LPN) { (o.A + o.s * (NX * NX))[idx] = (idx / NX == idx % NX) ? 1.0 : 0.0; (o.Q + o.s * (NX * NX))[idx] = 0.0; }
+      for (int idx = g; idx < NX * NU; idx += LPN) { (o.B + o.s * (NX * NU))[idx] = 0.0; }
+      for (int idx = g; idx < NU * NU; idx += LPN) (o.R + o.s * (NU * NU))[idx] = 0.0;
+      for (int idx = g; idx < kMaxEqRows * NX; idx += LPN) (o.C + o.s * (kMaxEqRows * NX))[idx] = 0.0;
+      for (int idx = g; idx < kMaxEqRows * NU; idx += LPN) (o.D + o.s * (kMaxEqRows * NU))[idx] = 0.0;
+      for (int idx = g; idx < kMaxEqRows; idx += LPN) (o.e + o.s * (kMaxEqRows))[idx] = 0.0;
+    }
     for (int idx = g; idx < NX; idx += LPN) {
       const double d = in.x[idx] - in.xnext[idx];
-      (o.b + o.s * (NX))[idx] = d; (o.q + o.s * (NX))[idx] = 0.0; (o.r + o.s * (NU))[idx] = 0.0;
+      (o.b + o.s * (NX))[idx] = d;
+      if constexpr (MAT) { (o.q + o.s * (NX))[idx] = 0.0; (o.r + o.s * (NU))[idx] = 0.0; }
       d2 += d * d;
     }
     d2 = node_allreduce_add<LPN>(d2);
-    if (g == 0) { (o.c + o.s * (1))[0] = 0.0; (o.nc + o.s * (1))[0] = 0; (o.perf + o.s * (3))[0] = 0.0; (o.perf + o.s * (3))[1] = d2; (o.perf + o.s * (3))[2] = 0.0; }
+    if (g == 0) { if constexpr (MAT) (o.c + o.s * (1))[0] = 0.0; (o.nc + o.s * (1))[0] = 0; (o.perf + o.s * (3))[0] = 0.0; (o.perf + o.s * (3))[1] = d2; (o.perf + o.s * (3))[2] = 0.0; }
     return;
   }
   const bool is_joint = g >= 6 && g < G;
@@ -609,6 +617,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     }
   }
   const int nc = row;
+  if constexpr (MAT)          // the LU kernel reads nc rows only; the zero padding exists for readers of the materialised model
   for (; row < kMaxEqRows; ++row) {
     if (g < G) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + g] = 0.0;
     if (g < 6) (o.C + o.s * (kMaxEqRows * NX))[row * NX + g] = 0.0;
@@ -647,7 +656,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     c1h[rr] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, g, rr);
     c1f[rr] = force_col(nl.cps[0], nl.com[0], imt, g, rr);
   }
-  for (int r = 0; r < NX; ++r) {
+  for (int r = MAT ? 0 : 3; r < (MAT ? NX : 12); ++r) {      // fused mode: the structural rows (0..2, 12..) are regenerated downstream
     double aq, ah_, bf, bj;
     if (r < 3 || r >= 12) {
       aq = (r == 6 + g) ? 1.0 : 0.0;
@@ -707,23 +716,26 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     for (int r = 0; r < NX; ++r) {
       const double dxr = nl.dx[r], dur = nl.du[r];
       // gradient entries use row c of the weight (as the reference kernel), the written element is (r, c)
-      if (g < G) { accq += sh.Q[cq * NX + r] * dxr; (o.Q + o.s * (NX * NX))[r * NX + cq] = dt * (sh.Q[r * NX + cq] + (r == cq ? shift : 0.0)); }
-      if (g < 6) { acch += sh.Q[ch * NX + r] * dxr; (o.Q + o.s * (NX * NX))[r * NX + ch] = dt * (sh.Q[r * NX + ch] + (r == ch ? shift : 0.0)); }
+      if (g < G) { accq += sh.Q[cq * NX + r] * dxr; if constexpr (MAT) (o.Q + o.s * (NX * NX))[r * NX + cq] = dt * (sh.Q[r * NX + cq] + (r == cq ? shift : 0.0)); }
+      if (g < 6) { acch += sh.Q[ch * NX + r] * dxr; if constexpr (MAT) (o.Q + o.s * (NX * NX))[r * NX + ch] = dt * (sh.Q[r * NX + ch] + (r == ch ? shift : 0.0)); }
       if (g < 12) {
         accf += sh.R[cf * NU + r] * dur;
-        double w = sh.R[r * NU + cf];
-        if (r == cf) w += shift;
-        if (stance_flag(mode, cf / 3) && r < 12 && r / 3 == cf / 3) {
-          const double* cn = nl.cone[r / 3];
-          const int a = r % 3, b2 = cf % 3;
-          const int lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
-          const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
-          w += cn[3] * cn[4 + a] * cn[4 + b2] + cn[2] * cn[7 + sidx];
+        const bool in_block = r < 12 && r / 3 == cf / 3;
+        if (MAT || in_block) {
+          double w = sh.R[r * NU + cf];
+          if (r == cf) w += shift;
+          if (stance_flag(mode, cf / 3) && in_block) {
+            const double* cn = nl.cone[r / 3];
+            const int a = r % 3, b2 = cf % 3;
+            const int lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
+            const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
+            w += cn[3] * cn[4 + a] * cn[4 + b2] + cn[2] * cn[7 + sidx];
+          }
+          if constexpr (MAT) (o.R + o.s * (NU * NU))[r * NU + cf] = dt * w;
+          if (in_block) (o.qrd + o.s * kQrdStride)[1 + 3 * cf + r % 3] = dt * w;
         }
-        (o.R + o.s * (NU * NU))[r * NU + cf] = dt * w;
-        if (r < 12 && r / 3 == cf / 3) (o.qrd + o.s * kQrdStride)[1 + 3 * cf + r % 3] = dt * w;
       }
-      if (is_joint) { accj += sh.R[cj * NU + r] * dur; (o.R + o.s * (NU * NU))[r * NU + cj] = dt * (sh.R[r * NU + cj] + (r == cj ? shift : 0.0)); }
+      if (is_joint) { accj += sh.R[cj * NU + r] * dur; if constexpr (MAT) (o.R + o.s * (NU * NU))[r * NU + cj] = dt * (sh.R[r * NU + cj] + (r == cj ? shift : 0.0)); }
     }
     if (g < G) { (o.q + o.s * (NX))[cq] = dt * accq; cost += 0.5 * nl.dx[cq] * accq; }
     if (g < 6) { (o.q + o.s * (NX))[ch] = dt * acch; cost += 0.5 * nl.dx[ch] * acch; }
@@ -740,7 +752,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   dyn_sse = node_allreduce_add<LPN>(dyn_sse);
   if (g == 0) {
     (o.qrd + o.s * kQrdStride)[0] = shift;
-    (o.c + o.s * (1))[0] = dt * cost;
+    if constexpr (MAT) (o.c + o.s * (1))[0] = dt * cost;
     (o.nc + o.s * (1))[0] = nc;
     (o.perf + o.s * (3))[0] = dt * cost; (o.perf + o.s * (3))[1] = dt * dyn_sse; (o.perf + o.s * (3))[2] = dt * eq_sse;
   }

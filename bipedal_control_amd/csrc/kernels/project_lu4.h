@@ -142,11 +142,12 @@ __device__ __forceinline__ void project_lu4(ProjectLuLds<NJ>& nl, bool valid, in
   const bool has_d1 = j < NU - 16, has_c1 = j < NX - 16, is_e = j == NX - 16;
   double vd0[R], vd1[R], vr0[R], vr1[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {                // rows >= nc are zero in HBM
-    vd0[r] = valid ? D[r * NU + j] : 0.0;
-    vd1[r] = (valid && has_d1) ? D[r * NU + 16 + j] : 0.0;
-    vr0[r] = valid ? C[r * NX + j] : 0.0;
-    vr1[r] = (valid && has_c1) ? C[r * NX + 16 + j] : ((valid && is_e) ? e[r] : 0.0);
+  for (int r = 0; r < R; ++r) {                // rows >= nc do not exist (the fused solve mode does not even write their zero padding)
+    const bool rv = valid && r < nc;
+    vd0[r] = rv ? D[r * NU + j] : 0.0;
+    vd1[r] = (rv && has_d1) ? D[r * NU + 16 + j] : 0.0;
+    vr0[r] = rv ? C[r * NX + j] : 0.0;
+    vr1[r] = (rv && has_c1) ? C[r * NX + 16 + j] : ((rv && is_e) ? e[r] : 0.0);
   }
   const int size = valid ? nc : 0;             // min(rows, cols), rows <= 16 < cols
   int nonzero = size;

@@ -179,11 +179,12 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   static_assert(NX == NU, "packed layout assumes nx == nu");
   const int l = threadIdx.x;
 
-  if (in.kind == 1) {  // event node: pass-through (same as the reference kernel; Px, Pu, Pe, nut were written by the LU kernel)
-    for (int idx = l; idx < NX * NX; idx += kWave) { out.At[idx] = in.A[idx]; out.Qt[idx] = in.Q[idx]; }
+  if (in.kind == 1) {  // event node: identity jump map, no input, no cost (what the lineariser writes for it in the materialised mode;
+                       // generated here so that the fused mode need not write it); Px, Pu, Pe, nut were written by the LU kernel
+    for (int idx = l; idx < NX * NX; idx += kWave) { out.At[idx] = (idx / NX == idx % NX) ? 1.0 : 0.0; out.Qt[idx] = 0.0; }
     for (int idx = l; idx < NX * NU; idx += kWave) { out.Bt[idx] = 0.0; out.Pt[idx] = 0.0; }
     for (int idx = l; idx < NU * NU; idx += kWave) out.Rt[idx] = 0.0;
-    if (l < NX) { out.bt[l] = in.b[l]; out.qt[l] = in.q[l]; }
+    if (l < NX) { out.bt[l] = in.b[l]; out.qt[l] = 0.0; }
     if (l < NU) out.rt[l] = 0.0;
     if (l == 0) extent[0] = 0;
     return;

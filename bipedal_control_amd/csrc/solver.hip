@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
 
 constexpr int kTrialWaves = 4; // same for the value-only trial kernel (smaller per-node LDS: four waves, 8 waves per CU)
 constexpr int kLinWaves = 4;   // wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS
-template <int NJ>
+template <int NJ, bool MAT>
 __global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
   using C = LinFastCfg<NJ>;
   constexpr int LPN = C::LPN, NPW = C::NPW;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_
   out.qrd = L.buf.qrd;
   out.s = s;
   out.prof = (valid && b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
-  linearize_fast<NJ>(*L.model, shared, lds[sub], valid, in, out, g);
+  linearize_fast<NJ, MAT>(*L.model, shared, lds[sub], valid, in, out, g);
 }
 
 template <int NJ>
@@ -640,7 +640,9 @@ template <int NJ> void bpmpc_solver::stage_linearize() {
     TIMED_LAUNCH("linearize", k_linearize<NJ>, batch * settings.max_nodes, kWave, L);
   } else {
     constexpr int NPW = LinFastCfg<NJ>::NPW;
-    TIMED_LAUNCH("linearize", k_linearize_fast<NJ>, (batch * settings.max_nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW), kLinWaves * kWave, L);
+    const int grid = (batch * settings.max_nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW);
+    if (settings.materialize_lq) TIMED_LAUNCH("linearize", (k_linearize_fast<NJ, true>), grid, kLinWaves * kWave, L);
+    else TIMED_LAUNCH("linearize", (k_linearize_fast<NJ, false>), grid, kLinWaves * kWave, L);
   }
 }
 template <int NJ> void bpmpc_solver::stage_project() {
@@ -707,7 +709,8 @@ template <int NJ> void bpmpc_solver::pipelined_backward() {
     L.k0 = lo;
     L.klen = hi - lo;
     const int nodes = batch * L.klen;
-    TIMED_LAUNCH_ON(producer_stream, "linearize", k_linearize_fast<NJ>, (nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW), kLinWaves * kWave, L);
+    if (settings.materialize_lq) TIMED_LAUNCH_ON(producer_stream, "linearize", (k_linearize_fast<NJ, true>), (nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW), kLinWaves * kWave, L);
+    else TIMED_LAUNCH_ON(producer_stream, "linearize", (k_linearize_fast<NJ, false>), (nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW), kLinWaves * kWave, L);
     if (max_rows <= 12) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 12>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
     else if (max_rows <= 14) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 14>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
     else TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 16>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
@@ -1217,6 +1220,11 @@ int bpmpc_solver_setup_commands(bpmpc_solver* s, int batch, double horizon, cons
 }
 int bpmpc_solver_rollout(bpmpc_solver* s, const double* t_start, const double* x_start, double duration, double* x_end, double* u_end, int* steps) {
   API_GUARD(s, { rollout(s, t_start, x_start, duration, x_end, u_end, steps); })
+}
+int bpmpc_solver_set_materialize(bpmpc_solver* s, int materialize_lq) {
+  if (!s) { set_last_error("bpmpc_solver_set_materialize: null solver handle"); return BPMPC_ERR_INVALID_ARGUMENT; }
+  s->settings.materialize_lq = materialize_lq != 0;
+  return BPMPC_OK;
 }
 int bpmpc_solver_set_profile(bpmpc_solver* s, int level) {
   if (!s || level < 0 || level > 2) { set_last_error("bpmpc_solver_set_profile: bad argument"); return BPMPC_ERR_INVALID_ARGUMENT; }

@@ -110,6 +110,12 @@ typedef struct {
                            linearisation/projection of the earlier stages (fast kernels only, results are bit-identical).
                            0 or 1 = one launch per stage.  Measured on MI355X: no gain (both sides are bound by LDS
                            bandwidth), so it is off by default; see DESIGN.md. */
+  int materialize_lq;   /* 0 (default): "fused" solve - the lineariser leaves in HBM only what the rest of the solve reads (rows 3..11
+                           of A and B, b, q, r, the active rows of C, D, e, a 320-byte record of the node-dependent part of Q and R);
+                           "A", "B", "Q", "R", "c", "C", "D", "e" of bpmpc_solver_read are then incomplete.
+                           != 0: the complete per-node LQ approximation of the reference ([OCS2-upstream] LinearQuadraticApproximator
+                           output: A, B, b, Q, R, q, r, c, C, D, e) is written - what the parity stages read and what the roofline
+                           unit of bench.py is defined on.  The solution (x, u, K) is the same bits in both modes. */
 } bpmpc_settings;
 
 typedef struct {
@@ -213,6 +219,8 @@ int bpmpc_solver_device_trajectories(bpmpc_solver* solver, double** x_dev, doubl
 /* Asynchronous device-to-device copy of the iterate into caller-owned device buffers (same shapes as above) on the
  * solver's stream - e.g. torch tensors that are then all-gathered over RCCL. */
 int bpmpc_solver_export_trajectories(bpmpc_solver* solver, double* x_dst_dev, double* u_dst_dev);
+/* Change settings.materialize_lq of a live solver. */
+int bpmpc_solver_set_materialize(bpmpc_solver* solver, int materialize_lq);
 /* Change settings.profile of a live solver (0 / 1 / 2 as above). */
 int bpmpc_solver_set_profile(bpmpc_solver* solver, int level);
 /* Accumulated HIP-event time of one kernel class since the last call with reset != 0 (needs settings.profile):

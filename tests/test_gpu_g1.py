@@ -31,7 +31,7 @@ def test_g1_linearize_matches_oracle(ctx, gait):
     bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
     B, NN = 3, 56
     prob = sc.trot_problem(itf, batch=B, n_intervals=36, gait=gait)
-    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN, materialize_lq=True)
     lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
     mpc.enqueue(); mpc.synchronize()          # one accepted step: a generic iterate
     mpc.stage("linearize"); mpc.synchronize()
@@ -103,7 +103,7 @@ def test_g1_full_size_properties(ctx):
     bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
     B, N, NN = 1024, 100, 120
     prob = sc.trot_problem(itf, batch=B, n_intervals=N, gait=WALK)
-    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN, sqp_iterations=3)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN, sqp_iterations=3, materialize_lq=True)
     mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
     for st in ("linearize", "project", "riccati"):
         mpc.stage(st)

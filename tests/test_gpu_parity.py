@@ -32,7 +32,7 @@ def _views(mpc, name, per_node):
 def test_linearize_matches_oracle(ctx):
     bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
     prob = sc.trot_problem(itf, batch=3, n_intervals=30)
-    mpc = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=48)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=48, materialize_lq=True)     # the complete LQ model is compared, not only what the solve reads
     lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
     # move away from the cold start so that every term is exercised: one accepted step first
     mpc.enqueue(); mpc.synchronize()
@@ -118,7 +118,7 @@ def test_full_size_properties(ctx):
     bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
     B, N = 256, 100
     prob = sc.trot_problem(itf, batch=B, n_intervals=N)
-    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=112, sqp_iterations=3)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=112, sqp_iterations=3, materialize_lq=True)
     mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
     for st in ("linearize", "project", "riccati"):
         mpc.stage(st)
@@ -153,7 +153,7 @@ def test_full_size_properties(ctx):
     # (a) permutation / sub-batch invariance, bitwise
     sub = [200, 3, 77]
     prob2 = dict(prob, x0=prob["x0"][sub], targets=[prob["targets"][i] for i in sub])
-    mpc2 = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=112, sqp_iterations=3)
+    mpc2 = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=112, sqp_iterations=3)      # ... and of the solve mode: this handle runs fused
     t2, x2, u2, _, _ = mpc2.run(prob2["t0"], prob2["x0"], prob2["schedule"], prob2["targets"], horizon=prob2["horizon"])
     for j, i in enumerate(sub):
         assert np.array_equal(x2[j], x[i]) and np.array_equal(u2[j], u[i])
@@ -291,3 +291,40 @@ def test_gait_event_on_the_window_boundaries(ctx, t0):
     n = st[0].n_nodes
     xo, uo, _, _ = ob.oracle_solve_like(prob, 0)
     assert xo.shape[0] == n + 1 and _rel(x[0, :n + 1], xo) < 1e-8 and _rel(u[0, :n], uo) < 1e-8
+
+
+@pytest.mark.parametrize("robot,gait", [("h1", "trot"), ("h1", "flying_trot"), ("g1", "standing_trot")])
+def test_fused_and_materialised_modes_are_bit_identical(ctx, robot, gait):
+    """settings.materialize_lq only decides what the lineariser leaves in HBM (the complete LQ model of the reference, or just what the
+    rest of the solve reads): x, u, K, the statistics and every buffer both modes write must agree bit for bit - also after the
+    handle has switched modes, and on a handle that is reused for another gait (stale rows / stale padding must never be read)."""
+    bp, sc = ctx["bp"], ctx["sc"]
+    itf = sc.interface(robot)
+    nx = itf.stateDim
+    prob = sc.trot_problem(itf, batch=5, n_intervals=45, gait=gait)
+    other = sc.trot_problem(itf, batch=5, n_intervals=45, gait="stance")
+    out = {}
+    for mat in (True, False):
+        mpc = bp.BatchedSqpMpc(itf, max_batch=5, max_nodes=72, sqp_iterations=3, return_gains=True, materialize_lq=mat)
+        mpc.run(other["t0"], other["x0"], other["schedule"], other["targets"], horizon=other["horizon"])     # leaves 12-row nodes with other contents behind
+        t, x, u, K, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+        n = st[0].n_nodes
+        mpc.stage("linearize"); mpc.stage("project"); mpc.synchronize()
+        extra = {k: mpc.read(k) for k in ("b", "q", "r", "perf", "nc", "Px", "Pu", "Pe", "nut", "At", "Bt", "bt", "Qt", "Rt", "Pt", "qt", "rt")}
+        A = mpc.read("A").reshape(5, 72, nx, nx)[:, :n, 3:12].copy()          # the dense rows are written in both modes
+        out[mat] = (x, u, K, [(s.step_size, s.merit_after, s.dynamics_sse_after, s.equality_sse_after, s.iterations) for s in st], extra, A, mpc)
+    a, b = out[True], out[False]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    kinds = a[6].read("g_kind").reshape(5, 72)[0, :a[5].shape[1]]
+    for k in a[4]:
+        if k in ("q", "r"):      # the cost gradient of an event node is zero by definition: only the materialised mode stores those zeros
+            va, vb = (v[k].reshape(5, 72, nx)[:, :len(kinds)][:, kinds == 0] for v in (a[4], b[4]))
+            assert np.array_equal(va, vb), k
+        else:
+            assert np.array_equal(a[4][k], b[4][k]), k
+    assert np.array_equal(a[5][:, kinds == 0], b[5][:, kinds == 0])
+    # switching a live handle: fused -> materialised gives the materialised handle's complete model
+    b[6].set_materialize(True)
+    b[6].stage("linearize"); b[6].synchronize()
+    for k in ("A", "B", "Q", "R", "C", "D", "e", "c"):
+        assert np.array_equal(a[6].read(k), b[6].read(k)), k

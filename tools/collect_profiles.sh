@@ -3,7 +3,7 @@
 # Produces under gpurun_out/<tag>_*: the rocprofv3 kernel-trace summary of the default bench command and two separate PMC passes
 # (FETCH_SIZE, WRITE_SIZE; never combined with API tracing).  Copy what should be judged into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT

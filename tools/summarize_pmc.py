@@ -35,8 +35,16 @@ def main(fetch_dir, write_dir, out):
         w, nw = write.get(name, [0.0, 1])
         kernels[name] = {"launches": nf, "FETCH_SIZE_KiB_per_launch": round(f / max(nf, 1), 1), "WRITE_SIZE_KiB_per_launch": round(w / max(nw, 1), 1),
                          "hbm_bytes_per_launch": int(1024 * (2.0 * f / max(nf, 1) + w / max(nw, 1)))}
-    lin = next((k for k in kernels if k.startswith("k_linearize_fast")), None)
+    # the roofline kernel is the materialised lineariser (template argument `true`); per-step totals of both solve modes: every kernel
+    # class runs once per step except the two linearisers, which split the steps between them
+    lin = next((k for k in kernels if k.startswith("k_linearize_fast") and k.endswith("true>")), None) or next((k for k in kernels if k.startswith("k_linearize_fast")), None)
+    lin_f = next((k for k in kernels if k.startswith("k_linearize_fast") and k.endswith("false>")), None)
+    ric = next((k for k in kernels if k.startswith("k_riccati_fast")), None)
+    steps = kernels[ric]["launches"] if ric else 0
+    per_step_common = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in kernels.items() if not k.startswith("k_linearize_fast") and not k.startswith("k_prepare")) / max(1, steps)
     res = {"batch": 256, "intervals": 100, "kernel": lin,
+           "materialised_hbm_bytes_per_step": int(per_step_common + kernels[lin]["hbm_bytes_per_launch"]) if lin and steps else None,
+           "fused_hbm_bytes_per_step": int(per_step_common + kernels[lin_f]["hbm_bytes_per_launch"]) if lin_f and steps else None,
            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 3 --warmup 1 --cpu-sample 0",
            "hbm_bytes_per_launch": kernels[lin]["hbm_bytes_per_launch"] if lin else None,
            "note": "FETCH_SIZE doubled (gfx950 reports half of the streamed read bytes, MI355X_MICROARCH.md); WRITE_SIZE as reported.",
