@@ -1,0 +1,44 @@
+// SYNTAX-CHECK STAND-IN (see ../../README.md) for ocs2_core: Types.h, ControllerBase / LinearController / FeedforwardController,
+// ModeSchedule, TargetTrajectories, PerformanceIndex.  Declarations only, written from SURVEY.md section 8(b); not OCS2.
+#pragma once
+#include <Eigen/Core>
+#include <memory>
+#include <string>
+#include <vector>
+namespace ocs2 {
+using scalar_t = double;
+using scalar_array_t = std::vector<scalar_t>;
+using size_array_t = std::vector<size_t>;
+using vector_t = Eigen::Matrix<scalar_t, Eigen::Dynamic, 1>;
+using matrix_t = Eigen::Matrix<scalar_t, Eigen::Dynamic, Eigen::Dynamic>;
+using vector_array_t = std::vector<vector_t>;
+using matrix_array_t = std::vector<matrix_t>;
+class ControllerBase { public: virtual ~ControllerBase() = default; };
+class LinearController final : public ControllerBase {
+ public:
+  LinearController(scalar_array_t, vector_array_t, matrix_array_t) {}
+};
+class FeedforwardController final : public ControllerBase {
+ public:
+  FeedforwardController(scalar_array_t, vector_array_t) {}
+};
+struct ModeSchedule { scalar_array_t eventTimes; size_array_t modeSequence; };
+struct TargetTrajectories { scalar_array_t timeTrajectory; vector_array_t stateTrajectory; vector_array_t inputTrajectory; };
+struct PerformanceIndex { scalar_t merit = 0, cost = 0, dualFeasibilitiesSSE = 0, dynamicsViolationSSE = 0, equalityConstraintsSSE = 0, inequalityConstraintsSSE = 0, equalityLagrangian = 0, inequalityLagrangian = 0; };
+struct ScalarFunctionQuadraticApproximation {};
+struct MultiplierCollection {};
+struct ProblemMetrics {};
+struct OptimalControlProblem {};
+struct PrimalSolution {
+  scalar_array_t timeTrajectory_;
+  vector_array_t stateTrajectory_, inputTrajectory_;
+  scalar_array_t postEventIndices_;
+  ModeSchedule modeSchedule_;
+  std::unique_ptr<ControllerBase> controllerPtr_;
+  PrimalSolution() = default;
+  PrimalSolution(const PrimalSolution& o) : timeTrajectory_(o.timeTrajectory_), stateTrajectory_(o.stateTrajectory_), inputTrajectory_(o.inputTrajectory_), modeSchedule_(o.modeSchedule_) {}
+  PrimalSolution& operator=(const PrimalSolution& o) { timeTrajectory_ = o.timeTrajectory_; stateTrajectory_ = o.stateTrajectory_; inputTrajectory_ = o.inputTrajectory_; modeSchedule_ = o.modeSchedule_; controllerPtr_.reset(); return *this; }
+  PrimalSolution(PrimalSolution&&) = default;
+  PrimalSolution& operator=(PrimalSolution&&) = default;
+};
+}  // namespace ocs2
