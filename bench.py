@@ -33,6 +33,11 @@ sys.path.insert(0, ROOT)
 BYTES_PER_NODE_H1 = 26444 - 3872
 BYTES_PER_NODE_24 = 30748 - 24 * 24 * 8      # nx = nu = 24 class, same rule
 HBM_PEAK_GBS = 8000.0              # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# FP64 peak: half of the guide's FP32 vector peak (157.3 TFLOP/s = 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz) - a wave64 v_fma_f64
+# issues in 4 cycles (16 lanes per clock and SIMD); v_mfma_f64_16x16x4_f64 runs at the same 32 FLOP/clk/SIMD (measured 64 cycles,
+# tools/probes/mfma_f64_probe.hip), so vector and matrix FP64 peaks coincide
+FP64_PEAK_TFLOPS = 78.6
+FP64_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9      # FP64 VALU lane-operations per second at full issue rate
 ROBOT_LABEL = {"h1": "Unitree H1", "openloong": "OpenLoong (nx = nu = 24)", "g1": "Unitree G1 (nx = nu = 24; self-defined configuration, not reference parity)"}
 KERNEL_CLASSES = ("linearize", "project_lu", "project", "riccati", "linesearch")
 
@@ -304,6 +309,13 @@ def main():
                "ms_per_solve": round(ms_per_step / max(1, total // world), 6),
                "kernel_ms_per_step": {k: round(v[0] / max(1, kt_steps), 4) for k, v in ktimes.items()},
                "roofline": roofline, "fused": fused}
+        if roofline is not None:
+            roofline["limiter"] = "not HBM: FP64 issue / latency at 2 waves per SIMD (roofline_fp64.linearize: wave_time_split, issue_frac)"
+        kms = out["kernel_ms_per_step"]
+        n_all_nodes = int(sum(g_nodes[p_grid])) if world == 1 else None
+        if world == 1:
+            out["roofline_fp64"] = roofline_fp64("h1" if nx == 22 else "g1", kms, n_intermediate_total, n_all_nodes, n_all_nodes,
+                                                 applicable=headline and scaling == "weak" and args.batch == 256)
         if world == 1 and args.cpu_sample > 0:
             if sweep:
                 out["cpu_baseline"] = cpu_baseline_sweep(itf, cp, min(args.cpu_sample, 16), x, stats, args.robot)
@@ -314,6 +326,50 @@ def main():
         assert gathered_ok, "gathered trajectories differ from the local result"
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_fp64(robot, kernel_ms, n_lin_nodes, n_nodes_total, n_stages_total, applicable):
+    """FP64 view of the five hot kernels: none of them is near the HBM roof, so what binds them?
+      restatement_flops    operation count of the CPU restatement for the work of one launch (profiles/flop_counts.json: instrumented
+                           scalar for the lineariser, standard dense-algebra counts behind it) - NOT a bound for the lineariser: the
+                           restatement differentiates in forward mode over 44 directions, the kernel uses analytic derivatives
+      executed             from the committed SQ counter passes of this same command (profiles/r02_sq_counters.json): VALU
+                           lane-operations (SQ_INSTS_VALU x 64) and FP64 MFMAs (x 2048 flop) per launch
+      issue_frac           executed lane-operations / launch time / the FP64 issue rate (16 lanes per clock and SIMD): the fraction of
+                           the vector pipe's FP64 issue slots the kernel fills - an upper bound of its FP64 utilisation, since every
+                           VALU instruction is counted as one FP64 slot
+      mfma_frac            MFMA flop / launch time / 78.6 TFLOP/s
+    Durations are this run's HIP-event times; the counter file only applies to the headline workload."""
+    cpath, fpath = os.path.join(ROOT, "profiles", "r02_sq_counters.json"), os.path.join(ROOT, "profiles", "flop_counts.json")
+    if not (os.path.exists(cpath) and os.path.exists(fpath)):
+        return None
+    try:
+        counters, flops = json.load(open(cpath)), json.load(open(fpath))["robots"][robot]
+    except Exception:
+        return None
+    classes = {"linearize": ("k_linearize_fast", flops["node_linearization"] * n_lin_nodes),
+               "project_lu": ("k_project_lu", flops["lu_projection"] * n_lin_nodes),
+               "project": ("k_project_fast", flops["change_of_variables"] * n_lin_nodes),
+               "riccati": ("k_riccati_fast", flops["riccati_stage"] * n_stages_total),
+               "linesearch": ("k_trial_fast", 2 * flops["flow_map"] * n_nodes_total + flops["ee_kinematics"] * n_nodes_total)}
+    out = {"peak_tflops": FP64_PEAK_TFLOPS, "note": "restatement_flops = CPU restatement's operation count (forward-mode AD for the lineariser: not a bound); "
+                                                     "issue_frac = executed VALU lane-ops / time / FP64 issue rate; counters from profiles/r02_sq_counters.json"}
+    for cls, (prefix, rflops) in classes.items():
+        ms = kernel_ms.get(cls)
+        if not ms:
+            continue
+        e = {"ms": ms, "restatement_flops": int(rflops), "restatement_tflops": round(rflops / (1e-3 * ms) / 1e12, 2)}
+        ck = next((v for k, v in counters.items() if k.startswith(prefix)), None) if applicable else None
+        if ck:
+            lane_ops = ck.get("SQ_INSTS_VALU", 0.0) * 64.0
+            mfma = ck.get("SQ_INSTS_VALU_MFMA_F64", 0.0)
+            e.update({"executed_valu_lane_ops": int(lane_ops), "executed_mfma_f64": int(mfma),
+                      "issue_frac": round(lane_ops / (1e-3 * ms) / FP64_LANE_OPS_PER_S, 4),
+                      "mfma_frac": round(mfma * 2048.0 / (1e-3 * ms) / (FP64_PEAK_TFLOPS * 1e12), 4),
+                      "wave_time_split": {"active": ck.get("active"), "parked_on_waitcnt_or_barrier": ck.get("stall_parked"), "issue_stall": ck.get("stall_issue")},
+                      "lds_bank_conflict_frac": ck.get("lds_conflict_frac"), "vgpr": ck.get("vgpr"), "lds_bytes": ck.get("lds_bytes")})
+        out[cls] = e
+    return out
 
 
 def _host_cpu():

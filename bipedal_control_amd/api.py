@@ -37,7 +37,7 @@ class BpmpcError(RuntimeError):
 class _Settings(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("max_nodes", C.c_int), ("sqp_iterations", C.c_int), ("dt", C.c_double),
                 ("return_gains", C.c_int), ("profile", C.c_int), ("stream", C.c_void_p), ("reference_kernels", C.c_int),
-                ("pipeline_chunks", C.c_int), ("materialize_lq", C.c_int)]
+                ("pipeline_chunks", C.c_int), ("materialize_lq", C.c_int), ("reg_prim", C.c_double)]
 
 
 class _Schedule(C.Structure):
@@ -211,7 +211,7 @@ class BatchedSqpMpc:
     MPC_MRT_Interface::advanceMpc() (BipedalController.cpp:339) for every problem of the batch at once."""
 
     def __init__(self, interface, max_batch, max_nodes, sqp_iterations=0, dt=0.0, return_gains=False, profile=False, device=0, stream=None,
-                 reference_kernels=False, pipeline_chunks=0, materialize_lq=False):
+                 reference_kernels=False, pipeline_chunks=0, materialize_lq=False, reg_prim=0.0):
         lib = load_library()
         self.interface = interface
         self.max_batch, self.max_nodes = int(max_batch), int(max_nodes)
@@ -222,7 +222,7 @@ class BatchedSqpMpc:
             # ordered against torch has to run on an explicit stream (torch.cuda.Stream().cuda_stream), see bench.py.
             raise ValueError("stream=0 (the default stream) cannot be handed over; pass an explicit stream handle or None for a solver-owned stream")
         st = _Settings(int(device), self.max_batch, self.max_nodes, int(sqp_iterations), float(dt), int(bool(return_gains)), int(profile),
-                       C.c_void_p(int(stream)) if stream is not None else None, int(bool(reference_kernels)), int(pipeline_chunks), int(bool(materialize_lq)))
+                       C.c_void_p(int(stream)) if stream is not None else None, int(bool(reference_kernels)), int(pipeline_chunks), int(bool(materialize_lq)), float(reg_prim))
         self._h = C.c_void_p()
         _check(lib.bpmpc_solver_create(interface.handle, C.byref(st), C.byref(self._h)))
         self._keep = None

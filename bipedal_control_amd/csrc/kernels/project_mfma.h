@@ -38,7 +38,7 @@ struct ProjectMfmaWorkspace {
 // order, a load issued behind a store would wait for that store to reach memory.
 template <int NJ, int NBC>
 __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
-                                                     double dt_over_mass, const double* Qc, const double* Rc) {
+                                                     double dt_over_mass, const double* Qc, const double* Rc, double reg, int nut) {
   using WS = ProjectMfmaWorkspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, KR = WS::KR, KS = KR / 4, BC = NX + 1;
   const int l = threadIdx.x, li = l & 15, lk = l >> 4;
@@ -158,12 +158,12 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
         const int ru = rr - BC, cu = col - BC;
         const bool top = rr < NX, bot = rr > NX && ru < NU;
         if (top) {
-          if (col < NX) out.Qt[rr * NX + col] = acc[r];
+          if (col < NX) out.Qt[rr * NX + col] = acc[r] + (rr == col ? reg : 0.0);      // reg: settings.reg_prim (HPIPM's), 0 by default
           else if (col == NX) out.qt[rr] = acc[r];
         } else if (bot) {
           if (col < NX) out.Pt[ru * NX + col] = acc[r];
           else if (col == NX) out.rt[ru] = acc[r];
-          else if (cu < NU) out.Rt[ru * NU + cu] = acc[r];
+          else if (cu < NU) out.Rt[ru * NU + cu] = acc[r] + ((ru == cu && ru < nut) ? reg : 0.0);
         }
       }
     }
@@ -173,7 +173,7 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
 
 template <int NJ>
 __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, int* extent, double dt,
-                                                   double dt_over_mass, const double* Qc, const double* Rc) {
+                                                   double dt_over_mass, const double* Qc, const double* Rc, double reg = 0.0) {
   using WS = ProjectMfmaWorkspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, LDW = WS::LDW, KR = WS::KR, BC = NX + 1, WC = WS::WC;
   static_assert(NX == NU, "packed layout assumes nx == nu");
@@ -181,7 +181,7 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
 
   if (in.kind == 1) {  // event node: identity jump map, no input, no cost (what the lineariser writes for it in the materialised mode;
                        // generated here so that the fused mode need not write it); Px, Pu, Pe, nut were written by the LU kernel
-    for (int idx = l; idx < NX * NX; idx += kWave) { out.At[idx] = (idx / NX == idx % NX) ? 1.0 : 0.0; out.Qt[idx] = 0.0; }
+    for (int idx = l; idx < NX * NX; idx += kWave) { const bool dg = idx / NX == idx % NX; out.At[idx] = dg ? 1.0 : 0.0; out.Qt[idx] = dg ? reg : 0.0; }
     for (int idx = l; idx < NX * NU; idx += kWave) { out.Bt[idx] = 0.0; out.Pt[idx] = 0.0; }
     for (int idx = l; idx < NU * NU; idx += kWave) out.Rt[idx] = 0.0;
     if (l < NX) { out.bt[l] = in.b[l]; out.qt[l] = 0.0; }
@@ -213,9 +213,9 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
   for (int idx = l; idx < NU * (LDW - WC); idx += kWave) ws.X[idx / (LDW - WC)][WC + idx % (LDW - WC)] = 0.0;   // columns beyond [Px Pe Pu]
 
-  if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass, Qc, Rc);
-  else if (nbc == 3) project_apply_blocks<NJ, 3>(ws, in, out, dt, dt_over_mass, Qc, Rc);
-  else project_apply_blocks<NJ, (WC + 15) / 16>(ws, in, out, dt, dt_over_mass, Qc, Rc);
+  if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
+  else if (nbc == 3) project_apply_blocks<NJ, 3>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
+  else project_apply_blocks<NJ, (WC + 15) / 16>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
 
   // ---- keep "beyond nut reads as zero": clear what an earlier, wider projection of this node left behind
   const int cov = 16 * (nbc <= 2 ? 2 : nbc) - BC;      // reduced-input indices written by the blocks of this call

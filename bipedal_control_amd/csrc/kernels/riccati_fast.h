@@ -25,6 +25,7 @@ struct RiccatiFastIO {
   // S, s and the status to the next one through `carry` (NX*NX + NX + 1 doubles).  The roll-out runs when k_lo == 0.
   int k_lo, k_hi;
   double* carry;
+  double reg;                // settings.reg_prim: the terminal value function starts at reg * I (every other stage gets it from the projection kernel)
 };
 
 // Workgroup barrier that orders LDS traffic only: outstanding global loads (the prefetch) and stores stay in flight.

@@ -158,6 +158,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
   }
   __syncthreads();
   if (tid == 0) ws.status = resumed ? (int)io.carry[NXX + NX] : 0;
+  if (!resumed && io.reg != 0.0 && tid < NX) ws.S[tid][tid] = io.reg;
   if (resumed) {
     for (int idx = tid; idx < NXX; idx += NT) ws.S[idx / NX][idx % NX] = io.carry[idx];
     if (tid < NX) ws.S[tid][NX] = io.carry[NXX + tid];

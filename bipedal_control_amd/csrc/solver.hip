@@ -92,6 +92,7 @@ struct Launch {
   int k0, klen;  // node range [k0, k0 + klen) of this launch (fast kernels; the horizon is pipelined in chunks)
   int cold;
   LineSearchSettings ls;
+  double reg_prim;
 };
 
 template <int NJ>
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kWave) void k_project_fast(Launch L) {
   out.rt = L.buf.rt + s * NU;
   in.qrd = L.buf.qrd + s * kQrdStride;
   const double dt = L.buf.g_dt[(size_t)g * L.N + k];
-  project_apply_mfma<NJ>(ws, in, out, L.buf.proj_extent + s, dt, dt * (1.0 / L.model->robot_mass), L.model->Q, L.model->R);   // as written by linearize_fast
+  project_apply_mfma<NJ>(ws, in, out, L.buf.proj_extent + s, dt, dt * (1.0 / L.model->robot_mass), L.model->Q, L.model->R, L.reg_prim);   // as written by linearize_fast
 }
 
 template <int NJ>
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu
   io.k_lo = L.k0;
   io.k_hi = L.k0 + L.klen;
   io.carry = L.buf.ric_carry + (size_t)b * (NX * NX + NX + 2);
+  io.reg = L.reg_prim;
   riccati_mfma<NJ, DB>(ws, io);
 }
 
@@ -577,6 +579,7 @@ struct bpmpc_solver {
     L.klen = settings.max_nodes;
     L.cold = cold ? 1 : 0;
     L.ls = ls;
+    L.reg_prim = settings.reg_prim;
     return L;
   }
 
@@ -1147,6 +1150,8 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
   try {
     s->rm = model_of(model);
     if (s->rm.nj != 10 && s->rm.nj != 12) { set_last_error("only 10- and 12-joint bipeds are instantiated"); return BPMPC_ERR_UNSUPPORTED; }
+    if (settings->reg_prim != 0.0 && settings->reference_kernels) { set_last_error("reg_prim is implemented by the fast kernels only"); return BPMPC_ERR_UNSUPPORTED; }
+    if (!(settings->reg_prim >= 0.0)) { set_last_error("reg_prim must be >= 0"); return BPMPC_ERR_INVALID_ARGUMENT; }
     s->dm = make_device_model(s->rm);
     s->settings = *settings;
     s->nx = s->rm.nx; s->nu = s->rm.nu;

@@ -116,6 +116,9 @@ typedef struct {
                            != 0: the complete per-node LQ approximation of the reference ([OCS2-upstream] LinearQuadraticApproximator
                            output: A, B, b, Q, R, q, r, c, C, D, e) is written - what the parity stages read and what the roofline
                            unit of bench.py is defined on.  The solution (x, u, K) is the same bits in both modes. */
+  double reg_prim;      /* [OCS2-upstream] HPIPM's reg_prim (hpipm_catkin sets 1e-12): added to the diagonal of every stage Hessian
+                           [R~ P~'; P~ Q~] of the projected QP, terminal stage included, before the Riccati factorisation.  0 (default) =
+                           exact recursion; 1e-12 moves the H1 input step by ~5e-9 relative (tests/test_recalled_behaviours.py). */
 } bpmpc_settings;
 
 typedef struct {

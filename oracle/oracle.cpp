@@ -33,6 +33,36 @@ struct Model {
 };
 
 // ------------------------------------------------------------------------------------------------
+// Operation counter (SURVEY.md section 8(d) "algorithmic flops ... instrument the templated scalar").  Only the separate build
+// liboracle_count.so (-DORACLE_COUNT_FLOPS) counts; in liboracle.so - the checker and the timed cpu_baseline - FL() is nothing.
+// One unit = one double-precision add, multiply, divide, square root or sin / cos evaluation of THIS restatement (forward-mode AD
+// over all nx + nu directions); an analytic or sparse differentiation needs far fewer, see DESIGN.md.
+// ------------------------------------------------------------------------------------------------
+#ifdef ORACLE_COUNT_FLOPS
+static unsigned long long g_flops = 0;
+#define FL(n) (g_flops += static_cast<unsigned long long>(n))
+#else
+#define FL(n) ((void)0)
+#endif
+
+// counting scalar for value-only evaluations of the templated functions
+struct CD {
+  double v;
+  CD() : v(0.0) {}
+  CD(double a) : v(a) {}  // NOLINT
+};
+inline CD operator+(CD a, CD b) { FL(1); return CD(a.v + b.v); }
+inline CD operator-(CD a, CD b) { FL(1); return CD(a.v - b.v); }
+inline CD operator-(CD a) { return CD(-a.v); }
+inline CD operator*(CD a, CD b) { FL(1); return CD(a.v * b.v); }
+inline CD operator/(CD a, CD b) { FL(1); return CD(a.v / b.v); }
+inline CD& operator+=(CD& a, CD b) { a = a + b; return a; }
+inline CD& operator-=(CD& a, CD b) { a = a - b; return a; }
+inline CD sin(CD a) { FL(1); return CD(std::sin(a.v)); }
+inline CD cos(CD a) { FL(1); return CD(std::cos(a.v)); }
+inline double val(CD a) { return a.v; }
+
+// ------------------------------------------------------------------------------------------------
 // forward-mode dual numbers
 // ------------------------------------------------------------------------------------------------
 template <int N>
@@ -42,23 +72,23 @@ struct Dual {
   Dual() : v(0.0) { for (int i = 0; i < N; ++i) d[i] = 0.0; }
   Dual(double a) : v(a) { for (int i = 0; i < N; ++i) d[i] = 0.0; }  // NOLINT
 };
-template <int N> inline Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-template <int N> inline Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> inline Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) { FL(1 + N); Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> inline Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) { FL(1 + N); Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
 template <int N> inline Dual<N> operator-(const Dual<N>& a) { Dual<N> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
-template <int N> inline Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-template <int N> inline Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; const double ib = 1.0 / b.v; r.v = a.v * ib; for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
-template <int N> inline Dual<N> operator+(const Dual<N>& a, double b) { Dual<N> r = a; r.v += b; return r; }
+template <int N> inline Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) { FL(1 + 3 * N); Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N> inline Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) { FL(2 + 3 * N); Dual<N> r; const double ib = 1.0 / b.v; r.v = a.v * ib; for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
+template <int N> inline Dual<N> operator+(const Dual<N>& a, double b) { FL(1); Dual<N> r = a; r.v += b; return r; }
 template <int N> inline Dual<N> operator+(double b, const Dual<N>& a) { return a + b; }
-template <int N> inline Dual<N> operator-(const Dual<N>& a, double b) { Dual<N> r = a; r.v -= b; return r; }
+template <int N> inline Dual<N> operator-(const Dual<N>& a, double b) { FL(1); Dual<N> r = a; r.v -= b; return r; }
 template <int N> inline Dual<N> operator-(double b, const Dual<N>& a) { return (-a) + b; }
-template <int N> inline Dual<N> operator*(const Dual<N>& a, double b) { Dual<N> r; r.v = a.v * b; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r; }
+template <int N> inline Dual<N> operator*(const Dual<N>& a, double b) { FL(1 + N); Dual<N> r; r.v = a.v * b; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r; }
 template <int N> inline Dual<N> operator*(double b, const Dual<N>& a) { return a * b; }
-template <int N> inline Dual<N> operator/(const Dual<N>& a, double b) { return a * (1.0 / b); }
+template <int N> inline Dual<N> operator/(const Dual<N>& a, double b) { FL(1); return a * (1.0 / b); }
 template <int N> inline Dual<N> operator/(double a, const Dual<N>& b) { return Dual<N>(a) / b; }
 template <int N> inline Dual<N>& operator+=(Dual<N>& a, const Dual<N>& b) { a = a + b; return a; }
 template <int N> inline Dual<N>& operator-=(Dual<N>& a, const Dual<N>& b) { a = a - b; return a; }
-template <int N> inline Dual<N> sin(const Dual<N>& a) { Dual<N> r; r.v = std::sin(a.v); const double c = std::cos(a.v); for (int i = 0; i < N; ++i) r.d[i] = c * a.d[i]; return r; }
-template <int N> inline Dual<N> cos(const Dual<N>& a) { Dual<N> r; r.v = std::cos(a.v); const double s = -std::sin(a.v); for (int i = 0; i < N; ++i) r.d[i] = s * a.d[i]; return r; }
+template <int N> inline Dual<N> sin(const Dual<N>& a) { FL(2 + N); Dual<N> r; r.v = std::sin(a.v); const double c = std::cos(a.v); for (int i = 0; i < N; ++i) r.d[i] = c * a.d[i]; return r; }
+template <int N> inline Dual<N> cos(const Dual<N>& a) { FL(2 + N); Dual<N> r; r.v = std::cos(a.v); const double s = -std::sin(a.v); for (int i = 0; i < N; ++i) r.d[i] = s * a.d[i]; return r; }
 inline double val(double a) { return a; }
 template <int N> inline double val(const Dual<N>& a) { return a.v; }
 
@@ -451,11 +481,13 @@ void node_lq(const Model& m, int kind, double dt, const double* x, const double*
     for (int j = 0; j < nx; ++j) {
       double t = 0;
       for (int l = 0; l < nx; ++l) t += A2[i * nx + l] * A1[l * nx + j];
+      FL(2 * nx + 5);
       o.A[i * nx + j] = (i == j ? 1.0 : 0.0) + h * (A1[i * nx + j] + A2[i * nx + j] + dt * t);
     }
     for (int j = 0; j < nu; ++j) {
       double t = 0;
       for (int l = 0; l < nx; ++l) t += A2[i * nx + l] * B1[l * nu + j];
+      FL(2 * nx + 4);
       o.B[i * nu + j] = h * (B1[i * nu + j] + B2[i * nu + j] + dt * t);
     }
     o.b[i] = x[i] + h * f1[i] + h * f2[i] - xnext[i];
@@ -466,6 +498,7 @@ void node_lq(const Model& m, int kind, double dt, const double* x, const double*
   for (int i = 0; i < nx; ++i) dx[i] = x[i] - xref[i];
   for (int i = 0; i < nu; ++i) du[i] = u[i] - unom[i];
   o.Q = m.Q; o.R = m.R;
+  FL(2 * nx + 2 * nu + (2 * nx + 3) * nx + (2 * nu + 3) * nu + 4 * 60 + nx * nx + nu * nu + nx + nu);   // b, dx, du, two mat-vecs + cost, four cones, dt scaling
   double c = 0;
   for (int i = 0; i < nx; ++i) { double t = 0; for (int j = 0; j < nx; ++j) t += m.Q[i * nx + j] * dx[j]; o.q[i] = t; c += 0.5 * dx[i] * t; }
   for (int i = 0; i < nu; ++i) { double t = 0; for (int j = 0; j < nu; ++j) t += m.R[i * nu + j] * du[j]; o.r[i] = t; c += 0.5 * du[i] * t; }
@@ -529,6 +562,7 @@ void node_lq(const Model& m, int kind, double dt, const double* x, const double*
     }
   }
   o.nc = row;
+  FL(2 * nx + 2 * row + (m.gain != 0.0 ? 2 * row * nx : 0));
   double dyn = 0, eq = 0;
   for (int i = 0; i < nx; ++i) dyn += o.b[i] * o.b[i];
   for (int i = 0; i < row; ++i) eq += o.e[i] * o.e[i];
@@ -708,9 +742,12 @@ void chol_solve(int n, const std::vector<double>& L, double* rhs, int nrhs, int 
   }
 }
 
-int riccati(int nx, int nu, int N, const std::vector<ProjectedLQ>& lq, const double* dx0, QPSolution& sol) {
+// reg: HPIPM's reg_prim ([OCS2-upstream] hpipm_catkin: 1e-12), added to the diagonal of every stage Hessian [R~ P~; P~' Q~] (and of the
+// terminal one, which is otherwise zero here) before the factorisation.  0 = exact recursion (the default of this restatement).
+int riccati(int nx, int nu, int N, const std::vector<ProjectedLQ>& lq, const double* dx0, QPSolution& sol, double reg = 0.0) {
   sol.dx.assign((N + 1) * nx, 0.0); sol.dut.assign(N * nu, 0.0); sol.Kt.assign(N * nu * nx, 0.0); sol.kt.assign(N * nu, 0.0);
   std::vector<double> S(nx * nx, 0.0), s(nx, 0.0), SA(nx * nx), Sb(nx), Sn(nx * nx), sn(nx);
+  for (int i = 0; i < nx; ++i) S[i * nx + i] = reg;
   for (int k = N - 1; k >= 0; --k) {
     const ProjectedLQ& n = lq[k];
     const int nt = n.nut;
@@ -727,7 +764,7 @@ int riccati(int nx, int nu, int N, const std::vector<ProjectedLQ>& lq, const dou
     for (int i = 0; i < nx; ++i)
       for (int j = 0; j < nt; ++j) { double t = 0; for (int l = 0; l < nx; ++l) t += S[i * nx + l] * n.B[l * nt + j]; SB[i * nt + j] = t; }
     for (int i = 0; i < nt; ++i)
-      for (int j = 0; j < nt; ++j) { double t = n.R[i * nt + j]; for (int l = 0; l < nx; ++l) t += n.B[l * nt + i] * SB[l * nt + j]; H[i * nt + j] = t; }
+      for (int j = 0; j < nt; ++j) { double t = n.R[i * nt + j] + (i == j ? reg : 0.0); for (int l = 0; l < nx; ++l) t += n.B[l * nt + i] * SB[l * nt + j]; H[i * nt + j] = t; }
     double* Kt = &sol.Kt[k * nu * nx];
     double* kt = &sol.kt[k * nu];
     if (nt > 0) {
@@ -739,7 +776,7 @@ int riccati(int nx, int nu, int N, const std::vector<ProjectedLQ>& lq, const dou
     }
     for (int i = 0; i < nx; ++i) {
       for (int j = 0; j < nx; ++j) {
-        double t = n.Q[i * nx + j];
+        double t = n.Q[i * nx + j] + (i == j ? reg : 0.0);
         for (int l = 0; l < nx; ++l) t += n.A[l * nx + i] * SA[l * nx + j];
         for (int l = 0; l < nt; ++l) t += G[l * nx + i] * Kt[l * nx + j];
         Sn[i * nx + j] = t;
@@ -783,7 +820,7 @@ struct StepOut {
 };
 
 // one QP: [OCS2-upstream] SqpSolver::setupQuadraticSubproblem + getOCPSolution
-int qp_step(const Model& m, const Problem& pb, const double* x0, const double* x, const double* u, StepOut& out) {
+int qp_step(const Model& m, const Problem& pb, const double* x0, const double* x, const double* u, StepOut& out, double reg_prim = 0.0) {
   const int nx = m.nx, nu = m.nu, N = pb.N;
   std::vector<ProjectedLQ> plq(N);
   std::vector<Projection> proj(N);
@@ -806,7 +843,7 @@ int qp_step(const Model& m, const Problem& pb, const double* x0, const double* x
   for (int i = 0; i < nx; ++i) { dx0[i] = x0[i] - x[i]; d0 += dx0[i] * dx0[i]; }
   out.base[1] += d0;  // account for the initial state in the performance
   QPSolution sol;
-  if (riccati(nx, nu, N, plq, dx0, sol) != 0) return -1;
+  if (riccati(nx, nu, N, plq, dx0, sol, reg_prim) != 0) return -1;
   // armijo descent metric with the projected cost and utilde ([OCS2-upstream] SqpSolver::getOCPSolution order)
   double metric = 0;
   for (int k = 0; k < N; ++k) {
@@ -941,6 +978,30 @@ int oracle_node_lq(const oracle_model* om, int kind, double dt, const double* x,
   return 0;
 }
 
+// Operation counts of this restatement at (x, u) in mode `mode` (liboracle_count.so only; -1 otherwise):
+//   out[0] flow map, value only          out[1] end-effector kinematics (4 contacts), value only
+//   out[2] flow map with all nx + nu forward-mode directions            out[3] end-effector kinematics with all directions
+//   out[4] one complete node linearisation (two flow-map Jacobians, RK2 combination, cost, soft cones, end-effector rows)
+int oracle_flop_counts(const oracle_model* om, const double* x, const double* u, int mode, double* out) {
+#ifdef ORACLE_COUNT_FLOPS
+  const Model& m = om->m;
+  CD xc[MAXX], uc[MAXX], fc[MAXX], pc[4][3], vc[4][3];
+  for (int i = 0; i < m.nx; ++i) { xc[i] = CD(x[i]); uc[i] = CD(u[i]); }
+  g_flops = 0; flow_map(m, xc, uc, fc); out[0] = static_cast<double>(g_flops);
+  g_flops = 0; ee_kinematics(m, xc, uc, pc, vc); out[1] = static_cast<double>(g_flops);
+  std::vector<double> f(m.nx), A(m.nx * m.nx), B(m.nx * m.nu), pos(12), vel(12), dpdx(12 * m.nx), dvdx(12 * m.nx), dvdu(12 * m.nu);
+  g_flops = 0; flow_map_lin(m, x, u, f.data(), A.data(), B.data()); out[2] = static_cast<double>(g_flops);
+  g_flops = 0; ee_lin(m, x, u, pos.data(), vel.data(), dpdx.data(), dvdx.data(), dvdu.data()); out[3] = static_cast<double>(g_flops);
+  NodeLQ lq;
+  const double z[4] = {0, 0, 0, 0};
+  g_flops = 0; node_lq(m, 0, 0.015, x, u, x, x, mode, z, z, lq); out[4] = static_cast<double>(g_flops);
+  return 0;
+#else
+  (void)om; (void)x; (void)u; (void)mode; (void)out;
+  return -1;
+#endif
+}
+
 int oracle_node_perf(const oracle_model* om, int kind, double dt, const double* x, const double* u, const double* xnext, const double* xref,
                      int mode, const double* zref4, const double* zdref4, double* perf) {
   node_perf(om->m, kind, dt, x, u, xnext, xref, mode, zref4, zdref4, perf);
@@ -960,10 +1021,14 @@ int oracle_lu_projection(int nc, int nx, int nu, const double* C, const double* 
 
 int oracle_qp_step(const oracle_model* om, int N, const int* kind, const double* dt, const int* mode, const double* zref, const double* zdref,
                    const double* xref, const double* x0, const double* x, const double* u, double* dx, double* du, double* K) {
+  return oracle_qp_step_reg(om, N, kind, dt, mode, zref, zdref, xref, x0, x, u, 0.0, dx, du, K);
+}
+int oracle_qp_step_reg(const oracle_model* om, int N, const int* kind, const double* dt, const int* mode, const double* zref, const double* zdref,
+                       const double* xref, const double* x0, const double* x, const double* u, double reg_prim, double* dx, double* du, double* K) {
   const Model& m = om->m;
   Problem pb{N, kind, dt, mode, zref, zdref, xref};
   StepOut so;
-  if (qp_step(m, pb, x0, x, u, so) != 0) return -1;
+  if (qp_step(m, pb, x0, x, u, so, reg_prim) != 0) return -1;
   std::memcpy(dx, so.dx.data(), sizeof(double) * so.dx.size());
   std::memcpy(du, so.du.data(), sizeof(double) * so.du.size());
   if (K) std::memcpy(K, so.K.data(), sizeof(double) * so.K.size());
@@ -978,7 +1043,7 @@ int oracle_solve(const oracle_model* om, int N, const int* kind, const double* d
   const int nx = m.nx, nu = m.nu;
   const int iters = static_cast<int>(opts[0]);
   const double g_max = opts[1], g_min = opts[2], alpha_decay = opts[3], alpha_min = opts[4], gamma_c = opts[5], armijo = opts[6],
-               delta_tol = opts[7];
+               delta_tol = opts[7], reg_prim = opts[8];
   const double cost_tol = 1e-4;  // [OCS2-upstream] sqp::Settings default costTol
   Problem pb{N, kind, dt, mode, zref, zdref, xref};
   std::vector<double> x(x_init, x_init + (N + 1) * nx), u(u_init, u_init + N * nu), xn((N + 1) * nx), un(N * nu);
@@ -986,7 +1051,7 @@ int oracle_solve(const oracle_model* om, int N, const int* kind, const double* d
   for (int it = 0; it < iters; ++it) {
     double* st = stats + 16 * it;
     for (int i = 0; i < 16; ++i) st[i] = 0;
-    if (qp_step(m, pb, x0, x.data(), u.data(), so) != 0) return -1;
+    if (qp_step(m, pb, x0, x.data(), u.data(), so, reg_prim) != 0) return -1;
     const double merit0 = so.base[0];
     const double viol0 = std::sqrt(so.base[1] + so.base[2]);
     st[0] = merit0; st[1] = so.base[1]; st[2] = so.base[2]; st[7] = so.armijo;

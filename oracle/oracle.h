@@ -60,6 +60,10 @@ int oracle_node_lq(const oracle_model*, int kind, double dt, const double* x, co
                    double* q, double* r, double* c, double* C, double* D, double* e, int* nc, double* perf);
 
 /* Value-only node metrics for the line search: perf[3] as above. */
+/* operation counts of the restatement (liboracle_count.so, built with -DORACLE_COUNT_FLOPS; returns -1 in liboracle.so):
+ * out[5] = flow map value, end-effector kinematics value, flow map with all forward-mode directions, end-effector kinematics with
+ * all directions, one complete node linearisation */
+int oracle_flop_counts(const oracle_model*, const double* x, const double* u, int mode, double* out);
 int oracle_node_perf(const oracle_model*, int kind, double dt, const double* x, const double* u, const double* xnext, const double* xref,
                      int mode, const double* zref4, const double* zdref4, double* perf);
 
@@ -69,7 +73,7 @@ int oracle_lu_projection(int nc, int nx, int nu, const double* C, const double* 
                          int* rank);
 
 /* Full solve.  Node arrays have N entries (intervals); x_init (N+1)*nx, u_init N*nu.
- * opts[8] = {sqp_iterations, g_max, g_min, alpha_decay, alpha_min, gamma_c, armijo_factor, delta_tol}
+ * opts[9] = {sqp_iterations, g_max, g_min, alpha_decay, alpha_min, gamma_c, armijo_factor, delta_tol}
  * Outputs: x_out (N+1)*nx, u_out N*nu, K_out N*nu*nx (nullable), stats[16 * iterations]:
  *   per iteration {merit0, dyn0, eq0, alpha, merit1, dyn1, eq1, armijo_descent, dx_norm, du_norm, n_trials, 0...}. */
 int oracle_solve(const oracle_model*, int N, const int* kind, const double* dt, const int* mode, const double* zref, const double* zdref,
@@ -80,6 +84,9 @@ int oracle_solve(const oracle_model*, int N, const int* kind, const double* dt, 
  * Outputs dx (N+1)*nx, du N*nu. */
 int oracle_qp_step(const oracle_model*, int N, const int* kind, const double* dt, const int* mode, const double* zref, const double* zdref,
                    const double* xref, const double* x0, const double* x, const double* u, double* dx, double* du, double* K);
+/* the same with HPIPM's reg_prim added to the diagonal of every stage Hessian (0 = oracle_qp_step) */
+int oracle_qp_step_reg(const oracle_model*, int N, const int* kind, const double* dt, const int* mode, const double* zref, const double* zdref,
+                   const double* xref, const double* x0, const double* x, const double* u, double reg_prim, double* dx, double* du, double* K);
 
 #ifdef __cplusplus
 }

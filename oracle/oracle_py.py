@@ -14,9 +14,30 @@ _ip = C.POINTER(C.c_int)
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "oracle.cpp")
-    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+    cnt = os.path.join(_HERE, "liboracle_count.so")
+    if force or not os.path.exists(so) or not os.path.exists(cnt) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
+
+
+def flop_counts(blob, x, u, mode=3):
+    """Operation counts of the restatement at (x, u) (liboracle_count.so, a separate build with the counter compiled in):
+    dict(flow_map, ee_kinematics, flow_map_ad, ee_kinematics_ad, node_linearization)."""
+    so = os.path.join(_HERE, "liboracle_count.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle_count.so"])
+    cl = C.CDLL(so)
+    cl.oracle_model_create.restype = C.c_void_p
+    cl.oracle_model_create.argtypes = [_dp, C.c_int]
+    cl.oracle_model_destroy.argtypes = [C.c_void_p]
+    blob, x, u = _arr(blob), _arr(x), _arr(u)
+    h = cl.oracle_model_create(_d(blob), len(blob))
+    out = np.zeros(5)
+    rc = cl.oracle_flop_counts(C.c_void_p(h), _d(x), _d(u), int(mode), _d(out))
+    cl.oracle_model_destroy(C.c_void_p(h))
+    if rc != 0:
+        raise RuntimeError("liboracle_count.so was built without ORACLE_COUNT_FLOPS")
+    return dict(zip(("flow_map", "ee_kinematics", "flow_map_ad", "ee_kinematics_ad", "node_linearization"), out.tolist()))
 
 
 def lib():
@@ -119,22 +140,22 @@ class OracleModel:
         keep = (kind, mode, dt, zref, zdref, xref)
         return keep, (int(nodes["N"]), _i(kind), _d(dt), _i(mode), _d(zref), _d(zdref), _d(xref))
 
-    def qp_step(self, nodes, x0, x, u):
+    def qp_step(self, nodes, x0, x, u, reg_prim=0.0):
         keep, args = self._node_args(nodes)
         N = int(nodes["N"])
         x0, x, u = _arr(x0), _arr(x), _arr(u)
         dx, du, K = np.zeros((N + 1, self.nx)), np.zeros((N, self.nu)), np.zeros((N, self.nu, self.nx))
-        rc = lib().oracle_qp_step(self.h, *args, _d(x0), _d(x), _d(u), _d(dx), _d(du), _d(K))
+        rc = lib().oracle_qp_step_reg(self.h, *args, _d(x0), _d(x), _d(u), C.c_double(reg_prim), _d(dx), _d(du), _d(K))
         if rc != 0:
             raise RuntimeError("oracle_qp_step failed")
         return dx, du, K
 
     def solve(self, nodes, x0, x_init, u_init, iterations=1, g_max=1e-2, g_min=1e-6, alpha_decay=0.5, alpha_min=1e-4, gamma_c=1e-6,
-              armijo_factor=1e-4, delta_tol=1e-4):
+              armijo_factor=1e-4, delta_tol=1e-4, reg_prim=0.0):
         keep, args = self._node_args(nodes)
         N = int(nodes["N"])
         x0, x_init, u_init = _arr(x0), _arr(x_init), _arr(u_init)
-        opts = np.array([iterations, g_max, g_min, alpha_decay, alpha_min, gamma_c, armijo_factor, delta_tol], float)
+        opts = np.array([iterations, g_max, g_min, alpha_decay, alpha_min, gamma_c, armijo_factor, delta_tol, reg_prim], float)
         xo, uo, K = np.zeros((N + 1, self.nx)), np.zeros((N, self.nu)), np.zeros((N, self.nu, self.nx))
         stats = np.zeros((iterations, 16))
         rc = lib().oracle_solve(self.h, *args, _d(x0), _d(x_init), _d(u_init), _d(opts), _d(xo), _d(uo), _d(K), _d(stats))

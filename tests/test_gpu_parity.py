@@ -328,3 +328,30 @@ def test_fused_and_materialised_modes_are_bit_identical(ctx, robot, gait):
     b[6].stage("linearize"); b[6].synchronize()
     for k in ("A", "B", "Q", "R", "C", "D", "e", "c"):
         assert np.array_equal(a[6].read(k), b[6].read(k)), k
+
+
+def test_reg_prim_setting_matches_oracle(ctx):
+    """settings.reg_prim = 1e-12 (HPIPM's primal regularisation, off by default): the HIP path and the oracle apply it identically (QP step
+    1e-9), and its effect on the step is the measured ~1e-9..1e-8 - visible, below the solve tolerance."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=2, n_intervals=40)
+    outs = []
+    for reg in (0.0, 1e-12, 1e-6):
+        mpc = bp.BatchedSqpMpc(itf, max_batch=2, max_nodes=56, return_gains=True, reg_prim=reg)
+        mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+        for st in ("linearize", "project", "riccati"):
+            mpc.stage(st)
+        mpc.synchronize()
+        nx = itf.stateDim
+        x = mpc.read("x").reshape(2, 57, nx); u = mpc.read("u").reshape(2, 56, nx)
+        dx = mpc.read("dx").reshape(2, 57, nx); du = mpc.read("du").reshape(2, 56, nx); K = mpc.read("K").reshape(2, 56, nx, nx)
+        om = ob.h1_oracle()
+        for b in range(2):
+            nodes = ob.oracle_nodes(prob, b)
+            N = nodes["N"]
+            odx, odu, oK = om.qp_step(nodes, prob["x0"][b], x[b, :N + 1], u[b, :N], reg_prim=reg)
+            assert _rel(dx[b, :N + 1], odx) < 1e-9 and _rel(du[b, :N], odu) < 1e-9 and _rel(K[b, :N], oK) < 1e-9
+        outs.append(du.copy())
+    assert 0.0 < _rel(outs[1], outs[0]) < 1e-7 < _rel(outs[2], outs[0])
+    with pytest.raises(bp.BpmpcError):
+        bp.BatchedSqpMpc(itf, max_batch=1, max_nodes=8, reg_prim=1e-12, reference_kernels=True)
