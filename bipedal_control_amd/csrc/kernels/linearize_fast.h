@@ -18,10 +18,16 @@
 
 namespace bpmpc {
 
-template <int NJ>
+// PACK: when the robot has more than 16 generalised coordinates but no more than 16 NON-TRIVIAL ones (12 leg joints: 3 Euler angles +
+// 12 joints = 15), the three base translations give up their lanes: every column they own is a constant (nothing in the dynamics depends
+// on the base position; their columns of df/dx are zero, of the contact Jacobians the identity), so lane l carries coordinate l + 3 and
+// the lanes 0..2 write those constant columns next to their other roles.  A node then fits 16 lanes and a wavefront serves four nodes
+// instead of two.  The roles that are numbered by LANE (momentum column l < 6, force column l < 12, contact l < 4) do not move.
+template <int NJ, bool PACK = false>
 struct LinFastCfg {
   static constexpr int NB = NJ + 1, G = 6 + NJ, NX = 12 + NJ, NU = 12 + NJ;
-  static constexpr int LPN = (G <= 16) ? 16 : 32;   // lanes per node
+  static constexpr int G0 = (PACK && G > 16 && G - 3 <= 16) ? 3 : 0;   // coordinate of lane 0
+  static constexpr int LPN = (G - G0 <= 16) ? 16 : 32;   // lanes per node
   static constexpr int NPW = kWave / LPN;           // nodes per wavefront
 };
 
@@ -155,23 +161,23 @@ struct LaneKin {    // what the contact part needs from the evaluation
 #else
 #define EVPROF(slot) ((void)0)
 #endif
-template <int NJ, bool DERIV = true, bool TWIST = true, class NodeLds = LinFastNodeLds<NJ>, class Shared = LinFastShared<NJ>>
+template <int NJ, bool DERIV = true, bool TWIST = true, class NodeLds = LinFastNodeLds<NJ>, class Shared = LinFastShared<NJ>, class Cfg = LinFastCfg<NJ>>
 __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& sh, NodeLds& nl, int stage, const LaneBody& lb, const int* path, int g,
                                           const double* xh /*LDS: momentum [6], base position [3]*/, double qg, double ujg, LaneEval& ev, LaneKin<NJ>& kin,
                                           long long* evp = nullptr) {
 #ifdef BPMPC_EVAL_PROFILE
   if (evp) evp[9] = clock64();
 #endif
-  using C = LinFastCfg<NJ>;
-  constexpr int NB = C::NB, G = C::G, LPN = C::LPN;
+  using C = Cfg;
+  constexpr int NB = C::NB, G = C::G, LPN = C::LPN, G0 = C::G0;    // g = lane in node + G0: coordinate c lives in lane c - G0
   const bool is_joint = g >= 6 && g < G, is_body = g >= 5 && g < G;
   const double mass_total = md.robot_mass;
   const double* pb = xh + 6;           // base position, read from LDS at every use (registers are the scarce resource here)
   // ---- sin/cos of the own angle; Euler sin/cos to everybody
   double sg = 0.0, cg = 1.0;
   if (g >= 3 && g < G) sincos(qg, &sg, &cg);
-  const double sy = __shfl(sg, 3, LPN), cy = __shfl(cg, 3, LPN), sp = __shfl(sg, 4, LPN), cp = __shfl(cg, 4, LPN), sr = __shfl(sg, 5, LPN),
-               cr = __shfl(cg, 5, LPN);
+  const double sy = __shfl(sg, 3 - G0, LPN), cy = __shfl(cg, 3 - G0, LPN), sp = __shfl(sg, 4 - G0, LPN), cp = __shfl(cg, 4 - G0, LPN),
+               sr = __shfl(sg, 5 - G0, LPN), cr = __shfl(cg, 5 - G0, LPN);
   kin.sy = sy; kin.cy = cy; kin.sp = sp; kin.cp = cp;
   EVPROF(0);
   // ---- joint-local transforms to LDS, chain walk
@@ -264,9 +270,9 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
   const double Ic[6] = {s[4] - Mc * (DD - Dv[0] * Dv[0]), s[5] + Mc * Dv[0] * Dv[1], s[6] + Mc * Dv[0] * Dv[2],
                         s[7] - Mc * (DD - Dv[1] * Dv[1]), s[8] + Mc * Dv[1] * Dv[2], s[9] - Mc * (DD - Dv[2] * Dv[2])};
   // whole-robot mass and com from lane 5 (the base body lane)
-  const double Mtot = __shfl(Mc, 5, LPN);
-  const double com[3] = {__shfl(Cc[0], 5, LPN), __shfl(Cc[1], 5, LPN), __shfl(Cc[2], 5, LPN)};
-  if constexpr (DERIV) { if (g == 0) for (int i = 0; i < 3; ++i) nl.com[stage][i] = com[i]; }
+  const double Mtot = __shfl(Mc, 5 - G0, LPN);
+  const double com[3] = {__shfl(Cc[0], 5 - G0, LPN), __shfl(Cc[1], 5 - G0, LPN), __shfl(Cc[2], 5 - G0, LPN)};
+  if constexpr (DERIV) { if (g == G0) for (int i = 0; i < 3; ++i) nl.com[stage][i] = com[i]; }
   EVPROF(3);
   // ---- centroidal momentum matrix column
   double Ac[6];
@@ -294,7 +300,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
     }
     double A12[9], A22[9], X12[9], X22[9];
     for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) { A12[3 * i + j] = __shfl(Ac[i], 3 + j, LPN); A22[3 * i + j] = __shfl(Ac[3 + i], 3 + j, LPN); }
+      for (int j = 0; j < 3; ++j) { A12[3 * i + j] = __shfl(Ac[i], 3 + j - G0, LPN); A22[3 * i + j] = __shfl(Ac[3 + i], 3 + j - G0, LPN); }
     const double* M = A22;
     const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
     const double idet = 1.0 / (M[0] * c00 + M[1] * c01 + M[2] * c02);
@@ -303,7 +309,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
     X22[6] = c02 * idet; X22[7] = (M[1] * M[6] - M[0] * M[7]) * idet; X22[8] = (M[0] * M[4] - M[1] * M[3]) * idet;
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) X12[3 * i + j] = -im * (A12[3 * i] * X22[j] + A12[3 * i + 1] * X22[3 + j] + A12[3 * i + 2] * X22[6 + j]);
-    if constexpr (DERIV) { if (g < 9) { nl.X12[stage][g] = X12[g]; nl.X22[stage][g] = X22[g]; } }
+    if constexpr (DERIV) { const int ln = g - G0; if (ln < 9) { nl.X12[stage][ln] = X12[ln]; nl.X22[stage][ln] = X22[ln]; } }
     mat3_vec(X22, &rhs[3], th);
     mat3_vec(X12, &rhs[3], pd);
     for (int i = 0; i < 3; ++i) pd[i] += im * rhs[i];
@@ -380,7 +386,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
     const double sel = ((lb.subtree >> m) & 1u) ? 1.0 : 0.0;
     for (int c = 0; c < 6; ++c) hs[c] += sel * nl.hb[m][c];
   }
-  const double ltot[3] = {__shfl(hs[0], 5, LPN), __shfl(hs[1], 5, LPN), __shfl(hs[2], 5, LPN)};
+  const double ltot[3] = {__shfl(hs[0], 5 - G0, LPN), __shfl(hs[1], 5 - G0, LPN), __shfl(hs[2], 5 - G0, LPN)};
   EVPROF(6);
   // ---- column 6+g: d(A v)/dq_g -> d v_base/dq_g, angular-momentum-rate row; joint-velocity column
   {
@@ -470,9 +476,10 @@ struct LinFastOut {
 // what the rest of the solve reads leaves the kernel - rows 3..11 of A and B (the others are structural and regenerated by the change
 // of variables), b, q, r, the nc rows of C, D, e, the 320-byte record of the node-dependent part of Q and R; 9.6 instead of 21.8 KB per
 // node.  The numbers that are written are the same bits in both modes.
-template <int NJ, bool MAT = true>
+// `ln`: lane inside the node's lane group; it carries coordinate g = ln + G0 (LinFastCfg) and the lane-numbered roles.
+template <int NJ, bool MAT = true, class Cfg = LinFastCfg<NJ, true>>
 __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ>& nl, bool valid,
-                                               const NodeInputs& in, const LinFastOut& o, int g) {
+                                               const NodeInputs& in, const LinFastOut& o, int ln) {
 #ifdef BPMPC_LINFAST_PROFILE
   long long lf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long lf_prev = clock64();
@@ -480,27 +487,30 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
 #else
 #define LFPROF(slot) ((void)0)
 #endif
-  using C = LinFastCfg<NJ>;
-  constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN;
+  using C = Cfg;
+  constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN, G0 = C::G0;
+  constexpr bool PACKED = G0 > 0;
+  const int g = ln + G0;
+  const bool tr = PACKED && ln < 3;    // this lane also writes the constant columns of base translation ln (x column 6 + ln)
   if (!valid) return;
   if (in.kind == 1) {  // event node: identity jump map, no input, no cost (LPN lanes write the node)
     double d2 = 0.0;
     if constexpr (MAT) {      // fused mode: the change of variables generates the identity jump map and the zero cost of an event node itself
-      for (int idx = g; idx < NX * NX; idx += LPN) { (o.A + o.s * (NX * NX))[idx] = (idx / NX == idx % NX) ? 1.0 : 0.0; (o.Q + o.s * (NX * NX))[idx] = 0.0; }
-      for (int idx = g; idx < NX * NU; idx += LPN) { (o.B + o.s * (NX * NU))[idx] = 0.0; }
-      for (int idx = g; idx < NU * NU; idx += LPN) (o.R + o.s * (NU * NU))[idx] = 0.0;
-      for (int idx = g; idx < kMaxEqRows * NX; idx += LPN) (o.C + o.s * (kMaxEqRows * NX))[idx] = 0.0;
-      for (int idx = g; idx < kMaxEqRows * NU; idx += LPN) (o.D + o.s * (kMaxEqRows * NU))[idx] = 0.0;
-      for (int idx = g; idx < kMaxEqRows; idx += LPN) (o.e + o.s * (kMaxEqRows))[idx] = 0.0;
+      for (int idx = ln; idx < NX * NX; idx += LPN) { (o.A + o.s * (NX * NX))[idx] = (idx / NX == idx % NX) ? 1.0 : 0.0; (o.Q + o.s * (NX * NX))[idx] = 0.0; }
+      for (int idx = ln; idx < NX * NU; idx += LPN) { (o.B + o.s * (NX * NU))[idx] = 0.0; }
+      for (int idx = ln; idx < NU * NU; idx += LPN) (o.R + o.s * (NU * NU))[idx] = 0.0;
+      for (int idx = ln; idx < kMaxEqRows * NX; idx += LPN) (o.C + o.s * (kMaxEqRows * NX))[idx] = 0.0;
+      for (int idx = ln; idx < kMaxEqRows * NU; idx += LPN) (o.D + o.s * (kMaxEqRows * NU))[idx] = 0.0;
+      for (int idx = ln; idx < kMaxEqRows; idx += LPN) (o.e + o.s * (kMaxEqRows))[idx] = 0.0;
     }
-    for (int idx = g; idx < NX; idx += LPN) {
+    for (int idx = ln; idx < NX; idx += LPN) {
       const double d = in.x[idx] - in.xnext[idx];
       (o.b + o.s * (NX))[idx] = d;
       if constexpr (MAT) { (o.q + o.s * (NX))[idx] = 0.0; (o.r + o.s * (NU))[idx] = 0.0; }
       d2 += d * d;
     }
     d2 = node_allreduce_add<LPN>(d2);
-    if (g == 0) { if constexpr (MAT) (o.c + o.s * (1))[0] = 0.0; (o.nc + o.s * (1))[0] = 0; (o.perf + o.s * (3))[0] = 0.0; (o.perf + o.s * (3))[1] = d2; (o.perf + o.s * (3))[2] = 0.0; }
+    if (ln == 0) { if constexpr (MAT) (o.c + o.s * (1))[0] = 0.0; (o.nc + o.s * (1))[0] = 0; (o.perf + o.s * (3))[0] = 0.0; (o.perf + o.s * (3))[1] = d2; (o.perf + o.s * (3))[2] = 0.0; }
     return;
   }
   const bool is_joint = g >= 6 && g < G;
@@ -508,11 +518,12 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   const int mode = in.mode;
   const double mass_total = md.robot_mass, imt = 1.0 / md.robot_mass;
   // ---- stage the node inputs in LDS: after this block nothing is read from global memory except model constants
-  for (int idx = g; idx < NX; idx += LPN) { nl.x[idx] = in.x[idx]; nl.u[idx] = in.u[idx]; }
-  // the entries of x_next and x_ref this lane needs later (rows 6+g and g)
-  const double xn_q = g < G ? in.xnext[6 + g] : 0.0, xn_h = g < 6 ? in.xnext[g] : 0.0;
-  const double xr_q = g < G ? in.xref[6 + g] : 0.0, xr_h = g < 6 ? in.xref[g] : 0.0;
-  if (g < kNumContacts) { nl.zref[g] = in.zref[g]; nl.zdref[g] = in.zdref[g]; }
+  for (int idx = ln; idx < NX; idx += LPN) { nl.x[idx] = in.x[idx]; nl.u[idx] = in.u[idx]; }
+  // the entries of x_next and x_ref this lane needs later (rows 6+g, ln and - packed lanes 0..2 - 6+ln)
+  const double xn_q = g < G ? in.xnext[6 + g] : 0.0, xn_h = ln < 6 ? in.xnext[ln] : 0.0;
+  const double xr_q = g < G ? in.xref[6 + g] : 0.0, xr_h = ln < 6 ? in.xref[ln] : 0.0;
+  const double xn_t = tr ? in.xnext[6 + ln] : 0.0, xr_t = tr ? in.xref[6 + ln] : 0.0;
+  if (ln < kNumContacts) { nl.zref[ln] = in.zref[ln]; nl.zdref[ln] = in.zdref[ln]; }
   LaneBody lb;
   {
     const int body = (g >= 5 && g < G) ? g - 5 : 0;
@@ -532,18 +543,19 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   LaneKin<NJ> kin;
 #ifdef BPMPC_EVAL_PROFILE
   long long evacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  eval_lane<NJ, true, true>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin, evacc);
+  eval_lane<NJ, true, true, LinFastNodeLds<NJ>, LinFastShared<NJ>, C>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin, evacc);
 #else
-  eval_lane<NJ, true, true>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
+  eval_lane<NJ, true, true, LinFastNodeLds<NJ>, LinFastShared<NJ>, C>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
 #endif
   LFPROF(1);
   // park the stage-one columns (HBM scratch) for the RK2 combination
   {
     double* pk = o.park + o.s * (15 * LPN);
-    for (int rr = 0; rr < 9; ++rr) pk[rr * LPN + g] = e1.ar_q[rr];
-    for (int rr = 0; rr < 6; ++rr) pk[9 * LPN + rr * LPN + g] = is_joint ? e1.br_j[rr] : 0.0;   // whole 128-byte lines
+    for (int rr = 0; rr < 9; ++rr) pk[rr * LPN + ln] = e1.ar_q[rr];
+    for (int rr = 0; rr < 6; ++rr) pk[9 * LPN + rr * LPN + ln] = is_joint ? e1.br_j[rr] : 0.0;   // whole 128-byte lines
   }
-  const double f1h_g = lane_pick6(e1.fh, g), v1g = e1.vg;
+  const double f1h_g = lane_pick6(e1.fh, ln), v1g = e1.vg;
+  const double v1t = ln == 0 ? kin.vb[0] : (ln == 1 ? kin.vb[1] : kin.vb[2]);     // base linear velocity component of the translation role
 
   // =========================== contact part (first stage only) ===========================
   if (g >= 5 && g < G)
@@ -554,7 +566,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
         cross3(kin.omg, r, t);
         for (int a = 0; a < 3; ++a) nl.cvel[i][a] = kin.vog[a] + t[a];
       }
-  if (g < kNumContacts && stance_flag(mode, g)) cone_terms(md, &nl.u[3 * g], true, nl.cone[g]);
+  if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(md, &nl.u[3 * ln], true, nl.cone[ln]);
   lds_wave_sync();
   // rows in registration order zeroForce_i, zeroVelocity_i, normalVelocity_i (src/BipedalRobotInterface.cpp:187-191)
   int row = 0;
@@ -586,7 +598,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
       for (int a = 0; a < 3; ++a) outv[a] = col6[a] + t[a];
     };
     double bq[3], bh[3], bj[3], hcol[6];
-    for (int l = 0; l < 6; ++l) hcol[l] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, g, 3 + l);
+    for (int l = 0; l < 6; ++l) hcol[l] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, ln, 3 + l);
     base_part(&e1.ar_q[3], bq);
     base_part(hcol, bh);
     base_part(e1.br_j, bj);
@@ -594,13 +606,13 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     for (int rr = 0; rr < nrows; ++rr) {
       const int type = stance ? 1 : (rr < 3 ? 0 : 2);
       const int a = (type == 2) ? 2 : rr;
-      double vq = 0.0, vh = 0.0, vf = 0.0, vj = 0.0, ev;
+      double vq = 0.0, vh = 0.0, vf = 0.0, vj = 0.0, vt = 0.0, ev;
       if (type == 0) {
-        vf = (g == 3 * i + a) ? 1.0 : 0.0;                           // ZeroForceConstraint.cpp:64-72
+        vf = (ln == 3 * i + a) ? 1.0 : 0.0;                          // ZeroForceConstraint.cpp:64-72
         ev = nl.u[3 * i + a];
       } else {
         vq = bq[a] + DJ[a];
-        if (md.pos_gain != 0.0 && a == 2) vq += md.pos_gain * Jc[a];
+        if (md.pos_gain != 0.0 && a == 2) { vq += md.pos_gain * Jc[a]; vt = ln == 2 ? md.pos_gain : 0.0; }   // d p_z / d (base z) = 1
         vh = bh[a];
         vj = bj[a] + Jc[a];
         ev = cv_i[a];
@@ -608,10 +620,11 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
         else { ev -= nl.zdref[i]; if (md.pos_gain != 0.0) ev += md.pos_gain * (cp_i[2] - nl.zref[i]); }
       }
       if (g < G) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + g] = vq;
-      if (g < 6) (o.C + o.s * (kMaxEqRows * NX))[row * NX + g] = vh;
-      if (g < 12) (o.D + o.s * (kMaxEqRows * NU))[row * NU + g] = vf;
+      if (tr) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + ln] = vt;       // base translation: the contact velocity does not depend on it
+      if (ln < 6) (o.C + o.s * (kMaxEqRows * NX))[row * NX + ln] = vh;
+      if (ln < 12) (o.D + o.s * (kMaxEqRows * NU))[row * NU + ln] = vf;
       if (is_joint) (o.D + o.s * (kMaxEqRows * NU))[row * NU + 12 + g - 6] = vj;
-      if (g == 0) (o.e + o.s * (kMaxEqRows))[row] = ev;
+      if (ln == 0) (o.e + o.s * (kMaxEqRows))[row] = ev;
       eq_sse += ev * ev;
       ++row;
     }
@@ -620,48 +633,55 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   if constexpr (MAT)          // the LU kernel reads nc rows only; the zero padding exists for readers of the materialised model
   for (; row < kMaxEqRows; ++row) {
     if (g < G) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + g] = 0.0;
-    if (g < 6) (o.C + o.s * (kMaxEqRows * NX))[row * NX + g] = 0.0;
-    if (g < 12) (o.D + o.s * (kMaxEqRows * NU))[row * NU + g] = 0.0;
+    if (tr) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + ln] = 0.0;
+    if (ln < 6) (o.C + o.s * (kMaxEqRows * NX))[row * NX + ln] = 0.0;
+    if (ln < 12) (o.D + o.s * (kMaxEqRows * NU))[row * NU + ln] = 0.0;
     if (is_joint) (o.D + o.s * (kMaxEqRows * NU))[row * NU + 12 + g - 6] = 0.0;
-    if (g == 0) (o.e + o.s * (kMaxEqRows))[row] = 0.0;
+    if (ln == 0) (o.e + o.s * (kMaxEqRows))[row] = 0.0;
   }
 
   LFPROF(2);
   // =========================== second RK2 stage ===========================
   LaneEval e2;
+  double v2t;                        // base linear velocity component ln of the second stage (translation role)
   {
-    if (g < 6) nl.xh2[g] = xh[g] + dt * lane_pick6(e1.fh, g);
-    if (g < 3) nl.xh2[6 + g] = pb[g] + dt * (g == 0 ? kin.vb[0] : (g == 1 ? kin.vb[1] : kin.vb[2]));
+    if (ln < 6) nl.xh2[ln] = xh[ln] + dt * lane_pick6(e1.fh, ln);
+    if (ln < 3) nl.xh2[6 + ln] = pb[ln] + dt * v1t;
     const double* xh2 = nl.xh2;      // published by the lds_wave_sync at the top of eval_lane
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
-    eval_lane<NJ, true, true>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
+    eval_lane<NJ, true, true, LinFastNodeLds<NJ>, LinFastShared<NJ>, C>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
+    v2t = ln == 0 ? kin2.vb[0] : (ln == 1 ? kin2.vb[1] : kin2.vb[2]);
   }
   LFPROF(3);
   // A2[rows 3..11][x columns 0..11] to LDS (a2 shares storage with the chain tables, dead now): columns 0..5 are the
   // momentum columns of lanes 0..5, columns 6..11 the q columns of lanes 0..5
   lds_wave_sync();
+  if (ln < 6)
+    for (int r = 0; r < 9; ++r) nl.a2[r][ln] = momentum_col(nl.X12[1], nl.X22[1], imt, mass_total, ln, r);
   if (g < 6)
-    for (int r = 0; r < 9; ++r) { nl.a2[r][g] = momentum_col(nl.X12[1], nl.X22[1], imt, mass_total, g, r); nl.a2[r][6 + g] = e2.ar_q[r]; }
+    for (int r = 0; r < 9; ++r) nl.a2[r][6 + g] = e2.ar_q[r];
+  if (tr)
+    for (int r = 0; r < 9; ++r) nl.a2[r][6 + ln] = 0.0;      // nothing depends on the base position
   lds_wave_sync();
   // rows of A and B;  A = I + dt/2 (A1 + A2 + dt A2 A1),  B = dt/2 (B1 + B2 + dt A2 B1)
   double c1q[9], c1h[9], c1f[9], c1j[9];
   {
     const double* pk = o.park + o.s * (15 * LPN);
-    for (int rr = 0; rr < 9; ++rr) c1q[rr] = pk[rr * LPN + g];
+    for (int rr = 0; rr < 9; ++rr) c1q[rr] = pk[rr * LPN + ln];
     for (int rr = 0; rr < 9; ++rr) c1j[rr] = 0.0;
-    if (is_joint) for (int rr = 3; rr < 9; ++rr) c1j[rr] = pk[9 * LPN + (rr - 3) * LPN + g];
+    if (is_joint) for (int rr = 3; rr < 9; ++rr) c1j[rr] = pk[9 * LPN + (rr - 3) * LPN + ln];
   }
   for (int rr = 0; rr < 9; ++rr) {
-    c1h[rr] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, g, rr);
-    c1f[rr] = force_col(nl.cps[0], nl.com[0], imt, g, rr);
+    c1h[rr] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, ln, rr);
+    c1f[rr] = force_col(nl.cps[0], nl.com[0], imt, ln, rr);
   }
   for (int r = MAT ? 0 : 3; r < (MAT ? NX : 12); ++r) {      // fused mode: the structural rows (0..2, 12..) are regenerated downstream
     double aq, ah_, bf, bj;
     if (r < 3 || r >= 12) {
       aq = (r == 6 + g) ? 1.0 : 0.0;
-      ah_ = (r == g) ? 1.0 : 0.0;
-      bf = (r < 3 && (g % 3) == r) ? dt * imt : 0.0;
+      ah_ = (r == ln) ? 1.0 : 0.0;
+      bf = (r < 3 && (ln % 3) == r) ? dt * imt : 0.0;
       bj = (r >= 12 && r == 12 + g - 6) ? dt : 0.0;
     } else {
       const int rr = r - 3;
@@ -671,19 +691,20 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
         sq += a * c1q[l]; sh += a * c1h[l]; sf += a * c1f[l]; sj += a * c1j[l];
       }
       // B1 rows 0..2 are (1/m) on the force components, rows 12.. are the identity on the joint velocities
-      sf += nl.a2[rr][g % 3] * imt;
+      sf += nl.a2[rr][ln % 3] * imt;
       sj += e2.ar_q[rr];
-      const double e2h = momentum_col(nl.X12[1], nl.X22[1], imt, mass_total, g, rr);
-      const double e2f = force_col(nl.cps[1], nl.com[1], imt, g, rr);
+      const double e2h = momentum_col(nl.X12[1], nl.X22[1], imt, mass_total, ln, rr);
+      const double e2f = force_col(nl.cps[1], nl.com[1], imt, ln, rr);
       const double e2j = rr < 3 ? 0.0 : e2.br_j[rr - 3];
       aq = ((r == 6 + g) ? 1.0 : 0.0) + hdt * (c1q[rr] + e2.ar_q[rr] + dt * sq);
-      ah_ = ((r == g) ? 1.0 : 0.0) + hdt * (c1h[rr] + e2h + dt * sh);
+      ah_ = ((r == ln) ? 1.0 : 0.0) + hdt * (c1h[rr] + e2h + dt * sh);
       bf = hdt * (c1f[rr] + e2f + dt * sf);
       bj = hdt * (c1j[rr] + e2j + dt * sj);
     }
     if (g < G) (o.A + o.s * (NX * NX))[r * NX + 6 + g] = aq;
-    if (g < 6) (o.A + o.s * (NX * NX))[r * NX + g] = ah_;
-    if (g < 12) (o.B + o.s * (NX * NU))[r * NU + g] = bf;
+    if (tr) (o.A + o.s * (NX * NX))[r * NX + 6 + ln] = (r == 6 + ln) ? 1.0 : 0.0;      // base translation: identity column
+    if (ln < 6) (o.A + o.s * (NX * NX))[r * NX + ln] = ah_;
+    if (ln < 12) (o.B + o.s * (NX * NU))[r * NU + ln] = bf;
     if (is_joint) (o.B + o.s * (NX * NU))[r * NU + 12 + g - 6] = bj;
   }
   // b = x + dt/2 (f1 + f2) - x_next
@@ -693,17 +714,24 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     (o.b + o.s * (NX))[6 + g] = bb;
     dyn_sse += bb * bb;
   }
-  if (g < 6) {
-    const double bb = (g < 6 ? xh[g] : 0.0) + hdt * f1h_g + hdt * lane_pick6(e2.fh, g) - xn_h;
-    (o.b + o.s * (NX))[g] = bb;
+  if (ln < 6) {
+    const double bb = (ln < 6 ? xh[ln] : 0.0) + hdt * f1h_g + hdt * lane_pick6(e2.fh, ln) - xn_h;
+    (o.b + o.s * (NX))[ln] = bb;
+    dyn_sse += bb * bb;
+  }
+  if (tr) {                          // base position: the same expression as a coordinate lane (q + dt/2 v1 + dt/2 v2 - x_next)
+    const double bb = pb[ln] + hdt * v1t + hdt * v2t - xn_t;
+    (o.b + o.s * (NX))[6 + ln] = bb;
     dyn_sse += bb * bb;
   }
   LFPROF(4);
   // =========================== cost ===========================
   lds_wave_sync();   // a2 is dead: its storage becomes dx / du
+  const double pt = tr ? pb[ln] : 0.0;       // read before dx / du overwrite nothing of x (x lives in its own array) - kept for symmetry
   if (g < G) nl.dx[6 + g] = qg - xr_q;
-  if (g < 6) nl.dx[g] = (g < 6 ? xh[g] : 0.0) - xr_h;
-  if (g < 12) nl.du[g] = nl.u[g] - nominal_input(md, mode, g);
+  if (tr) nl.dx[6 + ln] = pt - xr_t;
+  if (ln < 6) nl.dx[ln] = (ln < 6 ? xh[ln] : 0.0) - xr_h;
+  if (ln < 12) nl.du[ln] = nl.u[ln] - nominal_input(md, mode, ln);
   if (is_joint) nl.du[12 + g - 6] = ujg;
   lds_wave_sync();
   double shift = 0.0;
@@ -711,14 +739,15 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     if (stance_flag(mode, i)) shift += -nl.cone[i][2] * md.cone_shift;
   double cost = 0.0;
   {
-    const int cq = 6 + g, ch = g, cf = g, cj = 12 + g - 6;
-    double accq = 0.0, acch = 0.0, accf = 0.0, accj = 0.0;
+    const int cq = 6 + g, ch = ln, cf = ln, cj = 12 + g - 6, ct = 6 + ln;
+    double accq = 0.0, acch = 0.0, accf = 0.0, accj = 0.0, acct = 0.0;
     for (int r = 0; r < NX; ++r) {
       const double dxr = nl.dx[r], dur = nl.du[r];
       // gradient entries use row c of the weight (as the reference kernel), the written element is (r, c)
       if (g < G) { accq += sh.Q[cq * NX + r] * dxr; if constexpr (MAT) (o.Q + o.s * (NX * NX))[r * NX + cq] = dt * (sh.Q[r * NX + cq] + (r == cq ? shift : 0.0)); }
-      if (g < 6) { acch += sh.Q[ch * NX + r] * dxr; if constexpr (MAT) (o.Q + o.s * (NX * NX))[r * NX + ch] = dt * (sh.Q[r * NX + ch] + (r == ch ? shift : 0.0)); }
-      if (g < 12) {
+      if (tr) { acct += sh.Q[ct * NX + r] * dxr; if constexpr (MAT) (o.Q + o.s * (NX * NX))[r * NX + ct] = dt * (sh.Q[r * NX + ct] + (r == ct ? shift : 0.0)); }
+      if (ln < 6) { acch += sh.Q[ch * NX + r] * dxr; if constexpr (MAT) (o.Q + o.s * (NX * NX))[r * NX + ch] = dt * (sh.Q[r * NX + ch] + (r == ch ? shift : 0.0)); }
+      if (ln < 12) {
         accf += sh.R[cf * NU + r] * dur;
         const bool in_block = r < 12 && r / 3 == cf / 3;
         if (MAT || in_block) {
@@ -738,19 +767,20 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
       if (is_joint) { accj += sh.R[cj * NU + r] * dur; if constexpr (MAT) (o.R + o.s * (NU * NU))[r * NU + cj] = dt * (sh.R[r * NU + cj] + (r == cj ? shift : 0.0)); }
     }
     if (g < G) { (o.q + o.s * (NX))[cq] = dt * accq; cost += 0.5 * nl.dx[cq] * accq; }
-    if (g < 6) { (o.q + o.s * (NX))[ch] = dt * acch; cost += 0.5 * nl.dx[ch] * acch; }
-    if (g < 12) {
+    if (tr) { (o.q + o.s * (NX))[ct] = dt * acct; cost += 0.5 * nl.dx[ct] * acct; }
+    if (ln < 6) { (o.q + o.s * (NX))[ch] = dt * acch; cost += 0.5 * nl.dx[ch] * acch; }
+    if (ln < 12) {
       cost += 0.5 * nl.du[cf] * accf;
       if (stance_flag(mode, cf / 3)) accf += nl.cone[cf / 3][2] * nl.cone[cf / 3][4 + cf % 3];
       (o.r + o.s * (NU))[cf] = dt * accf;
     }
     if (is_joint) { (o.r + o.s * (NU))[cj] = dt * accj; cost += 0.5 * nl.du[cj] * accj; }
-    if (g < kNumContacts && stance_flag(mode, g)) cost += nl.cone[g][1];
+    if (ln < kNumContacts && stance_flag(mode, ln)) cost += nl.cone[ln][1];
   }
   // P (cost cross term) is structurally zero for this problem: the buffer is zero-filled once at allocation and never written
   cost = node_allreduce_add<LPN>(cost);
   dyn_sse = node_allreduce_add<LPN>(dyn_sse);
-  if (g == 0) {
+  if (ln == 0) {
     (o.qrd + o.s * kQrdStride)[0] = shift;
     if constexpr (MAT) (o.c + o.s * (1))[0] = dt * cost;
     (o.nc + o.s * (1))[0] = nc;
@@ -758,43 +788,46 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   }
   LFPROF(5);
 #ifdef BPMPC_LINFAST_PROFILE
-  if (o.prof && g == 0)
+  if (o.prof && ln == 0)
     for (int i = 0; i < 8; ++i) o.prof[i] = (double)lf_t[i];
 #endif
 #ifdef BPMPC_EVAL_PROFILE
-  if (o.prof && g == 0)
+  if (o.prof && ln == 0)
     for (int i = 0; i < 8; ++i) o.prof[i] = (double)evacc[i];
 #endif
 }
 
 // Value-only metrics of x + alpha dx, u + alpha du at one node for the filter line search (same lane layout as
 // linearize_fast; reference version: trial_node in linesearch.h).
-template <int NJ>
+template <int NJ, class Cfg = LinFastCfg<NJ, true>>
 __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastShared<NJ, false>& sh, LinFastNodeLds<NJ, false>& nl, bool valid,
                                            const NodeInputs& in, double alpha, const double* dx, const double* du, const double* dxn,
-                                           double* perf, int g) {
-  using C = LinFastCfg<NJ>;
-  constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN;
+                                           double* perf, int ln) {
+  using C = Cfg;
+  constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN, G0 = C::G0;
+  const int g = ln + G0;
+  const bool tr = G0 > 0 && ln < 3;    // see linearize_fast
   if (!valid) return;
   if (in.kind == 1) {
     double d2 = 0.0;
-    for (int idx = g; idx < NX; idx += LPN) {
+    for (int idx = ln; idx < NX; idx += LPN) {
       const double d = (in.x[idx] + alpha * dx[idx]) - (in.xnext[idx] + alpha * dxn[idx]);
       d2 += d * d;
     }
     d2 = node_allreduce_add<LPN>(d2);
-    if (g == 0) { perf[0] = 0.0; perf[1] = d2; perf[2] = 0.0; }
+    if (ln == 0) { perf[0] = 0.0; perf[1] = d2; perf[2] = 0.0; }
     return;
   }
   const bool is_joint = g >= 6 && g < G;
   const double dt = in.dt, hdt = 0.5 * in.dt;
   const int mode = in.mode;
-  for (int idx = g; idx < NX; idx += LPN) {
+  for (int idx = ln; idx < NX; idx += LPN) {
     nl.x[idx] = in.x[idx] + alpha * dx[idx];
     nl.u[idx] = in.u[idx] + alpha * du[idx];
   }
-  const double xn_q = g < G ? in.xnext[6 + g] + alpha * dxn[6 + g] : 0.0, xn_h = g < 6 ? in.xnext[g] + alpha * dxn[g] : 0.0;
-  const double xr_q = g < G ? in.xref[6 + g] : 0.0, xr_h = g < 6 ? in.xref[g] : 0.0;
+  const double xn_q = g < G ? in.xnext[6 + g] + alpha * dxn[6 + g] : 0.0, xn_h = ln < 6 ? in.xnext[ln] + alpha * dxn[ln] : 0.0;
+  const double xr_q = g < G ? in.xref[6 + g] : 0.0, xr_h = ln < 6 ? in.xref[ln] : 0.0;
+  const double xn_t = tr ? in.xnext[6 + ln] + alpha * dxn[6 + ln] : 0.0, xr_t = tr ? in.xref[6 + ln] : 0.0;
   LaneBody lb;
   {
     const int body = (g >= 5 && g < G) ? g - 5 : 0;
@@ -810,7 +843,8 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
   LaneEval e1;
   LaneKin<NJ> kin;
-  eval_lane<NJ, false, true, LinFastNodeLds<NJ, false>>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
+  eval_lane<NJ, false, true, LinFastNodeLds<NJ, false>, LinFastShared<NJ, false>, C>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
+  const double v1t = ln == 0 ? kin.vb[0] : (ln == 1 ? kin.vb[1] : kin.vb[2]);
   if (g >= 5 && g < G)
     for (int i = 0; i < kNumContacts; ++i)
       if (md.contact_body[i] == lb.body) {
@@ -820,7 +854,7 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
         for (int a = 0; a < 3; ++a) nl.cvel[i][a] = kin.vog[a] + t[a];
       }
   double cone_own[4] = {0.0, 0.0, 0.0, 0.0};          // h, barrier value, first and second derivative of this lane's contact
-  if (g < kNumContacts && stance_flag(mode, g)) cone_terms(md, &nl.u[3 * g], false, cone_own);
+  if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(md, &nl.u[3 * ln], false, cone_own);
   lds_wave_sync();
   double eq_sse = 0.0;
   for (int i = 0; i < kNumContacts; ++i) {
@@ -839,51 +873,61 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
     }
   }
   double cone_pen = 0.0;
-  if (g < kNumContacts && stance_flag(mode, g)) cone_pen = cone_own[1];
+  if (ln < kNumContacts && stance_flag(mode, ln)) cone_pen = cone_own[1];
   LaneEval e2;
+  double v2t;
   {
-    if (g < 6) nl.xh2[g] = xh[g] + dt * lane_pick6(e1.fh, g);
-    if (g < 3) nl.xh2[6 + g] = pb[g] + dt * (g == 0 ? kin.vb[0] : (g == 1 ? kin.vb[1] : kin.vb[2]));
+    if (ln < 6) nl.xh2[ln] = xh[ln] + dt * lane_pick6(e1.fh, ln);
+    if (ln < 3) nl.xh2[6 + ln] = pb[ln] + dt * v1t;
     const double* xh2 = nl.xh2;      // published by the lds_wave_sync at the top of eval_lane
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
-    eval_lane<NJ, false, false, LinFastNodeLds<NJ, false>>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
+    eval_lane<NJ, false, false, LinFastNodeLds<NJ, false>, LinFastShared<NJ, false>, C>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
+    v2t = ln == 0 ? kin2.vb[0] : (ln == 1 ? kin2.vb[1] : kin2.vb[2]);
   }
   double dyn_sse = 0.0;
   if (g < G) {
     const double bb = qg + hdt * e1.vg + hdt * e2.vg - xn_q;
     dyn_sse += bb * bb;
   }
-  if (g < 6) {
-    const double f1 = lane_pick6(e1.fh, g), f2 = lane_pick6(e2.fh, g);
-    const double bb = (g < 6 ? xh[g] : 0.0) + hdt * f1 + hdt * f2 - xn_h;
+  if (ln < 6) {
+    const double f1 = lane_pick6(e1.fh, ln), f2 = lane_pick6(e2.fh, ln);
+    const double bb = (ln < 6 ? xh[ln] : 0.0) + hdt * f1 + hdt * f2 - xn_h;
+    dyn_sse += bb * bb;
+  }
+  const double pt = tr ? pb[ln] : 0.0;
+  if (tr) {
+    const double bb = pt + hdt * v1t + hdt * v2t - xn_t;
     dyn_sse += bb * bb;
   }
   lds_wave_sync();   // the chain tables are dead: their storage becomes dx / du
   if (g < G) nl.dx[6 + g] = qg - xr_q;
-  if (g < 6) nl.dx[g] = (g < 6 ? xh[g] : 0.0) - xr_h;
-  if (g < 12) nl.du[g] = nl.u[g] - nominal_input(md, mode, g);
+  if (tr) nl.dx[6 + ln] = pt - xr_t;
+  if (ln < 6) nl.dx[ln] = (ln < 6 ? xh[ln] : 0.0) - xr_h;
+  if (ln < 12) nl.du[ln] = nl.u[ln] - nominal_input(md, mode, ln);
   if (is_joint) nl.du[12 + g - 6] = ujg;
   lds_wave_sync();
   double cost = cone_pen;
   {
-    const int cq = 6 + g, ch = g, cf = g, cj = 12 + g - 6;
-    double accq = 0.0, acch = 0.0, accf = 0.0, accj = 0.0;
+    const int cq = 6 + g, ch = ln, cf = ln, cj = 12 + g - 6, ct = 6 + ln;
+    double accq = 0.0, acch = 0.0, accf = 0.0, accj = 0.0, acct = 0.0;
     for (int r = 0; r < NX; ++r) {
       const double dxr = nl.dx[r], dur = nl.du[r];
       if (g < G) accq += md.Q[cq * NX + r] * dxr;       // cost weights from global memory (cache resident): this kernel stores next to nothing,
-      if (g < 6) acch += md.Q[ch * NX + r] * dxr;       // so the loads never queue behind stores, and the LDS they would take buys a third
-      if (g < 12) accf += md.R[cf * NU + r] * dur;      // workgroup per CU
+      if (tr) acct += md.Q[ct * NX + r] * dxr;
+      if (ln < 6) acch += md.Q[ch * NX + r] * dxr;      // so the loads never queue behind stores, and the LDS they would take buys a third
+      if (ln < 12) accf += md.R[cf * NU + r] * dur;     // workgroup per CU
       if (is_joint) accj += md.R[cj * NU + r] * dur;
     }
     if (g < G) cost += 0.5 * nl.dx[cq] * accq;
-    if (g < 6) cost += 0.5 * nl.dx[ch] * acch;
-    if (g < 12) cost += 0.5 * nl.du[cf] * accf;
+    if (tr) cost += 0.5 * nl.dx[ct] * acct;
+    if (ln < 6) cost += 0.5 * nl.dx[ch] * acch;
+    if (ln < 12) cost += 0.5 * nl.du[cf] * accf;
     if (is_joint) cost += 0.5 * nl.du[cj] * accj;
   }
   cost = node_allreduce_add<LPN>(cost);
   dyn_sse = node_allreduce_add<LPN>(dyn_sse);
-  if (g == 0) { perf[0] = dt * cost; perf[1] = dt * dyn_sse; perf[2] = dt * eq_sse; }
+  if (ln == 0) { perf[0] = dt * cost; perf[1] = dt * dyn_sse; perf[2] = dt * eq_sse; }
 }
 
 

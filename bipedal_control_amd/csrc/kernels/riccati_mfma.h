@@ -54,7 +54,11 @@ struct RiccatiMfmaWorkspace {
   alignas(16) double W[NBUF][RB][LDW];  // [A~ | b~ | B~]
   alignas(16) double PW[NBUF][RB][LDW]; // [Px | Pe | Pu]
   alignas(16) double SW[RB][LDW];       // sym(S) W
-  alignas(16) double M[NBUF][RB][LDW];  // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
+  // Rows of M = reduced inputs.  The single-buffered nx = 24 variant keeps 16 of them (rows 16.. of [P~ | r~ | R~] are zero whenever a
+  // stage has at most 16 reduced inputs - every mode of this problem family leaves at most nu - 10 = 14) so that two workgroups share
+  // a CU (79 KB each); a stage with more makes the sweep report a numerical failure instead of computing nonsense.
+  static constexpr int RBM = (!DB && NX > 22) ? 16 : RB;
+  alignas(16) double M[NBUF][RBM][LDW]; // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
   double r[NBUF][NU];
   alignas(16) double dx[2][NX];
   int status;
@@ -139,7 +143,7 @@ __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 
 template <int NJ, bool DB>
 __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, const RiccatiFastIO& io) {
   using WS = RiccatiMfmaWorkspace<NJ, DB>;
-  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccatiThreads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, ZR = WS::ZR, RCL = WS::RCL;
+  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccatiThreads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, ZR = WS::ZR, RCL = WS::RCL, RBM = WS::RBM;
   constexpr int NXX = NX * NX, NXU = NX * NU;
   constexpr int KS = (NX + 3) / 4;          // k-steps over the state dimension
   constexpr int BC = NX + 1;                // first column of B~ / Pu / R~ in the packed layouts
@@ -163,7 +167,19 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
     for (int idx = tid; idx < NXX; idx += NT) ws.S[idx / NX][idx % NX] = io.carry[idx];
     if (tid < NX) ws.S[tid][NX] = io.carry[NXX + tid];
   }
-  for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) ws.nut[idx] = (unsigned char)io.base.nut[idx];
+  int too_wide = 0;
+  for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) {
+    const int n = io.base.nut[idx];
+    ws.nut[idx] = (unsigned char)n;
+    too_wide |= (RBM < NU && n > RBM) ? 1 : 0;
+  }
+  if (RBM < NU && __syncthreads_or(too_wide)) {         // more reduced inputs than this variant holds: fail loudly (status 2 in bpmpc_stats)
+    if (tid == 0) {
+      if (io.k_lo > 0) io.carry[NXX + NX] = 1.0;
+      else { io.base.summary[0] = 0.0; io.base.summary[1] = 0.0; io.base.summary[2] = 0.0; io.base.summary[3] = 1.0; }
+    }
+    return;
+  }
 
   // Prefetch registers of the loader waves (0..2): 16-byte loads, element pairs (2 t, 2 t + 1) and (2 (t + 192), ..).
   constexpr int NLD = 3 * kWave;                       // loader threads
@@ -253,11 +269,13 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
           Qq[i][j] = pQ[e].x; Qq[i][j + 1] = pQ[e].y;
           PW[i][j] = pPx[e].x; PW[i][j + 1] = pPx[e].y;
           PW[i][BC + j] = pPu[e].x; PW[i][BC + j + 1] = pPu[e].y;
-          M[i][j] = pP[e].x; M[i][j + 1] = pP[e].y;
-          M[i][BC + j] = pR[e].x; M[i][BC + j + 1] = pR[e].y;
+          if (RBM >= NU || i < RBM) {                        // rows beyond the reduced inputs are zero and not kept
+            M[i][j] = pP[e].x; M[i][j + 1] = pP[e].y;
+            M[i][BC + j] = pR[e].x; M[i][BC + j + 1] = pR[e].y;
+          }
         }
       }
-      if (tid < NX) { W[tid][NX] = pv[0]; Qq[tid][NX] = pv[1]; M[tid][NX] = pv[2]; rvec[tid] = pv[2]; PW[tid][NX] = pv[3]; }
+      if (tid < NX) { W[tid][NX] = pv[0]; Qq[tid][NX] = pv[1]; if (RBM >= NU || tid < RBM) M[tid][NX] = pv[2]; rvec[tid] = pv[2]; PW[tid][NX] = pv[3]; }
     }
     lds_barrier();
     RMPROF(0);
@@ -307,7 +325,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-      blk_store<LDW, RB>(&M[0][0], r0, c0, l, acc);
+      blk_store<LDW, RBM>(&M[0][0], r0, c0, l, acc);
       if (c0 < 32) blk_store<LDN, RB>(&ws.G0[0][0], r0, c0, l, acc);
     }
     if (w == 3) flush_held();        // (wave 3 runs the elimination in P3, the other waves store and prefetch there)

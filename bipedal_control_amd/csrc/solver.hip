@@ -147,11 +147,13 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
 }
 
 constexpr int kTrialWaves = 4; // same for the value-only trial kernel (smaller per-node LDS: four waves, 8 waves per CU)
-constexpr int kLinWaves = 4;   // wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS
+// wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS.  Four at nx = 22 (75.9 KB, two
+// workgroups per CU); three at nx = 24, where a wave serves four nodes of 4.6 KB each (packed lanes, LinFastCfg): 66 KB, two workgroups per CU
+template <int NJ> constexpr int lin_waves() { return NJ <= 10 ? 4 : 3; }
 template <int NJ, bool MAT>
-__global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
-  using C = LinFastCfg<NJ>;
-  constexpr int LPN = C::LPN, NPW = C::NPW;
+__global__ __launch_bounds__(lin_waves<NJ>() * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
+  using C = LinFastCfg<NJ, true>;
+  constexpr int LPN = C::LPN, NPW = C::NPW, kLinWaves = lin_waves<NJ>();
   __shared__ LinFastNodeLds<NJ> lds[kLinWaves * NPW];
   __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
   load_shared_model<NJ>(*L.model, shared, threadIdx.x, kLinWaves * kWave);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(kLinWaves * kWave) __attribute__((amdgpu_waves_per_
   out.qrd = L.buf.qrd;
   out.s = s;
   out.prof = (valid && b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
-  linearize_fast<NJ, MAT>(*L.model, shared, lds[sub], valid, in, out, g);
+  linearize_fast<NJ, MAT, C>(*L.model, shared, lds[sub], valid, in, out, g);      // g: lane inside the node's group
 }
 
 template <int NJ>
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati(Launch L) {
 
 // The single-buffered variant is meant to run two workgroups per CU: cap its registers at 256 (VGPR + AGPR).
 template <int NJ, bool DB>
-__global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu((DB || NJ != 10) ? 1 : 2, (DB || NJ != 10) ? 8 : 2))) void k_riccati_fast(Launch L) {
+__global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu(DB ? 1 : 2, DB ? 8 : 2))) void k_riccati_fast(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   __shared__ RiccatiMfmaWorkspace<NJ, DB> ws;
   const int b = blockIdx.x;
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(kWave) void k_trial(Launch L) {
 
 template <int NJ>
 __global__ __launch_bounds__(kTrialWaves * kWave) void k_trial_fast(Launch L) {
-  using C = LinFastCfg<NJ>;
+  using C = LinFastCfg<NJ, true>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
   __shared__ LinFastNodeLds<NJ, false> lds[kTrialWaves * NPW];
   __shared__ LinFastShared<NJ, false> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(kTrialWaves * kWave) void k_trial_fast(Launch L) {
   const size_t s = valid ? (size_t)b * L.N + k : 0;
   const NodeInputs in = node_inputs<NJ>(L, b, k);
   const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
-  trial_fast<NJ>(*L.model, shared, lds[sub], valid, in, L.buf.alpha[b], dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
+  trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, L.buf.alpha[b], dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
 }
 
 template <int NJ>
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L) {
 // up.  The host never reads a flag back inside a solve, so consecutive solves queue without a gap.
 template <int NJ>
 __global__ __launch_bounds__(kDecideThreads) void k_ls_tail(Launch L, int max_trials) {
-  using C = LinFastCfg<NJ>;
+  using C = LinFastCfg<NJ, true>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW, CHUNK = (kDecideThreads / kWave) * NPW;
   const int b = blockIdx.x;
   if (L.buf.done[b]) return;
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(kDecideThreads) void k_ls_tail(Launch L, int max_tr
       const size_t s = (size_t)b * L.N + kk;
       const NodeInputs in = node_inputs<NJ>(L, b, kk);
       const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + kk) * NX;
-      trial_fast<NJ>(*L.model, shared, lds[sub], valid, in, al, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
+      trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, al, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
     }
     __threadfence();
     __syncthreads();
@@ -537,7 +539,7 @@ struct bpmpc_solver {
   int num_cus = 256;                                        // compute units of the device
   // One Riccati workgroup per problem: double buffered staging (one workgroup per CU) while every problem gets its own CU,
   // the leaner single-buffered variant (two workgroups per CU at nx = 22) for larger batches.
-  bool riccati_double_buffered() const { return batch <= num_cus || rm.nj != 10; }
+  bool riccati_double_buffered() const { return batch <= num_cus; }
   bool has_solution = false;                               // a solve has completed on the current setup
   bool has_rollout = false;                                // roll_x holds the end states of a rollout
   bool rollout_unchecked = false;                          // ... whose status flags have not been read back yet
@@ -642,7 +644,7 @@ template <int NJ> void bpmpc_solver::stage_linearize() {
   if (settings.reference_kernels) {
     TIMED_LAUNCH("linearize", k_linearize<NJ>, batch * settings.max_nodes, kWave, L);
   } else {
-    constexpr int NPW = LinFastCfg<NJ>::NPW;
+    constexpr int NPW = LinFastCfg<NJ, true>::NPW, kLinWaves = lin_waves<NJ>();
     const int grid = (batch * settings.max_nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW);
     if (settings.materialize_lq) TIMED_LAUNCH("linearize", (k_linearize_fast<NJ, true>), grid, kLinWaves * kWave, L);
     else TIMED_LAUNCH("linearize", (k_linearize_fast<NJ, false>), grid, kLinWaves * kWave, L);
@@ -676,7 +678,7 @@ template <int NJ> void bpmpc_solver::stage_linesearch() {
   for (double a = 1.0; a >= ls.alpha_min; a *= ls.alpha_decay) ++max_trials;
   if (!settings.reference_kernels) {
     // first round for everybody, later rounds per problem on the device (k_ls_tail): no read-back inside a solve
-    constexpr int NPW = LinFastCfg<NJ>::NPW;
+    constexpr int NPW = LinFastCfg<NJ, true>::NPW;
     hipLaunchKernelGGL(k_trial_fast<NJ>, dim3((batch * settings.max_nodes + kTrialWaves * NPW - 1) / (kTrialWaves * NPW)), dim3(kTrialWaves * kWave), 0, stream, L);
     hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L);
     hipLaunchKernelGGL(k_ls_tail<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L, max_trials);
@@ -699,7 +701,7 @@ template <int NJ> void bpmpc_solver::stage_linesearch() {
 // (linearise, LU, change of variables) of chunk c+1 run on their own stream while the latency-bound Riccati sweep of
 // chunk c occupies one workgroup per problem.  Only stream/event ordering is used, no device-side waiting.
 template <int NJ> void bpmpc_solver::pipelined_backward() {
-  constexpr int NPW = LinFastCfg<NJ>::NPW;
+  constexpr int NPW = LinFastCfg<NJ, true>::NPW, kLinWaves = lin_waves<NJ>();
   const int chunks = settings.pipeline_chunks;
   const int n = n_nodes_max;
   HIP_CHECK(hipEventRecord(ev_go, stream));
@@ -763,7 +765,7 @@ void allocate(bpmpc_solver* s) {
   Buffers& b = s->buf;
   b.proj_extent = s->alloc<int>("proj_extent", S, true);
   b.qrd = s->alloc<double>("qrd", S * kQrdStride);
-  b.lin_park = s->alloc<double>("lin_park", S * kLinParkDoublesPerLane * (6 + s->rm.nj <= 16 ? 16 : 32));
+  b.lin_park = s->alloc<double>("lin_park", S * kLinParkDoublesPerLane * (s->rm.nj == 10 ? LinFastCfg<10, true>::LPN : LinFastCfg<12, true>::LPN));
   b.x_prev = s->alloc<double>("x_prev", B * (N + 1) * NX); b.u_prev = s->alloc<double>("u_prev", S * NU);
   b.K_prev = s->alloc<double>("K_prev", S * NU * NX);
   b.tp_time = s->alloc<double>("tp_time", B * (N + 1)); b.tp_kind = s->alloc<int>("tp_kind", S, true);
