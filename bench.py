@@ -359,7 +359,8 @@ def roofline_fp64(robot, kernel_ms, n_lin_nodes, n_nodes_total, n_stages_total, 
         if not ms:
             continue
         e = {"ms": ms, "restatement_flops": int(rflops), "restatement_tflops": round(rflops / (1e-3 * ms) / 1e12, 2)}
-        ck = next((v for k, v in counters.items() if k.startswith(prefix)), None) if applicable else None
+        names = sorted((k for k in counters if k.startswith(prefix)), key=lambda k: (not k.endswith("true>"), k))     # the timed lineariser is <NJ, true>
+        ck = counters[names[0]] if (applicable and names) else None
         if ck:
             lane_ops = ck.get("SQ_INSTS_VALU", 0.0) * 64.0
             mfma = ck.get("SQ_INSTS_VALU_MFMA_F64", 0.0)
