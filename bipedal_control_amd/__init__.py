@@ -5,7 +5,7 @@ include/bpmpc.h); all arithmetic of the hot path runs in hand-written HIP kernel
 There is no CPU fallback: constructing a solver without the HIP library or without a GPU raises.
 """
 from .api import (BatchedSqpMpc, BipedalRobotInterface, BpmpcError, GaitSchedule, ModeSchedule, ModeSequenceTemplate,  # noqa: F401
-                  TargetTrajectories, load_library, loadModeSequenceTemplate, swing_reference, time_discretization_with_events)
+                  TargetTrajectories, WeightedWbc, load_library, loadModeSequenceTemplate, swing_reference, time_discretization_with_events)
 
 __all__ = ["BatchedSqpMpc", "BipedalRobotInterface", "BpmpcError", "GaitSchedule", "ModeSchedule", "ModeSequenceTemplate",
-           "TargetTrajectories", "load_library", "loadModeSequenceTemplate", "swing_reference", "time_discretization_with_events"]
+           "TargetTrajectories", "WeightedWbc", "load_library", "loadModeSequenceTemplate", "swing_reference", "time_discretization_with_events"]

@@ -409,3 +409,40 @@ class BatchedSqpMpc:
     def export_trajectories(self, x_dst_ptr, u_dst_ptr):
         """Async D2D copy of the iterate into device buffers given by raw pointers (e.g. torch tensors' data_ptr())."""
         _check(load_library().bpmpc_solver_export_trajectories(self._h, C.c_void_p(x_dst_ptr), C.c_void_p(u_dst_ptr)))
+
+
+class WeightedWbc:
+    """A batch of WeightedWbc instances on one MI355X (bipedal_wbc/include/bipedal_wbc/WeightedWbc.h; construction + loadTasksSetting as
+    in bipedal_controllers/src/BipedalController.cpp:97-100).  `update` mirrors WeightedWbc::update(stateDesired, inputDesired,
+    rbdStateMeasured, mode, period) (BipedalController.cpp:229) with a leading batch dimension; it returns (x, status) where
+    x[b] = [generalised accelerations, contact forces, joint torques] and status[b] = 1 when that robot's QP was not solved and its
+    previous solution was returned instead (lastQpSol_)."""
+
+    def __init__(self, interface, taskFile=None, max_batch=1, device=0):
+        lib = load_library()
+        self.interface = interface
+        self._h = C.c_void_p()
+        _check(lib.bpmpc_wbc_create(interface.handle, str(taskFile or interface.taskFile).encode(), int(device), int(max_batch), C.byref(self._h)))
+        n, nv = C.c_int(), C.c_int()
+        _check(lib.bpmpc_wbc_dims(self._h, C.byref(n), C.byref(nv)))
+        self.numDecisionVars, self.generalizedCoordinatesNum, self.max_batch = n.value, nv.value, int(max_batch)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.bpmpc_wbc_destroy(self._h)
+            self._h = None
+
+    def update(self, stateDesired, inputDesired, rbdStateMeasured, mode, period=0.002, debug=False):
+        x = _f64(stateDesired).reshape(-1, self.interface.stateDim)
+        B = x.shape[0]
+        u = _f64(inputDesired).reshape(B, self.interface.inputDim)
+        rbd = _f64(rbdStateMeasured).reshape(B, 2 * self.generalizedCoordinatesNum)
+        md = np.ascontiguousarray(np.broadcast_to(np.asarray(mode, np.int32), (B,)))
+        sol = np.zeros((B, self.numDecisionVars))
+        status = np.zeros(B, np.int32)
+        dbg = np.zeros((B, 1024)) if debug else None
+        _check(load_library().bpmpc_wbc_update(self._h, B, _d(x), _d(u), _d(rbd), _i(md), C.c_double(period), _d(sol), _i(status), _d(dbg)))
+        return (sol, status, dbg) if debug else (sol, status)
+
+    def reset(self):
+        _check(load_library().bpmpc_wbc_reset(self._h))

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbpmpc.so")
-SOURCES = ["solver.hip", "capi.cpp", "info_tree.cpp", "urdf_tree.cpp", "robot_model.cpp", "reference_gen.cpp", "device_model.cpp"]
+SOURCES = ["solver.hip", "wbc.hip", "capi.cpp", "info_tree.cpp", "urdf_tree.cpp", "robot_model.cpp", "reference_gen.cpp", "device_model.cpp"]
 
 
 def _newest_source():

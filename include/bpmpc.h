@@ -232,6 +232,27 @@ int bpmpc_solver_kernel_time(bpmpc_solver* solver, const char* kernel, int reset
 /* Sizes chosen by the last setup: nodes per problem (max over the batch) and number of distinct grids. */
 int bpmpc_solver_layout(const bpmpc_solver* solver, int* batch, int* n_nodes_max, int* n_grids, int* nx, int* nu);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Whole-body controller = WeightedWbc for a BATCH of robots (first slice)
+ *   construction replaced:  bipedal_controllers/src/BipedalController.cpp:97-100 (WeightedWbc + loadTasksSetting(taskFile))
+ *   update site replaced:   bipedal_controllers/src/BipedalController.cpp:229   wbc_->update(optimizedState, optimizedInput, measuredRbdState_, plannedMode, period)
+ *   tasks:                  bipedal_wbc/src/WbcBase.cpp:162-403, QP: bipedal_wbc/src/WeightedWbc.cpp:20-84 (qpOASES, nWSR 20)
+ * Decision vector per robot: [generalised accelerations (6 + nj), contact forces (12), joint torques (nj)].
+ * rbd_state_measured per robot: [ZYX Euler (3), base position (3), joints (nj), world angular velocity (3), linear velocity (3), joint velocities (nj)]
+ * (CentroidalModelRbdConversions layout, WbcBase.cpp:58-77).  A QP that cannot be solved (inconsistent constraints, more than 20 working-set
+ * changes) leaves the robot's previous solution in place - lastQpSol_, WeightedWbc.cpp:68-81 - and sets status 1; the handle keeps the last
+ * solutions between calls (zero after creation / bpmpc_wbc_reset).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct bpmpc_wbc bpmpc_wbc;
+int bpmpc_wbc_create(const bpmpc_model* model, const char* task_info_path, int device, int max_batch, bpmpc_wbc** out);
+void bpmpc_wbc_destroy(bpmpc_wbc* wbc);
+int bpmpc_wbc_dims(const bpmpc_wbc* wbc, int* n_decision_variables, int* n_generalized_coordinates);
+/* state_desired[batch*nx], input_desired[batch*nu], rbd_state_measured[batch*2*(6+nj)], mode[batch] -> solution[batch*n], status[batch] (nullable);
+ * debug (nullable, tests): batch*1024 doubles - M, nle, J, Jdot v, base-task right-hand side, rank / iterations / working set */
+int bpmpc_wbc_update(bpmpc_wbc* wbc, int batch, const double* state_desired, const double* input_desired, const double* rbd_state_measured,
+                     const int* mode, double period, double* solution, int* status, double* debug);
+int bpmpc_wbc_reset(bpmpc_wbc* wbc);
+
 #ifdef __cplusplus
 }
 #endif
