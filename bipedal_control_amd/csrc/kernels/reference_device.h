@@ -46,7 +46,7 @@ struct RefGenLds {
   int ms[kRefMaxEvents + 1];
   double time[kRefMaxGrid];
   int event[kRefMaxGrid];
-  int base, ne, nm, n_grid, status, rows;
+  int base, ne, nm, n_grid, status, rows, vrows;
 };
 
 struct DevSchedule {
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(64) void k_reference_grids(ReferenceGenArgs a) {
   const double t0 = a.t0[g];
   if (l == 0) {
     w.rows = 12;
+    w.vrows = 4;
     ref_build_schedule(w, a.lib, a.gait[g], a.gait_start[g], t0, a.horizon);
     int n = 0;
     if (w.status == kRefOk) {
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(64) void k_reference_grids(ReferenceGenArgs a) {
         for (int c = 0; c < 4; ++c) ref_swing(w, a, c, p, start, &z[c], &zd[c]);
         const int left = (mode == 1 || mode == 3) ? 3 : 4, right = (mode == 2 || mode == 3) ? 3 : 4;
         atomicMax(&w.rows, 2 * left + 2 * right);
+        atomicMax(&w.vrows, (left == 3 ? 6 : 2) + (right == 3 ? 6 : 2));   // rows that constrain a contact velocity (structured projection)
       }
     }
     const size_t i = (size_t)g * N + k;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(64) void k_reference_grids(ReferenceGenArgs a) {
   }
   for (int k = l; k <= N; k += 64) a.node_time[(size_t)g * (N + 1) + k] = (ok && k <= n) ? w.time[k] : 0.0;
   __syncthreads();
-  if (l == 0) { a.nodes[g] = n; a.status[g] = w.status; a.rows[g] = w.rows; }
+  if (l == 0) { a.nodes[g] = n; a.status[g] = w.status; a.rows[g] = w.rows | (w.vrows << 8); }
 }
 
 struct CommandTargetArgs {

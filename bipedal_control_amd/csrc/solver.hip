@@ -29,6 +29,7 @@
 #include "kernels/linearize_fast.h"
 #include "kernels/project_node.h"
 #include "kernels/project_lu4.h"
+#include "kernels/project_lu_s.h"
 #include "kernels/riccati.h"
 #include "kernels/riccati_fast.h"
 #include "kernels/riccati_mfma.h"
@@ -220,6 +221,35 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
   }
   project_lu4<NJ, RM>(lds[sub], valid, L.buf.nc[s], L.buf.D + s * kMaxEqRows * NU, L.buf.C + s * kMaxEqRows * NX, L.buf.e + s * kMaxEqRows, Px, Pu, Pe,
                   L.buf.nut + s, sub, j);
+}
+
+#ifndef BPMPC_STRUCTURED_LU
+#define BPMPC_STRUCTURED_LU 1      // constraint elimination through the block structure of D (project_lu_s.h); 0: FullPivLU on the whole D
+#endif
+template <int NJ, int RM>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_project_lu_s(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ ProjectLuSLds<NJ> lds[kLuNodes];
+  const int sub = threadIdx.x / kLuLanes, j = threadIdx.x % kLuLanes;
+  const int widx = blockIdx.x * kLuNodes + sub;
+  bool valid = widx < L.batch * L.klen;
+  const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
+  const int g = L.buf.p_grid[b];
+  valid = valid && L.buf.active[b] && k < L.buf.g_nodes[g];
+  const size_t s = valid ? (size_t)b * L.N + k : 0;
+  double* Px = L.buf.Px + s * NU * NX;
+  double* Pu = L.buf.Pu + s * NU * NU;
+  double* Pe = L.buf.Pe + s * NU;
+  const size_t gs = (size_t)g * L.N + k;
+  if (valid && L.buf.g_kind[gs] == 1) {   // event node: no input
+    for (int idx = j; idx < NU * NX; idx += kLuLanes) { Px[idx] = 0.0; Pu[idx] = 0.0; }
+    for (int idx = j; idx < NU; idx += kLuLanes) Pe[idx] = 0.0;
+    if (j == 0) L.buf.nut[s] = 0;
+    valid = false;
+  }
+  const int mode = valid ? (L.buf.g_mode[gs] & 3) : 3;
+  project_lu_s<NJ, RM>(lds[sub], valid, mode, L.buf.D + s * kMaxEqRows * NU, L.buf.C + s * kMaxEqRows * NX, L.buf.e + s * kMaxEqRows, Px, Pu, Pe,
+                       L.buf.nut + s, sub, j);
 }
 
 template <int NJ>
@@ -545,6 +575,7 @@ struct bpmpc_solver {
   bool rollout_unchecked = false;                          // ... whose status flags have not been read back yet
   std::vector<int> grid_kind;                               // host copy of the node kinds of the current setup [n_grids][N]
   int max_rows = kMaxEqRows;                                // largest number of equality rows over the nodes of the current setup
+  int max_vel_rows = 12;                                    // ... of rows that constrain a contact velocity (12 double stance, 8 single support, 4 flight)
   bool cold = true;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -655,6 +686,10 @@ template <int NJ> void bpmpc_solver::stage_project() {
   if (settings.reference_kernels) TIMED_LAUNCH("project", k_project<NJ>, batch * settings.max_nodes, kWave, L);
   else {
     const int lu_grid = (batch * settings.max_nodes + kLuNodes - 1) / kLuNodes;
+    if (BPMPC_STRUCTURED_LU) {
+      if (max_vel_rows <= 8) TIMED_LAUNCH("project_lu", (k_project_lu_s<NJ, 8>), lu_grid, kWave, L);
+      else TIMED_LAUNCH("project_lu", (k_project_lu_s<NJ, 12>), lu_grid, kWave, L);
+    } else
     if (max_rows <= 12) TIMED_LAUNCH("project_lu", (k_project_lu<NJ, 12>), lu_grid, kWave, L);
     else if (max_rows <= 14) TIMED_LAUNCH("project_lu", (k_project_lu<NJ, 14>), lu_grid, kWave, L);
     else TIMED_LAUNCH("project_lu", (k_project_lu<NJ, 16>), lu_grid, kWave, L);
@@ -716,6 +751,10 @@ template <int NJ> void bpmpc_solver::pipelined_backward() {
     const int nodes = batch * L.klen;
     if (settings.materialize_lq) TIMED_LAUNCH_ON(producer_stream, "linearize", (k_linearize_fast<NJ, true>), (nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW), kLinWaves * kWave, L);
     else TIMED_LAUNCH_ON(producer_stream, "linearize", (k_linearize_fast<NJ, false>), (nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW), kLinWaves * kWave, L);
+    if (BPMPC_STRUCTURED_LU) {
+      if (max_vel_rows <= 8) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu_s<NJ, 8>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
+      else TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu_s<NJ, 12>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
+    } else
     if (max_rows <= 12) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 12>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
     else if (max_rows <= 14) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 14>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
     else TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 16>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
@@ -897,7 +936,7 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   gdt.assign(S, 0.0); gstart.assign(S, 0.0); zref.assign(S * 4, 0.0); zdref.assign(S * 4, 0.0);
   s->node_times.assign((size_t)G * (N + 1), 0.0);
   SwingPlanner planner(s->rm.swing);
-  int nmax = 0, rows_max = 12;
+  int nmax = 0, rows_max = 12, vrows_max = 4;
   for (int g = 0; g < G; ++g) {
     const bpmpc_mode_schedule& sc = schedules[n_schedules == 1 ? 0 : first_problem[g]];
     ModeSchedule ms;
@@ -915,6 +954,7 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
       if (tab.kind[k] == 0) {                            // rows per contact: 3 in stance, 4 in swing (two contact points per foot)
         const int left = (tab.mode[k] == 1 || tab.mode[k] == 3) ? 3 : 4, right = (tab.mode[k] == 2 || tab.mode[k] == 3) ? 3 : 4;
         rows_max = std::max(rows_max, 2 * left + 2 * right);
+        vrows_max = std::max(vrows_max, (left == 3 ? 6 : 2) + (right == 3 ? 6 : 2));
       }
       for (int c = 0; c < 4; ++c) { zref[4 * i + c] = tab.zref[4 * k + c]; zdref[4 * i + c] = tab.zdref[4 * k + c]; }
     }
@@ -935,7 +975,7 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   // rejected call leaves the handle exactly as it was
   if (from_previous) preserve_previous(s, batch, warm_x != nullptr);
   s->batch = batch; s->n_grids = G; s->n_nodes_max = nmax; s->cold = (warm_x == nullptr);
-  s->max_rows = rows_max;
+  s->max_rows = rows_max; s->max_vel_rows = vrows_max;
   s->grid_nodes = nodes; s->grid_of_problem = pgrid; s->grid_kind = kind; s->has_solution = false;
   Buffers& bf = s->buf;
   upload(s, bf.g_kind, kind); upload(s, bf.g_mode, mode); upload(s, bf.g_nodes, nodes); upload(s, bf.g_dt, gdt); upload(s, bf.g_start, gstart);
@@ -1035,7 +1075,7 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
   HIP_CHECK(hipStreamSynchronize(s->stream));
   s->has_solution = false;
   s->batch = 0;                                           // stays unusable if a grid is rejected below
-  int nmax = 0, rows_max = 12;
+  int nmax = 0, rows_max = 12, vrows_max = 4;
   for (int g = 0; g < G; ++g) {
     const int st = status[g];
     if (st == kRefTileOrder) throw std::runtime_error("The initial time for template-tiling is not greater than the last event time.");
@@ -1044,9 +1084,10 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
     if (st >= kRefNoTouchDown) throw std::runtime_error("The time of touch-down for the last swing of the EE with ID " + std::to_string(st - kRefNoTouchDown) + " is not defined.");
     if (st >= kRefNoTakeOff) throw std::runtime_error("The time of take-off for the first swing of the EE with ID " + std::to_string(st - kRefNoTakeOff) + " is not defined.");
     nmax = std::max(nmax, nodes[g]);
-    rows_max = std::max(rows_max, rows[g]);
+    rows_max = std::max(rows_max, rows[g] & 255);
+    vrows_max = std::max(vrows_max, rows[g] >> 8);
   }
-  s->batch = batch; s->n_grids = G; s->n_nodes_max = nmax; s->cold = true; s->max_rows = rows_max;
+  s->batch = batch; s->n_grids = G; s->n_nodes_max = nmax; s->cold = true; s->max_rows = rows_max; s->max_vel_rows = vrows_max;
   s->grid_nodes = nodes; s->grid_of_problem = pgrid; s->grid_kind = kind;
   finish_setup(s, batch, nullptr, nullptr, from_previous);
 }
