@@ -609,7 +609,9 @@ struct bpmpc_solver {
     L.batch = batch;
     L.N = settings.max_nodes;
     L.k0 = 0;
-    L.klen = settings.max_nodes;
+    // node range of a launch: the longest grid of the current setup, not the solver's capacity - the per-node kernels map their
+    // workgroups onto batch x klen node slots and every slot beyond a problem's grid is a lane group that idles
+    L.klen = n_nodes_max > 0 ? n_nodes_max : settings.max_nodes;
     L.cold = cold ? 1 : 0;
     L.ls = ls;
     L.reg_prim = settings.reg_prim;
@@ -676,7 +678,7 @@ template <int NJ> void bpmpc_solver::stage_linearize() {
     TIMED_LAUNCH("linearize", k_linearize<NJ>, batch * settings.max_nodes, kWave, L);
   } else {
     constexpr int NPW = LinFastCfg<NJ, true>::NPW, kLinWaves = lin_waves<NJ>();
-    const int grid = (batch * settings.max_nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW);
+    const int grid = (batch * L.klen + kLinWaves * NPW - 1) / (kLinWaves * NPW);
     if (settings.materialize_lq) TIMED_LAUNCH("linearize", (k_linearize_fast<NJ, true>), grid, kLinWaves * kWave, L);
     else TIMED_LAUNCH("linearize", (k_linearize_fast<NJ, false>), grid, kLinWaves * kWave, L);
   }
@@ -685,7 +687,7 @@ template <int NJ> void bpmpc_solver::stage_project() {
   const Launch L = launch_params();
   if (settings.reference_kernels) TIMED_LAUNCH("project", k_project<NJ>, batch * settings.max_nodes, kWave, L);
   else {
-    const int lu_grid = (batch * settings.max_nodes + kLuNodes - 1) / kLuNodes;
+    const int lu_grid = (batch * L.klen + kLuNodes - 1) / kLuNodes;
     if (BPMPC_STRUCTURED_LU) {
       if (max_vel_rows <= 8) TIMED_LAUNCH("project_lu", (k_project_lu_s<NJ, 8>), lu_grid, kWave, L);
       else TIMED_LAUNCH("project_lu", (k_project_lu_s<NJ, 12>), lu_grid, kWave, L);
@@ -714,7 +716,7 @@ template <int NJ> void bpmpc_solver::stage_linesearch() {
   if (!settings.reference_kernels) {
     // first round for everybody, later rounds per problem on the device (k_ls_tail): no read-back inside a solve
     constexpr int NPW = LinFastCfg<NJ, true>::NPW;
-    hipLaunchKernelGGL(k_trial_fast<NJ>, dim3((batch * settings.max_nodes + kTrialWaves * NPW - 1) / (kTrialWaves * NPW)), dim3(kTrialWaves * kWave), 0, stream, L);
+    hipLaunchKernelGGL(k_trial_fast<NJ>, dim3((batch * L.klen + kTrialWaves * NPW - 1) / (kTrialWaves * NPW)), dim3(kTrialWaves * kWave), 0, stream, L);
     hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L);
     hipLaunchKernelGGL(k_ls_tail<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L, max_trials);
     HIP_CHECK(hipGetLastError());

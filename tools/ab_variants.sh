@@ -11,7 +11,7 @@ for v in "${VARIANTS[@]}"; do
   name="${v%%:*}"; flags="${v#*:}"
   NAMES="$NAMES $name"
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value $flags -o tools/probes/lib_$name.bin \
-      bipedal_control_amd/csrc/{solver.hip,capi.cpp,info_tree.cpp,urdf_tree.cpp,robot_model.cpp,reference_gen.cpp,device_model.cpp} > /tmp/ab_$name.log 2>&1 || echo "BUILD FAILED $name" ) &
+      bipedal_control_amd/csrc/{solver.hip,wbc.hip,capi.cpp,info_tree.cpp,urdf_tree.cpp,robot_model.cpp,reference_gen.cpp,device_model.cpp} > /tmp/ab_$name.log 2>&1 || echo "BUILD FAILED $name" ) &
 done
 wait
 cp bipedal_control_amd/libbpmpc.so /tmp/libbpmpc_keep.so
