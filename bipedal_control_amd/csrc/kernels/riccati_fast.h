@@ -81,10 +81,141 @@ __device__ __forceinline__ bool gauss_jordan_wave(double (&v)[ROWS], int nt) {
   return ok;
 }
 
+// The same elimination with the pivot column broadcast by DPP instead of v_readlane.  gfx90a+ DP-ALU DPP knows one control,
+// row_newbcast:P - lane P of every 16-lane row to all lanes of that row - and v_fmac_f64 takes it on src0.  Layout: every
+// row of 16 lanes holds the nt <= 16 columns of H in its lanes 0..nt-1 (four identical copies in the wave) and 16 - nt columns
+// of the right-hand side [G g] in the others, so lane p of the own row always holds the pivot column and one
+//     v[i] += bcast_p(v[i]) * (-row)                      (one instruction, no SGPR round trip)
+// replaces two v_readlane_b32 and an FMA: 4 (16 - nt) right-hand sides per wave, ~1/2 of the issue cycles per pivot.
+// Same operations on the same values as gauss_jordan_wave: bit-identical results.
+template <int P>
+__device__ __forceinline__ double row_bcast(double v) {       // v_mov_b64_dpp; hazards are the compiler's
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + P, 0xf, 0xf, true);
+}
+// acc -= bcast_P(acc) * m.  "VALU writes a VGPR -> DPP reads it" needs two wait states and the hazard recogniser does not look
+// into inline assembly: FIRST = the statement opens a pivot step (s_nop 1; as expensive as an FMA, tools/probes/dpp_f64_probe.hip);
+// the other updates of a step read registers that were last written a whole step earlier.
+template <int P, bool FIRST>
+__device__ __forceinline__ void fnmac_row_bcast(double& acc, double m) {
+  if constexpr (FIRST) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(P));
+  else asm volatile("v_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(P));
+}
+// One pivot step; `row` = pivot row P already normalised.  The reciprocal chain of pivot P + 1 (broadcast, v_rcp_f64, two
+// Newton steps, product: seven dependent instructions) is issued one instruction at a time between the independent updates of
+// this step - row P + 1 is updated first - so that it costs issue slots, not latency.
+template <int ROWS, int P>
+__device__ __forceinline__ void gauss_jordan_rows_step(double (&v)[ROWS], int nt, bool& ok, double row) {
+  constexpr bool has_next = P + 1 < ROWS;
+  constexpr int PN = has_next ? P + 1 : P;
+  double piv = 1.0, r = 0.0, e = 0.0, next_row = 0.0;
+  constexpr int F = has_next ? P + 1 : 0;        // the row updated first: the next pivot row
+  if constexpr (F != P) fnmac_row_bcast<P, true>(v[F], row);
+  int s = has_next ? 0 : 7;
+  auto chain = [&]() {
+    switch (s++) {
+      // (the empty volatile statements pin each result between the updates around it: the values are only needed by the
+      //  next step, and the compiler would otherwise sink the whole chain behind the last update; input-only, because the
+      //  hazard recogniser answers a register *defined* by inline assembly with a wait state in front of every reader)
+      case 0: piv = row_bcast<PN>(v[PN]); asm volatile("" :: "v"(piv)); break;
+      case 1: r = __builtin_amdgcn_rcp(piv); asm volatile("" :: "v"(r)); break;
+      case 2: e = __builtin_fma(-piv, r, 1.0); asm volatile("" :: "v"(e)); break;
+      case 3: r = __builtin_fma(r, e, r); asm volatile("" :: "v"(r)); break;
+      case 4: e = __builtin_fma(-piv, r, 1.0); asm volatile("" :: "v"(e)); break;
+      case 5: r = __builtin_fma(r, e, r); asm volatile("" :: "v"(r)); break;
+      case 6: next_row = v[PN] * r; asm volatile("" :: "v"(next_row)); break;
+      default: break;
+    }
+    __builtin_amdgcn_sched_barrier(0);     // the scheduler would sink the whole chain behind the updates otherwise
+  };
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i)
+    if (i != P && i != F) { chain(); fnmac_row_bcast<P, false>(v[i], row); }
+#pragma unroll
+  for (int t = 0; t < 7; ++t) chain();
+  v[P] = row;
+  if constexpr (has_next) {
+    if (P + 1 < nt) {  // wave-uniform
+      ok = ok && (piv > 0.0);
+      gauss_jordan_rows_step<ROWS, P + 1>(v, nt, ok, next_row);
+    }
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ bool gauss_jordan_rows(double (&v)[ROWS], int nt) {
+  if (nt <= 0) return true;
+  const double piv = row_bcast<0>(v[0]);
+  bool ok = piv > 0.0;
+  gauss_jordan_rows_step<ROWS, 0>(v, nt, ok, v[0] * fast_reciprocal(piv));
+  return ok;
+}
+
+// Forward elimination only, same row layout and pivot pipeline as gauss_jordan_rows: row P is divided by its pivot and
+// eliminated from the rows below it; emit(P, z, y) sees pivot row P before (z) and after (y) the division.  The rows end
+// up unit upper triangular in the H lanes; back_substitute_rows finishes H^-1 [G g].
+// The reciprocal of pivot P + 1 is the dependent chain of a step (update of row P + 1, broadcast, v_rcp_f64, Newton, product:
+// the wave is alone on its SIMD and waits for every link), so it takes ONE Newton step here: v_rcp_f64 is good to 4.6e-8,
+// one step to 2.2e-15 relative, two are correctly rounded (tools/probes/rcp_probe.hip) - a perturbation of the pivot by ten
+// ulp, the size of the rounding errors of the elimination itself.
+template <int ROWS, int P, class Emit>
+__device__ __forceinline__ void forward_eliminate_rows_step(double (&v)[ROWS], int nt, bool& ok, double row, Emit& emit) {
+  constexpr bool has_next = P + 1 < ROWS;
+  constexpr int PN = has_next ? P + 1 : P;
+  constexpr int CH = 5;                         // links of the chain
+  double piv = 1.0, r = 0.0, e = 0.0, next_row = 0.0;
+  if constexpr (has_next) fnmac_row_bcast<P, true>(v[PN], row);
+  int s = has_next ? 0 : CH;
+  auto chain = [&]() {
+    switch (s++) {
+      case 0: piv = row_bcast<PN>(v[PN]); asm volatile("" :: "v"(piv)); break;
+      case 1: r = __builtin_amdgcn_rcp(piv); asm volatile("" :: "v"(r)); break;
+      case 2: e = __builtin_fma(-piv, r, 1.0); asm volatile("" :: "v"(e)); break;
+      case 3: r = __builtin_fma(r, e, r); asm volatile("" :: "v"(r)); break;
+      case 4: next_row = v[PN] * r; asm volatile("" :: "v"(next_row)); break;
+      default: break;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#pragma unroll
+  for (int i = P + 2; i < ROWS; ++i) { chain(); fnmac_row_bcast<P, false>(v[i], row); }
+  emit(P, v[P], row);
+#pragma unroll
+  for (int t = 0; t < CH; ++t) chain();
+  v[P] = row;
+  if constexpr (has_next) {
+    if (P + 1 < nt) {  // wave-uniform
+      ok = ok && (piv > 0.0);
+      forward_eliminate_rows_step<ROWS, P + 1>(v, nt, ok, next_row, emit);
+    }
+  }
+}
+template <int ROWS, class Emit>
+__device__ __forceinline__ bool forward_eliminate_rows(double (&v)[ROWS], int nt, Emit&& emit) {
+  if (nt <= 0) return true;
+  const double piv = row_bcast<0>(v[0]);
+  bool ok = piv > 0.0;
+  forward_eliminate_rows_step<ROWS, 0>(v, nt, ok, v[0] * fast_reciprocal(piv), emit);
+  return ok;
+}
+template <int ROWS, int P>
+__device__ __forceinline__ void back_substitute_rows_step(double (&v)[ROWS], int nt) {
+  if constexpr (P >= 1) {
+    if (P < nt) {  // wave-uniform
+      fnmac_row_bcast<P, true>(v[0], v[P]);
+#pragma unroll
+      for (int i = 1; i < P; ++i) fnmac_row_bcast<P, false>(v[i], v[P]);
+    }
+    back_substitute_rows_step<ROWS, P - 1>(v, nt);
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void back_substitute_rows(double (&v)[ROWS], int nt) {
+  back_substitute_rows_step<ROWS, ROWS - 1>(v, nt);
+}
+
 // du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms (dx is in HBM, workgroup-visible).
-template <int NJ>
+template <int NJ, int NT = kRiccatiThreads>
 __device__ __forceinline__ void riccati_step_norms(int status, const RiccatiFastIO& io) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ, NT = kRiccatiThreads;
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
   constexpr int NXX = NX * NX, NXU = NX * NU;
   (void)NXX;
   const int tid = threadIdx.x;
@@ -107,7 +238,7 @@ __device__ __forceinline__ void riccati_step_norms(int status, const RiccatiFast
     if (i == 0) acc_arm += io.mscal[k];
   }
   if (tid < NX) { const double d = io.base.dx[(size_t)N * NX + tid]; acc_x += d * d; }
-  __shared__ double red3[3][kRiccatiThreads / kWave];
+  __shared__ double red3[3][NT / kWave];
   for (int off = kWave / 2; off >= 1; off >>= 1) {
     acc_arm += __shfl_down(acc_arm, off);
     acc_x += __shfl_down(acc_x, off);
@@ -117,7 +248,7 @@ __device__ __forceinline__ void riccati_step_norms(int status, const RiccatiFast
   __syncthreads();
   if (tid == 0) {
     double a = 0.0, x2 = 0.0, u2 = 0.0;
-    for (int w = 0; w < kRiccatiThreads / kWave; ++w) { a += red3[0][w]; x2 += red3[1][w]; u2 += red3[2][w]; }
+    for (int w = 0; w < NT / kWave; ++w) { a += red3[0][w]; x2 += red3[1][w]; u2 += red3[2][w]; }
     io.base.summary[0] = a;
     io.base.summary[1] = x2;
     io.base.summary[2] = u2;

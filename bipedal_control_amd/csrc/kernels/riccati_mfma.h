@@ -22,6 +22,12 @@
 
 #include "riccati_fast.h"
 
+#ifndef BPMPC_RICCATI_GJ_DPP
+#define BPMPC_RICCATI_GJ_DPP 1   // riccati_mfma8.h: pivot columns broadcast with DPP row_newbcast (riccati_fast.h); 0: v_readlane version only
+#endif
+#ifndef BPMPC_RICCATI4_GJ_DPP
+#define BPMPC_RICCATI4_GJ_DPP 0  // the same in this kernel: measured slower here (0.427 against 0.393 ms, batch 256), the elimination is not the
+#endif                           // long pole of its phase P3 - the wave that stores, prefetches and computes two blocks of Sn is
 #ifndef BPMPC_RICCATI_ABLATE
 #define BPMPC_RICCATI_ABLATE 0   // timing experiments: 1 no Gauss-Jordan, 2 no Acl/K stores, 3 no prefetch, 4 no mvec (wrong results)
 #endif
@@ -96,9 +102,9 @@ __device__ __forceinline__ void blk_store(double* Mx, int r0, int c0, int l, v4d
 //     when a set is consumed;
 //   * the state history stays in LDS (the workspace of the backward sweep is dead by now) and goes to HBM afterwards in one
 //     coalesced pass: inside the loop wave 0 issues no store, so no load ever waits for a store (vmcnt retires in order).
-template <int NJ>
+template <int NJ, int NT = kRiccatiThreads>
 __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 4) * nx doubles*/, int cap, int status, const RiccatiFastIO& io) {
-  constexpr int NX = 12 + NJ, NT = kRiccatiThreads, NXX = NX * NX;
+  constexpr int NX = 12 + NJ, NXX = NX * NX;
   const int tid = threadIdx.x;
   const int N = io.base.N;
   if (tid < NX) hist[tid] = io.base.dx0[tid];
@@ -137,7 +143,7 @@ __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 
     if (tid < NX) hist[tid] = hist[nk * NX + tid];      // input of the next pass
     __syncthreads();
   }
-  riccati_step_norms<NJ>(status, io);
+  riccati_step_norms<NJ, NT>(status, io);
 }
 
 template <int NJ, bool DB>
@@ -331,16 +337,24 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
     if (w == 3) flush_held();        // (wave 3 runs the elimination in P3, the other waves store and prefetch there)
     lds_barrier();
     RMPROF(3);
-    // ---- P3: wave 0: Y = H^-1 [G g] by Gauss-Jordan in registers; waves 1..3: [Sn | sn] = [Q | q] + A' SW(:, 0..nx)
+    // ---- P3: Y = H^-1 [G g] by Gauss-Jordan in registers on wave 3 (and wave 2 when one wave cannot hold all right-hand sides);
+    //          the other waves: [Sn | sn] = [Q | q] + A' SW(:, 0..nx)
+    // row layout of the elimination (riccati_fast.h): 16 - nt right-hand sides per 16-lane row, 4 rows per wave
+    const int rpr = 16 - nt;
+#if BPMPC_RICCATI4_GJ_DPP
+    const int gj_waves = 4 * rpr >= NX + 1 ? 1 : (8 * rpr >= NX + 1 && nt <= 12 ? 2 : 0);   // 0: the v_readlane version on wave 3
+#else
+    const int gj_waves = 0;
+#endif
+    const int sn_waves = gj_waves == 2 ? 2 : 3;
 #if BPMPC_RICCATI_ABLATE == 1
     if (false) {
 #else
-    if (w == 3) {
+    if (w == 3 && gj_waves == 0) {
 #endif
       const int col = l < nt ? BC + l : l - nt;
       const bool used = l < nt + NX + 1;
       bool ok;
-      // the elimination is the longest dependent chain of a stage: instantiate it for the actual number of rows
 #define BP_GJ_CASE(ROWS)                                                                      \
       {                                                                                       \
         double v[ROWS];                                                                       \
@@ -348,21 +362,52 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
         ok = gauss_jordan_wave<ROWS>(v, nt);                                                  \
         _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (used && i < nt && l >= nt) M[i][col] = v[i]; \
       }
+#if BPMPC_RICCATI4_GJ_DPP
+      BP_GJ_CASE(NU)
+#else
+      // the elimination is the longest dependent chain of a stage: instantiate it for the actual number of rows
       if (nt <= 8) BP_GJ_CASE(8)
       else if (nt == 9) BP_GJ_CASE(9)          // single support of this robot class: 14 rows of rank 13
       else if (nt <= 10) BP_GJ_CASE(10)
       else if (nt <= 12) BP_GJ_CASE(12)
       else BP_GJ_CASE(NU)
+#endif
+#undef BP_GJ_CASE
+      if (l == 0 && !ok) ws.status = 1;
+    } else if (w >= 4 - gj_waves && gj_waves > 0) {
+      if (w != 3) {                    // wave 2 is a loader: its share of the global memory traffic first
+        flush_held();
+#if BPMPC_RICCATI_ABLATE != 3
+        if (k > io.k_lo) prefetch();
+#endif
+      }
+      const int c16 = l & 15;
+      const int rhs = ((3 - w) * 4 + (l >> 4)) * rpr + (c16 - nt);      // right-hand side of this lane (lanes >= nt of the row)
+      const bool is_h = c16 < nt, is_rhs = !is_h && rhs < NX + 1;
+      const int col = is_h ? BC + c16 : (is_rhs ? rhs : 0);
+      bool ok;
+#define BP_GJ_CASE(ROWS)                                                                      \
+      {                                                                                       \
+        double v[ROWS];                                                                       \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) v[i] = ((is_h || is_rhs) && i < nt) ? M[i][col] : 0.0; \
+        lds_wave_sync();             /* every lane has its column before any right-hand side is overwritten (two waves: disjoint ones) */ \
+        ok = gauss_jordan_rows<ROWS>(v, nt);                                                  \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (is_rhs && i < nt) M[i][col] = v[i]; \
+      }
+      if (nt <= 8) BP_GJ_CASE(8)
+      else if (nt == 9) BP_GJ_CASE(9)          // single support of this robot class: 14 rows of rank 13
+      else if (nt <= 10) BP_GJ_CASE(10)
+      else BP_GJ_CASE(12)
 #undef BP_GJ_CASE
       if (l == 0 && !ok) ws.status = 1;
     } else {
-      // global memory traffic of the stage, off the critical path (the elimination on wave 3 is the long pole of P3) and
+      // global memory traffic of the stage, off the critical path (the elimination is the long pole of P3) and
       // as early as possible: outputs of the previous stage, then the operands of the next one
       flush_held();
 #if BPMPC_RICCATI_ABLATE != 3
       if (k > io.k_lo) prefetch();     // never beyond the chunk: earlier stages may not be projected yet
 #endif
-      for (int id = w; id < 4; id += 3) {
+      for (int id = w; id < 4; id += sn_waves) {
         const int r0 = 16 * (id >> 1), c0 = 16 * (id & 1);
         v4d acc = blk_load<LDN, RCL, ZR>(&Qq[0][0], r0, c0, l);
         const int acol = r0 + li < NX ? r0 + li : LDW - 1;             // the last padding column of W is always zero
@@ -379,6 +424,9 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
         blk_store<LDN, RB>(&ws.Sn[0][0], r0, c0, l, acc);
       }
     }
+#ifdef BPMPC_RICCATI_PROFILE
+    { const long long tn_ = clock64(); if (w == 0) tacc[6] += tn_ - tprev; if (w == 3) tacc[7] += tn_ - tprev; }   // own work of P3, before the barrier
+#endif
     lds_barrier();
     RMPROF(4);
     // ---- P4: wave w owns block w of each result: [S | s] first (the next stage waits for it), then [Acl | bcl], [K | kff]
@@ -443,7 +491,8 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
   flush_held();
 #ifdef BPMPC_RICCATI_PROFILE
   if (io.prof && tid == 0)
-    for (int i = 0; i < 8; ++i) io.prof[i] = (double)tacc[i];
+    for (int i = 0; i < 7; ++i) io.prof[i] = (double)tacc[i];
+  if (io.prof && tid == 3 * kWave) io.prof[7] = (double)tacc[7];
 #endif
   __syncthreads();
   if (io.k_lo > 0) {                                   // hand over to the launch that sweeps the earlier stages

@@ -1,0 +1,418 @@
+// Riccati sweep on the FP64 matrix cores, eight wavefronts per problem with fixed roles (HIP only; same mathematics as
+// riccati.h / riccati_mfma.h, used when every problem of the batch gets a CU of its own).
+//
+// The sweep is one dependent chain per problem: S_k needs S_{k+1}.  riccati_mfma.h walks a stage in five barrier-separated
+// phases on four wavefronts and everything a stage produces sits on that chain.  Only a part of it has to:
+//     SW = sym(S) W,  [G | g | H] = [P | r | R] + B' SW,  Sn = [Q | q] + A' SW          (as before)
+//     forward elimination of [H | G g]:  rows Z (pivot rows as they are eliminated) and Yn = D^-1 Z (divided by their pivots)
+//     [S | s] = Sn - Z' Yn                                                                 (= Sn - G' H^-1 [G g])
+// The gain Y = H^-1 [G g] (back substitution), [Acl | bcl] = [A | b] - B Y, [K | kff] = [Px | Pe] - Pu Y and m are outputs,
+// not inputs of the next stage: they are finished one stage later, beside the chain, from the other half of the double
+// buffered stage data.  Roles of the eight waves (w = wave index; waves w and w + 4 share a SIMD and its matrix core):
+//     C  w = 0..3   one per SIMD: blocks of SW, G, the S update; C0..C2 finish Acl, K of the previous stage while E eliminates
+//     L  w = 4, 5   prefetch (global -> registers, a whole stage ahead), staging (registers -> LDS); Sn blocks beside the elimination
+//     F  w = 6      blocks of SW, Sn; finishes the fourth block of Acl, K and m
+//     E  w = 7      forward elimination (on the chain) with SIMD 3 to itself - C3 idles meanwhile: the matrix core and the
+//                   issue port of a SIMD are shared by its waves, and a busy neighbour doubled the elimination time -,
+//                   then back substitution (beside the chain); a block of SW
+// Global loads are issued by L only and global stores by C / F only: vmcnt retires in order, so a wave that does both makes
+// its next wait for a load also wait for every store issued before it (riccati_mfma.h holds results in registers for a stage
+// to get around that).  Per stage: staging | B0 | SW | B1 | G (C3: a block of Sn) | B2 | forward elimination (others: Sn,
+// outputs of stage k + 1) | B3 | S update (E: back substitution) - four barriers, the S update needs none before the next
+// staging barrier.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "riccati_mfma.h"
+
+namespace bpmpc {
+
+constexpr int kRiccati8Threads = 512;
+
+template <int NJ>
+struct RiccatiMfma8Workspace {
+  static constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  static constexpr int RB = 32;                                  // two full 16-row blocks: plain block loads / stores
+  static constexpr int RE = 16;                                  // rows of the reduced-input matrices (nut <= 16, checked)
+  static constexpr int LDN = 34;
+  static constexpr int WC = NX + 1 + NU;
+  static constexpr int LDW = ((WC + 15) / 16) * 16 + 2;
+  static_assert(NX + 1 <= 32 && NU <= 32, "two block rows / columns");
+  alignas(16) double S[RB][LDN];        // [S | s], not symmetrised
+  alignas(16) double Qq[2][RB][LDN];    // [Q~ | q~]
+  alignas(16) double Sn[RB][LDN];       // [Sn | sn]
+  alignas(16) double Zt[RE][LDN];       // pivot rows of the forward elimination of [G | g]
+  alignas(16) double Yn[RE][LDN];       // the same rows divided by their pivots
+  alignas(16) double W[2][RB][LDW];     // [A~ | b~ | B~]
+  alignas(16) double PW[2][RB][LDW];    // [Px | Pe | Pu]
+  alignas(16) double SW[RB][LDW];       // sym(S) W
+  alignas(16) double M[2][RE][LDW];     // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
+  double r[2][NU];
+  int status;
+  unsigned char nut[kMaxRiccatiStages];
+};
+
+// Forward elimination of [H | G g], one column per lane (layout of gauss_jordan_wave).  After step p row p is divided by its
+// pivot and eliminated from the rows below; emit(p, z, y) sees the pivot row before (z) and after (y) the division.
+template <int ROWS, class Emit>
+__device__ __forceinline__ bool forward_eliminate_wave(double (&v)[ROWS], int nt, Emit&& emit) {
+  bool ok = true;
+#pragma unroll
+  for (int p = 0; p < ROWS; ++p) {
+    if (p < nt) {  // wave-uniform
+      double f[ROWS];
+#pragma unroll
+      for (int i = p; i < ROWS; ++i) f[i] = readlane_f64(v[i], p);
+      ok = ok && (f[p] > 0.0);
+      const double row = v[p] * fast_reciprocal(f[p]);
+      emit(p, v[p], row);
+#pragma unroll
+      for (int i = p + 1; i < ROWS; ++i) v[i] -= f[i] * row;
+      v[p] = row;
+    }
+  }
+  return ok;
+}
+// Back substitution on the rows left by forward_eliminate_wave (unit upper triangular in the H lanes): v <- H^-1 [.. | G g].
+template <int ROWS>
+__device__ __forceinline__ void back_substitute_wave(double (&v)[ROWS], int nt) {
+#pragma unroll
+  for (int p = ROWS - 1; p >= 1; --p) {
+    if (p < nt) {
+#pragma unroll
+      for (int i = 0; i < p; ++i) {
+        const double u = readlane_f64(v[i], p);
+        v[i] -= u * v[p];
+      }
+    }
+  }
+}
+
+template <int NJ>
+__device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, const RiccatiFastIO& io) {
+  using WS = RiccatiMfma8Workspace<NJ>;
+  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccati8Threads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, RE = WS::RE;
+  constexpr int NXX = NX * NX, NXU = NX * NU;
+  constexpr int KS = (NX + 3) / 4;          // k-steps over the state dimension
+  constexpr int BC = NX + 1;                // first column of B~ / Pu / R~ in the packed layouts
+  static_assert(NX == NU, "packed layouts assume nx == nu");
+  static_assert(NX + 1 + RE <= kWave, "one lane per column of [H | G g]");
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int li = l & 15, lk = l >> 4;       // operand row/column index and k index of this lane
+  const int N = io.base.N;
+  const bool role_c = w < 4, role_l = w == 4 || w == 5, role_f = w == 6, role_e = w == 7;
+
+  const int k_top = (io.k_hi < N ? io.k_hi : N) - 1;
+  const bool resumed = io.k_hi < N;
+  {
+    double* z = &ws.S[0][0];
+    constexpr int total = (int)(offsetof(WS, status) / sizeof(double));
+    for (int idx = tid; idx < total; idx += NT) z[idx] = 0.0;     // every matrix and its padding
+  }
+  __syncthreads();
+  if (tid == 0) ws.status = resumed ? (int)io.carry[NXX + NX] : 0;
+  if (!resumed && io.reg != 0.0 && tid < NX) ws.S[tid][tid] = io.reg;
+  if (resumed) {
+    for (int idx = tid; idx < NXX; idx += NT) ws.S[idx / NX][idx % NX] = io.carry[idx];
+    if (tid < NX) ws.S[tid][NX] = io.carry[NXX + tid];
+  }
+  int too_wide = 0;
+  for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) {
+    const int n = io.base.nut[idx];
+    ws.nut[idx] = (unsigned char)n;
+    too_wide |= n > RE ? 1 : 0;
+  }
+  if (__syncthreads_or(too_wide)) {         // more reduced inputs than this variant holds: fail loudly (status 2 in bpmpc_stats)
+    if (tid == 0) {
+      if (io.k_lo > 0) io.carry[NXX + NX] = 1.0;
+      else { io.base.summary[0] = 0.0; io.base.summary[1] = 0.0; io.base.summary[2] = 0.0; io.base.summary[3] = 1.0; }
+    }
+    return;
+  }
+
+  // Prefetch registers of the loader waves: 16-byte loads, element pairs (2 t, 2 t + 1), (2 (t + 128), ..), .., t = loader thread.
+  constexpr int NLD = 2 * kWave;
+  constexpr int NP2 = NXX / 2;                         // element pairs per matrix (nx is even)
+  constexpr int NPR = (NP2 + NLD - 1) / NLD;           // pairs per loader thread (2 at nx = 22, 3 at nx = 24)
+  static_assert(NXX % 2 == 0, "pairs");
+  const int tl = tid - 4 * kWave;                      // loader thread index (role L)
+  double2 pA[NPR], pB[NPR], pQ[NPR], pP[NPR], pR[NPR], pPx[NPR], pPu[NPR];
+  double pv[4];
+  const size_t o_top = (size_t)(k_top > 0 ? k_top : 0);
+  const int tp = role_l ? tl : 0;
+  const double2 *gA = reinterpret_cast<const double2*>(io.base.At + o_top * NXX) + tp,
+                *gB = reinterpret_cast<const double2*>(io.base.Bt + o_top * NXX) + tp,
+                *gQ = reinterpret_cast<const double2*>(io.base.Qt + o_top * NXX) + tp,
+                *gP = reinterpret_cast<const double2*>(io.base.Pt + o_top * NXX) + tp,
+                *gR = reinterpret_cast<const double2*>(io.base.Rt + o_top * NXX) + tp,
+                *gPx = reinterpret_cast<const double2*>(io.base.Px + o_top * NXX) + tp,
+                *gPu = reinterpret_cast<const double2*>(io.base.Pu + o_top * NXX) + tp;
+  const int tv = (role_l && tl < NX) ? tl : 0;
+  const double *gb = io.base.bt + o_top * NX + tv, *gq = io.base.qt + o_top * NX + tv, *gr = io.base.rt + o_top * NU + tv,
+               *ge = io.base.Pe + o_top * NU + tv;
+  auto prefetch = [&]() {                              // role L only
+#pragma unroll
+    for (int e = 0; e < NPR; ++e) {
+      if (e + 1 < NPR || tl + e * NLD < NP2) {
+        const int o = e * NLD;
+        pA[e] = gA[o]; pB[e] = gB[o]; pQ[e] = gQ[o]; pP[e] = gP[o]; pR[e] = gR[o]; pPx[e] = gPx[o]; pPu[e] = gPu[o];
+      }
+    }
+    if (tl < NX) { pv[0] = *gb; pv[1] = *gq; pv[2] = *gr; pv[3] = *ge; }
+    gA -= NP2; gB -= NP2; gQ -= NP2; gP -= NP2; gR -= NP2; gPx -= NP2; gPu -= NP2;
+    gb -= NX; gq -= NX; gr -= NU; ge -= NU;
+  };
+  if (role_l && k_top >= io.k_lo) prefetch();
+  __syncthreads();
+#ifdef BPMPC_RICCATI_PROFILE
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+#define RM8PROF(slot) do { const long long tn_ = clock64(); tacc[slot] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define RM8PROF(slot) ((void)0)
+#endif
+
+  // Outputs of a stage that are not on the chain (block bw of each): [Acl | bcl] = [A | b] - B Y, [K | kff] = [Px | Pe] - Pu Y,
+  // from the buffer set `buf` that stage was staged into (m = q~ - Y' r~, m0 = -r~' H^-1 g come from E, which holds Y in registers).
+  auto finish_outputs = [&](int k, int buf, int nt, int bw) {
+    double (*const W)[LDW] = ws.W[buf];
+    double (*const PW)[LDW] = ws.PW[buf];
+    double (*const M)[LDW] = ws.M[buf];
+    const int ksn = (nt + 3) >> 2;
+    const int r0 = 16 * (bw >> 1), c0 = 16 * (bw & 1);
+    const int row = r0 + li;
+    v4d acl = blk_load<LDW, 32, 0>(&W[0][0], r0, c0, l);
+    v4d kf = blk_load<LDW, 32, 0>(&PW[0][0], r0, c0, l);
+    double ab[4], ap[4], yb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = 4 * ks + lk;
+      yb[ks] = M[kk][c0 + li];                                   // rows >= nt of Y are zero
+      ab[ks] = -W[row][BC + kk];                                 // -B(i, kk); rows >= nx of W and PW are zero
+      ap[ks] = -PW[row][BC + kk];                                // -Pu(i, kk)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < ksn) {                                            // wave-uniform
+        acl = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[ks], yb[ks], acl, 0, 0, 0);
+        kf = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[ks], yb[ks], kf, 0, 0, 0);
+      }
+    }
+    double* Acl = io.Acl + (size_t)k * NXX;
+    double* Kf = io.Kfull + (size_t)k * NXU;
+    const int col = c0 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = r0 + lk + 4 * r;
+      if (rr < NX) {
+        if (col < NX) { Acl[rr * NX + col] = acl[r]; Kf[rr * NX + col] = kf[r]; }
+        else if (col == NX) { io.bcl[(size_t)k * NX + rr] = acl[r]; io.kff[(size_t)k * NU + rr] = kf[r]; }
+      }
+    }
+  };
+
+  int pend_k = -1, pend_nt = 0;          // stage whose outputs are still to be finished (uniform)
+  for (int k = k_top; k >= io.k_lo; --k) {
+    const int nt = ws.nut[k];            // max_nodes <= kMaxRiccatiStages is checked when the solver is created
+    const int cur = k & 1;
+    double (*const W)[LDW] = ws.W[cur];
+    double (*const PW)[LDW] = ws.PW[cur];
+    double (*const Qq)[LDN] = ws.Qq[cur];
+    double (*const M)[LDW] = ws.M[cur];
+    double* const rvec = ws.r[cur];
+    const int ksn = (nt + 3) >> 2;                   // k-steps over the reduced input
+    const int nbc = (BC + nt + 15) >> 4;             // block columns of the packed width nx + 1 + nt
+    auto sn_block = [&](int sid) {     // [Sn | sn] = [Q | q] + A' SW(:, 0..nx), block sid of four
+      const int r0 = 16 * (sid >> 1), c0 = 16 * (sid & 1);
+      v4d acc = blk_load<LDN, 32, 0>(&Qq[0][0], r0, c0, l);
+      const int acol = r0 + li < NX ? r0 + li : LDW - 1;             // the last padding column of W is always zero
+      double a[KS], b[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kk = 4 * ks + lk;
+        a[ks] = W[kk][acol];                                        // A'(i, kk)
+        b[ks] = ws.SW[kk][c0 + li];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+      blk_store<LDN, 32>(&ws.Sn[0][0], r0, c0, l, acc);
+    };
+    // ---- P0 (L): registers -> packed LDS layouts.  The projection kernel writes zeros beyond nt in B~, Pu, R~, P~, r~.
+    if (role_l) {
+#pragma unroll
+      for (int e = 0; e < NPR; ++e) {
+        if (e + 1 < NPR || tl + e * NLD < NP2) {
+          const int idx = 2 * (tl + e * NLD);
+          const int i = idx / NX, j = idx % NX;              // j even: the pair stays inside row i
+          W[i][j] = pA[e].x; W[i][j + 1] = pA[e].y;
+          W[i][BC + j] = pB[e].x; W[i][BC + j + 1] = pB[e].y;
+          Qq[i][j] = pQ[e].x; Qq[i][j + 1] = pQ[e].y;
+          PW[i][j] = pPx[e].x; PW[i][j + 1] = pPx[e].y;
+          PW[i][BC + j] = pPu[e].x; PW[i][BC + j + 1] = pPu[e].y;
+          if (i < RE) {                                      // rows beyond the reduced inputs are zero and not kept
+            M[i][j] = pP[e].x; M[i][j + 1] = pP[e].y;
+            M[i][BC + j] = pR[e].x; M[i][BC + j + 1] = pR[e].y;
+          }
+        }
+      }
+      if (tl < NX) { W[tl][NX] = pv[0]; Qq[tl][NX] = pv[1]; if (tl < RE) M[tl][NX] = pv[2]; rvec[tl] = pv[2]; PW[tl][NX] = pv[3]; }
+    }
+    lds_barrier();                     // B0
+    RM8PROF(0);
+    // ---- P1: SW = sym(S) W, s added to the b column: up to six blocks on C0..C3, F, E (L: the loads of the next stage)
+    if (role_l) {
+      if (k > io.k_lo) prefetch();     // never beyond the chunk: earlier stages may not be projected yet
+    } else {
+      const int id = w < 4 ? w : w - 2;
+      if (id < 2 * nbc) {
+        const int bi = id >= nbc ? 1 : 0;
+        const int r0 = 16 * bi, c0 = 16 * (id - bi * nbc);
+        const int row = r0 + li;
+        const double half = row < NX ? 0.5 : 0.0;
+        double a[KS], b[KS], sv[4];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int kk = 4 * ks + lk;
+          a[ks] = half * (ws.S[row][kk] + ws.S[kk][row]);
+          b[ks] = W[kk][c0 + li];
+        }
+        const double smask = (c0 + li == NX) ? 1.0 : 0.0;              // s rides in the b column; rows >= nx of S are zero
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = smask * ws.S[r0 + lk + 4 * r][NX];
+        __builtin_amdgcn_sched_barrier(0);
+        v4d acc = {sv[0], sv[1], sv[2], sv[3]};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+        blk_store<LDW, 32>(&ws.SW[0][0], r0, c0, l, acc);
+      }
+    }
+    lds_barrier();                     // B1
+    RM8PROF(1);
+    // ---- P2: [G | g | H] = [P | r | R] + B' SW: nbc <= 3 blocks on C0..C2 (the elimination waits for them); C3: block 3 of Sn
+    if (role_c) {
+      if (w < nbc) {
+        const int c0 = 16 * w;
+        v4d acc = blk_load<LDW, 32, 0>(&M[0][0], 0, c0, l);
+        double a[KS], b[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int kk = 4 * ks + lk;
+          a[ks] = W[kk][BC + li];                                    // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
+          b[ks] = ws.SW[kk][c0 + li];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+        blk_store<LDW, 32>(&M[0][0], 0, c0, l, acc);
+      } else if (w == 3) {
+        sn_block(3);
+      }
+    }
+    lds_barrier();                     // B2
+    RM8PROF(2);
+    // ---- P3 (E): forward elimination of [H | G g] -> Z, Yn;  B3;  back substitution -> Y (beside the chain)
+    //      C0..C2, F: outputs of stage k + 1;  L4: blocks 0, 2 of Sn, L5: block 1;  C3: nothing (shares its SIMD with E);  B3;
+    //      C0..C3: [S | s] = Sn - Z' Yn
+    if (role_e) {
+      // lane layout: with at most 4 (16 - nt) >= nx + 1 right-hand sides the DPP row layout of riccati_fast.h (every 16-lane row
+      // holds H in its lanes 0..nt-1 and 16 - nt right-hand sides), otherwise one column per lane of the wave (v_readlane)
+      const int rpr = 16 - nt;
+      const bool rows_layout = BPMPC_RICCATI_GJ_DPP && 4 * rpr >= NX + 1;
+      const int c16 = l & 15;
+      const int rid = rows_layout ? (l >> 4) * rpr + (c16 - nt) : l - nt;          // right-hand side of this lane
+      const bool is_h = rows_layout ? c16 < nt : l < nt;
+      const bool rhs = !is_h && rid < NX + 1;
+      const bool used = is_h || rhs;
+      const int col = is_h ? BC + (rows_layout ? c16 : l) : (rhs ? rid : 0);
+      bool ok;
+      // rows nt .. of Z and Yn up to the k-step boundary must read as zero (an earlier stage may have had more reduced inputs)
+      if (rhs) {
+        for (int i = nt; i < 4 * ksn; ++i) { ws.Zt[i][col] = 0.0; ws.Yn[i][col] = 0.0; }
+      }
+      auto emit = [&](int p, double z, double y) { if (rhs) { ws.Zt[p][col] = z; ws.Yn[p][col] = y; } };
+#define BP_GJ_CASE(ROWS, FWD, BWD)                                                            \
+      {                                                                                       \
+        double v[ROWS];                                                                       \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) { const double t = M[i][col]; v[i] = (used && i < nt) ? t : 0.0; } \
+        ok = FWD<ROWS>(v, nt, emit);                                                          \
+        if (l == 0 && !ok) ws.status = 1;                                                     \
+        RM8PROF(6);                                                                           \
+        lds_barrier();                 /* B3 */                                               \
+        RM8PROF(3);                                                                           \
+        BWD<ROWS>(v, nt);                                                                     \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (rhs && i < nt) M[i][col] = v[i]; \
+        /* m = q~ - Y' r~ (lanes of the columns < nx), m0 = -r~' y (column nx): this lane holds its column of Y */ \
+        double m0 = (rhs && rid < NX) ? Qq[rid][NX] : 0.0, m1 = 0.0;                          \
+        _Pragma("unroll") for (int i = 0; i + 1 < ROWS; i += 2) { m0 -= v[i] * rvec[i]; m1 -= v[i + 1] * rvec[i + 1]; } \
+        if (ROWS % 2) m0 -= v[ROWS - 1] * rvec[ROWS - 1];                                      \
+        if (rhs) { if (rid < NX) io.mvec[(size_t)k * NX + rid] = m0 + m1; else io.mscal[k] = m0 + m1; } \
+      }
+      // the elimination is the longest dependent chain of a stage: instantiate it for the actual number of rows
+      if (rows_layout) {
+        if (nt <= 8) BP_GJ_CASE(8, forward_eliminate_rows, back_substitute_rows)
+        else if (nt == 9) BP_GJ_CASE(9, forward_eliminate_rows, back_substitute_rows)          // single support of this robot class: 14 rows of rank 13
+        else BP_GJ_CASE(10, forward_eliminate_rows, back_substitute_rows)
+      } else {
+        if (nt <= 12) BP_GJ_CASE(12, forward_eliminate_wave, back_substitute_wave)
+        else BP_GJ_CASE(RE, forward_eliminate_wave, back_substitute_wave)
+      }
+#undef BP_GJ_CASE
+    } else {
+      if (role_l) sn_block(w - 4);
+      if (w == 4) sn_block(2);         // (not C3: a block of Sn beside E on SIMD 3 slowed the elimination from 2290 to 2720 cycles)
+      if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, cur ^ 1, pend_nt, w < 3 ? w : 3);
+      RM8PROF(6);
+      lds_barrier();                   // B3
+      RM8PROF(3);
+      if (role_c) {
+        const int r0 = 16 * (w >> 1), c0 = 16 * (w & 1);
+        v4d acc = blk_load<LDN, 32, 0>(&ws.Sn[0][0], r0, c0, l);
+        const int gcol = r0 + li < NX ? r0 + li : LDN - 1;              // the last padding column of Z is always zero
+        double ag[4], yb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int kk = 4 * ks + lk;
+          ag[ks] = -ws.Zt[kk][gcol];                                    // -Z'(i, kk)
+          yb[ks] = ws.Yn[kk][c0 + li];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          if (ks < ksn) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[ks], yb[ks], acc, 0, 0, 0);
+        blk_store<LDN, 32>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, two barriers ago
+      }
+    }
+    pend_k = k; pend_nt = nt;
+    RM8PROF(4);
+    // no barrier: the next staging writes the other buffer set, and its barrier orders S, Y and the status
+  }
+#ifdef BPMPC_RICCATI_PROFILE
+#if BPMPC_RICCATI_PROFILE == 2      // own work of every wave between B2 and B3
+  if (io.prof && l == 0) io.prof[w] = (double)tacc[6];
+#else
+  if (io.prof && tid == 0)
+    for (int i = 0; i < 7; ++i) io.prof[i] = (double)tacc[i];
+  if (io.prof && tid == 7 * kWave) io.prof[7] = (double)tacc[6];
+#endif
+#endif
+  __syncthreads();
+  if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, pend_k & 1, pend_nt, w < 3 ? w : 3);
+  __syncthreads();
+  if (io.k_lo > 0) {                                   // hand over to the launch that sweeps the earlier stages
+    for (int idx = tid; idx < NXX; idx += NT) io.carry[idx] = ws.S[idx / NX][idx % NX];
+    if (tid < NX) io.carry[NXX + tid] = ws.S[tid][NX];
+    if (tid == 0) io.carry[NXX + NX] = (double)ws.status;
+    return;
+  }
+  {
+    const int st = ws.status;
+    __syncthreads();                                   // the workspace is dead from here on: it holds the state history
+    constexpr int kHistCap = (int)(offsetof(WS, status) / sizeof(double)) / NX - 8;
+    static_assert(kHistCap >= 64, "roll-out history");
+    riccati_rollout_deep<NJ, NT>(reinterpret_cast<double*>(&ws), kHistCap, st, io);
+  }
+}
+
+}  // namespace bpmpc

@@ -33,6 +33,7 @@
 #include "kernels/riccati.h"
 #include "kernels/riccati_fast.h"
 #include "kernels/riccati_mfma.h"
+#include "kernels/riccati_mfma8.h"
 #include "kernels/project_mfma.h"
 #include "reference_gen.h"
 #include "kernels/reference_device.h"
@@ -223,6 +224,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
                   L.buf.nut + s, sub, j);
 }
 
+#ifndef BPMPC_RICCATI_WAVES8
+#define BPMPC_RICCATI_WAVES8 1     // one problem per CU (batch <= CUs): the eight-wave sweep with the gains off the critical path (riccati_mfma8.h)
+#endif
 #ifndef BPMPC_STRUCTURED_LU
 #define BPMPC_STRUCTURED_LU 1      // constraint elimination through the block structure of D (project_lu_s.h); 0: FullPivLU on the whole D
 #endif
@@ -303,18 +307,15 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati(Launch L) {
   riccati_problem<NJ>(ws, io);
 }
 
-// The single-buffered variant is meant to run two workgroups per CU: cap its registers at 256 (VGPR + AGPR).
-template <int NJ, bool DB>
-__global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu(DB ? 1 : 2, DB ? 8 : 2))) void k_riccati_fast(Launch L) {
+template <int NJ>
+__device__ __forceinline__ bool riccati_fast_io(const Launch& L, RiccatiFastIO& io) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ RiccatiMfmaWorkspace<NJ, DB> ws;
   const int b = blockIdx.x;
-  if (!L.buf.active[b]) return;
+  if (!L.buf.active[b]) return false;
   const size_t s0 = (size_t)b * L.N;
   double* dx0 = L.buf.dx0 + (size_t)b * NX;
   if (threadIdx.x < NX) dx0[threadIdx.x] = L.buf.p_x0[(size_t)b * NX + threadIdx.x] - L.buf.x[(size_t)b * (L.N + 1) * NX + threadIdx.x];
   __syncthreads();
-  RiccatiFastIO io;
   io.base.N = L.buf.g_nodes[L.buf.p_grid[b]];
   io.base.nut = L.buf.nut + s0;
   io.base.At = L.buf.At + s0 * NX * NX; io.base.Bt = L.buf.Bt + s0 * NX * NU; io.base.bt = L.buf.bt + s0 * NX;
@@ -334,7 +335,25 @@ __global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu
   io.k_hi = L.k0 + L.klen;
   io.carry = L.buf.ric_carry + (size_t)b * (NX * NX + NX + 2);
   io.reg = L.reg_prim;
+  return true;
+}
+
+// The single-buffered variant is meant to run two workgroups per CU: cap its registers at 256 (VGPR + AGPR).
+template <int NJ, bool DB>
+__global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu(DB ? 1 : 2, DB ? 8 : 2))) void k_riccati_fast(Launch L) {
+  __shared__ RiccatiMfmaWorkspace<NJ, DB> ws;
+  RiccatiFastIO io;
+  if (!riccati_fast_io<NJ>(L, io)) return;
   riccati_mfma<NJ, DB>(ws, io);
+}
+
+// Eight waves per problem with fixed roles (riccati_mfma8.h): one workgroup per CU.
+template <int NJ>
+__global__ __launch_bounds__(kRiccati8Threads) void k_riccati_fast8(Launch L) {
+  __shared__ RiccatiMfma8Workspace<NJ> ws;
+  RiccatiFastIO io;
+  if (!riccati_fast_io<NJ>(L, io)) return;
+  riccati_mfma8<NJ>(ws, io);
 }
 
 // Warm start of a receding-horizon solve from the previous solution, one wavefront per (problem, node).  [OCS2-upstream, recalled]
@@ -701,6 +720,7 @@ template <int NJ> void bpmpc_solver::stage_project() {
 template <int NJ> void bpmpc_solver::stage_riccati() {
   const Launch L = launch_params();
   if (settings.reference_kernels) TIMED_LAUNCH("riccati", k_riccati<NJ>, batch, kRiccatiThreads, L);
+  else if (riccati_double_buffered() && BPMPC_RICCATI_WAVES8) TIMED_LAUNCH("riccati", k_riccati_fast8<NJ>, batch, kRiccati8Threads, L);
   else if (riccati_double_buffered()) TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, true>), batch, kRiccatiThreads, L);
   else TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, false>), batch, kRiccatiThreads, L);
 }
@@ -764,7 +784,8 @@ template <int NJ> void bpmpc_solver::pipelined_backward() {
     HIP_CHECK(hipEventRecord(ev_chunk[c], producer_stream));
     HIP_CHECK(hipStreamWaitEvent(stream, ev_chunk[c], 0));
     if (c == 0) { L.klen = settings.max_nodes - lo; }   // problems on longer grids than n_nodes_max do not exist; keep k_hi >= N
-    if (riccati_double_buffered()) TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, true>), batch, kRiccatiThreads, L);
+    if (riccati_double_buffered() && BPMPC_RICCATI_WAVES8) TIMED_LAUNCH("riccati", k_riccati_fast8<NJ>, batch, kRiccati8Threads, L);
+    else if (riccati_double_buffered()) TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, true>), batch, kRiccatiThreads, L);
     else TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, false>), batch, kRiccatiThreads, L);
   }
 }

@@ -15,6 +15,7 @@ for v in "${VARIANTS[@]}"; do
 done
 wait
 cp bipedal_control_amd/libbpmpc.so /tmp/libbpmpc_keep.so
-/usr/local/graft/bin/gpurun --timeout 900 -- 'for rep in 1 2; do for v in '"$NAMES"'; do cp tools/probes/lib_$v.bin bipedal_control_amd/libbpmpc.so; echo -n "$v "; timeout 200 python bench.py '"$*"' --steps 30 --warmup 3 --cpu-sample 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"ms_per_step\"], d[\"kernel_ms_per_step\"], (d.get(\"fused\") or {}).get(\"ms_per_step\"))"; done; done' 2>&1 | grep -v "^\[gpurun\]\|amdgpu.ids\|^----\|^$" | tail -20
+# AB_PRE: optional command run first in the same call with the library as built in the tree (e.g. the GPU tests)
+/usr/local/graft/bin/gpurun --timeout ${AB_TIMEOUT:-900} -- "${AB_PRE:-true}"'; for rep in 1 2; do for v in '"$NAMES"'; do cp tools/probes/lib_$v.bin bipedal_control_amd/libbpmpc.so; echo -n "$v "; timeout 200 python bench.py '"$*"' --steps 30 --warmup 3 --cpu-sample 0 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"ms_per_step\"], d[\"kernel_ms_per_step\"], (d.get(\"fused\") or {}).get(\"ms_per_step\"))"; done; done' 2>&1 | grep -v "^\[gpurun\]\|amdgpu.ids\|^----\|^$" | tail -${AB_TAIL:-20}
 cp /tmp/libbpmpc_keep.so bipedal_control_amd/libbpmpc.so
 for v in $NAMES; do rm -f tools/probes/lib_$v.bin; done
