@@ -10,14 +10,15 @@
 // not inputs of the next stage: they are finished one stage later, beside the chain, from the other half of the double
 // buffered stage data.  Roles of the eight waves (w = wave index; waves w and w + 4 share a SIMD and its matrix core):
 //     C  w = 0..3   one per SIMD: blocks of SW, G, the S update; C0..C2 finish Acl, K of the previous stage while E eliminates
-//     L  w = 4, 5   prefetch (global -> registers, a whole stage ahead), staging (registers -> LDS); Sn blocks beside the elimination
-//     F  w = 6      blocks of SW, Sn; finishes the fourth block of Acl, K and m
+//     L  w = 4, 5   prefetch (global -> registers, a whole stage ahead), staging (registers -> LDS); Sn blocks beside the elimination;
+//                   L5 also m of the previous stage (its store is younger than the loads it waits for next, so it delays nothing)
+//     F  w = 6      a block of SW; finishes the fourth block of Acl, K
 //     E  w = 7      forward elimination (on the chain) with SIMD 3 to itself - C3 idles meanwhile: the matrix core and the
 //                   issue port of a SIMD are shared by its waves, and a busy neighbour doubled the elimination time -,
 //                   then back substitution (beside the chain); a block of SW
-// Global loads are issued by L only and global stores by C / F only: vmcnt retires in order, so a wave that does both makes
-// its next wait for a load also wait for every store issued before it (riccati_mfma.h holds results in registers for a stage
-// to get around that).  Per stage: staging | B0 | SW | B1 | G (C3: a block of Sn) | B2 | forward elimination (others: Sn,
+// vmcnt retires in order, so a wave's wait for a load also waits for every store it issued BEFORE that load (riccati_mfma.h
+// holds results in registers for a stage to get around that).  Here C and F only store, L4 only loads, and L5 stores (in P3) long before it
+// prefetches again (in P1 of the next stage) and waits for that (a stage later still).  Per stage: staging | B0 | SW | B1 | G (C3: a block of Sn) | B2 | forward elimination (others: Sn,
 // outputs of stage k + 1) | B3 | S update (E: back substitution) - four barriers, the S update needs none before the next
 // staging barrier.
 #pragma once
@@ -131,6 +132,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   }
 
   // Prefetch registers of the loader waves: 16-byte loads, element pairs (2 t, 2 t + 1), (2 (t + 128), ..), .., t = loader thread.
+  // (F as a third loader, 192 threads: measured slower, 0.343 against 0.336 ms)
   constexpr int NLD = 2 * kWave;
   constexpr int NP2 = NXX / 2;                         // element pairs per matrix (nx is even)
   constexpr int NPR = (NP2 + NLD - 1) / NLD;           // pairs per loader thread (2 at nx = 22, 3 at nx = 24)
@@ -168,12 +170,14 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = clock64();
 #define RM8PROF(slot) do { const long long tn_ = clock64(); tacc[slot] += tn_ - tprev; tprev = tn_; } while (0)
+#define RM8OWN(phase) do { if (BPMPC_RICCATI_PROFILE == 10 + (phase)) tacc[7] += clock64() - tprev; } while (0)   /* own work of a phase, before its barrier */
 #else
 #define RM8PROF(slot) ((void)0)
+#define RM8OWN(phase) ((void)0)
 #endif
 
   // Outputs of a stage that are not on the chain (block bw of each): [Acl | bcl] = [A | b] - B Y, [K | kff] = [Px | Pe] - Pu Y,
-  // from the buffer set `buf` that stage was staged into (m = q~ - Y' r~, m0 = -r~' H^-1 g come from E, which holds Y in registers).
+  // from the buffer set `buf` that stage was staged into.
   auto finish_outputs = [&](int k, int buf, int nt, int bw) {
     double (*const W)[LDW] = ws.W[buf];
     double (*const PW)[LDW] = ws.PW[buf];
@@ -209,6 +213,20 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         if (col < NX) { Acl[rr * NX + col] = acl[r]; Kf[rr * NX + col] = kf[r]; }
         else if (col == NX) { io.bcl[(size_t)k * NX + rr] = acl[r]; io.kff[(size_t)k * NU + rr] = kf[r]; }
       }
+    }
+  };
+
+  // m = q~ - Y' r~, m0 = -r~' H^-1 g of a finished stage (one wave).  Rows >= nt of Y and of r~ are zero (the projection kernel pads
+  // with zeros): all loads first, no branch per row.
+  auto finish_m = [&](int k, int buf) {
+    if (l <= NX) {
+      double yv[RE], rv[RE];
+#pragma unroll
+      for (int i = 0; i < RE; ++i) { yv[i] = ws.M[buf][i][l]; rv[i] = ws.r[buf][i]; }
+      double m0 = l < NX ? ws.Qq[buf][l][NX] : 0.0, m1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < RE; i += 2) { m0 -= yv[i] * rv[i]; m1 -= yv[i + 1] * rv[i + 1]; }
+      if (l < NX) io.mvec[(size_t)k * NX + l] = m0 + m1; else io.mscal[k] = m0 + m1;
     }
   };
 
@@ -259,12 +277,12 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       }
       if (tl < NX) { W[tl][NX] = pv[0]; Qq[tl][NX] = pv[1]; if (tl < RE) M[tl][NX] = pv[2]; rvec[tl] = pv[2]; PW[tl][NX] = pv[3]; }
     }
+    RM8OWN(0);
     lds_barrier();                     // B0
     RM8PROF(0);
     // ---- P1: SW = sym(S) W, s added to the b column: up to six blocks on C0..C3, F, E (L: the loads of the next stage)
-    if (role_l) {
-      if (k > io.k_lo) prefetch();     // never beyond the chunk: earlier stages may not be projected yet
-    } else {
+    if (role_l && k > io.k_lo) prefetch();     // never beyond the chunk: earlier stages may not be projected yet
+    if (w != 4 && w != 5) {
       const int id = w < 4 ? w : w - 2;
       if (id < 2 * nbc) {
         const int bi = id >= nbc ? 1 : 0;
@@ -288,6 +306,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         blk_store<LDW, 32>(&ws.SW[0][0], r0, c0, l, acc);
       }
     }
+    RM8OWN(1);
     lds_barrier();                     // B1
     RM8PROF(1);
     // ---- P2: [G | g | H] = [P | r | R] + B' SW: nbc <= 3 blocks on C0..C2 (the elimination waits for them); C3: block 3 of Sn
@@ -310,6 +329,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         sn_block(3);
       }
     }
+    RM8OWN(2);
     lds_barrier();                     // B2
     RM8PROF(2);
     // ---- P3 (E): forward elimination of [H | G g] -> Z, Yn;  B3;  back substitution -> Y (beside the chain)
@@ -343,11 +363,6 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         RM8PROF(3);                                                                           \
         BWD<ROWS>(v, nt);                                                                     \
         _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (rhs && i < nt) M[i][col] = v[i]; \
-        /* m = q~ - Y' r~ (lanes of the columns < nx), m0 = -r~' y (column nx): this lane holds its column of Y */ \
-        double m0 = (rhs && rid < NX) ? Qq[rid][NX] : 0.0, m1 = 0.0;                          \
-        _Pragma("unroll") for (int i = 0; i + 1 < ROWS; i += 2) { m0 -= v[i] * rvec[i]; m1 -= v[i + 1] * rvec[i + 1]; } \
-        if (ROWS % 2) m0 -= v[ROWS - 1] * rvec[ROWS - 1];                                      \
-        if (rhs) { if (rid < NX) io.mvec[(size_t)k * NX + rid] = m0 + m1; else io.mscal[k] = m0 + m1; } \
       }
       // the elimination is the longest dependent chain of a stage: instantiate it for the actual number of rows
       if (rows_layout) {
@@ -360,8 +375,9 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       }
 #undef BP_GJ_CASE
     } else {
-      if (role_l) sn_block(w - 4);
+      if (w == 4 || w == 5) sn_block(w - 4);
       if (w == 4) sn_block(2);         // (not C3: a block of Sn beside E on SIMD 3 slowed the elimination from 2290 to 2720 cycles)
+      if (w == 5 && pend_k >= 0) finish_m(pend_k, cur ^ 1);      // (not E after its back substitution: the staging barrier waited for it)
       if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, cur ^ 1, pend_nt, w < 3 ? w : 3);
       RM8PROF(6);
       lds_barrier();                   // B3
@@ -385,12 +401,15 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       }
     }
     pend_k = k; pend_nt = nt;
+    RM8OWN(4);
     RM8PROF(4);
     // no barrier: the next staging writes the other buffer set, and its barrier orders S, Y and the status
   }
 #ifdef BPMPC_RICCATI_PROFILE
 #if BPMPC_RICCATI_PROFILE == 2      // own work of every wave between B2 and B3
   if (io.prof && l == 0) io.prof[w] = (double)tacc[6];
+#elif BPMPC_RICCATI_PROFILE >= 10   // own work of every wave in phase BPMPC_RICCATI_PROFILE - 10 (0: staging, 1: SW, 2: G, 4: S update incl. E's back substitution)
+  if (io.prof && l == 0) io.prof[w] = (double)tacc[7];
 #else
   if (io.prof && tid == 0)
     for (int i = 0; i < 7; ++i) io.prof[i] = (double)tacc[i];
@@ -399,6 +418,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #endif
   __syncthreads();
   if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, pend_k & 1, pend_nt, w < 3 ? w : 3);
+  if (w == 5 && pend_k >= 0) finish_m(pend_k, pend_k & 1);
   __syncthreads();
   if (io.k_lo > 0) {                                   // hand over to the launch that sweeps the earlier stages
     for (int idx = tid; idx < NXX; idx += NT) io.carry[idx] = ws.S[idx / NX][idx % NX];
