@@ -212,16 +212,119 @@ __device__ __forceinline__ void back_substitute_rows(double (&v)[ROWS], int nt) 
   back_substitute_rows_step<ROWS, ROWS - 1>(v, nt);
 }
 
+__device__ __forceinline__ double quad_swap_pairs(double v) {       // value of the lane l ^ 1
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xf, 0xf, true);    // quad_perm:[1,0,3,2]
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
 // du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms (dx is in HBM, workgroup-visible).
+// One row of K per thread straight from global memory made every load instruction of a wave touch 64 rows x 176 B = all 88
+// cache lines of its 11 KB, eleven times over, with eight waves thrashing the 16 KB L1: 23 us of a 340 us kernel.  Now a wave
+// copies 32 consecutive rows (one contiguous 5.6 KB piece of K, each byte requested once, the next piece already in flight) into
+// its own LDS tile and works from there with two lanes per row; the partial sums meet through a DPP quad permutation.
+#ifndef BPMPC_STEP_NORMS_STAGED
+#define BPMPC_STEP_NORMS_STAGED 1
+#endif
+constexpr int kStepNormsScratch = 32 * 26;     // doubles of LDS per wave (StepNormsTile)
+template <int NJ>
+struct StepNormsTile {
+  static constexpr int NX = 12 + NJ, NCH = NX / 2, CP = (NCH + 1) / 2;      // 16-byte chunks per row, chunks per lane
+  static constexpr int ROWS = 32, LDR = 26;                                   // rows per wave and pass; row stride (13 chunks: odd, conflict free)
+  static constexpr int CPI = ROWS * NCH, LPL = (CPI + kWave - 1) / kWave;     // chunks per pass, loads per lane
+  static_assert(NX % 2 == 0 && 2 * CP <= LDR / 2 + 1 && NX <= LDR - 2 && ROWS * LDR == kStepNormsScratch, "tile");
+};
 template <int NJ, int NT = kRiccatiThreads>
-__device__ __forceinline__ void riccati_step_norms(int status, const RiccatiFastIO& io) {
+__device__ __forceinline__ void riccati_step_norms(int status, const RiccatiFastIO& io, const double* hist /* LDS: dx_0 .. dx_N, row stride nx, or null */,
+                                                   double* scratch /* LDS, (NT / 64) * 32 * 26 doubles */) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   constexpr int NXX = NX * NX, NXU = NX * NU;
   (void)NXX;
   const int tid = threadIdx.x;
   const int N = io.base.N;
-  // ---- du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms
   double acc_arm = 0.0, acc_x = 0.0, acc_u = 0.0;
+#if BPMPC_STEP_NORMS_STAGED
+  using T = StepNormsTile<NJ>;
+  constexpr int NCH = T::NCH, CP = T::CP, ROWS = T::ROWS, LDR = T::LDR, CPI = T::CPI, LPL = T::LPL, NW = NT / kWave;
+  const int w = tid >> 6, l = tid & 63;
+  double* tile = scratch + w * ROWS * LDR;
+  for (int idx = l; idx < ROWS * LDR; idx += kWave) tile[idx] = 0.0;      // the padding columns stay zero
+  const int total_rows = N * NU;
+  const long total_chunks = (long)total_rows * NCH;
+  const int n_pass = (total_rows + ROWS - 1) / ROWS;
+  const double2* Kc = reinterpret_cast<const double2*>(io.Kfull);
+  int trow[LPL], tch[LPL];
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) { const int c = l + kWave * j; trow[j] = c / NCH; tch[j] = c % NCH; }
+  // everything a pass reads from global memory is requested one pass ahead: the piece of K and, per output, kff, m, m0, nut
+  double bx[LPL], by[LPL];     // (an array of double2 carried around the loop stays in scratch memory)
+  double nkf = 0.0, nmv = 0.0, nms = 0.0;
+  int nnut = 0;
+  const int r = l >> 1, part = l & 1;
+  auto fetch = [&](int pass) {
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      const long c = (long)pass * CPI + l + kWave * j;
+      const bool ok = l + kWave * j < CPI && c < total_chunks;
+      const double2 v = Kc[ok ? c : 0];
+      bx[j] = v.x; by[j] = v.y;
+    }
+    const int g = pass * ROWS + r;
+    const size_t gc = g < total_rows ? g : 0;
+    const int k = (int)(gc / NU);
+    nkf = io.kff[gc]; nmv = io.mvec[gc]; nms = io.mscal[k]; nnut = io.base.nut[k];     // mvec: k nx + i = g (nu == nx)
+  };
+  lds_wave_sync();
+  if (w < n_pass) fetch(w);
+  for (int pass = w; pass < n_pass; pass += NW) {
+#pragma unroll
+    for (int j = 0; j < LPL; ++j)
+      if (l + kWave * j < CPI) { double2 v; v.x = bx[j]; v.y = by[j]; *reinterpret_cast<double2*>(tile + trow[j] * LDR + 2 * tch[j]) = v; }
+    const double kf = nkf, mv = nmv, ms = nms;
+    const int nutk = nnut;
+    lds_wave_sync();
+    if (pass + NW < n_pass) fetch(pass + NW);            // the next piece travels while this one is used
+    const int g = pass * ROWS + r;                       // output index: stage k, input i
+    const bool valid = g < total_rows;
+    const int k = valid ? g / NU : 0, i = valid ? g % NU : 0;
+    // dx from the history of the roll-out in LDS (from HBM when the horizon did not fit it); chunk 11 of a 22-wide row is the head
+    // of the next dx, it meets the zero padding of the tile
+    double2 xv[CP];
+    double d;
+    if (hist) {
+      const double2* dxk = reinterpret_cast<const double2*>(hist + (size_t)k * NX);
+#pragma unroll
+      for (int jj = 0; jj < CP; ++jj) xv[jj] = dxk[2 * jj + part];
+      d = hist[(size_t)k * NX + i];
+    } else {
+      const double2* dxk = reinterpret_cast<const double2*>(io.base.dx + (size_t)k * NX);
+#pragma unroll
+      for (int jj = 0; jj < CP; ++jj) xv[jj] = dxk[2 * jj + part];
+      d = io.base.dx[(size_t)k * NX + i];
+    }
+    const double2* row = reinterpret_cast<const double2*>(tile + r * LDR);
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < CP; ++jj) {
+      const double2 kv = row[2 * jj + part];
+      t0 += kv.x * xv[jj].x; t1 += kv.y * xv[jj].y;
+    }
+    double t = t0 + t1;
+    t += quad_swap_pairs(t);
+    if (valid && part == 0) {
+      t += kf;
+      if (nutk == 0) t = 0.0;                            // event node: no input
+      io.base.du[g] = t;
+      acc_u += t * t;
+      acc_x += d * d;                                    // NU == NX: the same index walks the state vector
+      acc_arm += mv * d;
+      if (i == 0) acc_arm += ms;
+    }
+    lds_wave_sync();                                     // the tile is rewritten by the next pass
+  }
+#else
+  (void)scratch; (void)hist;
+  // ---- du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms
   for (int idx = tid; idx < N * NU; idx += NT) {
     const int k = idx / NU, i = idx % NU;
     const double* dxk = io.base.dx + (size_t)k * NX;
@@ -237,6 +340,7 @@ __device__ __forceinline__ void riccati_step_norms(int status, const RiccatiFast
     acc_arm += io.mvec[(size_t)k * NX + i] * d;
     if (i == 0) acc_arm += io.mscal[k];
   }
+#endif
   if (tid < NX) { const double d = io.base.dx[(size_t)N * NX + tid]; acc_x += d * d; }
   __shared__ double red3[3][NT / kWave];
   for (int off = kWave / 2; off >= 1; off >>= 1) {

@@ -102,6 +102,9 @@ __device__ __forceinline__ void blk_store(double* Mx, int r0, int c0, int l, v4d
 //     when a set is consumed;
 //   * the state history stays in LDS (the workspace of the backward sweep is dead by now) and goes to HBM afterwards in one
 //     coalesced pass: inside the loop wave 0 issues no store, so no load ever waits for a store (vmcnt retires in order).
+// (Two lanes per row - half the loads, LDS reads and FMAs per lane, partial sums joined by a DPP quad permutation - was measured:
+//  0.3412 -> 0.339 ms at batch 256, 4.48 -> 4.51 ms at batch 4096; the step is bound by the LDS round trip of the state, not by its
+//  instruction count.  Not kept.)
 template <int NJ, int NT = kRiccatiThreads>
 __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 4) * nx doubles*/, int cap, int status, const RiccatiFastIO& io) {
   constexpr int NX = 12 + NJ, NXX = NX * NX;
@@ -140,10 +143,11 @@ __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 
     __syncthreads();
     for (int idx = tid; idx < nk * NX; idx += NT) io.base.dx[(size_t)(k0 + 1) * NX + idx] = hist[NX + idx];
     __syncthreads();
-    if (tid < NX) hist[tid] = hist[nk * NX + tid];      // input of the next pass
+    if (k0 + nk < N && tid < NX) hist[tid] = hist[nk * NX + tid];      // input of the next pass (a single pass leaves dx_0 .. dx_N for the step norms)
     __syncthreads();
   }
-  riccati_step_norms<NJ, NT>(status, io);
+  // the history stays for the step norms when the horizon fitted one pass; their tiles of K follow it in LDS
+  riccati_step_norms<NJ, NT>(status, io, N <= cap ? hist : nullptr, hist + (size_t)(cap + 4) * NX);
 }
 
 template <int NJ, bool DB>
@@ -504,7 +508,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
   {
     const int st = ws.status;
     __syncthreads();                                   // the workspace is dead from here on: it holds the state history
-    constexpr int kHistCap = (int)(sizeof(WS) / sizeof(double)) / NX - 8;
+    constexpr int kHistCap = ((int)(sizeof(WS) / sizeof(double)) - kStepNormsScratch * kRiccatiThreads / kWave) / NX - 8;
     static_assert(kHistCap >= 64, "roll-out history");
     riccati_rollout_deep<NJ>(reinterpret_cast<double*>(&ws), kHistCap, st, io);
   }

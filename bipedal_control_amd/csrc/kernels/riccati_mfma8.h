@@ -412,7 +412,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   if (io.prof && l == 0) io.prof[w] = (double)tacc[7];
 #else
   if (io.prof && tid == 0)
-    for (int i = 0; i < 7; ++i) io.prof[i] = (double)tacc[i];
+    for (int i = 0; i < 5; ++i) io.prof[i] = (double)tacc[i];     // [5]: roll-out + [6]: step norms, written behind the sweep
   if (io.prof && tid == 7 * kWave) io.prof[7] = (double)tacc[6];
 #endif
 #endif
@@ -429,9 +429,15 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   {
     const int st = ws.status;
     __syncthreads();                                   // the workspace is dead from here on: it holds the state history
-    constexpr int kHistCap = (int)(offsetof(WS, status) / sizeof(double)) / NX - 8;
+    constexpr int kHistCap = ((int)(offsetof(WS, status) / sizeof(double)) - kStepNormsScratch * NT / kWave) / NX - 8;
     static_assert(kHistCap >= 64, "roll-out history");
+#ifdef BPMPC_RICCATI_PROFILE
+    const long long tr0 = clock64();
+#endif
     riccati_rollout_deep<NJ, NT>(reinterpret_cast<double*>(&ws), kHistCap, st, io);
+#ifdef BPMPC_RICCATI_PROFILE
+    if (BPMPC_RICCATI_PROFILE == 1 && io.prof && tid == 0) io.prof[5] = (double)(clock64() - tr0);     // roll-out + step norms, whole horizon
+#endif
   }
 }
 
