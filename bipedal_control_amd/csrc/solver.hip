@@ -152,8 +152,11 @@ constexpr int kTrialWaves = 4; // same for the value-only trial kernel (smaller 
 // wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS.  Four at nx = 22 (75.9 KB, two
 // workgroups per CU); three at nx = 24, where a wave serves four nodes of 4.6 KB each (packed lanes, LinFastCfg): 66 KB, two workgroups per CU
 template <int NJ> constexpr int lin_waves() { return NJ <= 10 ? 4 : 3; }
+#ifndef BPMPC_LIN_WPE
+#define BPMPC_LIN_WPE __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 template <int NJ, bool MAT>
-__global__ __launch_bounds__(lin_waves<NJ>() * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
+__global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linearize_fast(Launch L) {
   using C = LinFastCfg<NJ, true>;
   constexpr int LPN = C::LPN, NPW = C::NPW, kLinWaves = lin_waves<NJ>();
   __shared__ LinFastNodeLds<NJ> lds[kLinWaves * NPW];
