@@ -582,8 +582,35 @@ struct HostStaging {   // host-side images of the tables bpmpc_solver_setup uplo
   std::vector<double> gdt, gstart, zref, zdref, tgt_t, tgt_x;
 };
 
+// Page-locked host memory for the small transfers of the MPC loop (setup_commands, fetch): a copy from / to pageable memory is
+// staged by the runtime and blocks the calling thread for ~10 us each; from / to pinned memory it is only enqueued.  Slices stay
+// valid until the next reset(), which the callers issue when everything in flight has been waited for.
+struct PinnedArena {
+  char* base = nullptr;
+  size_t cap = 0, used = 0, demand = 0;
+  // start of a new cycle: nothing of the previous one is in flight any more.  Grows to what the previous cycle asked for.
+  void reset() {
+    if (demand > cap) {
+      if (base) (void)hipHostFree(base);
+      base = nullptr; cap = 0;
+      const size_t want = std::max<size_t>(2 * demand, size_t(1) << 20);
+      if (hipHostMalloc(reinterpret_cast<void**>(&base), want) == hipSuccess) cap = want; else base = nullptr;
+    }
+    used = 0; demand = 0;
+  }
+  void* take(size_t bytes) {                              // nullptr: no room in this cycle, the caller uses the pageable path
+    const size_t at = (used + 63) & ~size_t(63);
+    demand = ((demand + 63) & ~size_t(63)) + bytes;
+    if (!base || at + bytes > cap) return nullptr;
+    used = at + bytes;
+    return base + at;
+  }
+  void release() { if (base) (void)hipHostFree(base); base = nullptr; cap = used = demand = 0; }
+};
+
 struct bpmpc_solver {
   HostStaging staging;
+  PinnedArena pin_up, pin_down;
   RobotModel rm;
   DeviceModel dm;
   DeviceModel* d_model = nullptr;
@@ -879,6 +906,15 @@ template <typename T>
 void upload(bpmpc_solver* s, T* dst, const std::vector<T>& src) {
   if (!src.empty()) HIP_CHECK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s->stream));
 }
+// the same through the pinned arena (pin_up.reset() by the caller, once nothing of the previous call is in flight)
+inline void upload_pinned(bpmpc_solver* s, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return;
+  void* stage = s->pin_up.take(bytes);
+  if (stage) std::memcpy(stage, src, bytes);
+  HIP_CHECK(hipMemcpyAsync(dst, stage ? stage : src, bytes, hipMemcpyHostToDevice, s->stream));
+}
+template <typename T>
+void upload_pinned(bpmpc_solver* s, T* dst, const std::vector<T>& src) { upload_pinned(s, dst, src.data(), src.size() * sizeof(T)); }
 
 void copy_pairs(bpmpc_solver* s, const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb, bool rearm) {
   const size_t work = (na > nb ? na : nb) / 2;
@@ -922,7 +958,9 @@ void finish_setup(bpmpc_solver* s, int batch, const double* warm_x, const double
     HIP_CHECK(hipGetLastError());
   }
   copy_pairs(s, bf.x, bf.x_init, (size_t)batch * (N + 1) * NX, bf.u, bf.u_init, (size_t)batch * N * NU, true);
-  HIP_CHECK(hipStreamSynchronize(s->stream));
+  // only the caller's warm-start arrays are still being read at this point: everything else was uploaded before the callers' own
+  // synchronisation, and whatever follows on the handle is ordered behind these kernels by the stream
+  if (!s->cold) HIP_CHECK(hipStreamSynchronize(s->stream));
 }
 
 void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
@@ -1068,11 +1106,12 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
   if (lib_d.size() > (size_t)kRefLibCapacity || lib_i.size() > (size_t)kRefLibCapacity) throw std::length_error("gait library exceeds the device capacity");
   if (from_previous) preserve_previous(s, batch, false);
   Buffers& bf = s->buf;
-  upload(s, bf.rg_t0, gt0); upload(s, bf.rg_gait, ggait); upload(s, bf.rg_start, gstart); upload(s, bf.lib_d, lib_d); upload(s, bf.lib_i, lib_i);
-  upload(s, bf.p_grid, pgrid);
-  HIP_CHECK(hipMemcpyAsync(bf.p_t0, t0, (size_t)batch * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  HIP_CHECK(hipMemcpyAsync(bf.p_cmd, cmd_vel, (size_t)batch * 4 * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  if (x0) HIP_CHECK(hipMemcpyAsync(bf.p_x0, x0, (size_t)batch * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  s->pin_up.reset();                                      // the previous call waited for its transfers (the synchronisation below)
+  upload_pinned(s, bf.rg_t0, gt0); upload_pinned(s, bf.rg_gait, ggait); upload_pinned(s, bf.rg_start, gstart); upload_pinned(s, bf.lib_d, lib_d);
+  upload_pinned(s, bf.lib_i, lib_i); upload_pinned(s, bf.p_grid, pgrid);
+  upload_pinned(s, bf.p_t0, t0, (size_t)batch * sizeof(double));
+  upload_pinned(s, bf.p_cmd, cmd_vel, (size_t)batch * 4 * sizeof(double));
+  if (x0) upload_pinned(s, bf.p_x0, x0, (size_t)batch * NX * sizeof(double));
   else HIP_CHECK(hipMemcpyAsync(bf.p_x0, bf.roll_x, (size_t)batch * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));   // closed loop on the device
   ReferenceGenArgs a{};
   a.lib.switching = bf.lib_d; a.lib.first_mode = bf.lib_i; a.lib.modes = bf.lib_i + first_mode.size(); a.lib.n_templates = n_gaits + 1;
@@ -1095,12 +1134,20 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
   HIP_CHECK(hipGetLastError());
   std::vector<int> nodes(G), status(G), rows(G), kind((size_t)G * N);
   s->node_times.assign((size_t)G * (N + 1), 0.0);
-  HIP_CHECK(hipMemcpyAsync(nodes.data(), bf.g_nodes, G * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-  HIP_CHECK(hipMemcpyAsync(status.data(), bf.rg_status, G * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-  HIP_CHECK(hipMemcpyAsync(rows.data(), bf.rg_rows, G * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-  HIP_CHECK(hipMemcpyAsync(kind.data(), bf.g_kind, kind.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-  HIP_CHECK(hipMemcpyAsync(s->node_times.data(), bf.g_time, s->node_times.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  HIP_CHECK(hipStreamSynchronize(s->stream));
+  {
+    s->pin_down.reset();
+    struct Down { void* host; const void* dev; size_t bytes; void* pin; };
+    Down down[5] = {{nodes.data(), bf.g_nodes, G * sizeof(int), nullptr}, {status.data(), bf.rg_status, G * sizeof(int), nullptr},
+                    {rows.data(), bf.rg_rows, G * sizeof(int), nullptr}, {kind.data(), bf.g_kind, kind.size() * sizeof(int), nullptr},
+                    {s->node_times.data(), bf.g_time, s->node_times.size() * sizeof(double), nullptr}};
+    for (Down& d : down) {
+      d.pin = s->pin_down.take(d.bytes);
+      HIP_CHECK(hipMemcpyAsync(d.pin ? d.pin : d.host, d.dev, d.bytes, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    for (Down& d : down)
+      if (d.pin) std::memcpy(d.host, d.pin, d.bytes);
+  }
   s->has_solution = false;
   s->batch = 0;                                           // stays unusable if a grid is rejected below
   int nmax = 0, rows_max = 12, vrows_max = 4;
@@ -1175,11 +1222,22 @@ void reset(bpmpc_solver* s) {
 
 void fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double* out_K, bpmpc_stats* stats) {
   const size_t N = s->settings.max_nodes, NX = s->nx, NU = s->nu, B = s->batch;
-  HIP_CHECK(hipStreamSynchronize(s->stream));
-  if (out_x) HIP_CHECK(hipMemcpy(out_x, s->buf.x, B * (N + 1) * NX * sizeof(double), hipMemcpyDeviceToHost));
-  if (out_u) HIP_CHECK(hipMemcpy(out_u, s->buf.u, B * N * NU * sizeof(double), hipMemcpyDeviceToHost));
-  if (out_K) {
-    HIP_CHECK(hipMemcpy(out_K, s->buf.K, B * N * NU * NX * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<double> raw(stats ? B * kStatsStride : 0);
+  {
+    // all transfers enqueued behind the solve, one wait; small results (the batch = 1 loop of the reference) land in pinned memory
+    // and are copied out by the host, large ones go straight to the caller's (pageable) arrays
+    s->pin_down.reset();
+    struct Down { void* host; const void* dev; size_t bytes; void* pin; };
+    Down down[4] = {{out_x, s->buf.x, B * (N + 1) * NX * sizeof(double), nullptr}, {out_u, s->buf.u, B * N * NU * sizeof(double), nullptr},
+                    {out_K, s->buf.K, B * N * NU * NX * sizeof(double), nullptr}, {stats ? raw.data() : nullptr, s->buf.stats, raw.size() * sizeof(double), nullptr}};
+    for (Down& d : down) {
+      if (!d.host) continue;
+      d.pin = d.bytes <= (size_t(4) << 20) ? s->pin_down.take(d.bytes) : nullptr;
+      HIP_CHECK(hipMemcpyAsync(d.pin ? d.pin : d.host, d.dev, d.bytes, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    for (Down& d : down)
+      if (d.host && d.pin) std::memcpy(d.host, d.pin, d.bytes);
   }
   if (out_t)
     for (size_t b = 0; b < B; ++b) {
@@ -1187,8 +1245,6 @@ void fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double*
       std::copy(s->node_times.begin() + (size_t)g * (N + 1), s->node_times.begin() + (size_t)g * (N + 1) + s->grid_nodes[g] + 1, out_t + b * (N + 1));
     }
   if (stats) {
-    std::vector<double> raw(B * kStatsStride);
-    HIP_CHECK(hipMemcpy(raw.data(), s->buf.stats, raw.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (size_t b = 0; b < B; ++b) {
       const double* r = &raw[b * kStatsStride];
       bpmpc_stats& st = stats[b];
@@ -1263,6 +1319,7 @@ void bpmpc_solver_destroy(bpmpc_solver* s) {
   for (void* p : s->allocations) (void)hipFree(p);
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->h_remaining) (void)hipHostFree(s->h_remaining);
+  s->pin_up.release(); s->pin_down.release();
   if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
