@@ -11,10 +11,10 @@
 // (row, k) of the 16x4 operand); the accumulator blocks are initialised from A, b, Q, q in the D layout and leave for HBM
 // in the same layout (16 consecutive doubles per row).  Only X and RX go through LDS.  The cost cross term P of the LQ
 // model is structurally zero for this problem and is not read (project_node.h handles a general P).
-// Everything beyond the reduced input dimension nut (columns of Bt, rows of Pt, rows/columns of Rt, rt) must read as zero
-// for the Riccati sweep.  The buffers start zero-filled and the blocks write exact zeros up to the block boundary; what
-// lies beyond is only rewritten when an earlier projection of the same node reached further (`extent`, one int per node),
-// so in the steady state no zero is stored twice.
+// The results leave in the packed layout of project_node.h (PackedLq): Wt = [At | bt | Bt], Qp = [Qt | qt], Mt = [Pt | rt | Rt], the
+// column layout of the products themselves.  Everything beyond the reduced input dimension nut must read as zero for the Riccati
+// sweep: inside the block columns that are computed the products are exact zeros there (X is zero padded); block columns
+// >= nbc and rows >= nut of Mt are not written at all - the sweep's staging masks them by nut.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -40,7 +40,7 @@ template <int NJ, int NBC>
 __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
                                                      double dt_over_mass, const double* Qc, const double* Rc, double reg, int nut) {
   using WS = ProjectMfmaWorkspace<NJ>;
-  constexpr int NX = WS::NX, NU = WS::NU, KR = WS::KR, KS = KR / 4, BC = NX + 1;
+  constexpr int NX = WS::NX, NU = WS::NU, KR = WS::KR, KS = KR / 4, BC = NX + 1, WP = PackedLq<NJ>::WP, QP = PackedLq<NJ>::QP;
   const int l = threadIdx.x, li = l & 15, lk = l >> 4;
   const double shift = in.qrd[0];
   // A-operands from HBM: rows 16 bi + li of R and of B, k = 4 ks + lk (out-of-range lanes read element 0 and are masked)
@@ -106,16 +106,11 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
       v4d acc = cA[bi][bj];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aB[bi][ks], b[ks], acc, 0, 0, 0);
-      const int col = 16 * bj + li;
+      // packed layout (PackedLq): the block is 16 aligned row segments of Wt; columns beyond nx + 1 + nut hold exact zeros (B x 0)
+      double* wrow = out.Wt + (16 * bi + lk) * WP + 16 * bj + li;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 16 * bi + lk + 4 * r;
-        if (rr < NX) {
-          if (col < NX) out.At[rr * NX + col] = acc[r];
-          else if (col == NX) out.bt[rr] = acc[r];
-          else if (col - BC < NU) out.Bt[rr * NU + (col - BC)] = acc[r];
-        }
-      }
+      for (int r = 0; r < 4; ++r)
+        if (16 * bi + lk + 4 * r < NX) wrow[4 * r * WP] = acc[r];
     }
   // ---- per block column bj:  RX(:, bj) = R X(:, bj) + [0 | r | 0]  ->  LDS,  then  X' RX(:, bj) + [Q | q | 0 ; 0](:, bj)
   //      -> Qt, qt (rows < nx);  Pt, rt, Rt (rows > nx)
@@ -145,6 +140,9 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
     for (int ks = 0; ks < KS; ++ks) b[ks] = ws.RX[4 * ks + lk][li];
 #pragma unroll
     for (int bi = 0; bi < NBC; ++bi) {
+      // rows of the packed result: < nx: [Qt | qt | Pt'], == nx: the Pe row (unused), > nx: [Pt | rt | Rt].  Block row 0 is all
+      // top rows, and of those only the columns up to nx are kept (Pt' is Pt again): nothing to do for block columns >= 2
+      if (bi == 0 && bj >= 2) continue;
       double a[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) a[ks] = ws.X[4 * ks + lk][16 * bi + li];         // X'(i, k)
@@ -154,16 +152,12 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int rr = 16 * bi + lk + 4 * r;             // row of the packed result: < nx: Px part, == nx: Pe, > nx: Pu part
-        const int ru = rr - BC, cu = col - BC;
-        const bool top = rr < NX, bot = rr > NX && ru < NU;
-        if (top) {
-          if (col < NX) out.Qt[rr * NX + col] = acc[r] + (rr == col ? reg : 0.0);      // reg: settings.reg_prim (HPIPM's), 0 by default
-          else if (col == NX) out.qt[rr] = acc[r];
-        } else if (bot) {
-          if (col < NX) out.Pt[ru * NX + col] = acc[r];
-          else if (col == NX) out.rt[ru] = acc[r];
-          else if (cu < NU) out.Rt[ru * NU + cu] = acc[r] + ((ru == cu && ru < nut) ? reg : 0.0);
+        const int rr = 16 * bi + lk + 4 * r;
+        const int ru = rr - BC;
+        if (rr < NX) {
+          if (bj < 2) out.Qp[rr * QP + col] = col <= NX ? acc[r] + (rr == col ? reg : 0.0) : 0.0;      // reg: settings.reg_prim (HPIPM's), 0 by default
+        } else if (rr > NX && ru < NU) {
+          out.Mt[ru * WP + col] = acc[r] + ((ru == col - BC && ru < nut) ? reg : 0.0);
         }
       }
     }
@@ -172,7 +166,7 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
 }
 
 template <int NJ>
-__device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, int* extent, double dt,
+__device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
                                                    double dt_over_mass, const double* Qc, const double* Rc, double reg = 0.0) {
   using WS = ProjectMfmaWorkspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, LDW = WS::LDW, KR = WS::KR, BC = NX + 1, WC = WS::WC;
@@ -180,13 +174,14 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   const int l = threadIdx.x;
 
   if (in.kind == 1) {  // event node: identity jump map, no input, no cost (what the lineariser writes for it in the materialised mode;
-                       // generated here so that the fused mode need not write it); Px, Pu, Pe, nut were written by the LU kernel
-    for (int idx = l; idx < NX * NX; idx += kWave) { const bool dg = idx / NX == idx % NX; out.At[idx] = dg ? 1.0 : 0.0; out.Qt[idx] = dg ? reg : 0.0; }
-    for (int idx = l; idx < NX * NU; idx += kWave) { out.Bt[idx] = 0.0; out.Pt[idx] = 0.0; }
-    for (int idx = l; idx < NU * NU; idx += kWave) out.Rt[idx] = 0.0;
-    if (l < NX) { out.bt[l] = in.b[l]; out.qt[l] = 0.0; }
-    if (l < NU) out.rt[l] = 0.0;
-    if (l == 0) extent[0] = 0;
+                       // generated here so that the fused mode need not write it); Px, Pu, Pe, nut = 0 were written by the LU kernel.
+                       // Packed layout: the first two block columns of Wt = [I | b | 0] and Qp = [reg I | 0]; the reader masks the rest
+    constexpr int WP = PackedLq<NJ>::WP, QP = PackedLq<NJ>::QP;
+    for (int idx = l; idx < NX * 32; idx += kWave) {
+      const int i = idx >> 5, j = idx & 31;
+      out.Wt[i * WP + j] = j < NX ? (i == j ? 1.0 : 0.0) : (j == NX ? in.b[i] : 0.0);
+      out.Qp[i * QP + j] = (i == j) ? reg : 0.0;
+    }
     return;
   }
   const int nut = out.nut[0];
@@ -217,20 +212,6 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   else if (nbc == 3) project_apply_blocks<NJ, 3>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
   else project_apply_blocks<NJ, (WC + 15) / 16>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
 
-  // ---- keep "beyond nut reads as zero": clear what an earlier, wider projection of this node left behind
-  const int cov = 16 * (nbc <= 2 ? 2 : nbc) - BC;      // reduced-input indices written by the blocks of this call
-  const int prev = extent[0];
-  if (prev > cov) {                                    // wave-uniform, rare (the mode of the node changed)
-    const int hi = prev < NU ? prev : NU, nz = hi - cov;
-    for (int idx = l; idx < NX * nz; idx += kWave) out.Bt[(idx / nz) * NU + cov + idx % nz] = 0.0;
-    for (int idx = l; idx < nz * NX; idx += kWave) out.Pt[(cov + idx / NX) * NX + idx % NX] = 0.0;
-    for (int idx = l; idx < hi * hi; idx += kWave) {
-      const int i = idx / hi, j = idx % hi;
-      if (i >= cov || j >= cov) out.Rt[i * NU + j] = 0.0;
-    }
-    if (l < nz) out.rt[cov + l] = 0.0;
-  }
-  if (l == 0) extent[0] = cov < NU ? cov : NU;
 }
 
 }  // namespace bpmpc

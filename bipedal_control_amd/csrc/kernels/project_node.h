@@ -26,6 +26,21 @@ struct ProjectOut {
   int* nut;
   double *At, *Bt, *bt;           // NX*NX, NX*NU (first nut columns, stride NU), NX
   double *Qt, *Rt, *Pt, *qt, *rt; // NX*NX, NU*NU (stride NU), NU*NX, NX, NU
+  double *Wt = nullptr, *Qp = nullptr, *Mt = nullptr;   // the same model in the packed layout of the fast kernels (PackedLq)
+};
+
+// The projected LQ model as the fast kernels exchange it (project_mfma.h writes, riccati_mfma*.h stage it into LDS unchanged):
+//     Wt [nx][WP] = [At | bt | Bt]      Qp [nx][QP] = [Qt | qt]      Mt [nu][WP] = [Pt | rt | Rt]
+// row-major with row strides of whole 16-column blocks, i.e. the column layout of the packed products.  A 16x16 accumulator
+// block of the matrix cores then leaves as 16 full, aligned 128-byte row segments under a row predicate only, where the
+// separate 22-wide matrices needed a three-way column predicate per store and 64-bit address arithmetic for each piece.
+// Contract: columns >= 16 nbc (nbc = block columns of nx + 1 + nut) and rows >= nut of Mt are NOT written; the reader masks them.
+template <int NJ>
+struct PackedLq {
+  static constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  static constexpr int WP = ((NX + 1 + NU + 15) / 16) * 16, QP = 32;
+  static constexpr int W_SIZE = NX * WP, Q_SIZE = NX * QP, M_SIZE = NU * WP;
+  static_assert(NX + 1 <= QP, "column nx inside the second block column");
 };
 
 template <int NJ>

@@ -10,11 +10,13 @@
 
 #include "../device_model.h"
 #include "riccati.h"
+#include "project_node.h"
 
 namespace bpmpc {
 
 struct RiccatiFastIO {
-  RiccatiIO base;            // same views as the reference kernel (Kt/kt unused)
+  RiccatiIO base;            // same views as the reference kernel (Kt/kt unused; At .. rt unused: the projected model comes packed)
+  const double *Wt, *Qp, *Mt; // per node PackedLq<NJ>::W_SIZE, Q_SIZE, M_SIZE: [At | bt | Bt], [Qt | qt], [Pt | rt | Rt] (project_node.h)
   double *Acl, *bcl;         // per node NX*NX, NX
   double *kff;               // per node NU
   double *mvec, *mscal;      // per node NX, 1

@@ -94,6 +94,95 @@ __device__ __forceinline__ void blk_store(double* Mx, int r0, int c0, int l, v4d
   }
 }
 
+// Prefetch registers and staging of the loader threads of the sweeps (riccati_mfma.h, riccati_mfma8.h).  The projected model
+// arrives in the packed layout of project_node.h (PackedLq: Wt = [At | bt | Bt], Qp = [Qt | qt], Mt = [Pt | rt | Rt], row strides
+// of whole block columns), which is the column layout of the LDS operands: a 16-byte pair of HBM is a 16-byte pair of LDS, one
+// ds_write_b128 each.  Loader thread t owns the pairs t, t + NLD, .. of every stream.  The writer leaves the block columns
+// >= nbc and the rows >= nut of Mt untouched; they are neither loaded nor trusted here, zeros are staged instead.
+//   NLD: loader threads; MR: rows of Mt that are kept (reduced inputs the sweep can hold); LDW / LDN: LDS leading dimensions.
+template <int NJ, int NLD, int MR, int LDW, int LDN>
+struct PackedStageLoader {
+  using PL = PackedLq<NJ>;
+  static constexpr int NX = PL::NX, NU = PL::NU, WP = PL::WP, QP = PL::QP, BC = NX + 1, NXX = NX * NX;
+  static constexpr int HW = WP / 2, HQ = QP / 2;                    // pairs per row in HBM
+  static constexpr int HQU = (NX + 2) / 2;                          // pairs per row of Qp that carry anything ([Q~ | q~]: nx + 1 columns)
+  static constexpr int NPW = NX * HW, NPQ = NX * HQU, NPM = MR * HW, NPX = NXX / 2;
+  static constexpr int SW = (NPW + NLD - 1) / NLD, SQ = (NPQ + NLD - 1) / NLD, SM = (NPM + NLD - 1) / NLD, SX = (NPX + NLD - 1) / NLD;
+  static_assert(LDW % 2 == 0 && LDN % 2 == 0 && NX % 2 == 0 && WP <= LDW && QP <= LDN && MR <= NU, "pairs stay aligned and inside the rows");
+  // (x / y halves in separate arrays of doubles: arrays of double2 that live across the stage loop end up in scratch memory)
+  double wx[SW], wy[SW], qx[SQ], qy[SQ], mx[SM], my[SM], pxx[SX], pxy[SX], pux[SX], puy[SX];
+  double pe;
+  const double2 *gW, *gQ, *gM, *gPx, *gPu;
+  const double* gPe;
+  // per slot, fixed for the whole sweep: LDS element offset of the pair, its column (and row, for Mt) for the masks; -1: no pair
+  int wo[SW], wc[SW], qo[SQ], mo[SM], mc[SM], mr[SM], xo[SX];
+  int tl;
+
+  __device__ __forceinline__ void init(const RiccatiFastIO& io, int tl_, bool loader, size_t k) {
+    tl = tl_;
+    const int tp = loader ? tl : 0;
+    gPx = reinterpret_cast<const double2*>(io.base.Px + k * NXX) + tp;
+    gPu = reinterpret_cast<const double2*>(io.base.Pu + k * NXX) + tp;
+    gPe = io.base.Pe + k * NU + ((loader && tl < NU) ? tl : 0);
+    gW = reinterpret_cast<const double2*>(io.Wt + k * PL::W_SIZE) + tp;
+    gM = reinterpret_cast<const double2*>(io.Mt + k * PL::M_SIZE) + tp;
+    // Qp: the thread's pairs are not t + e NLD of the HBM rows (the last pairs of a row carry nothing), so the pointer stands on
+    // the node and the pair offset is part of the slot
+    gQ = reinterpret_cast<const double2*>(io.Qp + k * PL::Q_SIZE);
+#pragma unroll
+    for (int e = 0; e < SW; ++e) { const int p = tp + e * NLD; const bool ok = p < NPW; wo[e] = ok ? (p / HW) * LDW + 2 * (p % HW) : -1; wc[e] = 2 * (p % HW); }
+#pragma unroll
+    for (int e = 0; e < SQ; ++e) { const int p = tp + e * NLD; const bool ok = p < NPQ; qo[e] = ok ? (p / HQU) * LDN + 2 * (p % HQU) : -1; }
+#pragma unroll
+    for (int e = 0; e < SM; ++e) { const int p = tp + e * NLD; const bool ok = p < NPM; mo[e] = ok ? (p / HW) * LDW + 2 * (p % HW) : -1; mc[e] = 2 * (p % HW); mr[e] = p / HW; }
+#pragma unroll
+    for (int e = 0; e < SX; ++e) { const int p = tp + e * NLD; const bool ok = p < NPX; xo[e] = ok ? ((2 * p) / NX) * LDW + (2 * p) % NX : -1; }
+  }
+  // loads of the stage the pointers stand on (its reduced input dimension: nt), then one stage down
+  __device__ __forceinline__ void prefetch(int nt) {
+    const int cend = 16 * ((BC + nt + 15) >> 4);                     // first column that is not written / not needed
+#pragma unroll
+    for (int e = 0; e < SW; ++e) if (((e + 1) * NLD <= NPW || wo[e] >= 0) && wc[e] < cend) { const double2 v = gW[e * NLD]; wx[e] = v.x; wy[e] = v.y; }
+#pragma unroll
+    for (int e = 0; e < SQ; ++e) if ((e + 1) * NLD <= NPQ || qo[e] >= 0) { const int p = tl + e * NLD; const double2 v = gQ[(p / HQU) * HQ + p % HQU]; qx[e] = v.x; qy[e] = v.y; }
+#pragma unroll
+    for (int e = 0; e < SM; ++e) if (((e + 1) * NLD <= NPM || mo[e] >= 0) && mr[e] < nt && mc[e] < cend) { const double2 v = gM[e * NLD]; mx[e] = v.x; my[e] = v.y; }
+#pragma unroll
+    for (int e = 0; e < SX; ++e) if ((e + 1) * NLD <= NPX || xo[e] >= 0) { const double2 a = gPx[e * NLD], b = gPu[e * NLD]; pxx[e] = a.x; pxy[e] = a.y; pux[e] = b.x; puy[e] = b.y; }
+    if (tl < NU) pe = *gPe;
+    gW -= PL::W_SIZE / 2; gQ -= PL::Q_SIZE / 2; gM -= PL::M_SIZE / 2; gPx -= NXX / 2; gPu -= NXX / 2; gPe -= NU;
+  }
+  // registers -> LDS: W = [A~ | b~ | B~], Qq = [Q~ | q~], M = [P~ | r~ | R~] (MR rows), PW = [Px | Pe | Pu], r~ also to rvec
+  __device__ __forceinline__ void stage(double (*W)[LDW], double (*PW)[LDW], double (*Qq)[LDN], double (*M)[LDW], double* rvec, int nt) const {
+    const int cend = 16 * ((BC + nt + 15) >> 4);
+    double* Wf = &W[0][0]; double* PWf = &PW[0][0]; double* Qf = &Qq[0][0]; double* Mf = &M[0][0];
+#pragma unroll
+    for (int e = 0; e < SW; ++e)
+      if ((e + 1) * NLD <= NPW || wo[e] >= 0) {     // only the last slot of a stream is partial; (a select between two double2 goes through scratch memory: component-wise)
+        const bool in = wc[e] < cend; double2 v; v.x = in ? wx[e] : 0.0; v.y = in ? wy[e] : 0.0; *reinterpret_cast<double2*>(Wf + wo[e]) = v;
+      }
+#pragma unroll
+    for (int e = 0; e < SQ; ++e)
+      if ((e + 1) * NLD <= NPQ || qo[e] >= 0) { double2 v; v.x = qx[e]; v.y = qy[e]; *reinterpret_cast<double2*>(Qf + qo[e]) = v; }
+#pragma unroll
+    for (int e = 0; e < SM; ++e)
+      if ((e + 1) * NLD <= NPM || mo[e] >= 0) {
+        const bool in = mr[e] < nt && mc[e] < cend;
+        double2 v; v.x = in ? mx[e] : 0.0; v.y = in ? my[e] : 0.0;
+        *reinterpret_cast<double2*>(Mf + mo[e]) = v;
+        if (mc[e] == NX) rvec[mr[e]] = v.x;                          // r~ (nx is even: the first element of its pair)
+      }
+#pragma unroll
+    for (int e = 0; e < SX; ++e)
+      if ((e + 1) * NLD <= NPX || xo[e] >= 0) {
+        double2 v; v.x = pxx[e]; v.y = pxy[e];
+        *reinterpret_cast<double2*>(PWf + xo[e]) = v;                // j even: the pair stays inside row i
+        PWf[xo[e] + BC] = pux[e]; PWf[xo[e] + BC + 1] = puy[e];      // odd column: two 8-byte writes
+      }
+    if (tl < NU) PW[tl][NX] = pe;
+  }
+};
+
 // Forward roll-out dx_{k+1} = Acl_k dx_k + bcl_k with the rows of three stages in flight (then du, Armijo metric and step
 // norms: riccati_step_norms).  The recurrence is one short mat-vec per stage, so whatever global-memory latency sits inside a
 // step dominates it:
@@ -191,35 +280,12 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
     return;
   }
 
-  // Prefetch registers of the loader waves (0..2): 16-byte loads, element pairs (2 t, 2 t + 1) and (2 (t + 192), ..).
+  // Prefetch registers and staging of the loader waves (0..2): PackedStageLoader, pairs t, t + 192, ..
   constexpr int NLD = 3 * kWave;                       // loader threads
-  constexpr int NP2 = NXX / 2;                         // element pairs per matrix (nx is even)
-  static_assert(NXX % 2 == 0 && NP2 <= 2 * NLD, "two pairs per loader thread");
   const bool loader = w < 3;
-  const bool second = loader && tid + NLD < NP2;
-  double2 pA[2], pB[2], pQ[2], pP[2], pR[2], pPx[2], pPu[2];
-  double pv[4];
-  const size_t o_top = (size_t)(k_top > 0 ? k_top : 0);
-  const int tp = loader ? tid : 0;
-  const double2 *gA = reinterpret_cast<const double2*>(io.base.At + o_top * NXX) + tp,
-                *gB = reinterpret_cast<const double2*>(io.base.Bt + o_top * NXX) + tp,
-                *gQ = reinterpret_cast<const double2*>(io.base.Qt + o_top * NXX) + tp,
-                *gP = reinterpret_cast<const double2*>(io.base.Pt + o_top * NXX) + tp,
-                *gR = reinterpret_cast<const double2*>(io.base.Rt + o_top * NXX) + tp,
-                *gPx = reinterpret_cast<const double2*>(io.base.Px + o_top * NXX) + tp,
-                *gPu = reinterpret_cast<const double2*>(io.base.Pu + o_top * NXX) + tp;
-  const int tv = tid < NX ? tid : 0;
-  const double *gb = io.base.bt + o_top * NX + tv, *gq = io.base.qt + o_top * NX + tv, *gr = io.base.rt + o_top * NU + tv,
-               *ge = io.base.Pe + o_top * NU + tv;
-  auto prefetch = [&]() {
-    if (!loader) return;
-    pA[0] = gA[0]; pB[0] = gB[0]; pQ[0] = gQ[0]; pP[0] = gP[0]; pR[0] = gR[0]; pPx[0] = gPx[0]; pPu[0] = gPu[0];
-    if (second) { pA[1] = gA[NLD]; pB[1] = gB[NLD]; pQ[1] = gQ[NLD]; pP[1] = gP[NLD]; pR[1] = gR[NLD]; pPx[1] = gPx[NLD]; pPu[1] = gPu[NLD]; }
-    if (tid < NX) { pv[0] = *gb; pv[1] = *gq; pv[2] = *gr; pv[3] = *ge; }
-    gA -= NP2; gB -= NP2; gQ -= NP2; gP -= NP2; gR -= NP2; gPx -= NP2; gPu -= NP2;
-    gb -= NX; gq -= NX; gr -= NU; ge -= NU;
-  };
-  if (k_top >= io.k_lo) prefetch();
+  PackedStageLoader<NJ, NLD, (RBM < NU ? RBM : NU), LDW, LDN> ld;
+  ld.init(io, tid, loader, (size_t)(k_top > 0 ? k_top : 0));
+  if (loader && k_top >= io.k_lo) ld.prefetch(io.base.nut[k_top > 0 ? k_top : 0]);     // the stage the loader's pointers stand on (the LDS copy of nut may not be visible yet)
   __syncthreads();
 #ifdef BPMPC_RICCATI_PROFILE
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -267,26 +333,8 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
     const int ksn = (nt + 3) >> 2;                   // k-steps over the reduced input
     const int nbc = (BC + nt + 15) >> 4;             // block columns of the packed width nx + 1 + nt
     const int ntb = (nt + 15) >> 4;                  // block rows of the reduced input
-    // ---- P0: registers -> packed LDS layouts.  The projection kernel writes zeros beyond nt in B~, Pu, R~, P~, r~.
-    if (loader) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        if (e == 0 || second) {
-          const int idx = 2 * (tid + e * NLD);
-          const int i = idx / NX, j = idx % NX;              // j even: the pair stays inside row i
-          W[i][j] = pA[e].x; W[i][j + 1] = pA[e].y;
-          W[i][BC + j] = pB[e].x; W[i][BC + j + 1] = pB[e].y;
-          Qq[i][j] = pQ[e].x; Qq[i][j + 1] = pQ[e].y;
-          PW[i][j] = pPx[e].x; PW[i][j + 1] = pPx[e].y;
-          PW[i][BC + j] = pPu[e].x; PW[i][BC + j + 1] = pPu[e].y;
-          if (RBM >= NU || i < RBM) {                        // rows beyond the reduced inputs are zero and not kept
-            M[i][j] = pP[e].x; M[i][j + 1] = pP[e].y;
-            M[i][BC + j] = pR[e].x; M[i][BC + j + 1] = pR[e].y;
-          }
-        }
-      }
-      if (tid < NX) { W[tid][NX] = pv[0]; Qq[tid][NX] = pv[1]; if (RBM >= NU || tid < RBM) M[tid][NX] = pv[2]; rvec[tid] = pv[2]; PW[tid][NX] = pv[3]; }
-    }
+    // ---- P0: registers -> packed LDS layouts; what the projection kernel does not write (block columns >= nbc, rows >= nt) is staged as zero
+    if (loader) ld.stage(W, PW, Qq, M, rvec, nt);
     lds_barrier();
     RMPROF(0);
     RMPROF(1);
@@ -382,7 +430,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
       if (w != 3) {                    // wave 2 is a loader: its share of the global memory traffic first
         flush_held();
 #if BPMPC_RICCATI_ABLATE != 3
-        if (k > io.k_lo) prefetch();
+        if (loader && k > io.k_lo) ld.prefetch(ws.nut[k - 1]);
 #endif
       }
       const int c16 = l & 15;
@@ -409,7 +457,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
       // as early as possible: outputs of the previous stage, then the operands of the next one
       flush_held();
 #if BPMPC_RICCATI_ABLATE != 3
-      if (k > io.k_lo) prefetch();     // never beyond the chunk: earlier stages may not be projected yet
+      if (loader && k > io.k_lo) ld.prefetch(ws.nut[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
 #endif
       for (int id = w; id < 4; id += sn_waves) {
         const int r0 = 16 * (id >> 1), c0 = 16 * (id & 1);

@@ -131,40 +131,12 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     return;
   }
 
-  // Prefetch registers of the loader waves: 16-byte loads, element pairs (2 t, 2 t + 1), (2 (t + 128), ..), .., t = loader thread.
+  // Prefetch registers and staging of the loader waves (PackedStageLoader, riccati_mfma.h): 128 threads, pairs t, t + 128, ..
   // (F as a third loader, 192 threads: measured slower, 0.343 against 0.336 ms)
   constexpr int NLD = 2 * kWave;
-  constexpr int NP2 = NXX / 2;                         // element pairs per matrix (nx is even)
-  constexpr int NPR = (NP2 + NLD - 1) / NLD;           // pairs per loader thread (2 at nx = 22, 3 at nx = 24)
-  static_assert(NXX % 2 == 0, "pairs");
-  const int tl = tid - 4 * kWave;                      // loader thread index (role L)
-  double2 pA[NPR], pB[NPR], pQ[NPR], pP[NPR], pR[NPR], pPx[NPR], pPu[NPR];
-  double pv[4];
-  const size_t o_top = (size_t)(k_top > 0 ? k_top : 0);
-  const int tp = role_l ? tl : 0;
-  const double2 *gA = reinterpret_cast<const double2*>(io.base.At + o_top * NXX) + tp,
-                *gB = reinterpret_cast<const double2*>(io.base.Bt + o_top * NXX) + tp,
-                *gQ = reinterpret_cast<const double2*>(io.base.Qt + o_top * NXX) + tp,
-                *gP = reinterpret_cast<const double2*>(io.base.Pt + o_top * NXX) + tp,
-                *gR = reinterpret_cast<const double2*>(io.base.Rt + o_top * NXX) + tp,
-                *gPx = reinterpret_cast<const double2*>(io.base.Px + o_top * NXX) + tp,
-                *gPu = reinterpret_cast<const double2*>(io.base.Pu + o_top * NXX) + tp;
-  const int tv = (role_l && tl < NX) ? tl : 0;
-  const double *gb = io.base.bt + o_top * NX + tv, *gq = io.base.qt + o_top * NX + tv, *gr = io.base.rt + o_top * NU + tv,
-               *ge = io.base.Pe + o_top * NU + tv;
-  auto prefetch = [&]() {                              // role L only
-#pragma unroll
-    for (int e = 0; e < NPR; ++e) {
-      if (e + 1 < NPR || tl + e * NLD < NP2) {
-        const int o = e * NLD;
-        pA[e] = gA[o]; pB[e] = gB[o]; pQ[e] = gQ[o]; pP[e] = gP[o]; pR[e] = gR[o]; pPx[e] = gPx[o]; pPu[e] = gPu[o];
-      }
-    }
-    if (tl < NX) { pv[0] = *gb; pv[1] = *gq; pv[2] = *gr; pv[3] = *ge; }
-    gA -= NP2; gB -= NP2; gQ -= NP2; gP -= NP2; gR -= NP2; gPx -= NP2; gPu -= NP2;
-    gb -= NX; gq -= NX; gr -= NU; ge -= NU;
-  };
-  if (role_l && k_top >= io.k_lo) prefetch();
+  PackedStageLoader<NJ, NLD, RE, LDW, LDN> ld;
+  ld.init(io, tid - 4 * kWave, role_l, (size_t)(k_top > 0 ? k_top : 0));
+  if (role_l && k_top >= io.k_lo) ld.prefetch(io.base.nut[k_top > 0 ? k_top : 0]);     // the stage the loader's pointers stand on (the LDS copy of nut may not be visible yet)
   __syncthreads();
 #ifdef BPMPC_RICCATI_PROFILE
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -257,31 +229,13 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
       blk_store<LDN, 32>(&ws.Sn[0][0], r0, c0, l, acc);
     };
-    // ---- P0 (L): registers -> packed LDS layouts.  The projection kernel writes zeros beyond nt in B~, Pu, R~, P~, r~.
-    if (role_l) {
-#pragma unroll
-      for (int e = 0; e < NPR; ++e) {
-        if (e + 1 < NPR || tl + e * NLD < NP2) {
-          const int idx = 2 * (tl + e * NLD);
-          const int i = idx / NX, j = idx % NX;              // j even: the pair stays inside row i
-          W[i][j] = pA[e].x; W[i][j + 1] = pA[e].y;
-          W[i][BC + j] = pB[e].x; W[i][BC + j + 1] = pB[e].y;
-          Qq[i][j] = pQ[e].x; Qq[i][j + 1] = pQ[e].y;
-          PW[i][j] = pPx[e].x; PW[i][j + 1] = pPx[e].y;
-          PW[i][BC + j] = pPu[e].x; PW[i][BC + j + 1] = pPu[e].y;
-          if (i < RE) {                                      // rows beyond the reduced inputs are zero and not kept
-            M[i][j] = pP[e].x; M[i][j + 1] = pP[e].y;
-            M[i][BC + j] = pR[e].x; M[i][BC + j + 1] = pR[e].y;
-          }
-        }
-      }
-      if (tl < NX) { W[tl][NX] = pv[0]; Qq[tl][NX] = pv[1]; if (tl < RE) M[tl][NX] = pv[2]; rvec[tl] = pv[2]; PW[tl][NX] = pv[3]; }
-    }
+    // ---- P0 (L): registers -> packed LDS layouts; what the projection kernel does not write (block columns >= nbc, rows >= nt) is staged as zero
+    if (role_l) ld.stage(W, PW, Qq, M, rvec, nt);
     RM8OWN(0);
     lds_barrier();                     // B0
     RM8PROF(0);
     // ---- P1: SW = sym(S) W, s added to the b column: up to six blocks on C0..C3, F, E (L: the loads of the next stage)
-    if (role_l && k > io.k_lo) prefetch();     // never beyond the chunk: earlier stages may not be projected yet
+    if (role_l && k > io.k_lo) ld.prefetch(ws.nut[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
     if (w != 4 && w != 5) {
       const int id = w < 4 ? w : w - 2;
       if (id < 2 * nbc) {

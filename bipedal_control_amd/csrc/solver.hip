@@ -65,10 +65,10 @@ struct Buffers {
   int* nc;
   // projection
   double *Px, *Pu, *Pe, *At, *Bt, *bt, *Qt, *Rt, *Pt, *qt, *rt;
+  double *Wt, *Qp, *Mt;   // the projected model in the packed layout of the fast kernels (PackedLq, project_node.h)
   int* nut;
   double* lin_park;    // per node 15 doubles per lane: scratch of the linearisation kernel
   double* qrd;         // per node kQrdStride doubles: node-dependent part of Q, R in compact form (linearize_fast.h)
-  int* proj_extent;    // per node: reduced-input extent written by the last fast projection (see project_mfma.h)
   // riccati
   double *Kt, *kt, *dx, *du, *K, *summary, *dx0;
   double *Acl, *bcl, *kff, *mvec, *mscal, *rprof;
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(kWave) void k_project_fast(Launch L) {
   out.rt = L.buf.rt + s * NU;
   in.qrd = L.buf.qrd + s * kQrdStride;
   const double dt = L.buf.g_dt[(size_t)g * L.N + k];
-  project_apply_mfma<NJ>(ws, in, out, L.buf.proj_extent + s, dt, dt * (1.0 / L.model->robot_mass), L.model->Q, L.model->R, L.reg_prim);   // as written by linearize_fast
+  out.Wt = L.buf.Wt + s * PackedLq<NJ>::W_SIZE; out.Qp = L.buf.Qp + s * PackedLq<NJ>::Q_SIZE; out.Mt = L.buf.Mt + s * PackedLq<NJ>::M_SIZE;
+  project_apply_mfma<NJ>(ws, in, out, dt, dt * (1.0 / L.model->robot_mass), L.model->Q, L.model->R, L.reg_prim);   // as written by linearize_fast
 }
 
 template <int NJ>
@@ -326,6 +327,7 @@ __device__ __forceinline__ bool riccati_fast_io(const Launch& L, RiccatiFastIO& 
   io.base.At = L.buf.At + s0 * NX * NX; io.base.Bt = L.buf.Bt + s0 * NX * NU; io.base.bt = L.buf.bt + s0 * NX;
   io.base.Qt = L.buf.Qt + s0 * NX * NX; io.base.Rt = L.buf.Rt + s0 * NU * NU; io.base.Pt = L.buf.Pt + s0 * NU * NX;
   io.base.qt = L.buf.qt + s0 * NX; io.base.rt = L.buf.rt + s0 * NU;
+  io.Wt = L.buf.Wt + s0 * PackedLq<NJ>::W_SIZE; io.Qp = L.buf.Qp + s0 * PackedLq<NJ>::Q_SIZE; io.Mt = L.buf.Mt + s0 * PackedLq<NJ>::M_SIZE;
   io.base.Px = L.buf.Px + s0 * NU * NX; io.base.Pu = L.buf.Pu + s0 * NU * NU; io.base.Pe = L.buf.Pe + s0 * NU;
   io.base.dx0 = dx0;
   io.base.Kt = nullptr; io.base.kt = nullptr;
@@ -857,7 +859,6 @@ int translate(const std::exception& e) {
 void allocate(bpmpc_solver* s) {
   const size_t B = s->settings.max_batch, N = s->settings.max_nodes, NX = s->nx, NU = s->nu, S = B * N;
   Buffers& b = s->buf;
-  b.proj_extent = s->alloc<int>("proj_extent", S, true);
   b.qrd = s->alloc<double>("qrd", S * kQrdStride);
   b.lin_park = s->alloc<double>("lin_park", S * kLinParkDoublesPerLane * (s->rm.nj == 10 ? LinFastCfg<10, true>::LPN : LinFastCfg<12, true>::LPN));
   b.x_prev = s->alloc<double>("x_prev", B * (N + 1) * NX); b.u_prev = s->alloc<double>("u_prev", S * NU);
@@ -889,6 +890,10 @@ void allocate(bpmpc_solver* s) {
   b.At = s->alloc<double>("At", S * NX * NX); b.Bt = s->alloc<double>("Bt", S * NX * NU); b.bt = s->alloc<double>("bt", S * NX);
   b.Qt = s->alloc<double>("Qt", S * NX * NX); b.Rt = s->alloc<double>("Rt", S * NU * NU); b.Pt = s->alloc<double>("Pt", S * NU * NX);
   b.qt = s->alloc<double>("qt", S * NX); b.rt = s->alloc<double>("rt", S * NU); b.nut = s->alloc<int>("nut", S, true);
+  {
+    const size_t wp = ((NX + 1 + NU + 15) / 16) * 16;      // PackedLq<NJ>::WP, QP
+    b.Wt = s->alloc<double>("Wt", S * NX * wp); b.Qp = s->alloc<double>("Qp", S * NX * 32); b.Mt = s->alloc<double>("Mt", S * NU * wp);
+  }
   b.Kt = s->alloc<double>("Kt", S * NU * NX); b.kt = s->alloc<double>("kt", S * NU);
   b.dx = s->alloc<double>("dx", B * (N + 1) * NX); b.du = s->alloc<double>("du", S * NU);
   b.K = s->alloc<double>("K", S * NU * NX);   // feedback gains (also the forward roll-out operator of the fast Riccati kernel)

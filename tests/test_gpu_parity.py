@@ -310,7 +310,7 @@ def test_fused_and_materialised_modes_are_bit_identical(ctx, robot, gait):
         t, x, u, K, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
         n = st[0].n_nodes
         mpc.stage("linearize"); mpc.stage("project"); mpc.synchronize()
-        extra = {k: mpc.read(k) for k in ("b", "q", "r", "perf", "nc", "Px", "Pu", "Pe", "nut", "At", "Bt", "bt", "Qt", "Rt", "Pt", "qt", "rt")}
+        extra = {k: mpc.read(k) for k in ("b", "q", "r", "perf", "nc", "Px", "Pu", "Pe", "nut", "Wt", "Qp", "Mt")}      # the projected model in the packed layout of the fast kernels
         A = mpc.read("A").reshape(5, 72, nx, nx)[:, :n, 3:12].copy()          # the dense rows are written in both modes
         out[mat] = (x, u, K, [(s.step_size, s.merit_after, s.dynamics_sse_after, s.equality_sse_after, s.iterations) for s in st], extra, A, mpc)
     a, b = out[True], out[False]
