@@ -12,7 +12,7 @@
 //     C  w = 0..3   one per SIMD: blocks of SW, G, the S update; C0..C2 finish Acl, K of the previous stage while E eliminates
 //     L  w = 4, 5   prefetch (global -> registers, a whole stage ahead), staging (registers -> LDS); Sn blocks beside the elimination;
 //                   L5 also m of the previous stage (its store is younger than the loads it waits for next, so it delays nothing)
-//     F  w = 6      a block of SW; finishes the fourth block of Acl, K
+//     F  w = 6      third loader; a block of SW; finishes the fourth block of Acl, K
 //     E  w = 7      forward elimination (on the chain) with SIMD 3 to itself - C3 idles meanwhile: the matrix core and the
 //                   issue port of a SIMD are shared by its waves, and a busy neighbour doubled the elimination time -,
 //                   then back substitution (beside the chain); a block of SW
@@ -101,7 +101,10 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   const int li = l & 15, lk = l >> 4;       // operand row/column index and k index of this lane
   const int N = io.base.N;
-  const bool role_c = w < 4, role_l = w == 4 || w == 5, role_f = w == 6, role_e = w == 7;
+  #ifndef BPMPC_RICCATI8_LOADERS
+#define BPMPC_RICCATI8_LOADERS 3     // loader waves 4 .. : L4, L5 and F (with the packed stage loader three are 1 % faster than two)
+#endif
+  const bool role_c = w < 4, role_l = w >= 4 && w < 4 + BPMPC_RICCATI8_LOADERS, role_f = w == 6, role_e = w == 7;
 
   const int k_top = (io.k_hi < N ? io.k_hi : N) - 1;
   const bool resumed = io.k_hi < N;
@@ -132,8 +135,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   }
 
   // Prefetch registers and staging of the loader waves (PackedStageLoader, riccati_mfma.h): 128 threads, pairs t, t + 128, ..
-  // (F as a third loader, 192 threads: measured slower, 0.343 against 0.336 ms)
-  constexpr int NLD = 2 * kWave;
+  constexpr int NLD = BPMPC_RICCATI8_LOADERS * kWave;
   PackedStageLoader<NJ, NLD, RE, LDW, LDN> ld;
   ld.init(io, tid - 4 * kWave, role_l, (size_t)(k_top > 0 ? k_top : 0));
   if (role_l && k_top >= io.k_lo) ld.prefetch(io.base.nut[k_top > 0 ? k_top : 0]);     // the stage the loader's pointers stand on (the LDS copy of nut may not be visible yet)
