@@ -233,8 +233,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 #ifndef BPMPC_STRUCTURED_LU
 #define BPMPC_STRUCTURED_LU 1      // constraint elimination through the block structure of D (project_lu_s.h); 0: FullPivLU on the whole D
 #endif
+#ifndef BPMPC_LUS_WPE
+#define BPMPC_LUS_WPE __attribute__((amdgpu_waves_per_eu(4, 4)))     // 68 registers, 9 KB of LDS per wave: four waves per SIMD, 0.107 -> 0.095 ms (five: the same)
+#endif
 template <int NJ, int RM>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_project_lu_s(Launch L) {
+__global__ __launch_bounds__(kWave) BPMPC_LUS_WPE void k_project_lu_s(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   __shared__ ProjectLuSLds<NJ> lds[kLuNodes];
   const int sub = threadIdx.x / kLuLanes, j = threadIdx.x % kLuLanes;
