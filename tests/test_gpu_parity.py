@@ -226,8 +226,8 @@ def test_pipelined_horizon_chunks_are_bit_identical(ctx):
 
 def test_solver_reuse_across_gaits_matches_fresh_solver(ctx):
     """A solver handle that has projected wider reduced inputs at a node before (double stance, nut = 10) must give the same
-    bits afterwards on a narrower problem (single support, nut = 9) as a fresh handle: the projection only clears the
-    stale part of its zero-padded outputs (project_mfma.h, `extent`)."""
+    bits afterwards on a narrower problem (single support, nut = 9) as a fresh handle: the projection does not write the block columns
+    and rows beyond nx + 1 + nut of the packed model (project_node.h, PackedLq), the sweep's staging masks them by nut."""
     bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
     trot = sc.trot_problem(itf, batch=4, n_intervals=60)
     stance = sc.trot_problem(itf, batch=4, n_intervals=60, gait="stance")
