@@ -11,6 +11,7 @@
 #include "../device_model.h"
 #include "riccati.h"
 #include "project_node.h"
+#include "linesearch.h"
 
 namespace bpmpc {
 
@@ -28,6 +29,10 @@ struct RiccatiFastIO {
   int k_lo, k_hi;
   double* carry;
   double reg;                // settings.reg_prim: the terminal value function starts at reg * I (every other stage gets it from the projection kernel)
+  // linesearch_begin of the problem (PerformanceIndex of the linearised iterate, alpha = 1, done flag) needs nothing of the sweep:
+  // a wave that idles during the serial roll-out does it, instead of a launch of its own behind this kernel
+  bool with_ls;
+  ProblemLS ls;
 };
 
 // Workgroup barrier that orders LDS traffic only: outstanding global loads (the prefetch) and stores stay in flight.
@@ -45,6 +50,31 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
+}
+// linesearch_begin (linesearch.h) on one wavefront of a larger workgroup: the same sums in the same order
+template <int NJ>
+__device__ __forceinline__ void linesearch_begin_wave(double* partial /*kWave*3 + 5 LDS*/, const ProblemLS& p, int lane) {
+  constexpr int NX = 12 + NJ;
+  {
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int k = lane; k < p.n_nodes; k += kWave) { a += p.node_perf[3 * k]; b += p.node_perf[3 * k + 1]; c += p.node_perf[3 * k + 2]; }
+    if (lane < NX) { const double d = p.x0[lane] - p.x[lane]; b += d * d; }
+    partial[lane] = a; partial[kWave + lane] = b; partial[2 * kWave + lane] = c;
+  }
+  lds_wave_sync();
+  if (lane < 3) {
+    double s = 0.0;
+    for (int i = 0; i < kWave; ++i) s += partial[lane * kWave + i];
+    partial[3 * kWave + 2 + lane] = s;
+  }
+  lds_wave_sync();
+  if (lane == 0) {
+    p.base[0] = partial[3 * kWave + 2]; p.base[1] = partial[3 * kWave + 3]; p.base[2] = partial[3 * kWave + 4];
+    p.alpha[0] = 1.0;
+    const bool run = p.active[0] != 0;
+    p.done[0] = run ? 0 : 1;
+    if (run) atomicAdd(p.remaining, 1);
+  }
 }
 struct d2 { double x, y; };
 __device__ __forceinline__ d2 lds_pair(const double* p) {  // 16-byte aligned pair

@@ -228,6 +228,9 @@ __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 
         step(rB, bB, j + 1); load(rB, bB, k0 + j + 4);
         step(rC, bC, j + 2); load(rC, bC, k0 + j + 5);
       }
+    } else if (k0 == 0 && io.with_ls && tid < 2 * kWave) {
+      // wave 1 has nothing to do here: it prepares the line search of this problem (LDS: the step norms' tile area behind the history)
+      linesearch_begin_wave<NJ>(hist + (size_t)(cap + 4) * NX, io.ls, tid - kWave);
     }
     __syncthreads();
     for (int idx = tid; idx < nk * NX; idx += NT) io.base.dx[(size_t)(k0 + 1) * NX + idx] = hist[NX + idx];

@@ -317,10 +317,39 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati(Launch L) {
 }
 
 template <int NJ>
-__device__ __forceinline__ bool riccati_fast_io(const Launch& L, RiccatiFastIO& io) {
+__device__ __forceinline__ ProblemLS problem_ls(const Launch& L, int b) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  ProblemLS p;
+  const size_t s0 = (size_t)b * L.N;
+  p.n_nodes = L.buf.g_nodes[L.buf.p_grid[b]];
+  p.node_perf = L.buf.perf + s0 * 3;
+  p.trial_perf = L.buf.trial_perf + s0 * 3;
+  p.x0 = L.buf.p_x0 + (size_t)b * NX;
+  p.x = L.buf.x + (size_t)b * (L.N + 1) * NX;
+  p.u = L.buf.u + s0 * NU;
+  p.dx = L.buf.dx + (size_t)b * (L.N + 1) * NX;
+  p.du = L.buf.du + s0 * NU;
+  p.summary = L.buf.summary + (size_t)b * 4;
+  p.base = L.buf.base + (size_t)b * 3;
+  p.alpha = L.buf.alpha + b;
+  p.done = L.buf.done + b;
+  p.active = L.buf.active + b;
+  p.iterations = L.buf.iterations + b;
+  p.stats = L.buf.stats + (size_t)b * kStatsStride;
+  p.remaining = L.buf.remaining;
+  return p;
+}
+
+template <int NJ>
+__device__ __forceinline__ bool riccati_fast_io(const Launch& L, RiccatiFastIO& io, double* lds_scratch /* 3 * 64 + 5 doubles: the kernel's workspace */) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   const int b = blockIdx.x;
-  if (!L.buf.active[b]) return false;
+  io.with_ls = L.k0 == 0;                                  // the launch that sweeps down to stage 0 (and rolls out) also opens the line search
+  if (io.with_ls) io.ls = problem_ls<NJ>(L, b);
+  if (!L.buf.active[b]) {                                  // a finished problem: only its line-search flags (done = 1)
+    if (io.with_ls && threadIdx.x < kWave) linesearch_begin_wave<NJ>(lds_scratch, io.ls, threadIdx.x);
+    return false;
+  }
   const size_t s0 = (size_t)b * L.N;
   double* dx0 = L.buf.dx0 + (size_t)b * NX;
   if (threadIdx.x < NX) dx0[threadIdx.x] = L.buf.p_x0[(size_t)b * NX + threadIdx.x] - L.buf.x[(size_t)b * (L.N + 1) * NX + threadIdx.x];
@@ -353,7 +382,7 @@ template <int NJ, bool DB>
 __global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu(DB ? 1 : 2, DB ? 8 : 2))) void k_riccati_fast(Launch L) {
   __shared__ RiccatiMfmaWorkspace<NJ, DB> ws;
   RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io)) return;
+  if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
   riccati_mfma<NJ, DB>(ws, io);
 }
 
@@ -362,7 +391,7 @@ template <int NJ>
 __global__ __launch_bounds__(kRiccati8Threads) void k_riccati_fast8(Launch L) {
   __shared__ RiccatiMfma8Workspace<NJ> ws;
   RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io)) return;
+  if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
   riccati_mfma8<NJ>(ws, io);
 }
 
@@ -439,30 +468,6 @@ __global__ __launch_bounds__(kWave) void k_warm_shift(Launch L) {
     }
     u[(size_t)i * NU + l] = a * uff0 + (1.0 - a) * uff1 + kx;
   }
-}
-
-template <int NJ>
-__device__ __forceinline__ ProblemLS problem_ls(const Launch& L, int b) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  ProblemLS p;
-  const size_t s0 = (size_t)b * L.N;
-  p.n_nodes = L.buf.g_nodes[L.buf.p_grid[b]];
-  p.node_perf = L.buf.perf + s0 * 3;
-  p.trial_perf = L.buf.trial_perf + s0 * 3;
-  p.x0 = L.buf.p_x0 + (size_t)b * NX;
-  p.x = L.buf.x + (size_t)b * (L.N + 1) * NX;
-  p.u = L.buf.u + s0 * NU;
-  p.dx = L.buf.dx + (size_t)b * (L.N + 1) * NX;
-  p.du = L.buf.du + s0 * NU;
-  p.summary = L.buf.summary + (size_t)b * 4;
-  p.base = L.buf.base + (size_t)b * 3;
-  p.alpha = L.buf.alpha + b;
-  p.done = L.buf.done + b;
-  p.active = L.buf.active + b;
-  p.iterations = L.buf.iterations + b;
-  p.stats = L.buf.stats + (size_t)b * kStatsStride;
-  p.remaining = L.buf.remaining;
-  return p;
 }
 
 template <int NJ>
@@ -766,7 +771,7 @@ template <int NJ> void bpmpc_solver::stage_linesearch() {
   if (settings.reference_kernels) HIP_CHECK(hipMemsetAsync(buf.remaining, 0, sizeof(int), stream));   // only the host loop below reads the counter
   hipEvent_t ev_a, ev_b;
   time_begin("linesearch", &ev_a, &ev_b);
-  hipLaunchKernelGGL(k_ls_begin<NJ>, dim3(batch), dim3(kWave), 0, stream, L);
+  if (settings.reference_kernels) hipLaunchKernelGGL(k_ls_begin<NJ>, dim3(batch), dim3(kWave), 0, stream, L);   // fast path: done inside the Riccati kernel
   // alpha = 1, 1/2, ... >= alpha_min  ([OCS2-upstream] SqpSolver::takeStep do-while)
   int max_trials = 0;
   for (double a = 1.0; a >= ls.alpha_min; a *= ls.alpha_decay) ++max_trials;
