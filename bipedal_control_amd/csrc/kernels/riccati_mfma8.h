@@ -165,9 +165,9 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kk = 4 * ks + lk;
-      yb[ks] = M[kk][c0 + li];                                   // rows >= nt of Y are zero
-      ab[ks] = -W[row][BC + kk];                                 // -B(i, kk); rows >= nx of W and PW are zero
-      ap[ks] = -PW[row][BC + kk];                                // -Pu(i, kk)
+      yb[ks] = M[kk][c0 + li];                                   // -Y (E stores the gain negated); rows >= nt are zero
+      ab[ks] = W[row][BC + kk];                                  // B(i, kk); rows >= nx of W and PW are zero
+      ap[ks] = PW[row][BC + kk];                                 // Pu(i, kk)
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -199,7 +199,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       for (int i = 0; i < RE; ++i) { yv[i] = ws.M[buf][i][l]; rv[i] = ws.r[buf][i]; }
       double m0 = l < NX ? ws.Qq[buf][l][NX] : 0.0, m1 = 0.0;
 #pragma unroll
-      for (int i = 0; i < RE; i += 2) { m0 -= yv[i] * rv[i]; m1 -= yv[i + 1] * rv[i + 1]; }
+      for (int i = 0; i < RE; i += 2) { m0 += yv[i] * rv[i]; m1 += yv[i + 1] * rv[i + 1]; }     // yv: -Y
       if (l < NX) io.mvec[(size_t)k * NX + l] = m0 + m1; else io.mscal[k] = m0 + m1;
     }
   };
@@ -307,7 +307,11 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       if (rhs) {
         for (int i = nt; i < 4 * ksn; ++i) { ws.Zt[i][col] = 0.0; ws.Yn[i][col] = 0.0; }
       }
-      auto emit = [&](int p, double z, double y) { if (rhs) { ws.Zt[p][col] = z; ws.Yn[p][col] = y; } };
+      // every lane stores, the ones without a right-hand side into four spare columns (nx + 2 ..: never read as Z; as Yn they only make
+      // columns > nx + 1 of S, which no product reads): a lane predicate here is an s_and_saveexec / branch pair per pivot on the critical wave
+      static_assert(NX + 2 + 3 < LDN - 1 && 4 * KS <= NX + 2, "spare columns of Z / Yn");
+      const int ecol = rhs ? col : NX + 2 + (l & 3);
+      auto emit = [&](int p, double z, double y) { ws.Zt[p][ecol] = z; ws.Yn[p][ecol] = y; };
 #define BP_GJ_CASE(ROWS, FWD, BWD)                                                            \
       {                                                                                       \
         double v[ROWS];                                                                       \
@@ -318,7 +322,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         lds_barrier();                 /* B3 */                                               \
         RM8PROF(3);                                                                           \
         BWD<ROWS>(v, nt);                                                                     \
-        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (rhs && i < nt) M[i][col] = v[i]; \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (rhs && i < nt) M[i][col] = -v[i];    /* -Y: saves the negations of the four output blocks */ \
       }
       // the elimination is the longest dependent chain of a stage: instantiate it for the actual number of rows
       if (rows_layout) {
