@@ -27,8 +27,12 @@ template <int NJ>
 struct ProjectMfmaWorkspace {
   static constexpr int NX = 12 + NJ, NU = 12 + NJ;
   static constexpr int KR = ((NX + 3) / 4) * 4;                  // rows used as the k index (nx rounded up to the k-step)
-  static constexpr int WC = NX + 1 + NU;
-  static constexpr int LDW = ((WC + 15) / 16) * 16 + 2;
+  // Three block columns of the packed operand: nx + 1 + nut <= 48, i.e. up to 25 (nx = 22: all) / 23 (nx = 24) reduced inputs.  The sweeps
+  // hold at most 16 at nx = 24 and report a numerical failure beyond that, so a wider node is cut off here rather than given a fourth block
+  // column - which cost the nx = 24 kernel its third wave per SIMD (16.1 KB of LDS and 171 registers instead of 13.1 KB and <= 168).
+  static constexpr int NBC_MAX = 3;
+  static constexpr int WC = (NX + 1 + NU < 16 * NBC_MAX) ? NX + 1 + NU : 16 * NBC_MAX;     // columns of [Px | Pe | Pu] that are kept
+  static constexpr int LDW = 16 * NBC_MAX + 2;
   alignas(16) double X[KR][LDW];        // [Px | Pe | Pu], zero padded
   alignas(16) double RX[KR][16 + 2];    // one block column of R X + [0 | r | 0] at a time (13 KB of LDS per wave in total: 12 waves per CU)
 };
@@ -201,7 +205,7 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int idx = l + it * kWave;
-      if (idx < NU * NX) { ws.X[idx / NX][idx % NX] = vx[it]; ws.X[idx / NX][BC + idx % NX] = vu[it]; }
+      if (idx < NU * NX) { ws.X[idx / NX][idx % NX] = vx[it]; if (BC + idx % NX < WC) ws.X[idx / NX][BC + idx % NX] = vu[it]; }
     }
   }
   if (l < NU) ws.X[l][NX] = out.Pe[l];
@@ -209,8 +213,7 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   for (int idx = l; idx < NU * (LDW - WC); idx += kWave) ws.X[idx / (LDW - WC)][WC + idx % (LDW - WC)] = 0.0;   // columns beyond [Px Pe Pu]
 
   if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
-  else if (nbc == 3) project_apply_blocks<NJ, 3>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
-  else project_apply_blocks<NJ, (WC + 15) / 16>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
+  else project_apply_blocks<NJ, WS::NBC_MAX>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
 
 }
 
