@@ -895,14 +895,17 @@ void allocate(bpmpc_solver* s) {
   b.C = s->alloc<double>("C", S * kMaxEqRows * NX); b.D = s->alloc<double>("D", S * kMaxEqRows * NU); b.e = s->alloc<double>("e", S * kMaxEqRows);
   b.perf = s->alloc<double>("perf", S * 3); b.nc = s->alloc<int>("nc", S, true);
   b.Px = s->alloc<double>("Px", S * NU * NX); b.Pu = s->alloc<double>("Pu", S * NU * NU); b.Pe = s->alloc<double>("Pe", S * NU);
-  b.At = s->alloc<double>("At", S * NX * NX); b.Bt = s->alloc<double>("Bt", S * NX * NU); b.bt = s->alloc<double>("bt", S * NX);
-  b.Qt = s->alloc<double>("Qt", S * NX * NX); b.Rt = s->alloc<double>("Rt", S * NU * NU); b.Pt = s->alloc<double>("Pt", S * NU * NX);
-  b.qt = s->alloc<double>("qt", S * NX); b.rt = s->alloc<double>("rt", S * NU); b.nut = s->alloc<int>("nut", S, true);
-  {
+  b.nut = s->alloc<int>("nut", S, true);
+  b.At = b.Bt = b.bt = b.Qt = b.Rt = b.Pt = b.qt = b.rt = b.Kt = b.kt = b.Wt = b.Qp = b.Mt = nullptr;
+  if (s->settings.reference_kernels) {      // the projected model as plain matrices and the gain scratch of the reference sweep (24 KB per node)
+    b.At = s->alloc<double>("At", S * NX * NX); b.Bt = s->alloc<double>("Bt", S * NX * NU); b.bt = s->alloc<double>("bt", S * NX);
+    b.Qt = s->alloc<double>("Qt", S * NX * NX); b.Rt = s->alloc<double>("Rt", S * NU * NU); b.Pt = s->alloc<double>("Pt", S * NU * NX);
+    b.qt = s->alloc<double>("qt", S * NX); b.rt = s->alloc<double>("rt", S * NU);
+    b.Kt = s->alloc<double>("Kt", S * NU * NX); b.kt = s->alloc<double>("kt", S * NU);
+  } else {                                  // ... packed, for the fast kernels (22.5 KB per node at nx = 22)
     const size_t wp = ((NX + 1 + NU + 15) / 16) * 16;      // PackedLq<NJ>::WP, QP
     b.Wt = s->alloc<double>("Wt", S * NX * wp); b.Qp = s->alloc<double>("Qp", S * NX * 32); b.Mt = s->alloc<double>("Mt", S * NU * wp);
   }
-  b.Kt = s->alloc<double>("Kt", S * NU * NX); b.kt = s->alloc<double>("kt", S * NU);
   b.dx = s->alloc<double>("dx", B * (N + 1) * NX); b.du = s->alloc<double>("du", S * NU);
   b.K = s->alloc<double>("K", S * NU * NX);   // feedback gains (also the forward roll-out operator of the fast Riccati kernel)
   b.Acl = s->alloc<double>("Acl", S * NX * NX); b.bcl = s->alloc<double>(nullptr, S * NX); b.kff = s->alloc<double>(nullptr, S * NU);
