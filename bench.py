@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not wrap kernels in HIP events")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class inside the timed region (default: the linearisation kernel only)")
-    ap.add_argument("--robot", default="h1", choices=["h1", "openloong", "g1"],
+    ap.add_argument("--robot", default="h1", choices=["h1", "openloong", "g1", "hunter"],
                     help="h1 = the headline workload (nx = nu = 22); g1 = BASELINE.json configs[3] (nx = nu = 24, self-defined configuration); "
                          "openloong = the reference's own 12-joint robot")
     ap.add_argument("--gait", default=None, help="gait template of the trot workload (default: trot; g1: standing_trot = \"walk\")")

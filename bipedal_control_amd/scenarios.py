@@ -16,7 +16,10 @@ OPENLOONG = dict(task=os.path.join(ROOT, "assets/openloong/task.info"), urdf=os.
 # tools/make_assets.py (see assets/ATTRIBUTION.md); results on it are self-defined, not reference parity
 G1 = dict(task=os.path.join(ROOT, "assets/g1/task.info"), urdf=os.path.join(ROOT, "assets/g1/g1_mpc.urdf"),
           reference=os.path.join(ROOT, "assets/g1/reference.info"), gait=os.path.join(ROOT, "assets/g1/gait.info"))
-ROBOTS = {"h1": H1, "openloong": OPENLOONG, "g1": G1}
+# Hunter: the reference's third complete configuration (10 leg joints) and the only one with model_settings.positionErrorGain != 0
+HUNTER = dict(task=os.path.join(ROOT, "assets/hunter/task.info"), urdf=os.path.join(ROOT, "assets/hunter/hunter_mpc.urdf"),
+              reference=os.path.join(ROOT, "assets/hunter/reference.info"), gait=os.path.join(ROOT, "assets/hunter/gait.info"))
+ROBOTS = {"h1": H1, "openloong": OPENLOONG, "g1": G1, "hunter": HUNTER}
 DT = 0.015
 SEED = 20241008
 # phase offset of the steady-state gait: the template starts 3.5 periods-halves before t = 0 so that t0 = 0 is mid-swing

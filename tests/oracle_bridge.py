@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ASSETS = os.path.join(ROOT, "assets", "h1")
 
 
-_URDF = {"h1": "h1_mpc.urdf", "openloong": "openloong_mpc.urdf", "g1": "g1_mpc.urdf"}
+_URDF = {"h1": "h1_mpc.urdf", "openloong": "openloong_mpc.urdf", "g1": "g1_mpc.urdf", "hunter": "hunter_mpc.urdf"}
 
 
 @functools.lru_cache(maxsize=None)
