@@ -58,7 +58,10 @@ WbcSettings load_wbc_settings(const std::string& task_info, int nj) {
   need("swingLegTask.kd", &s.swing_kd);
   const std::vector<double> kp = load_matrix(*t, "baseAccelPDTask.baseKp", 6, 1), kd = load_matrix(*t, "baseAccelPDTask.baseKd", 6, 1);
   for (int i = 0; i < 6; ++i) { s.base_kp[i] = kp[i]; s.base_kd[i] = kd[i]; }
-  need("noContactMotionTask.tolerance", &s.contact_tolerance);
+  // [OCS2-upstream] loadData::loadPtreeValue keeps the member's initial value when the key is absent (it only warns): the Hunter
+  // configuration has no noContactMotionTask section, and WbcBase.h:131 initialises noContactMotionTolerance_{} = 0
+  s.contact_tolerance = 0.0;
+  (void)t->get("noContactMotionTask.tolerance", &s.contact_tolerance);
   need("weight.swingLeg", &s.w_swing);
   need("weight.baseAccel", &s.w_base);
   need("weight.contactForce", &s.w_force);

@@ -39,7 +39,8 @@ def load_settings(task_path, nj):
                 friction=float(ingest.info_get(t, "frictionConeTask.frictionCoefficient")),
                 swing_kp=float(ingest.info_get(t, "swingLegTask.kp")), swing_kd=float(ingest.info_get(t, "swingLegTask.kd")),
                 base_kp=ingest.load_matrix(t, "baseAccelPDTask.baseKp", 6, 1)[:, 0], base_kd=ingest.load_matrix(t, "baseAccelPDTask.baseKd", 6, 1)[:, 0],
-                contact_tolerance=float(ingest.info_get(t, "noContactMotionTask.tolerance")),
+                # absent in the Hunter configuration: loadPtreeValue keeps noContactMotionTolerance_{} = 0 (WbcBase.h:131, WbcBase.cpp:446)
+                contact_tolerance=float(ingest.info_get(t, "noContactMotionTask.tolerance") or 0.0),
                 w_swing=float(ingest.info_get(t, "weight.swingLeg")), w_base=float(ingest.info_get(t, "weight.baseAccel")),
                 w_force=float(ingest.info_get(t, "weight.contactForce")))
 

@@ -110,7 +110,7 @@ def _tight(p, sol, tol=1e-7):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("robot", ["h1", "g1"])
+@pytest.mark.parametrize("robot", ["h1", "g1", "hunter"])
 def test_hip_wbc_matches_oracle(robot):
     import bipedal_control_amd as bp
     from bipedal_control_amd import scenarios as sc
@@ -144,7 +144,7 @@ def test_hip_wbc_matches_oracle(robot):
         obj = lambda xx: 0.5 * xx @ p["H"] @ xx + p["g"] @ xx                                  # noqa: E731
         assert abs(obj(sol[b]) - obj(so)) < 1e-9 * max(1.0, abs(obj(so)))
         assert _tight(p, sol[b]) == _tight(p, so)
-        if robot == "h1":
+        if robot in ("h1", "hunter"):
             # five joints per leg: the minimiser is unique.  With six (G1, OpenLoong) a swing leg keeps one direction - the rotation
             # about the line through its two sole points - that neither a task nor a constraint sees, the QP has a line of minimisers
             # (qpOASES picks one through its regularisation) and only the gauge-free statements above are comparable
