@@ -38,7 +38,8 @@ HBM_PEAK_GBS = 8000.0              # /opt/skills/guides/MI355X_MICROARCH.md: HBM
 # tools/probes/mfma_f64_probe.hip), so vector and matrix FP64 peaks coincide
 FP64_PEAK_TFLOPS = 78.6
 FP64_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9      # FP64 VALU lane-operations per second at full issue rate
-ROBOT_LABEL = {"h1": "Unitree H1", "openloong": "OpenLoong (nx = nu = 24)", "g1": "Unitree G1 (nx = nu = 24; self-defined configuration, not reference parity)"}
+ROBOT_LABEL = {"h1": "Unitree H1", "openloong": "OpenLoong (nx = nu = 24)", "g1": "Unitree G1 (nx = nu = 24; self-defined configuration, not reference parity)",
+               "hunter": "Hunter (the reference's configuration with positionErrorGain 20)"}
 KERNEL_CLASSES = ("linearize", "project_lu", "project", "riccati", "linesearch")
 
 
