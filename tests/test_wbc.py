@@ -110,7 +110,7 @@ def _tight(p, sol, tol=1e-7):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("robot", ["h1", "g1", "hunter"])
+@pytest.mark.parametrize("robot", ["h1", "g1", "hunter", "openloong"])
 def test_hip_wbc_matches_oracle(robot):
     import bipedal_control_amd as bp
     from bipedal_control_amd import scenarios as sc
