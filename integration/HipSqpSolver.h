@@ -4,9 +4,9 @@
 //   bipedal_controllers/src/BipedalController.cpp:303-308          (SqpMpc + setReferenceManager + addSynchronizedModule)
 //   ocs2_bipedal_robot_ros/src/BipedalRobotSqpMpcNode.cpp:70-72,85  (SqpMpc + MPC_ROS_Interface)
 // through HipSqpMpc.h.  Lives in the reference tree (e.g. ocs2_bipedal_robot/include/ocs2_bipedal_robot/solver/) and is compiled
-// there, against the real OCS2 / Eigen headers.  In THIS repository it is only syntax-checked against integration/mock_ocs2 (a
-// stand-in for the handful of OCS2 / Eigen declarations it touches; see tests/test_integration_headers.py) - that check pins nothing
-// about OCS2's behaviour.  The list of SolverBase virtuals is the one recalled in SURVEY.md section 8(b): verify it against the OCS2
+// there, against the real OCS2 / Eigen headers.  In THIS repository it is syntax-checked against integration/mock_ocs2 (stand-ins for
+// the handful of OCS2 / Eigen declarations it touches; tests/test_integration_headers.py) and executed against the library with them
+// (integration/mock_run.cpp, tests/test_gpu_adaptor_mock_run.py) - neither pins anything about OCS2's behaviour.  The list of SolverBase virtuals is the one recalled in SURVEY.md section 8(b): verify it against the OCS2
 // checkout in use (a missing override is a compile error there, never silent).
 //
 // What SolverBase::run does before it reaches runImpl - preRun(): ReferenceManager::preSolverRun (SwitchedModelReferenceManager::

@@ -1,5 +1,6 @@
-// SYNTAX-CHECK STAND-IN (see ../../README.md) for ocs2_core: Types.h, ControllerBase / LinearController / FeedforwardController,
-// ModeSchedule, TargetTrajectories, PerformanceIndex.  Declarations only, written from SURVEY.md section 8(b); not OCS2.
+// STAND-IN (see ../../README.md) for ocs2_core: Types.h, ControllerBase / LinearController / FeedforwardController,
+// ModeSchedule, TargetTrajectories, PerformanceIndex.  Written from SURVEY.md section 8(b); not OCS2.  The controllers keep what they are
+// constructed from, so that integration/mock_run.cpp can print what the adaptor handed over.
 #pragma once
 #include <Eigen/Core>
 #include <memory>
@@ -13,14 +14,21 @@ using vector_t = Eigen::Matrix<scalar_t, Eigen::Dynamic, 1>;
 using matrix_t = Eigen::Matrix<scalar_t, Eigen::Dynamic, Eigen::Dynamic>;
 using vector_array_t = std::vector<vector_t>;
 using matrix_array_t = std::vector<matrix_t>;
-class ControllerBase { public: virtual ~ControllerBase() = default; };
+class ControllerBase { public: virtual ~ControllerBase() = default; virtual ControllerBase* clone() const = 0; };
 class LinearController final : public ControllerBase {
  public:
-  LinearController(scalar_array_t, vector_array_t, matrix_array_t) {}
+  LinearController(scalar_array_t t, vector_array_t bias, matrix_array_t gain) : timeStamp_(std::move(t)), biasArray_(std::move(bias)), gainArray_(std::move(gain)) {}
+  LinearController* clone() const override { return new LinearController(*this); }
+  scalar_array_t timeStamp_;
+  vector_array_t biasArray_;
+  matrix_array_t gainArray_;
 };
 class FeedforwardController final : public ControllerBase {
  public:
-  FeedforwardController(scalar_array_t, vector_array_t) {}
+  FeedforwardController(scalar_array_t t, vector_array_t u) : timeStamp_(std::move(t)), uffArray_(std::move(u)) {}
+  FeedforwardController* clone() const override { return new FeedforwardController(*this); }
+  scalar_array_t timeStamp_;
+  vector_array_t uffArray_;
 };
 struct ModeSchedule { scalar_array_t eventTimes; size_array_t modeSequence; };
 struct TargetTrajectories { scalar_array_t timeTrajectory; vector_array_t stateTrajectory; vector_array_t inputTrajectory; };
@@ -36,8 +44,8 @@ struct PrimalSolution {
   ModeSchedule modeSchedule_;
   std::unique_ptr<ControllerBase> controllerPtr_;
   PrimalSolution() = default;
-  PrimalSolution(const PrimalSolution& o) : timeTrajectory_(o.timeTrajectory_), stateTrajectory_(o.stateTrajectory_), inputTrajectory_(o.inputTrajectory_), modeSchedule_(o.modeSchedule_) {}
-  PrimalSolution& operator=(const PrimalSolution& o) { timeTrajectory_ = o.timeTrajectory_; stateTrajectory_ = o.stateTrajectory_; inputTrajectory_ = o.inputTrajectory_; modeSchedule_ = o.modeSchedule_; controllerPtr_.reset(); return *this; }
+  PrimalSolution(const PrimalSolution& o) : timeTrajectory_(o.timeTrajectory_), stateTrajectory_(o.stateTrajectory_), inputTrajectory_(o.inputTrajectory_), modeSchedule_(o.modeSchedule_), controllerPtr_(o.controllerPtr_ ? o.controllerPtr_->clone() : nullptr) {}
+  PrimalSolution& operator=(const PrimalSolution& o) { timeTrajectory_ = o.timeTrajectory_; stateTrajectory_ = o.stateTrajectory_; inputTrajectory_ = o.inputTrajectory_; modeSchedule_ = o.modeSchedule_; controllerPtr_.reset(o.controllerPtr_ ? o.controllerPtr_->clone() : nullptr); return *this; }
   PrimalSolution(PrimalSolution&&) = default;
   PrimalSolution& operator=(PrimalSolution&&) = default;
 };

@@ -1,0 +1,66 @@
+"""The OCS2 adaptor EXECUTED: integration/mock_run.cpp links integration/HipSqpMpc.h / HipSqpSolver.h against libbpmpc.so with the labelled
+stand-ins of integration/mock_ocs2 in place of OCS2 and runs three MPC iterations (cold start through bpmpc_solve_batch, then two
+receding-horizon runs through setup_from_previous / run / fetch).  What it hands back through SolverBase::getPrimalSolution - time,
+state and input trajectories with the terminal input repeated, LinearController bias uff_k = u_k - K_k x_k and gains - must equal the
+same solves through the Python mirror.  This checks the adaptor's logic; it pins nothing about OCS2 (mock_ocs2/README.md)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("robot,urdf", [("h1", "h1_mpc.urdf"), ("hunter", "hunter_mpc.urdf")])
+def test_adaptor_runs_and_matches_the_python_mirror(tmp_path, robot, urdf):
+    import bipedal_control_amd as bp
+    from bipedal_control_amd import scenarios as sc
+    exe = str(tmp_path / "mock_run")
+    lib = os.path.join(ROOT, "bipedal_control_amd")
+    inc = [os.path.join(ROOT, d) for d in ("include", "integration", os.path.join("integration", "mock_ocs2"))]
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror"] + [a for i in inc for a in ("-I", i)] + [os.path.join(ROOT, "integration", "mock_run.cpp"),
+                   "-L", lib, "-lbpmpc", "-Wl,-rpath," + lib, "-o", exe], check=True)
+    out = subprocess.run([exe, os.path.join(ROOT, "assets", robot), urdf], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == 3
+
+    def fields(line):
+        w = line.split()
+        return {w[i]: float(w[i + 1]) for i in range(0, len(w) - 1, 2)}
+
+    itf = sc.interface(robot)
+    nx = nu = itf.stateDim
+    horizon, period = 1.005, 0.02
+    gs = bp.GaitSchedule(itf)
+    gs.insertModeSequenceTemplate(bp.loadModeSequenceTemplate(sc.ROBOTS[robot]["gait"], "trot"), -1.225, 3 * horizon)
+    sched = gs.getModeSchedule(-horizon, 3 * horizon)
+    x0 = itf.getInitialState()
+    mpc = bp.BatchedSqpMpc(itf, max_batch=1, max_nodes=96, return_gains=True)
+    iterations = 0
+    for k in range(3):
+        t0 = k * period
+        target = [itf.cmdVelToTargetTrajectories((0.3, 0.0, 0.0, 0.0), t0, x0, horizon)]
+        if k == 0:
+            t, x, u, K, st = mpc.run(t0, x0.reshape(1, nx), sched, target, horizon=horizon, gains=True)
+        else:
+            t, x, u, K, st = mpc.advance(t0, x0.reshape(1, nx), sched, target, horizon=horizon, gains=True)
+        n = st[0].n_nodes
+        iterations += st[0].iterations
+        # multiple_shooting::toPrimalSolution: n + 1 points, input and gain of the terminal point repeat the last interval's
+        ku = np.minimum(np.arange(n + 1), n - 1)
+        tt, xx, uu, KK = t[0, :n + 1], x[0, :n + 1], u[0, ku], K[0, ku]
+        bias = uu - np.einsum("kij,kj->ki", KK, xx)
+        i = np.arange(n + 1)[:, None]
+        st_ = float(np.sum(tt * (1 + np.arange(n + 1) % 3)))
+        sx = float(np.sum(xx * (1 + (i + np.arange(nx)[None, :]) % 7)))
+        su = float(np.sum(uu * (1 + (i + np.arange(nu)[None, :]) % 5)))
+        sb = float(np.sum(bias * (1 + (i + np.arange(nu)[None, :]) % 4)))
+        a, b = np.meshgrid(np.arange(nu), np.arange(nx), indexing="ij")
+        sk = float(np.sum(KK * (1 + (a + 2 * b) % 3)[None]))
+        got = fields(out[k])
+        assert got["run"] == k and got["points"] == n + 1 and got["iterations"] == iterations
+        assert got["merit"] == st[0].merit_after and got["dyn"] == st[0].dynamics_sse_after and got["final"] == tt[-1]
+        for name, ref in (("st", st_), ("sx", sx), ("su", su), ("sb", sb), ("sk", sk)):       # sums in another order: rounding only
+            assert abs(got[name] - ref) <= 1e-11 * max(1.0, abs(ref)), (k, name, got[name], ref)
