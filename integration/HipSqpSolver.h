@@ -157,7 +157,10 @@ class HipSqpSolver final : public SolverBase {
     runImpl(initTime, initState, finalTime);
   }
 
-  // multiple_shooting::toPrimalSolution: inputs and gains of the terminal node (and of pre-event nodes) repeat the previous one
+  // multiple_shooting::toPrimalSolution [OCS2-upstream, recalled; restated in oracle/reference_py.py primal_solution_arrays]: one
+  // entry per node time; the input and gain of the terminal node AND of every pre-event node repeat the previous entry.  The engine
+  // stores u = 0, K = 0 at event nodes (they have no input), so a pre-event node - the first of two nodes at the same time - must not
+  // be copied verbatim: the LinearController would interpolate forces, joint velocities and gains towards zero before every gait event.
   void fillPrimalSolution(const ModeSchedule& ms) {
     const int n = stats_.n_nodes;
     primalSolution_ = PrimalSolution();
@@ -165,14 +168,22 @@ class HipSqpSolver final : public SolverBase {
     vector_array_t uff;
     matrix_array_t gains;
     primalSolution_.timeTrajectory_.reserve(n + 1);
+    using RowMajorMap = Eigen::Map<const Eigen::Matrix<scalar_t, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>>;
     for (int k = 0; k <= n; ++k) {
-      const int ku = std::min(k, n - 1);
+      const bool preEvent = k < n && t_[k + 1] == t_[k];          // event nodes have zero duration: the grid repeats the event time
+      const bool repeat = k > 0 && (k == n || preEvent);
       primalSolution_.timeTrajectory_.push_back(t_[k]);
       primalSolution_.stateTrajectory_.emplace_back(Eigen::Map<const vector_t>(&x_[static_cast<size_t>(k) * nx_], nx_));
-      primalSolution_.inputTrajectory_.emplace_back(Eigen::Map<const vector_t>(&u_[static_cast<size_t>(ku) * nu_], nu_));
+      if (repeat) {
+        primalSolution_.inputTrajectory_.push_back(primalSolution_.inputTrajectory_.back());
+      } else {
+        const int ku = std::min(k, n - 1);                        // k == n only with n == 0 ... never (n >= 1); k == 0 is never repeated
+        primalSolution_.inputTrajectory_.emplace_back(Eigen::Map<const vector_t>(&u_[static_cast<size_t>(ku) * nu_], nu_));
+      }
       if (settings_.useFeedbackPolicy) {
-        const matrix_t Kk = Eigen::Map<const Eigen::Matrix<scalar_t, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>>(
-            &K_[static_cast<size_t>(ku) * nu_ * nx_], nu_, nx_);
+        matrix_t Kk;
+        if (repeat) Kk = gains.back();
+        else Kk = RowMajorMap(&K_[static_cast<size_t>(std::min(k, n - 1)) * nu_ * nx_], nu_, nx_);
         uff.push_back(primalSolution_.inputTrajectory_.back() - Kk * primalSolution_.stateTrajectory_.back());
         gains.push_back(Kk);
       }

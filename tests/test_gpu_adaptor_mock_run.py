@@ -1,8 +1,10 @@
 """The OCS2 adaptor EXECUTED: integration/mock_run.cpp links integration/HipSqpMpc.h / HipSqpSolver.h against libbpmpc.so with the labelled
 stand-ins of integration/mock_ocs2 in place of OCS2 and runs three MPC iterations (cold start through bpmpc_solve_batch, then two
 receding-horizon runs through setup_from_previous / run / fetch).  What it hands back through SolverBase::getPrimalSolution - time,
-state and input trajectories with the terminal input repeated, LinearController bias uff_k = u_k - K_k x_k and gains - must equal the
-same solves through the Python mirror.  This checks the adaptor's logic; it pins nothing about OCS2 (mock_ocs2/README.md)."""
+state and input trajectories, LinearController bias uff_k = u_k - K_k x_k and gains, with the input / gain of the terminal node and
+of every pre-event node repeating the previous entry - must equal the same solves through the Python mirror, arranged by the ORACLE's
+restatement of multiple_shooting::toPrimalSolution (oracle/reference_py.py primal_solution_arrays; the round-2 version of this test
+repeated the adaptor's own indexing and so could not see that event nodes exported u = 0, K = 0).  This checks the adaptor's logic; it pins nothing about OCS2 (mock_ocs2/README.md)."""
 import os
 import subprocess
 
@@ -18,6 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_adaptor_runs_and_matches_the_python_mirror(tmp_path, robot, urdf):
     import bipedal_control_amd as bp
     from bipedal_control_amd import scenarios as sc
+    from oracle import reference_py as rp
+    from tests import oracle_bridge as ob
     exe = str(tmp_path / "mock_run")
     lib = os.path.join(ROOT, "bipedal_control_amd")
     inc = [os.path.join(ROOT, d) for d in ("include", "integration", os.path.join("integration", "mock_ocs2"))]
@@ -48,10 +52,14 @@ def test_adaptor_runs_and_matches_the_python_mirror(tmp_path, robot, urdf):
             t, x, u, K, st = mpc.advance(t0, x0.reshape(1, nx), sched, target, horizon=horizon, gains=True)
         n = st[0].n_nodes
         iterations += st[0].iterations
-        # multiple_shooting::toPrimalSolution: n + 1 points, input and gain of the terminal point repeat the last interval's
-        ku = np.minimum(np.arange(n + 1), n - 1)
-        tt, xx, uu, KK = t[0, :n + 1], x[0, :n + 1], u[0, ku], K[0, ku]
-        bias = uu - np.einsum("kij,kj->ki", KK, xx)
+        # multiple_shooting::toPrimalSolution as the oracle restates it, on the oracle's own node table of this problem
+        nodes = ob.oracle_nodes({"schedule": sched, "targets": target, "t0": t0, "x0": x0.reshape(1, nx), "horizon": horizon}, 0, robot=robot)
+        assert int(nodes["N"]) == n and (np.asarray(nodes["kind"])[:n] == 1).sum() >= 2        # gait events inside the horizon: the case that matters
+        tt, xx, bias, KK = rp.primal_solution_arrays(nodes, x[0, :n + 1], u[0, :n], K[0, :n])
+        assert np.array_equal(tt, t[0, :n + 1])
+        uu = bias + np.einsum("kij,kj->ki", KK, xx)
+        for j in np.nonzero(np.asarray(nodes["kind"])[:n] == 1)[0]:                             # pre-event entries repeat, they are not zero
+            assert np.array_equal(KK[j], KK[j - 1]) and np.abs(KK[j]).max() > 0
         i = np.arange(n + 1)[:, None]
         st_ = float(np.sum(tt * (1 + np.arange(n + 1) % 3)))
         sx = float(np.sum(xx * (1 + (i + np.arange(nx)[None, :]) % 7)))

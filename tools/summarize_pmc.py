@@ -25,7 +25,7 @@ def per_kernel(directory, counter):
     return acc
 
 
-def main(fetch_dir, write_dir, out):
+def main(fetch_dir, write_dir, out, extra=""):
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     kernels = {}
     for name in sorted(set(fetch) | set(write)):
@@ -42,10 +42,12 @@ def main(fetch_dir, write_dir, out):
     ric = next((k for k in kernels if k.startswith("k_riccati_fast")), None)
     steps = kernels[ric]["launches"] if ric else 0
     per_step_common = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in kernels.items() if not k.startswith("k_linearize_fast") and not k.startswith("k_prepare")) / max(1, steps)
-    res = {"batch": 256, "intervals": 100, "kernel": lin,
+    import re
+    mb, mi = re.search(r"--batch (\d+)", extra), re.search(r"--intervals (\d+)", extra)
+    res = {"batch": int(mb.group(1)) if mb else 256, "intervals": int(mi.group(1)) if mi else (150 if "gait-sweep" in extra else 100), "bench_arguments": extra, "kernel": lin,
            "materialised_hbm_bytes_per_step": int(per_step_common + kernels[lin]["hbm_bytes_per_launch"]) if lin and steps else None,
            "fused_hbm_bytes_per_step": int(per_step_common + kernels[lin_f]["hbm_bytes_per_launch"]) if lin_f and steps else None,
-           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 3 --warmup 1 --cpu-sample 0",
+           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 " + extra,
            "hbm_bytes_per_launch": kernels[lin]["hbm_bytes_per_launch"] if lin else None,
            "note": "FETCH_SIZE doubled (gfx950 reports half of the streamed read bytes, MI355X_MICROARCH.md); WRITE_SIZE as reported.",
            "all_kernels": kernels}
@@ -55,4 +57,4 @@ def main(fetch_dir, write_dir, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
