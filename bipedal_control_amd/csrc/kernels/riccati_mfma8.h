@@ -131,6 +131,9 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       if (io.k_lo > 0) io.carry[NXX + NX] = 1.0;
       else { io.base.summary[0] = 0.0; io.base.summary[1] = 0.0; io.base.summary[2] = 0.0; io.base.summary[3] = 1.0; }
     }
+    // the roll-out, which normally opens the line search of this problem, is skipped: open it here, otherwise done / alpha / base keep the
+    // previous iteration's values and k_ls_decide would skip the problem instead of reporting the failure (advisor r02)
+    if (io.k_lo == 0 && io.with_ls && tid < kWave) linesearch_begin_wave<NJ>(&ws.S[0][0], io.ls, tid);
     return;
   }
 

@@ -697,16 +697,18 @@ struct bpmpc_solver {
   }
   void collect_timers() {
     for (auto& kv : timers) {
+      hipError_t first_error = hipSuccess;                 // the events are destroyed whatever happens; the first failure is reported afterwards
       for (auto& pr : kv.second.pending) {
         float ms = 0.f;
-        HIP_CHECK(hipEventSynchronize(pr.second));
-        HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
-        kv.second.total_ms += ms;
-        kv.second.launches += 1;
+        hipError_t e = hipEventSynchronize(pr.second);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, pr.first, pr.second);
+        if (e == hipSuccess) { kv.second.total_ms += ms; kv.second.launches += 1; }
+        else if (first_error == hipSuccess) first_error = e;
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
       }
       kv.second.pending.clear();
+      if (first_error != hipSuccess) throw DeviceError(std::string("kernel timers: ") + hipGetErrorString(first_error));
     }
   }
 
@@ -1016,7 +1018,8 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   std::vector<double>&gdt = hs.gdt, &gstart = hs.gstart, &zref = hs.zref, &zdref = hs.zdref;
   kind.assign(S, 0); mode.assign(S, STANCE); nodes.assign(G, 0); pgrid.assign(batch, 0);
   gdt.assign(S, 0.0); gstart.assign(S, 0.0); zref.assign(S * 4, 0.0); zdref.assign(S * 4, 0.0);
-  s->node_times.assign((size_t)G * (N + 1), 0.0);
+  // (the handle's own node times are replaced only after every check below has passed: a rejected call leaves the handle as it was)
+  std::vector<double> node_times((size_t)G * (N + 1), 0.0);
   SwingPlanner planner(s->rm.swing);
   int nmax = 0, rows_max = 12, vrows_max = 4;
   for (int g = 0; g < G; ++g) {
@@ -1040,7 +1043,7 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
       }
       for (int c = 0; c < 4; ++c) { zref[4 * i + c] = tab.zref[4 * k + c]; zdref[4 * i + c] = tab.zdref[4 * k + c]; }
     }
-    std::copy(tab.node_time.begin(), tab.node_time.end(), s->node_times.begin() + (size_t)g * (N + 1));
+    std::copy(tab.node_time.begin(), tab.node_time.end(), node_times.begin() + (size_t)g * (N + 1));
   }
   std::vector<double>&tgt_t = hs.tgt_t, &tgt_x = hs.tgt_x;
   std::vector<int>& tgt_n = hs.tgt_n;
@@ -1048,14 +1051,25 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   for (int b = 0; b < batch; ++b) {
     pgrid[b] = grid_of[b];
     const bpmpc_target& t = targets[b];
-    if (t.n_points < 1 || t.n_points > kMaxTargetPoints || !t.times || !t.states) throw std::invalid_argument("target trajectories need 1..8 points");
-    tgt_n[b] = t.n_points;
-    std::copy(t.times, t.times + t.n_points, tgt_t.begin() + (size_t)b * kMaxTargetPoints);
-    std::copy(t.states, t.states + (size_t)t.n_points * NX, tgt_x.begin() + (size_t)b * kMaxTargetPoints * NX);
+    if (t.n_points < 1 || !t.times || !t.states) throw std::invalid_argument("target trajectories need at least one point");
+    // A TargetTrajectories of any length (the ROS reference manager hands its own over verbatim, integration/HipSqpSolver.h): only the
+    // points that the piecewise-linear interpolation can touch for query times in [t0, t0 + horizon] are kept - the last one before the
+    // window, the ones inside, the first one behind it (interpolate_targets: segment [lower_bound(t) - 1, lower_bound(t)], constant
+    // extrapolation) - which gives bit-identical references.  The device tables hold kMaxTargetPoints of them.
+    const double lo = t0[b], hi = t0[b] + horizon;
+    const int i0 = std::max(0, static_cast<int>(std::lower_bound(t.times, t.times + t.n_points, lo) - t.times) - 1);
+    const int i1 = std::min(t.n_points - 1, static_cast<int>(std::lower_bound(t.times, t.times + t.n_points, hi) - t.times));
+    const int np = i1 - i0 + 1;
+    if (np > kMaxTargetPoints)
+      throw std::invalid_argument("target trajectory has " + std::to_string(np) + " points inside the horizon, the solver holds " + std::to_string(kMaxTargetPoints));
+    tgt_n[b] = np;
+    std::copy(t.times + i0, t.times + i0 + np, tgt_t.begin() + (size_t)b * kMaxTargetPoints);
+    std::copy(t.states + (size_t)i0 * NX, t.states + (size_t)(i0 + np) * NX, tgt_x.begin() + (size_t)b * kMaxTargetPoints * NX);
   }
   // every host-side check (grids, targets) has passed: only now do the solution buffers trade places with the kept copy, so a
   // rejected call leaves the handle exactly as it was
   if (from_previous) preserve_previous(s, batch, warm_x != nullptr);
+  s->node_times.swap(node_times);
   s->batch = batch; s->n_grids = G; s->n_nodes_max = nmax; s->cold = (warm_x == nullptr);
   s->max_rows = rows_max; s->max_vel_rows = vrows_max;
   s->grid_nodes = nodes; s->grid_of_problem = pgrid; s->grid_kind = kind; s->has_solution = false;
@@ -1149,13 +1163,13 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
   hipLaunchKernelGGL(k_command_targets, dim3((batch + 63) / 64), dim3(64), 0, s->stream, c);
   HIP_CHECK(hipGetLastError());
   std::vector<int> nodes(G), status(G), rows(G), kind((size_t)G * N);
-  s->node_times.assign((size_t)G * (N + 1), 0.0);
+  std::vector<double> node_times((size_t)G * (N + 1), 0.0);   // becomes the handle's copy once every grid has been accepted
   {
     s->pin_down.reset();
     struct Down { void* host; const void* dev; size_t bytes; void* pin; };
     Down down[5] = {{nodes.data(), bf.g_nodes, G * sizeof(int), nullptr}, {status.data(), bf.rg_status, G * sizeof(int), nullptr},
                     {rows.data(), bf.rg_rows, G * sizeof(int), nullptr}, {kind.data(), bf.g_kind, kind.size() * sizeof(int), nullptr},
-                    {s->node_times.data(), bf.g_time, s->node_times.size() * sizeof(double), nullptr}};
+                    {node_times.data(), bf.g_time, node_times.size() * sizeof(double), nullptr}};
     for (Down& d : down) {
       d.pin = s->pin_down.take(d.bytes);
       HIP_CHECK(hipMemcpyAsync(d.pin ? d.pin : d.host, d.dev, d.bytes, hipMemcpyDeviceToHost, s->stream));
@@ -1178,6 +1192,7 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
     rows_max = std::max(rows_max, rows[g] & 255);
     vrows_max = std::max(vrows_max, rows[g] >> 8);
   }
+  s->node_times.swap(node_times);
   s->batch = batch; s->n_grids = G; s->n_nodes_max = nmax; s->cold = true; s->max_rows = rows_max; s->max_vel_rows = vrows_max;
   s->grid_nodes = nodes; s->grid_of_problem = pgrid; s->grid_kind = kind;
   finish_setup(s, batch, nullptr, nullptr, from_previous);
@@ -1343,7 +1358,12 @@ void bpmpc_solver_destroy(bpmpc_solver* s) {
 #define API_GUARD(solver, ...)                                                                    \
   if (!(solver)) { set_last_error("null solver handle"); return BPMPC_ERR_INVALID_ARGUMENT; }      \
   try { HIP_CHECK(hipSetDevice((solver)->settings.device)); __VA_ARGS__; }                               \
-  catch (const std::exception& e) { return translate(e); }                                        \
+  catch (const std::exception& e) {                                                               \
+    /* a call that threw between enqueueing copies from / to the pinned arenas and its own synchronisation: wait for them before the */ \
+    /* next call recycles (or frees) that memory */                                               \
+    if ((solver)->stream) (void)hipStreamSynchronize((solver)->stream);                           \
+    return translate(e);                                                                          \
+  }                                                                                               \
   return BPMPC_OK;
 
 int bpmpc_solver_setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const double* x0, const bpmpc_mode_schedule* schedules,
@@ -1407,6 +1427,9 @@ int bpmpc_solver_read(bpmpc_solver* s, const char* name, double* out, long capac
   if (!s || !name) { set_last_error("bpmpc_solver_read: null argument"); return BPMPC_ERR_INVALID_ARGUMENT; }
   try {
     if (!out) {                                             // size query
+#if defined(BPMPC_EVAL_PROFILE)
+      if (std::string(name) == "evprof") return 16;
+#endif
       auto q = s->named.find(name);
       if (q == s->named.end()) throw std::invalid_argument(std::string("unknown buffer ") + name);
       if (q->second.second > 0x7fffffffu) throw std::length_error("bpmpc_solver_read: buffer exceeds 2^31 elements");

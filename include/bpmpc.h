@@ -212,8 +212,15 @@ int bpmpc_solver_fetch(bpmpc_solver* solver, double* out_t, double* out_x, doubl
  * "linearize", "project", "riccati", "linesearch". */
 int bpmpc_solver_stage(bpmpc_solver* solver, const char* stage);
 /* Copy a named device buffer to the host (tests): "x","u","xref","A","B","b","Q","R","P","q","r","c","C","D","e","nc","perf",
- * "Px","Pu","Pe","nut","At","Bt","bt","Qt","Rt","Pt","qt","rt","dx","du","K","summary".  Integer buffers are converted to
- * double.  Returns the element count or a negative status; out == NULL only queries the element count. */
+ * "Px","Pu","Pe","nut","dx","du","K","Acl","summary","stats","g_kind","g_mode","g_nodes","g_dt","g_start","g_zref","g_zdref","g_time",
+ * "p_grid","x0".  The projected LQ model depends on the kernel set:
+ *   settings.reference_kernels = 1:  plain matrices "At","Bt","bt","Qt","Rt","Pt","qt","rt" and the gain scratch "Kt","kt";
+ *   fast kernels (default):          the packed layout "Wt" = [At | bt | Bt] (nx rows of WP columns), "Qp" = [Qt | qt] (nx rows of 32
+ *                                    columns), "Mt" = [Pt | rt | Rt] (nu rows of WP columns), WP = 16 * ceil((nx + 1 + nu) / 16); block
+ *                                    columns beyond nx + 1 + nut and rows >= nut of Mt are not written (kernels/project_node.h PackedLq);
+ *                                    the plain names return "unknown buffer".
+ * Integer buffers are converted to double.  Returns the element count or a negative status; out == NULL only queries the element
+ * count. */
 int bpmpc_solver_read(bpmpc_solver* solver, const char* name, double* out, long capacity);
 /* Device pointers of the iterate, for zero-copy hand-off (e.g. an RCCL gather through torch.distributed):
  * x: batch*(max_nodes+1)*nx doubles, u: batch*max_nodes*nu doubles.  Valid until the next setup with a warm start from the previous

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+from tests.tolerances import rel_K, rel_u, rel_x  # noqa: E402  (per physical block: forces vs joint velocities, ...)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -32,7 +34,7 @@ def test_one_call_entry_point_and_warm_start(ctx):
     n = st[0].n_nodes
     for b in range(3):
         xo, uo, Ko, _ = ob.oracle_solve_like(prob, b)
-        assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8 and _rel(K[b, :n], Ko) < 1e-7
+        assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11 and rel_K(K[b, :n], Ko) < 1e-10
     # warm start: the previous solution is the initial iterate of the next solve (mpc.coldStart false, task.info:173);
     # the measured state differs from the first node of the iterate, so dx_0 != 0
     x0b = prob["x0"] + 1e-3
@@ -42,7 +44,7 @@ def test_one_call_entry_point_and_warm_start(ctx):
         p2 = dict(prob, x0=x0b, targets=[itf.cmdVelToTargetTrajectories((0.3, 0, 0, 0), 0.0, x0b[b], prob["horizon"]) for b in range(3)])
         xo, uo, _, sto = ob.oracle_solve_like(p2, b, x_init=x[b, :n + 1], u_init=u[b, :n])
         assert st2[b].step_size == sto[0][3]
-        assert _rel(x2[b, :n + 1], xo) < 1e-8 and _rel(u2[b, :n], uo) < 1e-8
+        assert rel_x(x2[b, :n + 1], xo) < 1e-11 and rel_u(u2[b, :n], uo) < 1e-11
         assert np.abs(x2[b, 0] - x0b[b]).max() < 1e-12 or st2[b].step_size < 1.0    # full step lands on the measured state
 
 
@@ -76,7 +78,7 @@ def test_iterations_and_convergence_flags(ctx):
     xo, uo, _, sto = ob.oracle_solve_like(prob, 0, iterations=10)
     its = int(sum(1 for r in sto if r[10] > 0))
     assert st[0].iterations == its and 1 < its <= 10                  # converged before the iteration cap, like the oracle
-    assert _rel(x[0, :21], xo) < 1e-7 and st[0].dynamics_sse_after + st[0].equality_sse_after < 1e-8
+    assert rel_x(x[0, :21], xo) < 1e-7 and st[0].dynamics_sse_after + st[0].equality_sse_after < 1e-8
 
 
 def test_bench_contract():
@@ -160,7 +162,7 @@ def test_backtracking_rounds_on_device_match_oracle(ctx):
         for b in range(B):
             xo, uo, _, sto = ob.oracle_solve_like(p2, b, x_init=x[b, :n + 1], u_init=u[b, :n])
             assert st2[b].step_size == sto[0][3], (d, b, st2[b].step_size, sto[0][3])
-            assert _rel(x2[b, :n + 1], xo) < 1e-8 and _rel(u2[b, :n], uo) < 1e-8
+            assert rel_x(x2[b, :n + 1], xo) < 1e-11 and rel_u(u2[b, :n], uo) < 1e-11
             seen.add(st2[b].step_size)
     assert min(seen) <= 0.25 and len(seen) >= 2, seen      # the device-side rounds were really exercised
 
@@ -183,3 +185,43 @@ def test_profile_levels(ctx):
     assert mpc.kernel_time("linearize")[1] == 0
     with pytest.raises(bp.BpmpcError):
         mpc.set_profile(7)
+
+
+def test_long_target_trajectories_are_cropped_exactly(ctx):
+    """The ROS reference manager hands its TargetTrajectories over verbatim (integration/HipSqpSolver.h); one with more than the
+    device's 8 points used to be a runtime error that stopped the controller.  Only the points the piecewise-linear
+    interpolation can touch inside [t0, t0 + horizon] are kept - same reference bits - and a rejected setup leaves the handle usable."""
+    bp, sc, ob, itf = ctx
+    nx = itf.stateDim
+    horizon, t0 = 30 * sc.DT, 0.2
+    x0 = sc.perturbed_initial_states(itf, 2)
+    sched = sc.gait_schedule(itf, "trot", t0, horizon)
+    rng = np.random.default_rng(5)
+    times = np.concatenate([np.linspace(-3.0, 0.1, 9), [0.31, 0.47], np.linspace(0.7, 6.0, 11)])       # 22 points, 2 strictly inside the window
+    base = itf.cmdVelToTargetTrajectories((0.3, 0.0, 0.0, 0.1), t0, x0[0], horizon).stateTrajectory[0]
+    states = base[None, :] + 0.02 * rng.standard_normal((len(times), nx))
+    tt = bp.TargetTrajectories(times, states)
+    prob = dict(t0=t0, x0=x0, schedule=sched, targets=[tt, tt], horizon=horizon)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=2, max_nodes=48)
+    t, x, u, _, st = mpc.run(t0, x0, sched, [tt, tt], horizon=horizon)
+    n = st[0].n_nodes
+    xref = mpc.read("xref").reshape(2, 48, nx)[:, :n].copy()
+    # the same bits as handing over just the four points that matter (last before the window, two inside, first behind it) ...
+    keep = slice(8, 12)
+    assert times[8] < t0 <= times[9] and times[10] < t0 + horizon <= times[11]
+    four = bp.TargetTrajectories(times[keep], states[keep])
+    t4, x4, u4, _, _ = mpc.run(t0, x0, sched, [four, four], horizon=horizon)
+    assert np.array_equal(mpc.read("xref").reshape(2, 48, nx)[:, :n], xref) and np.array_equal(x4, x) and np.array_equal(u4, u)
+    t, x, u, _, st = mpc.run(t0, x0, sched, [tt, tt], horizon=horizon)
+    for b in range(2):
+        nodes = ob.oracle_nodes(prob, b)                                # ... and what the oracle interpolates from the full 22-point trajectory
+        assert np.abs(xref[b] - np.asarray(nodes["xref"])[:n]).max() < 1e-14
+        xo, uo, _, _ = ob.oracle_solve_like(prob, b)
+        assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11
+    # more than 8 points inside the window: a clear error, and the handle keeps its previous setup (node times included)
+    dense = bp.TargetTrajectories(np.linspace(t0, t0 + horizon, 12), base[None, :] + np.zeros((12, 1)))
+    with pytest.raises(bp.BpmpcError) as e:
+        mpc.setup(t0 + 0.1, x0, sc.gait_schedule(itf, "trot", t0 + 0.1, horizon), [dense, dense], horizon=horizon)
+    assert "inside the horizon" in str(e.value)
+    t2, x2, u2, _, st2 = mpc.fetch()
+    assert np.array_equal(t2, t) and np.array_equal(x2, x) and np.array_equal(u2, u)

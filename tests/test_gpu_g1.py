@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+from tests.tolerances import rel_K, rel_u, rel_x  # noqa: E402  (per physical block: forces vs joint velocities, ...)
 ROBOT = "g1"
 WALK = "standing_trot"
 
@@ -74,7 +76,7 @@ def test_g1_qp_step_matches_oracle(ctx):
         nodes = ob.oracle_nodes(prob, b, robot=ROBOT)
         N = nodes["N"]
         odx, odu, oK = om.qp_step(nodes, prob["x0"][b], x[b, :N + 1], u[b, :N])
-        assert _rel(dx[b, :N + 1], odx) < 1e-9 and _rel(du[b, :N], odu) < 1e-9 and _rel(K[b, :N], oK) < 1e-9
+        assert rel_x(dx[b, :N + 1], odx) < 1e-9 and rel_u(du[b, :N], odu) < 1e-9 and rel_K(K[b, :N], oK) < 1e-9
 
 
 @pytest.mark.parametrize("gait,iterations", [(WALK, 1), (WALK, 3), ("trot", 2)])
@@ -89,11 +91,11 @@ def test_g1_solve_matches_oracle(ctx, gait, iterations):
         n = stats[b].n_nodes
         its = int(sum(1 for r in st if r[10] > 0))
         assert stats[b].iterations == its and stats[b].step_size == st[its - 1][3]
-        assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8 and _rel(K[b, :n], Ko) < 1e-7
+        assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11 and rel_K(K[b, :n], Ko) < 1e-10
     # reference kernel bodies (lane-emulation verified on the CPU tier) agree with the fast ones
     ref = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=72, sqp_iterations=iterations, reference_kernels=True)
     t2, x2, u2, _, _ = ref.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
-    assert _rel(x2, x) < 1e-9 and _rel(u2, u) < 1e-9
+    assert rel_x(x2, x) < 1e-9 and rel_u(u2, u) < 1e-9
 
 
 def test_g1_full_size_properties(ctx):
@@ -139,7 +141,7 @@ def test_g1_full_size_properties(ctx):
     # the batch of 1024 runs the four-wave Riccati sweep (two problems per CU), a batch that fits one problem per CU the eight-wave
     # one (riccati_mfma8.h): the same mathematics in another elimination order, so the two agree to rounding, not bitwise
     for j, i in enumerate(sub):
-        assert _rel(x2[j], x[i]) < 1e-10 and _rel(u2[j], u[i]) < 1e-10
+        assert rel_x(x2[j], x[i]) < 1e-10 and rel_u(u2[j], u[i]) < 1e-10
     # ... and bitwise between two batches on the same sweep: another size, another order
     sub3 = [517, 1000, 3, 42]
     prob3 = dict(prob, x0=prob["x0"][sub3], targets=[prob["targets"][i] for i in sub3])
@@ -149,4 +151,4 @@ def test_g1_full_size_properties(ctx):
         assert np.array_equal(x2[j], x3[sub3.index(i)]) and np.array_equal(u2[j], u3[sub3.index(i)])
     xo, uo, _, _ = ob.oracle_solve_like(prob2, 1, iterations=3, robot=ROBOT)
     nn = st2[1].n_nodes
-    assert _rel(x2[1, :nn + 1], xo) < 1e-8 and _rel(u2[1, :nn], uo) < 1e-8
+    assert rel_x(x2[1, :nn + 1], xo) < 1e-11 and rel_u(u2[1, :nn], uo) < 1e-11

@@ -6,6 +6,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+from tests.tolerances import rel_K, rel_u, rel_x  # noqa: E402  (per physical block: forces vs joint velocities, ...)
+
 ROBOT = "hunter"
 
 
@@ -35,7 +37,7 @@ def test_hunter_solve_matches_oracle(ctx, gait):
         xo, uo, Ko, so = ob.oracle_solve_like(prob, b, iterations=2, robot=ROBOT)
         n = st[b].n_nodes
         assert st[b].step_size == so[st[b].iterations - 1][3]
-        assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8 and _rel(K[b, :n], Ko) < 1e-7
+        assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11 and rel_K(K[b, :n], Ko) < 1e-10
     # the LQ model at the solution: every quantity of problem 0 against the oracle's node_lq
     mpc.stage("linearize"); mpc.synchronize()
     shapes = dict(A=(22, 22), B=(22, 22), b=(22,), q=(22,), r=(22,), C=(16, 22), D=(16, 22), e=(16,), perf=(3,))
@@ -54,7 +56,7 @@ def test_hunter_solve_matches_oracle(ctx, gait):
     assert np.array_equal(x2, x) and np.array_equal(u2, u) and np.array_equal(K2, K)
     ref = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN, sqp_iterations=2, reference_kernels=True)
     t3, x3, u3, _, _ = ref.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
-    assert _rel(x3, x) < 1e-9 and _rel(u3, u) < 1e-9
+    assert rel_x(x3, x) < 1e-9 and rel_u(u3, u) < 1e-9
 
 
 def test_hunter_large_batch_and_commands(ctx):
@@ -71,10 +73,10 @@ def test_hunter_large_batch_and_commands(ctx):
     small = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=64, sqp_iterations=2)
     t2, x2, u2, _, _ = small.run(prob2["t0"], prob2["x0"], prob2["schedule"], prob2["targets"], horizon=prob2["horizon"])
     for j, i in enumerate(sub):
-        assert _rel(x2[j], x[i]) < 1e-10 and _rel(u2[j], u[i]) < 1e-10
+        assert rel_x(x2[j], x[i]) < 1e-10 and rel_u(u2[j], u[i]) < 1e-10
     xo, uo, _, _ = ob.oracle_solve_like(prob, 123, iterations=2, robot=ROBOT)
     n = st[123].n_nodes
-    assert _rel(x[123, :n + 1], xo) < 1e-8 and _rel(u[123, :n], uo) < 1e-8
+    assert rel_x(x[123, :n + 1], xo) < 1e-11 and rel_u(u[123, :n], uo) < 1e-11
     # commands path: trot template of hunter's gait.info, 0.3 m/s forward
     horizon = 40 * sc.DT
     tm = [bp.loadModeSequenceTemplate(sc.ROBOTS[ROBOT]["gait"], "trot")]

@@ -1,13 +1,19 @@
 """GPU parity tests (through the C ABI): HIP path vs the CPU oracle on the same seeded inputs.
 Tolerances (FP64 both sides; different summation order and analytic-vs-AD derivatives):
   LQ model entries                 1e-11 relative to max(1, |oracle|_max) per quantity
-  QP step dx, du, K                1e-9  relative to max(1, |oracle|_max)
-  solve output x, u                1e-8  relative
+  QP step dx, du, K                1e-9  relative, PER PHYSICAL BLOCK (tests/tolerances.py: momentum / base pose / joints of a state,
+                                         contact forces / joint velocities of an input, the six row x column blocks of a gain)
+  solve output x, u                1e-11 relative per block; K 1e-10 (measured on MI355X: 4e-14 / 5e-15, profiles/r03_parity_blocks.json;
+                                         the OpenLoong cold start with its semi-definite input cost: 1e-9 / 1e-8)
+The worst value per block that the hardware achieved is written to gpurun_out/parity_blocks.json by test_solve_matches_oracle
+(committed copy: profiles/r03_parity_blocks.json).
 """
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+from tests.tolerances import rel_K, rel_u, rel_x  # noqa: E402  (per physical block: forces vs joint velocities, ...)
 
 
 def _rel(a, b):
@@ -22,6 +28,20 @@ def ctx():
     from tests import oracle_bridge as ob
     itf = scenarios.h1_interface()
     return dict(bp=bp, sc=scenarios, ob=ob, itf=itf)
+
+
+def _write_report(key, report):
+    """Achieved per-block errors, for the record (never fails a test)."""
+    import json
+    import os
+    try:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_blocks.json")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = report
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except Exception:
+        pass
 
 
 def _views(mpc, name, per_node):
@@ -72,9 +92,9 @@ def test_qp_step_matches_oracle(ctx):
         nodes = ob.oracle_nodes(prob, b)
         N = nodes["N"]
         odx, odu, oK = om.qp_step(nodes, prob["x0"][b], x[b, :N + 1], u[b, :N])
-        assert _rel(dx[b, :N + 1], odx) < 1e-9
-        assert _rel(du[b, :N], odu) < 1e-9
-        assert _rel(K[b, :N], oK) < 1e-9
+        assert rel_x(dx[b, :N + 1], odx) < 1e-9
+        assert rel_u(du[b, :N], odu) < 1e-9
+        assert rel_K(K[b, :N], oK) < 1e-9
 
 
 @pytest.mark.parametrize("iterations", [1, 3])
@@ -83,16 +103,18 @@ def test_solve_matches_oracle(ctx, iterations):
     prob = sc.trot_problem(itf, batch=4, n_intervals=50)
     mpc = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=64, sqp_iterations=iterations, return_gains=True)
     t, x, u, K, stats = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    report = {}
     for b in range(4):
         xo, uo, Ko, st = ob.oracle_solve_like(prob, b, iterations=iterations)
         n = stats[b].n_nodes
         its = int(sum(1 for r in st if r[10] > 0))
         assert stats[b].iterations == its
         assert abs(stats[b].step_size - st[its - 1][3]) == 0.0
-        assert _rel(x[b, :n + 1], xo) < 1e-8
-        assert _rel(u[b, :n], uo) < 1e-8
-        assert _rel(K[b, :n], Ko) < 1e-7
+        assert rel_x(x[b, :n + 1], xo, report) < 1e-11
+        assert rel_u(u[b, :n], uo, report) < 1e-11
+        assert rel_K(K[b, :n], Ko, report) < 1e-10
         assert _rel(stats[b].merit_after, st[its - 1][4]) < 1e-9
+    _write_report("solve_%d_iterations" % iterations, report)
 
 
 def test_stance_config1(ctx):
@@ -104,7 +126,7 @@ def test_stance_config1(ctx):
     xo, uo, Ko, st = ob.oracle_solve_like(prob, 0)
     assert stats[0].n_nodes == 20
     assert np.allclose(t[0, :21], np.arange(21) * 0.015, atol=1e-12)
-    assert _rel(x[0, :21], xo) < 1e-8 and _rel(u[0, :20], uo) < 1e-8
+    assert rel_x(x[0, :21], xo) < 1e-11 and rel_u(u[0, :20], uo) < 1e-11
     # stance: joint velocities are pinned by the zero-velocity constraints
     assert np.abs(u[0, 0, 12:]).max() < 1e-9
 
@@ -172,11 +194,13 @@ def test_openloong_24_dof_class(ctx):
         xo, uo, Ko, st = ob.oracle_solve_like(prob, b, robot="openloong")
         n = stats[b].n_nodes
         assert stats[b].step_size == st[0][3]
-        assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8 and _rel(K[b, :n], Ko) < 1e-7
+        # looser than H1's 1e-11: with six joints per leg the input cost J'RJ is only positive SEMI-definite (two contact points per rigid
+        # foot), the cold-start step moves a swing-leg joint by ~10 rad and the stage Hessians are ill conditioned (measured 1.6e-11)
+        assert rel_x(x[b, :n + 1], xo) < 1e-9 and rel_u(u[b, :n], uo) < 1e-9 and rel_K(K[b, :n], Ko) < 1e-8
     # reference kernels (lane-emulation verified) and fast kernels agree
     ref = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=64, reference_kernels=True)
     t2, x2, u2, _, _ = ref.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
-    assert _rel(x2, x) < 1e-9 and _rel(u2, u) < 1e-9
+    assert rel_x(x2, x) < 1e-9 and rel_u(u2, u) < 1e-9
 
 
 def test_per_problem_schedules_gait_sweep(ctx):
@@ -194,7 +218,7 @@ def test_per_problem_schedules_gait_sweep(ctx):
         n = stats[b].n_nodes
         counts.add(n)
         assert n == xo.shape[0] - 1
-        assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8
+        assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11
     assert len(counts) >= 3      # different gaits => different numbers of event nodes
 
 
@@ -258,7 +282,7 @@ def test_repeated_solves_are_bit_identical(ctx, batch):
     for b in (0, batch - 1):
         xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
         n = st[b].n_nodes
-        assert _rel(x[b, :n + 1], xo) < 1e-8 and _rel(u[b, :n], uo) < 1e-8 and _rel(K[b, :n], Ko) < 1e-7
+        assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11 and rel_K(K[b, :n], Ko) < 1e-10
 
 
 @pytest.mark.parametrize("n_intervals,max_nodes", [(1, 8), (2, 8), (3, 8), (450, 512)])
@@ -272,7 +296,7 @@ def test_shortest_and_longest_horizons(ctx, n_intervals, max_nodes):
     assert n >= n_intervals and all(s.status == 0 for s in st)
     xo, uo, Ko, so = ob.oracle_solve_like(prob, 1)
     assert xo.shape[0] == n + 1 and st[1].step_size == so[0][3]
-    assert _rel(x[1, :n + 1], xo) < 1e-8 and _rel(u[1, :n], uo) < 1e-8 and _rel(K[1, :n], Ko) < 1e-7
+    assert rel_x(x[1, :n + 1], xo) < 1e-11 and rel_u(u[1, :n], uo) < 1e-11 and rel_K(K[1, :n], Ko) < 1e-10
 
 
 @pytest.mark.parametrize("t0", [0.175, 0.175 - 30 * 0.015])
@@ -290,7 +314,7 @@ def test_gait_event_on_the_window_boundaries(ctx, t0):
     t, x, u, _, st = mpc.run(t0, x0, sched, tg, horizon=horizon)
     n = st[0].n_nodes
     xo, uo, _, _ = ob.oracle_solve_like(prob, 0)
-    assert xo.shape[0] == n + 1 and _rel(x[0, :n + 1], xo) < 1e-8 and _rel(u[0, :n], uo) < 1e-8
+    assert xo.shape[0] == n + 1 and rel_x(x[0, :n + 1], xo) < 1e-11 and rel_u(u[0, :n], uo) < 1e-11
 
 
 @pytest.mark.parametrize("robot,gait", [("h1", "trot"), ("h1", "flying_trot"), ("g1", "standing_trot")])
@@ -350,7 +374,7 @@ def test_reg_prim_setting_matches_oracle(ctx):
             nodes = ob.oracle_nodes(prob, b)
             N = nodes["N"]
             odx, odu, oK = om.qp_step(nodes, prob["x0"][b], x[b, :N + 1], u[b, :N], reg_prim=reg)
-            assert _rel(dx[b, :N + 1], odx) < 1e-9 and _rel(du[b, :N], odu) < 1e-9 and _rel(K[b, :N], oK) < 1e-9
+            assert rel_x(dx[b, :N + 1], odx) < 1e-9 and rel_u(du[b, :N], odu) < 1e-9 and rel_K(K[b, :N], oK) < 1e-9
         outs.append(du.copy())
     assert 0.0 < _rel(outs[1], outs[0]) < 1e-7 < _rel(outs[2], outs[0])
     with pytest.raises(bp.BpmpcError):
