@@ -272,20 +272,17 @@ def main():
             bytes_per_node = BYTES_PER_NODE_H1 if nx == 22 else BYTES_PER_NODE_24
             alg_bytes = bytes_per_node * n_intermediate_total / launches_per_step
             achieved = alg_bytes / avg_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "linearize_traffic.json")       # PMC passes of the same command (tools/collect_profiles.sh)
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("batch") == B and tj.get("intervals") == NI and (args.robot, gait, sweep) == ("h1", "trot", False):
-                        traffic = tj.get("hbm_bytes_per_launch")
-                        if fused is not None:
-                            fused["hbm_bytes_per_step"] = tj.get("fused_hbm_bytes_per_step")
-                            fused["materialised_hbm_bytes_per_step"] = tj.get("materialised_hbm_bytes_per_step")
-                except Exception:
-                    traffic = None
-            roofline = {"kernel": "k_linearize_fast<%d>" % (nx - 12), "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_us": round(1e6 * avg_s, 2),
+            # HBM bytes seen by the PMC counters for this workload, when a committed pass of the same command exists (builder run, not
+            # measured in this process: counters need rocprofv3 around the whole command)
+            prof = committed_traffic(args.robot, gait, sweep, B, NI)
+            traffic = prof["kernels"].get("linearize_materialised") if prof else None
+            if fused is not None and prof:
+                fused["hbm_bytes_per_step"] = prof.get("fused_hbm_bytes_per_step")
+                fused["materialised_hbm_bytes_per_step"] = prof.get("materialised_hbm_bytes_per_step")
+                fused["hbm_bytes_source"] = prof["source"]
+            roofline = {"kernel": "k_linearize_fast<%d, true>" % (nx - 12), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": (prof["source"] if prof else None),
+                        "avg_launch_us": round(1e6 * avg_s, 2),
                         "algorithmic_bytes_per_launch": round(alg_bytes), "launches_per_step": launches_per_step,
                         "node_linearizations_per_s": round(n_intermediate_total / launches_per_step / avg_s, 1), "measured_on": "rank 0"}
         headline = (args.robot, gait, sweep, NI) == ("h1", "trot", False, 100)
@@ -310,23 +307,104 @@ def main():
                "ms_per_solve": round(ms_per_step / max(1, total // world), 6),
                "kernel_ms_per_step": {k: round(v[0] / max(1, kt_steps), 4) for k, v in ktimes.items()},
                "roofline": roofline, "fused": fused}
-        if roofline is not None:
-            roofline["limiter"] = "not HBM: FP64 issue / latency at 2 waves per SIMD (roofline_fp64.linearize: wave_time_split, issue_frac)"
         kms = out["kernel_ms_per_step"]
         n_all_nodes = int(sum(g_nodes[p_grid])) if world == 1 else None
         if world == 1:
             out["roofline_fp64"] = roofline_fp64("h1" if nx == 22 else "g1", kms, n_intermediate_total, n_all_nodes, n_all_nodes,
                                                  applicable=headline and scaling == "weak" and args.batch == 256)
+            nut_mean = float(mpc.read("nut").reshape(B, max_nodes)[:, :n_nodes][kinds[p_grid][:, :n_nodes] == 0].mean())
+            out["roofline_all"] = roofline_all(nx, nu, nut_mean, kms, n_intermediate_total, n_all_nodes, out.get("roofline_fp64"),
+                                               committed_traffic(args.robot, gait, sweep, B, NI))
+        if roofline is not None:
+            # what binds the roofline kernel: the largest of the fractions of the three roofs it could sit under, "latency" when none of them
+            # is half used (then the kernel waits: low occupancy / dependent chains, see roofline_fp64.<kernel>.wave_time_split)
+            fr = {"hbm": roofline["frac"]}
+            e = (out.get("roofline_fp64") or {}).get("linearize") or {}
+            if "issue_frac" in e:
+                fr["fp64-issue"] = e["issue_frac"]
+                fr["mfma"] = e["mfma_frac"]
+            top = max(fr, key=fr.get)
+            roofline["bound"] = top if fr[top] >= 0.5 else "latency"
+            roofline["bound_fracs"] = fr
+            roofline["bound_note"] = ("`frac` stays achieved / HBM peak (the roof the north-star names); fp64-issue / mfma fractions use executed-instruction "
+                                      "counts from profiles/r02_sq_counters.json (builder run) at this run's kernel time")
         if world == 1 and args.cpu_sample > 0:
             if sweep:
                 out["cpu_baseline"] = cpu_baseline_sweep(itf, cp, min(args.cpu_sample, 16), x, stats, args.robot)
             else:
                 out["cpu_baseline"] = cpu_baseline(prob, min(args.cpu_sample, B), x, u, stats, args.robot)
+                out["cpu_baseline_analytic"] = cpu_baseline_analytic(prob, min(args.cpu_sample, B), x, stats, args.robot)
         print(json.dumps(out), flush=True)
     if use_dist:
         assert gathered_ok, "gathered trajectories differ from the local result"
         dist.barrier()
         dist.destroy_process_group()
+
+
+def committed_traffic(robot, gait, sweep, batch, intervals):
+    """HBM bytes per launch from the committed PMC passes (tools/collect_profiles.sh, FETCH_SIZE x 2 + WRITE_SIZE as the guide prescribes)
+    of the bench command with this workload, or None.  profiles/traffic_index.json maps a workload key to the summary file."""
+    try:
+        index = json.load(open(os.path.join(ROOT, "profiles", "traffic_index.json")))
+        key = "%s:%s:%s:%d:%d" % (robot, "gait-sweep" if sweep else gait, "sweep" if sweep else "trot", batch, intervals)
+        name = index.get(key)
+        if not name:
+            return None
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+    ks = tj.get("all_kernels", {})
+
+    def pick(prefix, suffix=""):
+        for k, v in ks.items():
+            if k.startswith(prefix) and k.endswith(suffix):
+                return v.get("hbm_bytes_per_launch")
+        return None
+    kernels = {"linearize_materialised": pick("k_linearize_fast", "true>"), "linearize_fused": pick("k_linearize_fast", "false>"),
+               "project_lu": pick("k_project_lu"), "project": pick("k_project_fast"), "riccati": pick("k_riccati_fast"), "linesearch": pick("k_trial_fast")}
+    return {"source": "profiles/%s (builder run of the same command under rocprofv3 --pmc; not measured in this process)" % name, "kernels": kernels,
+            "materialised_hbm_bytes_per_step": tj.get("materialised_hbm_bytes_per_step"), "fused_hbm_bytes_per_step": tj.get("fused_hbm_bytes_per_step")}
+
+
+def roofline_all(nx, nu, nut_mean, kernel_ms, n_lin_nodes, n_nodes_total, fp64, prof):
+    """One roofline entry per hot kernel class of the MATERIALISED step (DESIGN.md section 4 defines the units):
+      algorithmic bytes per unit = what the stage must read and write if every operand moved exactly once, in the reference's own data
+      model (dense node matrices; nut = mean number of reduced inputs of this workload):
+        linearize   node inputs + the materialised LQ model without the structurally zero cost cross term
+        project_lu  C, D, e (16 rows each) in; Px, Pu, Pe out
+        project     A, B, b, Q, R, q, r, Px, Pu, Pe in; projected At, Bt, bt, Qt, Rt, Pt, qt, rt out (Bt, Rt, Pt, rt at nut columns / rows)
+        riccati     projected model + Px, Pu, Pe in; K, dx, du out
+        linesearch  x, u, dx, du, x_next, dx_next, xref, swing references in; 3 sums out
+      frac = algorithmic bytes / kernel time / 8 TB/s;  traffic_ratio = PMC bytes of the committed pass / algorithmic bytes (> 1: re-reads,
+      padding, scratch).  bound: as for `roofline` (largest of hbm / fp64-issue / mfma if >= 0.5, else latency)."""
+    d = 8.0
+    proj_model = nx * nx + nx * nut_mean + nx + nx * nx + nx + nut_mean * nut_mean + nut_mean * nx + nut_mean
+    pxe = nu * nx + nu * nu + nu
+    units = {
+        "linearize": (n_lin_nodes, float(BYTES_PER_NODE_H1 if nx == 22 else BYTES_PER_NODE_24), "linearize_materialised"),
+        "project_lu": (n_lin_nodes, d * (16 * (nx + nu + 1) + pxe), "project_lu"),
+        "project": (n_lin_nodes, d * (nx * nx + nx * nu + nx + nx * nx + nu * nu + nx + nu + pxe + proj_model), "project"),
+        "riccati": (n_nodes_total, d * (proj_model + pxe + nu * nx + nx + nu), "riccati"),
+        "linesearch": (n_nodes_total, d * (3 * nx + 2 * nu + 2 * nx + 8 + 3), "linesearch"),
+    }
+    out = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "mean_reduced_inputs": round(nut_mean, 3), "traffic_source": prof["source"] if prof else None}
+    dominant = max((k for k in units if kernel_ms.get(k)), key=lambda k: kernel_ms[k], default=None)
+    for cls, (n_units, bytes_per_unit, pkey) in units.items():
+        ms = kernel_ms.get(cls)
+        if not ms or not n_units:
+            continue
+        alg = bytes_per_unit * n_units
+        ach = alg / (1e-3 * ms) / 1e9
+        fr = {"hbm": round(ach / HBM_PEAK_GBS, 4)}
+        e = (fp64 or {}).get(cls) or {}
+        if "issue_frac" in e:
+            fr["fp64-issue"], fr["mfma"] = e["issue_frac"], e["mfma_frac"]
+        top = max(fr, key=fr.get)
+        tr = (prof or {}).get("kernels", {}).get(pkey)
+        out[cls] = {"ms": ms, "algorithmic_bytes_per_unit": round(bytes_per_unit), "units": int(n_units), "achieved": round(ach, 1), "frac": fr["hbm"],
+                    "bound": top if fr[top] >= 0.5 else "latency", "bound_fracs": fr, "traffic": tr,
+                    "traffic_ratio": round(tr / alg, 3) if tr else None, "dominant": cls == dominant}
+    return out
 
 
 def roofline_fp64(robot, kernel_ms, n_lin_nodes, n_nodes_total, n_stages_total, applicable):
@@ -419,6 +497,57 @@ def cpu_baseline(prob, sample, x_gpu, u_gpu, stats, robot="h1"):
             "note": "the port differentiates with 44-direction dual numbers where the reference runs CppAD-generated sparse code: likely 2-4x slower than "
                     "the reference's own LQ approximation; a large GPU/CPU ratio says nothing about kernel quality",
             "host_cpu": _host_cpu(), "host_cores": os.cpu_count(), "max_abs_x_diff_vs_gpu": worst, "value_3_threads": threads3}
+
+
+def cpu_baseline_analytic(prob, sample, x_gpu, stats, robot="h1"):
+    """A fairer single-thread CPU figure than `cpu_baseline`: the engine's own kernel bodies with ANALYTIC derivatives
+    (kernels/{centroidal_eval,node_lq,project_node,riccati}.h) compiled by g++ -O3 -march=native on this box through the lane-emulation
+    shim of the CPU test tier (tests/hostemu: test infrastructure, never linked into the product) - a stand-in for the reference's
+    CppAD-generated sparse code, where the C++ oracle differentiates with 44-direction dual numbers.  Per problem: one QP step
+    (linearise, FullPivLU projection, Riccati) and the evaluation of the full-step trial on every node (all problems of the benchmark
+    accept alpha = 1; the filter decision itself is a handful of comparisons).  `value` of the bench line is unaffected."""
+    import ctypes as C
+    import numpy as np
+    from tests import oracle_bridge as ob
+    from tests.hostemu import build_hostemu
+    from oracle import reference_py as rp
+    try:
+        lib = C.CDLL(build_hostemu.build(optimised=True))
+    except Exception as e:      # no compiler on this box
+        return {"value": None, "why": "could not build tests/hostemu with -O3 -march=native: %s" % e}
+    lib.emu_model_create.restype = C.c_void_p
+    d = os.path.join(ROOT, "assets", robot)
+    urdf = {"h1": "h1_mpc.urdf", "openloong": "openloong_mpc.urdf", "g1": "g1_mpc.urdf", "hunter": "hunter_mpc.urdf"}[robot]
+    h = C.c_void_p(lib.emu_model_create(os.path.join(d, urdf).encode(), os.path.join(d, "task.info").encode(), os.path.join(d, "reference.info").encode()))
+    if not h:
+        return {"value": None, "why": "emu_model_create failed"}
+    m = ob.model(robot)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    f = lambda a: a.ctypes.data_as(dp)      # noqa: E731
+    pre = []
+    for b in range(sample):
+        nodes = ob.oracle_nodes(prob, b, robot=robot)
+        xi, ui = rp.cold_start(m, nodes, prob["x0"][b])
+        c = lambda a, t=float: np.ascontiguousarray(a, t)      # noqa: E731
+        pre.append((int(nodes["N"]), c(nodes["kind"], np.int32), c(nodes["dt"]), c(nodes["mode"], np.int32), c(nodes["zref"]), c(nodes["zdref"]),
+                    c(nodes["xref"]), c(prob["x0"][b]), c(xi), c(ui)))
+    nxx = pre[0][8].shape[1]
+    worst, failures = 0.0, 0
+    outs = [(np.zeros_like(p[8]), np.zeros_like(p[9]), np.zeros((p[0], nxx, nxx))) for p in pre]
+    pb, pa = np.zeros(3), np.zeros(3)
+    t0 = time.perf_counter()
+    for (N, kind, dt, mode, zr, zd, xr, x0, xi, ui), (xn, un, K) in zip(pre, outs):
+        failures += int(lib.emu_solve_iteration(h, N, kind.ctypes.data_as(ip), f(dt), mode.ctypes.data_as(ip), f(zr), f(zd), f(xr), f(x0), f(xi), f(ui),
+                                                f(xn), f(un), f(K), f(pb), f(pa)) != 0)
+    spent = time.perf_counter() - t0
+    for b, (xn, _, _) in enumerate(outs):
+        if stats[b].step_size == 1.0:
+            worst = max(worst, float(np.abs(x_gpu[b, :stats[b].n_nodes + 1] - xn).max()))
+    lib.emu_model_destroy(h)
+    return {"value": round(sample / spent, 3), "unit": "solves/s", "cores": 1, "kind": "port", "ms_per_solve": round(1e3 * spent / sample, 3),
+            "sample": "%d of the same problems: QP step with analytic derivatives + full-step trial evaluation per problem, reference pre-pass excluded" % sample,
+            "what": "the engine's reference kernel bodies under lane emulation (tests/hostemu, g++ -O3 -march=native), one thread",
+            "host_cpu": _host_cpu(), "host_cores": os.cpu_count(), "failures": failures, "max_abs_x_diff_vs_gpu": worst}
 
 
 def cpu_baseline_sweep(itf, cp, sample, x_gpu, stats, robot):

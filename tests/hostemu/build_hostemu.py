@@ -7,16 +7,19 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libbpmpc_hostemu.so")
 
 
-def build(force=False):
+def build(force=False, optimised=False):
+    """optimised: -O3 -march=native into a second library, built on the box that runs it (bench.py's cpu_baseline_analytic leg)."""
     csrc = os.path.join(ROOT, "bipedal_control_amd", "csrc")
     srcs = [os.path.join(HERE, "hostemu.cpp")] + [os.path.join(csrc, f) for f in ("info_tree.cpp", "urdf_tree.cpp", "robot_model.cpp", "device_model.cpp")]
     newest = max(os.path.getmtime(p) for p in srcs)
     for root, _, files in os.walk(os.path.join(csrc, "kernels")):
         newest = max([newest] + [os.path.getmtime(os.path.join(root, f)) for f in files])
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
-        return LIB
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DBPMPC_HOST_EMULATION", "-o", LIB] + srcs)
-    return LIB
+    lib = LIB.replace(".so", "_native.so") if optimised else LIB
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= newest:
+        return lib
+    flags = ["-O3", "-march=native"] if optimised else ["-O2"]
+    subprocess.check_call(["g++"] + flags + ["-std=c++17", "-fPIC", "-shared", "-DBPMPC_HOST_EMULATION", "-o", lib] + srcs)
+    return lib
 
 
 if __name__ == "__main__":

@@ -128,4 +128,29 @@ int emu_qp_step(void* mv, int N, const int* kind, const double* dt, const int* m
   return 0;
 }
 
+// One SQP iteration of one problem through the emulated kernel bodies, as far as a timing baseline needs it (bench.py
+// `cpu_baseline_analytic`): QP step (linearise with ANALYTIC derivatives -> project -> Riccati), then the full-step trial
+// x + dx, u + du evaluated on every node (what the filter line search looks at first; every problem of the benchmark accepts it).
+// perf_before / perf_after: {cost, dynamics SSE, equality SSE} summed over the nodes.
+int emu_solve_iteration(void* mv, int N, const int* kind, const double* dt, const int* mode, const double* zref, const double* zdref,
+                        const double* xref, const double* x0, const double* x, const double* u, double* x_new, double* u_new, double* K,
+                        double* perf_before, double* perf_after) {
+  EmuModel* m = static_cast<EmuModel*>(mv);
+  const int nx = m->dm.nj + 12, nu = nx;
+  std::vector<double> dx((N + 1) * nx), du(N * nu);
+  double summary[4];
+  if (emu_qp_step(mv, N, kind, dt, mode, zref, zdref, xref, x0, x, u, dx.data(), du.data(), K, summary, perf_before) != 0) return -1;
+  if (summary[3] != 0.0) return 2;
+  for (int i = 0; i < (N + 1) * nx; ++i) x_new[i] = x[i] + dx[i];
+  for (int i = 0; i < N * nu; ++i) u_new[i] = u[i] + du[i];
+  perf_after[0] = perf_after[1] = perf_after[2] = 0.0;
+  for (int k = 0; k < N; ++k) {
+    double perf[3];
+    NodeInputs in{kind[k], mode[k], dt[k], x_new + k * nx, u_new + k * nu, x_new + (k + 1) * nx, xref + k * nx, zref + 4 * k, zdref + 4 * k};
+    if (m->dm.nj == 10) run_perf<10>(m->dm, in, perf); else run_perf<12>(m->dm, in, perf);
+    for (int i = 0; i < 3; ++i) perf_after[i] += perf[i];
+  }
+  return 0;
+}
+
 }  // extern "C"

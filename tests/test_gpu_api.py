@@ -91,7 +91,9 @@ def test_bench_contract():
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["scaling"] == "weak" and d["n_gpus"] == 1 and d["steps"] == 3
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["bound"] in ("hbm", "fp64-issue", "mfma", "latency")
+    assert set(("linearize", "riccati")) <= set(d["roofline_all"]) and any(v.get("dominant") for v in d["roofline_all"].values() if isinstance(v, dict))
+    assert d["cpu_baseline_analytic"]["max_abs_x_diff_vs_gpu"] < 1e-8 and d["cpu_baseline_analytic"]["failures"] == 0
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-4
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["max_abs_x_diff_vs_gpu"] < 1e-8
     assert "workload" in d["config"] and d["value"] > 0
