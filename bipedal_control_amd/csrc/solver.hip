@@ -34,6 +34,7 @@
 #include "kernels/riccati_fast.h"
 #include "kernels/riccati_mfma.h"
 #include "kernels/riccati_mfma8.h"
+#include "kernels/riccati_dma8.h"
 #include "kernels/project_mfma.h"
 #include "reference_gen.h"
 #include "kernels/reference_device.h"
@@ -82,6 +83,7 @@ struct Buffers {
   double *g_time, *rg_t0, *rg_start, *p_t0, *p_cmd, *lib_d;
   int *rg_gait, *rg_status, *rg_rows, *lib_i;
   double* ric_carry;   // per problem NX*NX + NX + 1: value function and status handed from one horizon chunk to the next
+  double* zero_page;   // 16 bytes of zeros: source of every LDS-DMA chunk that must read as zero (riccati_dma8.h)
   // line search
   double *trial_perf, *base, *alpha, *stats;
   int *done, *active, *iterations, *remaining;
@@ -395,6 +397,25 @@ __global__ __launch_bounds__(kRiccati8Threads) void k_riccati_fast8(Launch L) {
   riccati_mfma8<NJ>(ws, io);
 }
 
+// The same sweep with the stage data staged by LDS-DMA into triple buffers (riccati_dma8.h): nx = 22 only (151 KB of LDS).
+// MEASURED AND REJECTED (round 3, tools/ab_variants.sh on one box, batch 256): 0.358 ms against 0.333 ms of riccati_mfma8.h.  With the
+// requests switched off (wrong results) the triple-buffered structure runs at 0.318 ms - register staging was costing ~0.3 k cycles of the
+// stage, not the 1.2 k its phase profile suggested - and the requests themselves add ~0.9 k cycles per stage whoever issues them (one
+// wave 0.358, two waves 0.425, three 0.428): an LDS-DMA piece occupies the LDS write port for ~60 cycles per KB (16 B/clk, the guide's
+// "issue cost"), eight times what the forty ds_write_b128 of the register path take, and the chain's operand reads wait behind it.
+// Kept behind the macro as the record of the experiment.
+#ifndef BPMPC_RICCATI8_DMA
+#define BPMPC_RICCATI8_DMA 0
+#endif
+template <int NJ>
+__global__ __launch_bounds__(kRiccati8Threads) void k_riccati_dma8(Launch L) {
+  __shared__ RiccatiDma8Workspace<NJ> ws;
+  RiccatiFastIO io;
+  if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
+  riccati_dma8<NJ>(ws, io, L.buf.zero_page);
+}
+template <int NJ> constexpr bool riccati_dma8_fits() { return BPMPC_RICCATI8_DMA && sizeof(RiccatiDma8Workspace<NJ>) <= 160 * 1024; }
+
 // Warm start of a receding-horizon solve from the previous solution, one wavefront per (problem, node).  [OCS2-upstream, recalled]
 // SqpSolver::initializeStateInputTrajectories with a non-empty PrimalSolution: for an intermediate node with
 // intervalStart <= second-to-last and intervalEnd <= last time of the previous solution,
@@ -630,7 +651,8 @@ struct bpmpc_solver {
   int num_cus = 256;                                        // compute units of the device
   // One Riccati workgroup per problem: double buffered staging (one workgroup per CU) while every problem gets its own CU,
   // the leaner single-buffered variant (two workgroups per CU at nx = 22) for larger batches.
-  bool riccati_double_buffered() const { return batch <= num_cus; }
+  bool riccati8_always = false;                             // experiment: BPMPC_RICCATI8_ALWAYS=1 runs the eight-wave sweep (one workgroup per CU) at every batch size
+  bool riccati_double_buffered() const { return riccati8_always || batch <= num_cus; }
   bool has_solution = false;                               // a solve has completed on the current setup
   bool has_rollout = false;                                // roll_x holds the end states of a rollout
   bool rollout_unchecked = false;                          // ... whose status flags have not been read back yet
@@ -716,6 +738,7 @@ struct bpmpc_solver {
   template <int NJ> void stage_linearize();
   template <int NJ> void stage_project();
   template <int NJ> void stage_riccati();
+  template <int NJ> void launch_riccati8(const Launch& L);
   template <int NJ> void stage_linesearch();
   template <int NJ> void pipelined_backward();
   template <int NJ> void run_iterations();
@@ -764,9 +787,13 @@ template <int NJ> void bpmpc_solver::stage_project() {
 template <int NJ> void bpmpc_solver::stage_riccati() {
   const Launch L = launch_params();
   if (settings.reference_kernels) TIMED_LAUNCH("riccati", k_riccati<NJ>, batch, kRiccatiThreads, L);
-  else if (riccati_double_buffered() && BPMPC_RICCATI_WAVES8) TIMED_LAUNCH("riccati", k_riccati_fast8<NJ>, batch, kRiccati8Threads, L);
+  else if (riccati_double_buffered() && BPMPC_RICCATI_WAVES8) launch_riccati8<NJ>(L);
   else if (riccati_double_buffered()) TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, true>), batch, kRiccatiThreads, L);
   else TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, false>), batch, kRiccatiThreads, L);
+}
+template <int NJ> void bpmpc_solver::launch_riccati8(const Launch& L) {
+  if constexpr (riccati_dma8_fits<NJ>()) TIMED_LAUNCH("riccati", k_riccati_dma8<NJ>, batch, kRiccati8Threads, L);
+  else TIMED_LAUNCH("riccati", k_riccati_fast8<NJ>, batch, kRiccati8Threads, L);
 }
 template <int NJ> void bpmpc_solver::stage_linesearch() {
   const Launch L = launch_params();
@@ -828,7 +855,7 @@ template <int NJ> void bpmpc_solver::pipelined_backward() {
     HIP_CHECK(hipEventRecord(ev_chunk[c], producer_stream));
     HIP_CHECK(hipStreamWaitEvent(stream, ev_chunk[c], 0));
     if (c == 0) { L.klen = settings.max_nodes - lo; }   // problems on longer grids than n_nodes_max do not exist; keep k_hi >= N
-    if (riccati_double_buffered() && BPMPC_RICCATI_WAVES8) TIMED_LAUNCH("riccati", k_riccati_fast8<NJ>, batch, kRiccati8Threads, L);
+    if (riccati_double_buffered() && BPMPC_RICCATI_WAVES8) launch_riccati8<NJ>(L);
     else if (riccati_double_buffered()) TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, true>), batch, kRiccatiThreads, L);
     else TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, false>), batch, kRiccatiThreads, L);
   }
@@ -876,6 +903,7 @@ void allocate(bpmpc_solver* s) {
   b.tp_time = s->alloc<double>("tp_time", B * (N + 1)); b.tp_kind = s->alloc<int>("tp_kind", S, true);
   b.tp_nodes = s->alloc<int>("tp_nodes", B, true); b.tp_grid = s->alloc<int>("tp_grid", B, true);
   b.ric_carry = s->alloc<double>("ric_carry", B * (NX * NX + NX + 2));   // S, s, status, scratch word
+  b.zero_page = s->alloc<double>(nullptr, 2);
   b.roll_t = s->alloc<double>(nullptr, B); b.roll_x0 = s->alloc<double>(nullptr, B * NX); b.roll_x = s->alloc<double>("roll_x", B * NX);
   b.roll_u = s->alloc<double>("roll_u", B * NU); b.roll_steps = s->alloc<int>(nullptr, B * 2); b.roll_status = s->alloc<int>(nullptr, B);
   b.g_time = s->alloc<double>("g_time", B * (N + 1)); b.rg_t0 = s->alloc<double>(nullptr, B); b.rg_start = s->alloc<double>(nullptr, B);
@@ -1315,6 +1343,7 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     s->nx = s->rm.nx; s->nu = s->rm.nu;
     HIP_CHECK(hipSetDevice(settings->device));
     { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, settings->device)); s->num_cus = prop.multiProcessorCount; }
+    { const char* e = std::getenv("BPMPC_RICCATI8_ALWAYS"); s->riccati8_always = e && e[0] == '1'; }
     if (settings->stream) { s->stream = static_cast<hipStream_t>(settings->stream); }
     else { HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
     if (s->settings.pipeline_chunks <= 0) s->settings.pipeline_chunks = 1;
