@@ -108,9 +108,12 @@ __device__ __forceinline__ void lu_s_step(LuSLane& s, int j) {
 
 // `valid` false: the lanes run along with an empty problem and write nothing.  RM: upper bound of the velocity-row counts of the
 // launch (12 double stance, 8 single support / flight).
-template <int NJ, int RM>
+// PK: the joint rows of the packed operand [Px | Pe | Pu] go to Vt (row stride PackedLq::WP, columns below the first unwritten block
+// column 16 ceil((nx + 1 + nut) / 16)) and Px / Pu are not written at all: their force rows are zeros and single ones that every
+// reader generates from the contact mode (project_struct.h, riccati_mfma.h), 2.6 KB per node instead of 7.9.
+template <int NJ, int RM, bool PK = false>
 __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, int mode, const double* D, const double* C, const double* e, double* Px,
-                                             double* Pu, double* Pe, int* nut_out, int sub, int j) {
+                                             double* Pu, double* Pe, int* nut_out, int sub, int j, double* Vt = nullptr) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ, R = 12;
   static_assert(NJ <= 16 && NX + 1 <= 32, "lane layout");
   const bool has_d = j < NJ, has_c1 = j < NX - 16, is_e = j == NX - 16;
@@ -180,6 +183,50 @@ __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, 
   const int kc = free_col ? nsf + cpos - rank : 0;             // reduced-input column of this lane's free D column
   static_assert(NU % 2 == 0, "row passes");
   constexpr int HR = NU / 2;
+  if constexpr (PK) {
+    // packed joint rows: two passes of 24 columns through the tile (rows = joints)
+    constexpr int WP = PackedLq<NJ>::WP, BC = NX + 1, PW = 24;
+    static_assert(NJ <= (12 + NJ) / 2 && PW <= 12 + NJ + 2 && 2 * PW <= WP, "the tile holds nj rows of 24 columns");
+    // complete rows of 48 columns (three block columns, what the change of variables keeps: project_struct.h NBC_MAX), zeros beyond the
+    // reduced inputs: the readers load them without a mask (a mask is two instructions per pair on the sweep's critical path) and every
+    // row is three whole 128-byte lines
+    constexpr int cend = 2 * PW;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int c0 = pass * PW;
+      lds_wave_sync();
+#pragma unroll
+      for (int row = 0; row < NJ; ++row) { nl.tile[row][j] = 0.0; if (j < PW - 16) nl.tile[row][16 + j] = 0.0; }
+      lds_wave_sync();
+#pragma unroll
+      for (int p = 0; p < R; ++p) {
+        if (p < NJ) {
+          const int row = nl.colat[p];
+          if (p < rank) {
+            if (j >= c0 && j < c0 + PW) nl.tile[row][j - c0] = -vr0[p];                                         // Px column j
+            if ((has_c1 || is_e) && 16 + j >= c0 && 16 + j < c0 + PW) nl.tile[row][16 + j - c0] = -vr1[p];     // Px column 16 + j, Pe
+          }
+          if (free_col) {
+            const int col = BC + kc;
+            if (col >= c0 && col < c0 + PW) nl.tile[row][col - c0] = p < rank ? -vd[p] : (p == cpos ? 1.0 : 0.0);
+          }
+        }
+      }
+      lds_wave_sync();
+      if (valid) {
+        if (c0 + j < cend) {
+#pragma unroll
+          for (int row = 0; row < NJ; ++row) Vt[row * WP + c0 + j] = nl.tile[row][j];
+        }
+        if (j < PW - 16 && c0 + 16 + j < cend) {
+#pragma unroll
+          for (int row = 0; row < NJ; ++row) Vt[row * WP + c0 + 16 + j] = nl.tile[row][16 + j];
+        }
+        if (NX >= c0 && NX < c0 + PW && j < NJ) Pe[12 + j] = nl.tile[j][NX - c0];
+      }
+    }
+    if (valid && j < 12) Pe[j] = pe_force;
+  } else {
   // [Px | Pe]: force rows are zero (Pe: -F for swing components), joint row colat[p] = -y_p for p < rank
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -241,6 +288,7 @@ __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, 
         for (int row = 0; row < HR; ++row) Pu[(r0 + row) * NU + 16 + j] = nl.tile[row][16 + j];
       }
     }
+  }
   }
   if (valid && j == 0) nut_out[0] = nut;
 }

@@ -160,6 +160,7 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
         const int ru = rr - BC;
         if (rr < NX) {
           if (bj < 2) out.Qp[rr * QP + col] = col <= NX ? acc[r] + (rr == col ? reg : 0.0) : 0.0;      // reg: settings.reg_prim (HPIPM's), 0 by default
+          // (whole 128-byte segments: leaving the zero columns 24.. unwritten made the kernel SLOWER, 2.65 -> 2.87 ms at batch 4096 - partial lines)      // reg: settings.reg_prim (HPIPM's), 0 by default
         } else if (rr > NX && ru < NU) {
           out.Mt[ru * WP + col] = acc[r] + ((ru == col - BC && ru < nut) ? reg : 0.0);
         }
@@ -186,6 +187,8 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
       out.Wt[i * WP + j] = j < NX ? (i == j ? 1.0 : 0.0) : (j == NX ? in.b[i] : 0.0);
       out.Qp[i * QP + j] = (i == j) ? reg : 0.0;
     }
+    if (out.Vt)
+      for (int idx = l; idx < NJ * 48; idx += kWave) out.Vt[(idx / 48) * WP + idx % 48] = 0.0;
     return;
   }
   const int nut = out.nut[0];
@@ -212,6 +215,14 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
   for (int idx = l; idx < NU * (LDW - WC); idx += kWave) ws.X[idx / (LDW - WC)][WC + idx % (LDW - WC)] = 0.0;   // columns beyond [Px Pe Pu]
 
+  if (out.Vt) {                                        // joint rows of X in the packed layout the sweep's loaders read (columns < 16 nbc)
+    constexpr int WP = PackedLq<NJ>::WP;
+    lds_wave_sync();
+    for (int idx = l; idx < NJ * WP; idx += kWave) {
+      const int r = idx / WP, c = idx % WP;
+      if (c < 48) out.Vt[idx] = ws.X[12 + r][c];         // complete rows of three block columns (X is zero padded)
+    }
+  }
   if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
   else project_apply_blocks<NJ, WS::NBC_MAX>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
 

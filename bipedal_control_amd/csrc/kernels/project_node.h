@@ -20,6 +20,7 @@ struct ProjectIn {
   const double *C, *D, *e;        // 16*NX, 16*NU, 16
   const double *A, *B, *b, *Q, *R, *P, *q, *r;
   const double* qrd = nullptr;    // compact node-dependent part of Q, R (linearize_fast.h kQrdStride), fast kernels only
+  const double* Vt = nullptr;     // joint rows of the packed [Px | Pe | Pu] (project_lu_s.h, row stride PackedLq::WP), structured fast path only
 };
 struct ProjectOut {
   double *Px, *Pu, *Pe;           // NU*NX, NU*NU (first nut columns), NU
@@ -27,6 +28,7 @@ struct ProjectOut {
   double *At, *Bt, *bt;           // NX*NX, NX*NU (first nut columns, stride NU), NX
   double *Qt, *Rt, *Pt, *qt, *rt; // NX*NX, NU*NU (stride NU), NU*NX, NX, NU
   double *Wt = nullptr, *Qp = nullptr, *Mt = nullptr;   // the same model in the packed layout of the fast kernels (PackedLq)
+  double* Vt = nullptr;           // dense fast path: the joint rows of [Px | Pe | Pu] packed for the sweep's loaders (the structured elimination writes them itself)
 };
 
 // The projected LQ model as the fast kernels exchange it (project_mfma.h writes, riccati_mfma*.h stage it into LDS unchanged):

@@ -46,6 +46,7 @@ struct RiccatiDma8Workspace {
   double r[2][RE];                      // r~ of the stage, copied out of M before G overwrites it
   int status;
   unsigned char nut[kMaxRiccatiStages];
+  unsigned char mode[kMaxRiccatiStages];
 };
 
 // One LDS-DMA request of 16 bytes per lane: LDS[lds_dst + 16 lane] <- *gsrc.  M0 carries the destination base and belongs to the
@@ -140,42 +141,6 @@ struct DmaStageRequests {
   }
 };
 
-// [Px | Pe | Pu] through registers (riccati_mfma.h PackedStageLoader, the part that is left): pairs t, t + NLD, .. of Px and Pu.
-template <int NJ, int NLD, int LDW>
-struct PwRegisterLoader {
-  static constexpr int NX = 12 + NJ, NU = 12 + NJ, BC = NX + 1, NXX = NX * NX, NPX = NXX / 2, SX = (NPX + NLD - 1) / NLD;
-  double pxx[SX], pxy[SX], pux[SX], puy[SX], pe;
-  const double2 *gPx, *gPu;
-  const double* gPe;
-  int xo[SX], tl;
-  __device__ __forceinline__ void init(const RiccatiFastIO& io, int tl_, bool loader, size_t k) {
-    tl = tl_;
-    const int tp = loader ? tl : 0;
-    gPx = reinterpret_cast<const double2*>(io.base.Px + k * NXX) + tp;
-    gPu = reinterpret_cast<const double2*>(io.base.Pu + k * NXX) + tp;
-    gPe = io.base.Pe + k * NU + ((loader && tl < NU) ? tl : 0);
-#pragma unroll
-    for (int e = 0; e < SX; ++e) { const int p = tp + e * NLD; xo[e] = p < NPX ? ((2 * p) / NX) * LDW + (2 * p) % NX : -1; }
-  }
-  __device__ __forceinline__ void prefetch() {       // the stage the pointers stand on, then one stage down
-#pragma unroll
-    for (int e = 0; e < SX; ++e) if ((e + 1) * NLD <= NPX || xo[e] >= 0) { const double2 a = gPx[e * NLD], b = gPu[e * NLD]; pxx[e] = a.x; pxy[e] = a.y; pux[e] = b.x; puy[e] = b.y; }
-    if (tl < NU) pe = *gPe;
-    gPx -= NXX / 2; gPu -= NXX / 2; gPe -= NU;
-  }
-  __device__ __forceinline__ void stage(double (*PW)[LDW]) const {
-    double* PWf = &PW[0][0];
-#pragma unroll
-    for (int e = 0; e < SX; ++e)
-      if ((e + 1) * NLD <= NPX || xo[e] >= 0) {
-        double2 v; v.x = pxx[e]; v.y = pxy[e];
-        *reinterpret_cast<double2*>(PWf + xo[e]) = v;                // j even: the pair stays inside row i
-        PWf[xo[e] + BC] = pux[e]; PWf[xo[e] + BC + 1] = puy[e];      // odd column: two 8-byte writes
-      }
-    if (tl < NU) PW[tl][NX] = pe;
-  }
-};
-
 template <int NJ>
 __device__ __forceinline__ void riccati_dma8(RiccatiDma8Workspace<NJ>& ws, const RiccatiFastIO& io, const double* zero_page) {
   using WS = RiccatiDma8Workspace<NJ>;
@@ -209,6 +174,7 @@ __device__ __forceinline__ void riccati_dma8(RiccatiDma8Workspace<NJ>& ws, const
   for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) {
     const int n = io.base.nut[idx];
     ws.nut[idx] = (unsigned char)n;
+    ws.mode[idx] = (unsigned char)(n > 0 ? (io.mode[idx] & 3) : kModeEvent);
     too_wide |= n > RE ? 1 : 0;
   }
   if (__syncthreads_or(too_wide)) {         // more reduced inputs than this variant holds: fail loudly (status 2 in bpmpc_stats)
@@ -227,7 +193,7 @@ __device__ __forceinline__ void riccati_dma8(RiccatiDma8Workspace<NJ>& ws, const
   constexpr int NDW = BPMPC_DMA8_ISSUERS;   // waves 4 .. that issue the requests; none of them stores to global memory
   const bool role_d = w >= 4 && w < 4 + NDW;
   DmaStageRequests<NJ, NDW, LDW, LDN, RE> dma;
-  PwRegisterLoader<NJ, NLD, LDW> pw;
+  PwVtLoader<NJ, NLD, LDW> pw;
   dma.init(role_d ? w - 4 : 0, l);
   pw.init(io, tid - 4 * kWave, role_l, (size_t)(k_top > 0 ? k_top : 0));
   const unsigned ldsW0 = lds_address(&ws.W[0][0][0]), ldsQ0 = lds_address(&ws.Qq[0][0][0]), ldsM0 = lds_address(&ws.M[0][0][0]);
@@ -239,7 +205,7 @@ __device__ __forceinline__ void riccati_dma8(RiccatiDma8Workspace<NJ>& ws, const
     dma.template issue<(P == 0 ? 0 : (P == 1 ? J1 : J2)), (P == 0 ? J1 : (P == 1 ? J2 : DMA::JMAX))>(io, (size_t)k, nt, zero_page, ldsW0 + kWBytes * (unsigned)(k % 3), ldsQ0 + kQBytes * (unsigned)(k & 1),
               ldsM0 + kMBytes * (unsigned)(k & 1));
   };
-  if (role_l && k_top >= io.k_lo) pw.prefetch();
+  if (role_l && k_top >= io.k_lo) { const int n0 = io.base.nut[k_top]; pw.prefetch(n0 > 0 ? (io.mode[k_top] & 3) : kModeEvent); }
   using Part0 = std::integral_constant<int, 0>; using Part1 = std::integral_constant<int, 1>; using Part2 = std::integral_constant<int, 2>;
   if (role_d && k_top >= io.k_lo) {                                        // (the LDS copy of nut may not be visible yet)
     const int nt0 = io.base.nut[k_top];
@@ -334,7 +300,7 @@ __device__ __forceinline__ void riccati_dma8(RiccatiDma8Workspace<NJ>& ws, const
     lds_barrier();                     // B0
     // ---- P1: SW = sym(S) W, s added to the b column: up to six blocks on C0..C3, F, E
     //      L: the requests of the next stage (their buffers were last read in P3 of the stage before this one); wave 5 keeps r~, q~
-    if (role_l && k > io.k_lo) pw.prefetch();                              // never beyond the chunk: earlier stages may not be projected yet
+    if (role_l && k > io.k_lo) pw.prefetch(ws.mode[k - 1]);                              // never beyond the chunk: earlier stages may not be projected yet
     const bool ahead = role_d && k > io.k_lo;                              // wave 4 issues the requests of stage k - 1, a third here, a third in P2, a third in P3:
     const int nt_next = k > io.k_lo ? ws.nut[k - 1] : 0;                   // all of them at once kept it ~3 k cycles and the barrier B1 waited for it (0.385 ms)
     if (ahead) issue_part(k - 1, nt_next, Part0{});

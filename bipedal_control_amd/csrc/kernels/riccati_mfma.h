@@ -69,6 +69,7 @@ struct RiccatiMfmaWorkspace {
   alignas(16) double dx[2][NX];
   int status;
   unsigned char nut[kMaxRiccatiStages]; // reduced input dimensions of all stages (a global load per stage would sit on the critical path)
+  unsigned char mode[kMaxRiccatiStages]; // contact mode of the stages (the force rows of [Px | Pe | Pu] are generated from it)
 };
 
 // D-layout of v_mfma_f64_16x16x4_f64: lane l, register r  <->  row (l / 16) + 4 r, column l % 16 of the 16x16 block.
@@ -94,6 +95,67 @@ __device__ __forceinline__ void blk_store(double* Mx, int r0, int c0, int l, v4d
   }
 }
 
+constexpr int kModeEvent = 4;                 // contact mode code of an event node (no inputs: no ones in the force rows)
+
+// [Px | Pe | Pu] of a stage for the sweeps.  Its joint rows arrive packed from the elimination kernel (Vt: row stride WP, the column
+// layout of the LDS operand, a 16-byte pair of HBM is a 16-byte pair of LDS, complete rows: zeros beyond the reduced inputs); its
+// FORCE rows are not stored anywhere: row c < 12 is zero except Pe_c in column nx and, for a component of a stance contact, a single 1
+// in its own reduced-input column nx + 1 + (c - first stance component) (project_lu_s.h) - generated from the contact mode of the stage.
+// Loader thread t owns the pairs t, t + NLD, .. of both parts and rewrites all of them at every stage (the buffers are reused across
+// modes).  The staging (registers -> LDS) sits on the sweep's critical path - a loader wave issues an instruction every ~8 cycles and
+// the staging barrier waits for it -, so everything that can be decided a stage ahead is decided in prefetch(): the first value of a
+// force-row pair is LOADED (Pe_c for the pair that opens at column nx, otherwise 0.0 or 1.0 from a two-entry table), the second is a
+// register set there; stage() is four ds_write_b128 with fixed addresses.  (First version: masks, mode look-ups and selects in stage(),
+// +60 instructions = +0.5 k cycles per stage, 0.334 -> 0.354 ms per sweep.)
+template <int NJ, int NLD, int LDW>
+struct PwVtLoader {
+  using PL = PackedLq<NJ>;
+  static constexpr int NX = PL::NX, NU = PL::NU, WP = PL::WP, BC = NX + 1, HW = WP / 2;
+  static constexpr int NPV = NJ * HW, NPF = 12 * HW;
+  static constexpr int SV = (NPV + NLD - 1) / NLD, SF = (NPF + NLD - 1) / NLD;
+  static_assert(NX % 2 == 0 && LDW % 2 == 0 && WP <= LDW, "column nx opens a pair; pairs stay aligned and inside the rows");
+  double vx[SV], vy[SV], fx[SF], fy[SF];
+  const double2* gV;
+  const double* gPe;
+  const double* zero_one;                       // {0.0, 1.0} in global memory
+  int vo[SV], fo[SF], fc[SF], fr[SF];           // LDS element offset of the pair (-1: none); force rows: first column, component
+  int tl;
+  __device__ __forceinline__ void init(const RiccatiFastIO& io, int tl_, bool loader, size_t k) {
+    tl = tl_;
+    const int tp = loader ? tl : 0;
+    gV = reinterpret_cast<const double2*>(io.Vt + k * (NJ * WP)) + tp;
+    gPe = io.base.Pe + k * NU;
+    zero_one = io.zero_one;
+#pragma unroll
+    for (int e = 0; e < SV; ++e) { const int p = tp + e * NLD; vo[e] = p < NPV ? (12 + p / HW) * LDW + 2 * (p % HW) : -1; }
+#pragma unroll
+    for (int e = 0; e < SF; ++e) { const int p = tp + e * NLD; fo[e] = p < NPF ? (p / HW) * LDW + 2 * (p % HW) : -1; fc[e] = 2 * (p % HW); fr[e] = p < NPF ? p / HW : 0; }
+  }
+  // the stage the pointers stand on (contact mode code `mode`: 0..3, kModeEvent for an event node), then one stage down
+  __device__ __forceinline__ void prefetch(int mode) {
+    const int c0s = mode == 2 ? 6 : 0, nsf = mode == 3 ? 12 : ((mode == 0 || mode >= kModeEvent) ? 0 : 6);
+#pragma unroll
+    for (int e = 0; e < SV; ++e) { const double2 v = gV[vo[e] >= 0 ? e * NLD : -tl]; vx[e] = v.x; vy[e] = v.y; }     // (a lane without a pair re-reads pair 0 of the node)
+#pragma unroll
+    for (int e = 0; e < SF; ++e) {
+      const int s = fr[e] - c0s;                                       // position among the stance components
+      const int ucol = (s >= 0 && s < nsf) ? BC + s : -1;
+      fx[e] = *(fc[e] == NX ? gPe + fr[e] : zero_one + (fc[e] == ucol ? 1 : 0));
+      fy[e] = fc[e] + 1 == ucol ? 1.0 : 0.0;
+    }
+    gV -= (NJ * WP) / 2; gPe -= NU;
+  }
+  __device__ __forceinline__ void stage(double (*PW)[LDW]) const {
+    double* PWf = &PW[0][0];
+#pragma unroll
+    for (int e = 0; e < SV; ++e)
+      if ((e + 1) * NLD <= NPV || vo[e] >= 0) { double2 v; v.x = vx[e]; v.y = vy[e]; *reinterpret_cast<double2*>(PWf + vo[e]) = v; }
+#pragma unroll
+    for (int e = 0; e < SF; ++e)
+      if ((e + 1) * NLD <= NPF || fo[e] >= 0) { double2 v; v.x = fx[e]; v.y = fy[e]; *reinterpret_cast<double2*>(PWf + fo[e]) = v; }
+  }
+};
+
 // Prefetch registers and staging of the loader threads of the sweeps (riccati_mfma.h, riccati_mfma8.h).  The projected model
 // arrives in the packed layout of project_node.h (PackedLq: Wt = [At | bt | Bt], Qp = [Qt | qt], Mt = [Pt | rt | Rt], row strides
 // of whole block columns), which is the column layout of the LDS operands: a 16-byte pair of HBM is a 16-byte pair of LDS, one
@@ -106,24 +168,21 @@ struct PackedStageLoader {
   static constexpr int NX = PL::NX, NU = PL::NU, WP = PL::WP, QP = PL::QP, BC = NX + 1, NXX = NX * NX;
   static constexpr int HW = WP / 2, HQ = QP / 2;                    // pairs per row in HBM
   static constexpr int HQU = (NX + 2) / 2;                          // pairs per row of Qp that carry anything ([Q~ | q~]: nx + 1 columns)
-  static constexpr int NPW = NX * HW, NPQ = NX * HQU, NPM = MR * HW, NPX = NXX / 2;
-  static constexpr int SW = (NPW + NLD - 1) / NLD, SQ = (NPQ + NLD - 1) / NLD, SM = (NPM + NLD - 1) / NLD, SX = (NPX + NLD - 1) / NLD;
+  static constexpr int NPW = NX * HW, NPQ = NX * HQU, NPM = MR * HW;
+  static constexpr int SW = (NPW + NLD - 1) / NLD, SQ = (NPQ + NLD - 1) / NLD, SM = (NPM + NLD - 1) / NLD;
   static_assert(LDW % 2 == 0 && LDN % 2 == 0 && NX % 2 == 0 && WP <= LDW && QP <= LDN && MR <= NU, "pairs stay aligned and inside the rows");
   // (x / y halves in separate arrays of doubles: arrays of double2 that live across the stage loop end up in scratch memory)
-  double wx[SW], wy[SW], qx[SQ], qy[SQ], mx[SM], my[SM], pxx[SX], pxy[SX], pux[SX], puy[SX];
-  double pe;
-  const double2 *gW, *gQ, *gM, *gPx, *gPu;
-  const double* gPe;
+  double wx[SW], wy[SW], qx[SQ], qy[SQ], mx[SM], my[SM];
+  const double2 *gW, *gQ, *gM;
+  PwVtLoader<NJ, NLD, LDW> pw;                                      // [Px | Pe | Pu]
   // per slot, fixed for the whole sweep: LDS element offset of the pair, its column (and row, for Mt) for the masks; -1: no pair
-  int wo[SW], wc[SW], qo[SQ], mo[SM], mc[SM], mr[SM], xo[SX];
+  int wo[SW], wc[SW], qo[SQ], mo[SM], mc[SM], mr[SM];
   int tl;
 
   __device__ __forceinline__ void init(const RiccatiFastIO& io, int tl_, bool loader, size_t k) {
     tl = tl_;
     const int tp = loader ? tl : 0;
-    gPx = reinterpret_cast<const double2*>(io.base.Px + k * NXX) + tp;
-    gPu = reinterpret_cast<const double2*>(io.base.Pu + k * NXX) + tp;
-    gPe = io.base.Pe + k * NU + ((loader && tl < NU) ? tl : 0);
+    pw.init(io, tl_, loader, k);
     gW = reinterpret_cast<const double2*>(io.Wt + k * PL::W_SIZE) + tp;
     gM = reinterpret_cast<const double2*>(io.Mt + k * PL::M_SIZE) + tp;
     // Qp: the thread's pairs are not t + e NLD of the HBM rows (the last pairs of a row carry nothing), so the pointer stands on
@@ -135,11 +194,9 @@ struct PackedStageLoader {
     for (int e = 0; e < SQ; ++e) { const int p = tp + e * NLD; const bool ok = p < NPQ; qo[e] = ok ? (p / HQU) * LDN + 2 * (p % HQU) : -1; }
 #pragma unroll
     for (int e = 0; e < SM; ++e) { const int p = tp + e * NLD; const bool ok = p < NPM; mo[e] = ok ? (p / HW) * LDW + 2 * (p % HW) : -1; mc[e] = 2 * (p % HW); mr[e] = p / HW; }
-#pragma unroll
-    for (int e = 0; e < SX; ++e) { const int p = tp + e * NLD; const bool ok = p < NPX; xo[e] = ok ? ((2 * p) / NX) * LDW + (2 * p) % NX : -1; }
   }
   // loads of the stage the pointers stand on (its reduced input dimension: nt), then one stage down
-  __device__ __forceinline__ void prefetch(int nt) {
+  __device__ __forceinline__ void prefetch(int nt, int mode) {
     const int cend = 16 * ((BC + nt + 15) >> 4);                     // first column that is not written / not needed
 #pragma unroll
     for (int e = 0; e < SW; ++e) if (((e + 1) * NLD <= NPW || wo[e] >= 0) && wc[e] < cend) { const double2 v = gW[e * NLD]; wx[e] = v.x; wy[e] = v.y; }
@@ -147,15 +204,13 @@ struct PackedStageLoader {
     for (int e = 0; e < SQ; ++e) if ((e + 1) * NLD <= NPQ || qo[e] >= 0) { const int p = tl + e * NLD; const double2 v = gQ[(p / HQU) * HQ + p % HQU]; qx[e] = v.x; qy[e] = v.y; }
 #pragma unroll
     for (int e = 0; e < SM; ++e) if (((e + 1) * NLD <= NPM || mo[e] >= 0) && mr[e] < nt && mc[e] < cend) { const double2 v = gM[e * NLD]; mx[e] = v.x; my[e] = v.y; }
-#pragma unroll
-    for (int e = 0; e < SX; ++e) if ((e + 1) * NLD <= NPX || xo[e] >= 0) { const double2 a = gPx[e * NLD], b = gPu[e * NLD]; pxx[e] = a.x; pxy[e] = a.y; pux[e] = b.x; puy[e] = b.y; }
-    if (tl < NU) pe = *gPe;
-    gW -= PL::W_SIZE / 2; gQ -= PL::Q_SIZE / 2; gM -= PL::M_SIZE / 2; gPx -= NXX / 2; gPu -= NXX / 2; gPe -= NU;
+    pw.prefetch(mode);
+    gW -= PL::W_SIZE / 2; gQ -= PL::Q_SIZE / 2; gM -= PL::M_SIZE / 2;
   }
   // registers -> LDS: W = [A~ | b~ | B~], Qq = [Q~ | q~], M = [P~ | r~ | R~] (MR rows), PW = [Px | Pe | Pu], r~ also to rvec
   __device__ __forceinline__ void stage(double (*W)[LDW], double (*PW)[LDW], double (*Qq)[LDN], double (*M)[LDW], double* rvec, int nt) const {
     const int cend = 16 * ((BC + nt + 15) >> 4);
-    double* Wf = &W[0][0]; double* PWf = &PW[0][0]; double* Qf = &Qq[0][0]; double* Mf = &M[0][0];
+    double* Wf = &W[0][0]; double* Qf = &Qq[0][0]; double* Mf = &M[0][0];
 #pragma unroll
     for (int e = 0; e < SW; ++e)
       if ((e + 1) * NLD <= NPW || wo[e] >= 0) {     // only the last slot of a stream is partial; (a select between two double2 goes through scratch memory: component-wise)
@@ -172,14 +227,7 @@ struct PackedStageLoader {
         *reinterpret_cast<double2*>(Mf + mo[e]) = v;
         if (mc[e] == NX) rvec[mr[e]] = v.x;                          // r~ (nx is even: the first element of its pair)
       }
-#pragma unroll
-    for (int e = 0; e < SX; ++e)
-      if ((e + 1) * NLD <= NPX || xo[e] >= 0) {
-        double2 v; v.x = pxx[e]; v.y = pxy[e];
-        *reinterpret_cast<double2*>(PWf + xo[e]) = v;                // j even: the pair stays inside row i
-        PWf[xo[e] + BC] = pux[e]; PWf[xo[e] + BC + 1] = puy[e];      // odd column: two 8-byte writes
-      }
-    if (tl < NU) PW[tl][NX] = pe;
+    pw.stage(PW);
   }
 };
 
@@ -273,6 +321,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
   for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) {
     const int n = io.base.nut[idx];
     ws.nut[idx] = (unsigned char)n;
+    ws.mode[idx] = (unsigned char)(n > 0 ? (io.mode[idx] & 3) : kModeEvent);      // (an event node has no inputs)
     too_wide |= (RBM < NU && n > RBM) ? 1 : 0;
   }
   if (RBM < NU && __syncthreads_or(too_wide)) {         // more reduced inputs than this variant holds: fail loudly (status 2 in bpmpc_stats)
@@ -291,7 +340,11 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
   const bool loader = w < 3;
   PackedStageLoader<NJ, NLD, (RBM < NU ? RBM : NU), LDW, LDN> ld;
   ld.init(io, tid, loader, (size_t)(k_top > 0 ? k_top : 0));
-  if (loader && k_top >= io.k_lo) ld.prefetch(io.base.nut[k_top > 0 ? k_top : 0]);     // the stage the loader's pointers stand on (the LDS copy of nut may not be visible yet)
+  if (loader && k_top >= io.k_lo) {     // the stage the loader's pointers stand on (the LDS copies of nut and mode may not be visible yet)
+    const int kt = k_top > 0 ? k_top : 0, n0 = io.base.nut[kt];
+    ld.prefetch(n0, n0 > 0 ? (io.mode[kt] & 3) : kModeEvent);
+  }
+  auto prefetch_next = [&](int k) { ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]); };
   __syncthreads();
 #ifdef BPMPC_RICCATI_PROFILE
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -436,7 +489,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
       if (w != 3) {                    // wave 2 is a loader: its share of the global memory traffic first
         flush_held();
 #if BPMPC_RICCATI_ABLATE != 3
-        if (loader && k > io.k_lo) ld.prefetch(ws.nut[k - 1]);
+        if (loader && k > io.k_lo) prefetch_next(k);
 #endif
       }
       const int c16 = l & 15;
@@ -463,7 +516,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
       // as early as possible: outputs of the previous stage, then the operands of the next one
       flush_held();
 #if BPMPC_RICCATI_ABLATE != 3
-      if (loader && k > io.k_lo) ld.prefetch(ws.nut[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
+      if (loader && k > io.k_lo) prefetch_next(k);     // never beyond the chunk: earlier stages may not be projected yet
 #endif
       for (int id = w; id < 4; id += sn_waves) {
         const int r0 = 16 * (id >> 1), c0 = 16 * (id & 1);

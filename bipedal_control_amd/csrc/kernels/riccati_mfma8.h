@@ -51,6 +51,7 @@ struct RiccatiMfma8Workspace {
   double r[2][NU];
   int status;
   unsigned char nut[kMaxRiccatiStages];
+  unsigned char mode[kMaxRiccatiStages];
 };
 
 // Forward elimination of [H | G g], one column per lane (layout of gauss_jordan_wave).  After step p row p is divided by its
@@ -124,6 +125,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) {
     const int n = io.base.nut[idx];
     ws.nut[idx] = (unsigned char)n;
+    ws.mode[idx] = (unsigned char)(n > 0 ? (io.mode[idx] & 3) : kModeEvent);
     too_wide |= n > RE ? 1 : 0;
   }
   if (__syncthreads_or(too_wide)) {         // more reduced inputs than this variant holds: fail loudly (status 2 in bpmpc_stats)
@@ -141,7 +143,10 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   constexpr int NLD = BPMPC_RICCATI8_LOADERS * kWave;
   PackedStageLoader<NJ, NLD, RE, LDW, LDN> ld;
   ld.init(io, tid - 4 * kWave, role_l, (size_t)(k_top > 0 ? k_top : 0));
-  if (role_l && k_top >= io.k_lo) ld.prefetch(io.base.nut[k_top > 0 ? k_top : 0]);     // the stage the loader's pointers stand on (the LDS copy of nut may not be visible yet)
+  if (role_l && k_top >= io.k_lo) {     // the stage the loader's pointers stand on (the LDS copies of nut and mode may not be visible yet)
+    const int kt = k_top > 0 ? k_top : 0, n0 = io.base.nut[kt];
+    ld.prefetch(n0, n0 > 0 ? (io.mode[kt] & 3) : kModeEvent);
+  }
   __syncthreads();
 #ifdef BPMPC_RICCATI_PROFILE
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -240,7 +245,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     lds_barrier();                     // B0
     RM8PROF(0);
     // ---- P1: SW = sym(S) W, s added to the b column: up to six blocks on C0..C3, F, E (L: the loads of the next stage)
-    if (role_l && k > io.k_lo) ld.prefetch(ws.nut[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
+    if (role_l && k > io.k_lo) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
     if (w != 4 && w != 5) {
       const int id = w < 4 ? w : w - 2;
       if (id < 2 * nbc) {

@@ -162,7 +162,19 @@ def test_full_size_properties(ctx):
     violated = (np.abs(res_eq) > 1e-8).sum(axis=2)
     dropped = nc - (nu - nut)
     assert np.all(violated[:, inter] <= dropped[:, inter]) and dropped[:, inter].max() <= 2
-    Pu = mpc.read("Pu").reshape(B, 112, nu, nu)[:, :n]
+    # null-space basis of the projection: its joint rows come packed from the elimination kernel (Vt = joint rows of [Px | Pe | Pu], row
+    # stride 48), its force rows are single ones in the columns of the stance components (generated by every reader from the contact mode)
+    Vt = mpc.read("Vt").reshape(B, 112, nu - 12, 48)[:, :n]
+    mode = mpc.read("g_mode")[:n].astype(int) & 3
+    Pu = np.zeros((B, n, nu, nu))
+    for k in range(n):
+        if kind[k] != 0:
+            continue
+        first, count = (6 if mode[k] == 2 else 0), {0: 0, 1: 6, 2: 6, 3: 12}[mode[k]]
+        for b_ in range(B):
+            nt = int(nut[b_, k])
+            Pu[b_, k, first + np.arange(count), np.arange(count)] = 1.0
+            Pu[b_, k, 12:, :nt] = Vt[b_, k, :, nx + 1:nx + 1 + nt]
     DPu = np.einsum("bkij,bkjl->bkil", D[:, :n], Pu)
     assert np.abs(DPu[:, inter]).max() < 1e-10
     mpc.reset(); mpc.enqueue(); mpc.synchronize()
@@ -334,7 +346,7 @@ def test_fused_and_materialised_modes_are_bit_identical(ctx, robot, gait):
         t, x, u, K, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
         n = st[0].n_nodes
         mpc.stage("linearize"); mpc.stage("project"); mpc.synchronize()
-        extra = {k: mpc.read(k) for k in ("b", "q", "r", "perf", "nc", "Px", "Pu", "Pe", "nut", "Wt", "Qp", "Mt")}      # the projected model in the packed layout of the fast kernels
+        extra = {k: mpc.read(k) for k in ("b", "q", "r", "perf", "nc", "Vt", "Pe", "nut", "Wt", "Qp", "Mt")}      # the projected model in the packed layout of the fast kernels
         A = mpc.read("A").reshape(5, 72, nx, nx)[:, :n, 3:12].copy()          # the dense rows are written in both modes
         out[mat] = (x, u, K, [(s.step_size, s.merit_after, s.dynamics_sse_after, s.equality_sse_after, s.iterations) for s in st], extra, A, mpc)
     a, b = out[True], out[False]
@@ -379,3 +391,45 @@ def test_reg_prim_setting_matches_oracle(ctx):
     assert 0.0 < _rel(outs[1], outs[0]) < 1e-7 < _rel(outs[2], outs[0])
     with pytest.raises(bp.BpmpcError):
         bp.BatchedSqpMpc(itf, max_batch=1, max_nodes=8, reg_prim=1e-12, reference_kernels=True)
+
+
+@pytest.mark.parametrize("robot,gait", [("h1", "trot"), ("h1", "standing_trot"), ("h1", "flying_trot"), ("hunter", "trot"), ("g1", "standing_trot"),
+                                         ("openloong", "flying_trot")])
+def test_structured_and_dense_change_of_variables_agree(ctx, robot, gait, monkeypatch):
+    """project_struct.h (inner dimension = joint rows only, force rows assembled: 42 matrix-core instructions per node) against
+    project_mfma.h (dense, 120): the packed projected model Wt = [At | bt | Bt], Qp = [Qt | qt], Mt = [Pt | rt | Rt] of every node, in
+    the region the sweep reads (block columns < nbc, rows < nut of Mt), on all four contact modes, after one accepted step."""
+    bp, sc = ctx["bp"], ctx["sc"]
+    itf = sc.interface(robot)
+    nx = itf.stateDim
+    wp = ((2 * nx + 1 + 15) // 16) * 16
+    B, N = 3, 64
+    prob = sc.trot_problem(itf, batch=B, n_intervals=45, gait=gait)
+    got = {}
+    for dense in ("0", "1"):
+        monkeypatch.setenv("BPMPC_DENSE_PROJECT", dense)
+        mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=N)
+        lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+        mpc.enqueue(); mpc.synchronize()                                  # away from the cold start
+        mpc.stage("linearize"); mpc.stage("project"); mpc.synchronize()
+        got[dense] = {k: mpc.read(k) for k in ("Wt", "Qp", "Mt", "nut", "g_kind", "g_mode")}
+        n = lay["n_nodes_max"]
+    nut = got["0"]["nut"].reshape(B, N)[:, :n].astype(int)
+    assert np.array_equal(nut, got["1"]["nut"].reshape(B, N)[:, :n])
+    kind = got["0"]["g_kind"][:n].astype(int)
+    modes = set(got["0"]["g_mode"][:n].astype(int)[kind == 0] & 3)
+    assert modes >= ({0, 1, 2} if "flying" in gait else ({1, 2} if gait == "trot" else {1, 2, 3}))
+    W = {d: got[d]["Wt"].reshape(B, N, nx, wp)[:, :n] for d in got}
+    Q = {d: got[d]["Qp"].reshape(B, N, nx, 32)[:, :n] for d in got}
+    M = {d: got[d]["Mt"].reshape(B, N, nx, wp)[:, :n] for d in got}
+    worst = 0.0
+    for b in range(B):
+        for k in range(n):
+            nt = nut[b, k]
+            cend = 16 * ((nx + 1 + nt + 15) // 16) if kind[k] == 0 else 32
+            pairs = [(W["0"][b, k, :, :cend], W["1"][b, k, :, :cend]), (Q["0"][b, k, :, :nx + 1], Q["1"][b, k, :, :nx + 1])]
+            if kind[k] == 0:
+                pairs.append((M["0"][b, k, :nt, :cend], M["1"][b, k, :nt, :cend]))
+            for a, d in pairs:
+                worst = max(worst, _rel(a, d))
+    assert worst < 1e-12, worst
