@@ -98,10 +98,14 @@ def _f64(a):
 class BipedalRobotInterface:
     """Problem definition: model constants + settings (BipedalRobotInterface.cpp:67-204)."""
 
-    def __init__(self, taskFile, urdfFile, referenceFile):
+    def __init__(self, taskFile, urdfFile, referenceFile, useHardFrictionConeConstraint=False):
+        """Fourth argument as in the reference (BipedalRobotInterface.h:66-69): friction cones as inequality constraints, which the SQP
+        solver penalises with sqp.inequalityConstraintMu / Delta (include/bpmpc.h bpmpc_model_create_ex)."""
         lib = load_library()
         self._h = C.c_void_p()
-        _check(lib.bpmpc_model_create(str(urdfFile).encode(), str(taskFile).encode(), str(referenceFile).encode(), C.byref(self._h)))
+        self.useHardFrictionConeConstraint = bool(useHardFrictionConeConstraint)
+        _check(lib.bpmpc_model_create_ex(str(urdfFile).encode(), str(taskFile).encode(), str(referenceFile).encode(),
+                                         1 if useHardFrictionConeConstraint else 0, C.byref(self._h)))
         nx, nu, nc, nj = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _check(lib.bpmpc_model_dims(self._h, C.byref(nx), C.byref(nu), C.byref(nc), C.byref(nj)))
         self.stateDim, self.inputDim, self.numThreeDofContacts, self.actuatedDofNum = nx.value, nu.value, nc.value, nj.value

@@ -60,6 +60,11 @@ int bpmpc_model_create(const char* urdf, const char* task, const char* reference
     return (int)BPMPC_OK;
   });
 }
+int bpmpc_model_create_ex(const char* urdf, const char* task, const char* reference, int use_hard_friction_cone, bpmpc_model** out) {
+  const int rc = bpmpc_model_create(urdf, task, reference, out);
+  if (rc == BPMPC_OK) (*out)->rm.hard_friction_cone = use_hard_friction_cone != 0;
+  return rc;
+}
 void bpmpc_model_destroy(bpmpc_model* m) { delete m; }
 
 int bpmpc_model_dims(const bpmpc_model* m, int* nx, int* nu, int* n_contacts, int* n_joints) {
@@ -98,6 +103,7 @@ int bpmpc_model_get(const bpmpc_model* m, const char* name, double* out, int cap
     if (n == "joint_parent") { std::vector<double> t(nj); for (int j = 0; j < nj; ++j) t[j] = r.parent[j + 1]; return copy_out(t.data(), nj, out, capacity); }
     if (n == "contact_body") { std::vector<double> t(kNumContacts); for (int c = 0; c < kNumContacts; ++c) t[c] = r.contact_body[c]; return copy_out(t.data(), t.size(), out, capacity); }
     if (n == "cone") return list({r.friction_coefficient, r.cone_regularization, r.cone_gripper_force, r.cone_hessian_shift, r.barrier_mu, r.barrier_delta});
+    if (n == "hard_cone") return list({r.hard_friction_cone ? 1.0 : 0.0, r.sqp_inequality_mu, r.sqp_inequality_delta});
     if (n == "swing") return list({r.swing.lift_off_velocity, r.swing.touch_down_velocity, r.swing.swing_height, r.swing.swing_time_scale});
     if (n == "rollout") return list({r.rollout.abs_tol, r.rollout.rel_tol, r.rollout.time_step, (double)r.rollout.max_steps_per_second, r.mrt_frequency, r.mpc_frequency});
     if (n == "sqp") return list({r.sqp.dt, (double)r.sqp.sqp_iteration, r.sqp.delta_tol, r.sqp.g_max, r.sqp.g_min});

@@ -47,6 +47,13 @@ DeviceModel make_device_model(const RobotModel& m) {
   d.cone_shift = m.cone_hessian_shift;
   d.barrier_mu = m.barrier_mu;
   d.barrier_delta = m.barrier_delta;
+  d.cone_gauss_newton = 0;
+  if (m.hard_friction_cone) {     // see device_model.h; [OCS2-upstream, recalled] multiple_shooting::setupIntermediateNode, inequality constraints as penalty
+    d.barrier_mu = m.sqp_inequality_mu;
+    d.barrier_delta = m.sqp_inequality_delta;
+    d.cone_shift = 0.0;
+    d.cone_gauss_newton = 1;
+  }
   d.pos_gain = m.position_error_gain;
   d.robot_mass = m.robot_mass;
   return d;

@@ -21,6 +21,9 @@ struct DeviceModel {
   double Q[kMaxState * kMaxState];     // nx x nx, row major with stride nx
   double R[kMaxState * kMaxState];     // nu x nu, row major with stride nu
   double friction, cone_reg, cone_grip, cone_shift, barrier_mu, barrier_delta, pos_gain, robot_mass;
+  // hard friction cone (inequality constraint, penalised by the SQP solver through its LINEAR approximation): barrier_mu / barrier_delta hold
+  // sqp.inequalityConstraintMu / Delta, cone_shift is 0 and the second derivative of the cone does not enter the Hessian (Gauss-Newton)
+  int cone_gauss_newton;
 };
 
 DeviceModel make_device_model(const RobotModel& m);

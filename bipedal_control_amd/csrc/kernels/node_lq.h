@@ -48,6 +48,7 @@ struct NodeWorkspace {
 
 // [OCS2-upstream] RelaxedBarrierPenalty
 BP_DEVICE void relaxed_barrier(double mu, double delta, double h, double* p, double* dp, double* ddp) {
+  if (!(mu > 0.0)) { *p = 0.0; *dp = 0.0; *ddp = 0.0; return; }      // no penalty configured (hard cone with sqp.inequalityConstraintMu = 0, the upstream default)
   if (h > delta) {
     *p = -mu * log(h);
     *dp = -mu / h;
@@ -86,6 +87,9 @@ BP_DEVICE void cone_terms(const DeviceModel& md, const double* F, bool deriv, do
     out[10] = -(Fx2 + md.cone_reg) / T32; // yy
     out[11] = 0.0;                        // yz
     out[12] = 0.0;                        // zz
+    if (md.cone_gauss_newton) {           // hard cone: penalty of the LINEAR approximation of the constraint, p'' dh dh' only (device_model.h)
+      out[7] = 0.0; out[8] = 0.0; out[10] = 0.0;
+    }
   }
 }
 

@@ -209,6 +209,8 @@ RobotModel load_robot_model(const std::string& urdf_path, const std::string& tas
   task->get("sqp.deltaTol", &m.sqp.delta_tol);
   task->get("sqp.g_max", &m.sqp.g_max);
   task->get("sqp.g_min", &m.sqp.g_min);
+  task->get("sqp.inequalityConstraintMu", &m.sqp_inequality_mu);
+  task->get("sqp.inequalityConstraintDelta", &m.sqp_inequality_delta);
   task->get("mpc.timeHorizon", &m.time_horizon);
   task->get("mpc.mrtDesiredFrequency", &m.mrt_frequency);
   task->get("mpc.mpcDesiredFrequency", &m.mpc_frequency);

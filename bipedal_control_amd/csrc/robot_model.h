@@ -47,6 +47,11 @@ struct RobotModel {
   double com_height = 0, target_displacement_velocity = 0, target_rotation_velocity = 0;
   double friction_coefficient = 0.7, cone_regularization = 25.0, cone_gripper_force = 0.0, cone_hessian_shift = 1e-6;
   double barrier_mu = 0.1, barrier_delta = 5.0;
+  // BipedalRobotInterface(..., useHardFrictionConeConstraint) (BipedalRobotInterface.cpp:68-69,181-182): the cone is an inequality
+  // constraint of the problem instead of a soft constraint; the SQP solver penalises it with sqp.inequalityConstraintMu / Delta
+  // (task.info:74-75; [OCS2-upstream] defaults 0 - no penalty - and 1e-6)
+  bool hard_friction_cone = false;
+  double sqp_inequality_mu = 0.0, sqp_inequality_delta = 1e-6;
   double position_error_gain = 0, phase_transition_stance_time = 0;
   double time_horizon = 1.0;
   SwingConfig swing;

@@ -31,8 +31,10 @@ def h1_interface():
 
 
 def interface(robot="h1"):
-    r = ROBOTS[robot]
-    itf = BipedalRobotInterface(r["task"], r["urdf"], r["reference"])
+    """robot name, optionally with the suffix ":hard" = useHardFrictionConeConstraint (friction cones as inequality constraints)."""
+    name, _, variant = robot.partition(":")
+    r = ROBOTS[name]
+    itf = BipedalRobotInterface(r["task"], r["urdf"], r["reference"], useHardFrictionConeConstraint=(variant == "hard"))
     itf.gaitFile = r["gait"]
     return itf
 

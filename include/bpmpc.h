@@ -42,6 +42,14 @@ const char* bpmpc_version(void);
 typedef struct bpmpc_model bpmpc_model;
 
 int bpmpc_model_create(const char* urdf_path, const char* task_info_path, const char* reference_info_path, bpmpc_model** out);
+/* The same with the fourth constructor argument of the reference, useHardFrictionConeConstraint (BipedalRobotInterface.h:66-69, default
+ * false; BipedalRobotInterface.cpp:181-182): the friction cone of every stance contact is an INEQUALITY constraint of the problem instead of
+ * a soft constraint.  The SQP solver handles it as [OCS2-upstream, recalled] ocs2_sqp does: the relaxed barrier of task.info's
+ * sqp.inequalityConstraintMu / sqp.inequalityConstraintDelta (:74-75) on the LINEAR approximation of the constraint, times dt, added to the
+ * stage cost before the projection (value, gradient p'(h) dh/du, Gauss-Newton Hessian p''(h) dh dh'; neither the cone's own second
+ * derivative nor its hessianDiagonalShift).  Mu = 0 (the upstream default when the key is absent) means no penalty at all. */
+int bpmpc_model_create_ex(const char* urdf_path, const char* task_info_path, const char* reference_info_path, int use_hard_friction_cone,
+                          bpmpc_model** out);
 void bpmpc_model_destroy(bpmpc_model* model);
 /* CentroidalModelInfo.stateDim / inputDim / numThreeDofContacts / actuatedDofNum */
 int bpmpc_model_dims(const bpmpc_model* model, int* nx, int* nu, int* n_contacts, int* n_joints);

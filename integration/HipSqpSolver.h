@@ -33,6 +33,7 @@ struct HipSqpSolverSettings {
   int maxNodes = 160;        // shooting intervals incl. event nodes: timeHorizon / sqp.dt + 2 per gait event inside the horizon
   int sqpIterations = 0;     // <= 0: sqp.sqpIteration of task.info
   bool useFeedbackPolicy = true;   // sqp.useFeedbackPolicy (task.info:80): LinearController, otherwise FeedforwardController
+  bool useHardFrictionConeConstraint = false;   // the interface's fourth constructor argument (BipedalRobotInterface.h:66-69): cones as inequality constraints
 };
 
 class HipSqpSolver final : public SolverBase {
@@ -44,7 +45,7 @@ class HipSqpSolver final : public SolverBase {
   HipSqpSolver(const std::string& taskFile, const std::string& urdfFile, const std::string& referenceFile, const OptimalControlProblem& ocp,
                Settings settings = Settings())
       : settings_(settings), ocp_(ocp) {
-    check(bpmpc_model_create(urdfFile.c_str(), taskFile.c_str(), referenceFile.c_str(), &model_));
+    check(bpmpc_model_create_ex(urdfFile.c_str(), taskFile.c_str(), referenceFile.c_str(), settings_.useHardFrictionConeConstraint ? 1 : 0, &model_));
     bpmpc_settings s{};
     s.device = settings_.device;
     s.max_batch = 1;

@@ -335,7 +335,7 @@ def contact_jacobian_joints(model, q):
 # ----------------------------------------------------------------------------------------------
 
 
-def build_model(urdf_path, task_path, reference_path):
+def build_model(urdf_path, task_path, reference_path, use_hard_friction_cone=False):
     task = parse_info(task_path)
     ref = parse_info(reference_path)
     joint_names = load_std_vector(task, "model_settings.jointNames", str)
@@ -369,6 +369,11 @@ def build_model(urdf_path, task_path, reference_path):
     m["cone_regularization"] = 25.0
     m["cone_gripper_force"] = 0.0
     m["cone_hessian_shift"] = 1e-6
+    # BipedalRobotInterface.cpp:68-69,181-182: with useHardFrictionConeConstraint the cone is an inequality constraint of the problem and the
+    # SQP solver penalises it with sqp.inequalityConstraintMu / Delta (task.info:74-75; [OCS2-upstream] defaults 0 / 1e-6)
+    m["hard_friction_cone"] = bool(use_hard_friction_cone)
+    m["ineq_mu"] = float(info_get(task, "sqp.inequalityConstraintMu", 0.0))
+    m["ineq_delta"] = float(info_get(task, "sqp.inequalityConstraintDelta", 1e-6))
     m["position_error_gain"] = float(info_get(task, "model_settings.positionErrorGain"))
     m["phase_transition_stance_time"] = float(info_get(task, "model_settings.phaseTransitionStanceTime"))
     m["swing"] = {k: float(info_get(task, "swing_trajectory_config." + k))
@@ -407,4 +412,6 @@ def model_blob(m):
              m["inertia"].reshape(-1), m["contact_body"], m["contact_off"].reshape(-1), m["Q"].reshape(-1), m["R"].reshape(-1),
              [m["friction_coefficient"], m["cone_regularization"], m["cone_gripper_force"], m["cone_hessian_shift"],
               m["barrier_mu"], m["barrier_delta"], m["position_error_gain"], m["robot_mass"]]]
+    if m.get("hard_friction_cone"):
+        parts.append([1.0, m["ineq_mu"], m["ineq_delta"]])
     return np.concatenate([np.asarray(p, float).reshape(-1) for p in parts])

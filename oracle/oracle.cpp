@@ -29,6 +29,11 @@ struct Model {
   double coff[4][3];
   std::vector<double> Q, R;
   double mu, reg, grip, shift, bmu, bdelta, gain, robot_mass;
+  // useHardFrictionConeConstraint (src/BipedalRobotInterface.cpp:68-69,181-182): the cone is an inequality constraint of the problem;
+  // [OCS2-upstream, recalled] the SQP solver turns inequality constraints into a relaxed-barrier penalty of their LINEAR approximation
+  // with sqp.inequalityConstraintMu / Delta (task.info:74-75) - see node_lq
+  int hard = 0;
+  double imu = 0.0, idelta = 1e-6;
   bool anc[MAXB][MAXB];  // anc[j][b]: joint j (1..nj) lies on the path base -> body b (inclusive)
 };
 
@@ -367,6 +372,7 @@ void weight_compensating_input(const Model& m, const bool* flags, double* u) {
 }
 // [OCS2-upstream] RelaxedBarrierPenalty
 inline void relaxed_barrier(double mu, double delta, double h, double* p, double* dp, double* ddp) {
+  if (!(mu > 0.0)) { *p = 0.0; *dp = 0.0; *ddp = 0.0; return; }      // no penalty configured ([OCS2-upstream] sqp.inequalityConstraintMu defaults to 0)
   if (h > delta) {
     *p = -mu * std::log(h); *dp = -mu / h; *ddp = mu / (h * h);
   } else {
@@ -413,7 +419,7 @@ double node_cost_value(const Model& m, const double* x, const double* u, const d
   for (int k = 0; k < 4; ++k)
     if (flags[k]) {
       double p, dp, ddp;
-      relaxed_barrier(m.bmu, m.bdelta, cone_value(m, u + 3 * k), &p, &dp, &ddp);
+      relaxed_barrier(m.hard ? m.imu : m.bmu, m.hard ? m.idelta : m.bdelta, cone_value(m, u + 3 * k), &p, &dp, &ddp);
       c += p;
     }
   return c;
@@ -513,6 +519,21 @@ void node_lq(const Model& m, int kind, double dt, const double* x, const double*
     const double g[3] = {-F[0] / T, -F[1] / T, m.mu};
     double H[9] = {-(Fy2 + m.reg) / T32, F[0] * F[1] / T32, 0, F[0] * F[1] / T32, -(Fx2 + m.reg) / T32, 0, 0, 0, 0};
     double p, dp, ddp;
+    if (m.hard) {
+      // Hard cone = inequality constraint of the OCP (BipedalRobotInterface.cpp:181-182).  [OCS2-upstream, recalled] ocs2_sqp handles
+      // state-input inequality constraints as a penalty: multiple_shooting::setupIntermediateNode takes their LINEAR approximation
+      // h + dh/du du >= 0 and adds RelaxedBarrierPenalty(sqp.inequalityConstraintMu, sqp.inequalityConstraintDelta) of it to the cost
+      // (penaltyCostQuadraticApproximation: value p(h), gradient p'(h) dh, Gauss-Newton Hessian p''(h) dh dh'), times dt like the rest of
+      // the intermediate cost and BEFORE the projection.  The constraint's own second derivative and its hessianDiagonalShift
+      // (FrictionConeConstraint.cpp:163-206) belong to getQuadraticApproximation, which this path never calls.
+      relaxed_barrier(m.imu, m.idelta, hval, &p, &dp, &ddp);
+      c += p;
+      for (int i = 0; i < 3; ++i) {
+        o.r[3 * k + i] += dp * g[i];
+        for (int j = 0; j < 3; ++j) o.R[(3 * k + i) * nu + 3 * k + j] += ddp * g[i] * g[j];
+      }
+      continue;
+    }
     relaxed_barrier(m.bmu, m.bdelta, hval, &p, &dp, &ddp);
     c += p;
     for (int i = 0; i < 3; ++i) {
@@ -900,7 +921,7 @@ oracle_model* oracle_model_create(const double* blob, int n) {
   if (nj < 1 || nj > MAXJ) return nullptr;
   const int nx = 12 + nj;
   const int expect = 1 + nj + 9 * nj + 3 * nj + 3 * nj + (nj + 1) * 13 + 4 + 12 + 2 * nx * nx + 8;
-  if (n != expect) return nullptr;
+  if (n != expect && n != expect + 3) return nullptr;      // optional trailer: hard friction cone flag, sqp.inequalityConstraintMu, Delta
   oracle_model* om = new oracle_model;
   Model& m = om->m;
   m.nj = nj; m.nx = nx; m.nu = nx;
@@ -918,6 +939,7 @@ oracle_model* oracle_model_create(const double* blob, int n) {
   m.Q.assign(p, p + nx * nx); p += nx * nx;
   m.R.assign(p, p + nx * nx); p += nx * nx;
   m.mu = *p++; m.reg = *p++; m.grip = *p++; m.shift = *p++; m.bmu = *p++; m.bdelta = *p++; m.gain = *p++; m.robot_mass = *p++;
+  if (n == expect + 3) { m.hard = *p++ != 0.0 ? 1 : 0; m.imu = *p++; m.idelta = *p++; }
   for (int j = 0; j <= nj; ++j)
     for (int b = 0; b <= nj; ++b) {
       bool a = false;

@@ -16,8 +16,11 @@ _URDF = {"h1": "h1_mpc.urdf", "openloong": "openloong_mpc.urdf", "g1": "g1_mpc.u
 
 @functools.lru_cache(maxsize=None)
 def model(robot="h1"):
-    d = os.path.join(ROOT, "assets", robot)
-    return ingest.build_model(os.path.join(d, _URDF[robot]), os.path.join(d, "task.info"), os.path.join(d, "reference.info"))
+    """robot name, optionally with the suffix ":hard" = BipedalRobotInterface(..., useHardFrictionConeConstraint = true)."""
+    name, _, variant = robot.partition(":")
+    d = os.path.join(ROOT, "assets", name)
+    return ingest.build_model(os.path.join(d, _URDF[name]), os.path.join(d, "task.info"), os.path.join(d, "reference.info"),
+                              use_hard_friction_cone=(variant == "hard"))
 
 
 @functools.lru_cache(maxsize=None)
