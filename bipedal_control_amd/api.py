@@ -410,6 +410,17 @@ class BatchedSqpMpc:
         _check(load_library().bpmpc_solver_device_trajectories(self._h, C.byref(xp), C.byref(up)))
         return C.cast(xp, C.c_void_p).value, C.cast(up, C.c_void_p).value
 
+    def constraint_values(self):
+        """Values of the active equality rows at the current iterate (after a solve: the solution): (values [B, max_nodes, 16],
+        rows [B, max_nodes], modes [B, max_nodes]) - include/bpmpc.h bpmpc_solver_constraint_values."""
+        lay = self.layout()
+        B = lay["batch"]
+        v = np.zeros((B, self.max_nodes, 16))
+        rows = np.zeros((B, self.max_nodes), np.int32)
+        modes = np.zeros((B, self.max_nodes), np.int32)
+        _check(load_library().bpmpc_solver_constraint_values(self._h, _d(v), _i(rows), _i(modes)))
+        return v, rows, modes
+
     def export_trajectories(self, x_dst_ptr, u_dst_ptr):
         """Async D2D copy of the iterate into device buffers given by raw pointers (e.g. torch tensors' data_ptr())."""
         _check(load_library().bpmpc_solver_export_trajectories(self._h, C.c_void_p(x_dst_ptr), C.c_void_p(u_dst_ptr)))

@@ -799,10 +799,12 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
 
 // Value-only metrics of x + alpha dx, u + alpha du at one node for the filter line search (same lane layout as
 // linearize_fast; reference version: trial_node in linesearch.h).
-template <int NJ, class Cfg = LinFastCfg<NJ, true>>
+// EQV: also store the values of the active equality rows (registration order zeroForce_i, zeroVelocity_i, normalVelocity_i per contact,
+// BipedalRobotInterface.cpp:187-191) to eqv[0..nc): the solution metrics of the solver observers (bpmpc_solver_constraint_values).
+template <int NJ, class Cfg = LinFastCfg<NJ, true>, bool EQV = false>
 __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastShared<NJ, false>& sh, LinFastNodeLds<NJ, false>& nl, bool valid,
                                            const NodeInputs& in, double alpha, const double* dx, const double* du, const double* dxn,
-                                           double* perf, int ln) {
+                                           double* perf, int ln, double* eqv = nullptr) {
   using C = Cfg;
   constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN, G0 = C::G0;
   const int g = ln + G0;
@@ -857,6 +859,7 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(md, &nl.u[3 * ln], false, cone_own);
   lds_wave_sync();
   double eq_sse = 0.0;
+  int row = 0;
   for (int i = 0; i < kNumContacts; ++i) {
     const double cz = nl.cpos[i][2];
     if (stance_flag(mode, i)) {
@@ -864,14 +867,17 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
         double ev = nl.cvel[i][a];
         if (md.pos_gain != 0.0 && a == 2) ev += md.pos_gain * cz;
         eq_sse += ev * ev;
+        if constexpr (EQV) { if (ln == 0) eqv[row] = ev; ++row; }
       }
     } else {
-      for (int a = 0; a < 3; ++a) { const double ev = nl.u[3 * i + a]; eq_sse += ev * ev; }
+      for (int a = 0; a < 3; ++a) { const double ev = nl.u[3 * i + a]; eq_sse += ev * ev; if constexpr (EQV) { if (ln == 0) eqv[row] = ev; ++row; } }
       double ev = nl.cvel[i][2] - in.zdref[i];
       if (md.pos_gain != 0.0) ev += md.pos_gain * (cz - in.zref[i]);
       eq_sse += ev * ev;
+      if constexpr (EQV) { if (ln == 0) eqv[row] = ev; ++row; }
     }
   }
+  (void)row;
   double cone_pen = 0.0;
   if (ln < kNumContacts && stance_flag(mode, ln)) cone_pen = cone_own[1];
   LaneEval e2;

@@ -237,6 +237,13 @@ int bpmpc_solver_device_trajectories(bpmpc_solver* solver, double** x_dev, doubl
 /* Asynchronous device-to-device copy of the iterate into caller-owned device buffers (same shapes as above) on the
  * solver's stream - e.g. torch tensors that are then all-gathered over RCCL. */
 int bpmpc_solver_export_trajectories(bpmpc_solver* solver, double* x_dst_dev, double* u_dst_dev);
+/* Solution metrics for solver observers (the reference adds SolverObserver::ConstraintTermObserver on "<foot>_zeroVelocity",
+ * ocs2_bipedal_robot_ros/src/BipedalRobotSqpMpcNode.cpp:74-86): the values of the active state-input equality rows at the CURRENT iterate
+ * (after a solve: the solution) of every intermediate node, values[b][k][0..rows[b][k]) in registration order per contact i = 0..3:
+ * zeroForce_i (3 rows, swing), zeroVelocity_i (3 rows, stance), normalVelocity_i (1 row, swing) (BipedalRobotInterface.cpp:187-191).
+ * values: [batch][max_nodes][16]; rows, modes (optional): [batch][max_nodes], 0 / -1 for event nodes and beyond the grid; mode bit 0 =
+ * left foot in stance, bit 1 = right foot (MotionPhaseDefinition.h:57-76).  A debugging path: synchronises. */
+int bpmpc_solver_constraint_values(bpmpc_solver* solver, double* values, int* rows, int* modes);
 /* Change settings.materialize_lq of a live solver. */
 int bpmpc_solver_set_materialize(bpmpc_solver* solver, int materialize_lq);
 /* Change settings.profile of a live solver (0 / 1 / 2 as above). */

@@ -33,6 +33,7 @@ struct HipSqpSolverSettings {
   int maxNodes = 160;        // shooting intervals incl. event nodes: timeHorizon / sqp.dt + 2 per gait event inside the horizon
   int sqpIterations = 0;     // <= 0: sqp.sqpIteration of task.info
   bool useFeedbackPolicy = true;   // sqp.useFeedbackPolicy (task.info:80): LinearController, otherwise FeedforwardController
+  bool computeSolutionMetrics = false;   // fill getSolutionMetrics() after every run (one more kernel and a read-back: for solver observers)
   bool useHardFrictionConeConstraint = false;   // the interface's fourth constructor argument (BipedalRobotInterface.h:66-69): cones as inequality constraints
 };
 
@@ -77,6 +78,10 @@ class HipSqpSolver final : public SolverBase {
   }
   scalar_t getFinalTime() const override { return primalSolution_.timeTrajectory_.empty() ? 0.0 : primalSolution_.timeTrajectory_.back(); }
   void getPrimalSolution(scalar_t /*finalTime*/, PrimalSolution* primalSolutionPtr) const override { *primalSolutionPtr = primalSolution_; }
+  /** Values of the state-input equality constraint terms at the solution, per node and per term in registration order
+   *  ("<foot>_zeroForce", "<foot>_zeroVelocity", "<foot>_normalVelocity" for each contact, BipedalRobotInterface.cpp:187-191): what the
+   *  reference's ConstraintTermObserver on "<foot>_zeroVelocity" reads (BipedalRobotSqpMpcNode.cpp:74-86).  Evaluated on request only
+   *  (Settings::computeSolutionMetrics), as the reference says of its observers: debugging, slows the solver down. */
   const ProblemMetrics& getSolutionMetrics() const override { return problemMetrics_; }
   size_t getNumIterations() const override { return totalNumIterations_; }
   const OptimalControlProblem& getOptimalControlProblem() const override { return ocp_; }
@@ -138,6 +143,7 @@ class HipSqpSolver final : public SolverBase {
     }
     haveSolution_ = true;
     fillPrimalSolution(ms);
+    if (settings_.computeSolutionMetrics) fillSolutionMetrics();
     PerformanceIndex before, after;
     before.merit = before.cost = stats_.merit_before;
     before.dynamicsViolationSSE = stats_.dynamics_sse_before;
@@ -193,6 +199,31 @@ class HipSqpSolver final : public SolverBase {
       primalSolution_.controllerPtr_.reset(new LinearController(primalSolution_.timeTrajectory_, std::move(uff), std::move(gains)));
     } else {
       primalSolution_.controllerPtr_.reset(new FeedforwardController(primalSolution_.timeTrajectory_, primalSolution_.inputTrajectory_));
+    }
+  }
+
+  // ProblemMetrics [OCS2-upstream, recalled]: intermediates[k].stateInputEqConstraint = one vector per constraint term in registration order
+  // (3 per contact: zeroForce_i, zeroVelocity_i, normalVelocity_i), empty where the term is inactive; event nodes go to preJumps (no terms).
+  void fillSolutionMetrics() {
+    const int N = settings_.maxNodes, n = stats_.n_nodes;
+    std::vector<double> values(static_cast<size_t>(N) * 16);
+    std::vector<int> rows(N), modes(N);
+    check(bpmpc_solver_constraint_values(solver_, values.data(), rows.data(), modes.data()));
+    problemMetrics_.clear();
+    for (int k = 0; k < n; ++k) {
+      Metrics m;
+      if (modes[k] < 0) { problemMetrics_.preJumps.push_back(m); continue; }
+      m.stateInputEqConstraint.assign(12, vector_t());
+      int row = 0;
+      for (int i = 0; i < 4; ++i) {
+        const bool stance = i < 2 ? (modes[k] & 1) != 0 : (modes[k] & 2) != 0;
+        auto take = [&](int term, int count) {
+          m.stateInputEqConstraint[3 * i + term] = Eigen::Map<const vector_t>(&values[static_cast<size_t>(k) * 16 + row], count);
+          row += count;
+        };
+        if (stance) take(1, 3); else { take(0, 3); take(2, 1); }
+      }
+      problemMetrics_.intermediates.push_back(m);
     }
   }
 

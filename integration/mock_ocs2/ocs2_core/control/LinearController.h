@@ -35,7 +35,14 @@ struct TargetTrajectories { scalar_array_t timeTrajectory; vector_array_t stateT
 struct PerformanceIndex { scalar_t merit = 0, cost = 0, dualFeasibilitiesSSE = 0, dynamicsViolationSSE = 0, equalityConstraintsSSE = 0, inequalityConstraintsSSE = 0, equalityLagrangian = 0, inequalityLagrangian = 0; };
 struct ScalarFunctionQuadraticApproximation {};
 struct MultiplierCollection {};
-struct ProblemMetrics {};
+// [OCS2-upstream, recalled] ocs2_oc/oc_data/ProblemMetrics.h: one Metrics per node; the equality-constraint members hold one vector per TERM of
+// the constraint collection, in registration order (empty for a term that is not active at that time).  Only what the adaptor fills.
+struct Metrics { scalar_t cost = 0; vector_t dynamicsViolation; vector_array_t stateEqConstraint, stateInputEqConstraint; };
+struct ProblemMetrics {
+  Metrics final;
+  std::vector<Metrics> preJumps, intermediates;
+  void clear() { final = Metrics(); preJumps.clear(); intermediates.clear(); }
+};
 struct OptimalControlProblem {};
 struct PrimalSolution {
   scalar_array_t timeTrajectory_;

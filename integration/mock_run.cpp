@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
     mpcSettings.coldStart_ = false;
     ocs2::bipedal_robot::HipSqpSolver::Settings ss;
     ss.maxNodes = 96;
+    ss.computeSolutionMetrics = true;
     ocs2::bipedal_robot::HipSqpMpc mpc(mpcSettings, task, urdf, reference, ocp, ss);
     mpc.getSolverPtr()->setReferenceManager(refs);
     mpc.getSolverPtr()->addSynchronizedModule(std::make_shared<ocs2::SolverSynchronizedModule>());
@@ -80,9 +81,19 @@ int main(int argc, char** argv) {
         for (int a = 0; a < nu; ++a)
           for (int b = 0; b < nx; ++b) sk += ctrl->gainArray_[i](a, b) * (1 + (a + 2 * b) % 3);      // by (row, column): independent of the storage order
       }
+      // what a ConstraintTermObserver on "<foot>_zeroVelocity" would see (BipedalRobotSqpMpcNode.cpp:74-86): term 3 i + 1 of every intermediate node
+      const ocs2::ProblemMetrics& metrics = mpc.getSolverPtr()->getSolutionMetrics();
+      double szv = 0;
+      size_t nzv = 0;
+      for (size_t i = 0; i < metrics.intermediates.size(); ++i)
+        for (int c = 0; c < 4; ++c) {
+          const ocs2::vector_t& v = metrics.intermediates[i].stateInputEqConstraint[3 * c + 1];
+          for (long j = 0; j < v.size(); ++j) { szv += v.data()[j] * (1 + (i + c + j) % 3); ++nzv; }
+        }
       const ocs2::PerformanceIndex& perf = mpc.getSolverPtr()->getPerformanceIndeces();
-      std::printf("run %d points %zu iterations %zu merit %.17g dyn %.17g st %.17g sx %.17g su %.17g sb %.17g sk %.17g final %.17g\n", k, n,
-                  mpc.getSolverPtr()->getNumIterations(), perf.merit, perf.dynamicsViolationSSE, st, sx, su, sb, sk, mpc.getSolverPtr()->getFinalTime());
+      std::printf("run %d points %zu iterations %zu merit %.17g dyn %.17g st %.17g sx %.17g su %.17g sb %.17g sk %.17g final %.17g nzv %zu szv %.17g prejumps %zu\n", k, n,
+                  mpc.getSolverPtr()->getNumIterations(), perf.merit, perf.dynamicsViolationSSE, st, sx, su, sb, sk, mpc.getSolverPtr()->getFinalTime(), nzv, szv,
+                  metrics.preJumps.size());
     }
     bpmpc_model_destroy(model);
   } catch (const std::exception& e) {

@@ -72,3 +72,24 @@ def test_adaptor_runs_and_matches_the_python_mirror(tmp_path, robot, urdf):
         assert got["merit"] == st[0].merit_after and got["dyn"] == st[0].dynamics_sse_after and got["final"] == tt[-1]
         for name, ref in (("st", st_), ("sx", sx), ("su", su), ("sb", sb), ("sk", sk)):       # sums in another order: rounding only
             assert abs(got[name] - ref) <= 1e-11 * max(1.0, abs(ref)), (k, name, got[name], ref)
+        # ProblemMetrics: the "<foot>_zeroVelocity" terms of every intermediate node at the solution, from the ORACLE's constraint rows there
+        om = ob.oracle(robot)
+        kinds, modes = np.asarray(nodes["kind"])[:n], np.asarray(nodes["mode"])[:n]
+        szv, nzv, i_inter = 0.0, 0, 0
+        for j in range(n):
+            if kinds[j] != 0:
+                continue
+            lq = om.node_lq(0, nodes["dt"][j], x[0, j], u[0, j], x[0, j + 1], nodes["xref"][j], modes[j], nodes["zref"][j], nodes["zdref"][j])
+            e, row = np.asarray(lq["e"]), 0
+            for c in range(4):
+                stance = (modes[j] & 1) != 0 if c < 2 else (modes[j] & 2) != 0
+                if stance:
+                    for a in range(3):
+                        szv += e[row + a] * (1 + (i_inter + c + a) % 3)
+                    nzv += 3
+                    row += 3
+                else:
+                    row += 4
+            assert row == lq["nc"]
+            i_inter += 1
+        assert got["nzv"] == nzv and got["prejumps"] == int((kinds != 0).sum()) and abs(got["szv"] - szv) <= 1e-9 * max(1.0, abs(szv)), (got["szv"], szv)

@@ -227,3 +227,27 @@ def test_long_target_trajectories_are_cropped_exactly(ctx):
     assert "inside the horizon" in str(e.value)
     t2, x2, u2, _, st2 = mpc.fetch()
     assert np.array_equal(t2, t) and np.array_equal(x2, x) and np.array_equal(u2, u)
+
+
+def test_constraint_values_at_the_solution_match_oracle(ctx):
+    """bpmpc_solver_constraint_values (solution metrics for solver observers, BipedalRobotSqpMpcNode.cpp:74-86): the active equality rows of
+    every intermediate node at the accepted iterate against the oracle's constraint evaluation there; rows / modes bookkeeping; event nodes."""
+    bp, sc, ob, itf = ctx
+    prob = sc.trot_problem(itf, batch=2, n_intervals=40, gait="flying_trot")
+    mpc = bp.BatchedSqpMpc(itf, max_batch=2, max_nodes=56)
+    t, x, u, _, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    v, rows, modes = mpc.constraint_values()
+    om = ob.h1_oracle()
+    n = st[0].n_nodes
+    seen = set()
+    for b in range(2):
+        nodes = ob.oracle_nodes(prob, b)
+        for k in range(n):
+            if nodes["kind"][k] != 0:
+                assert rows[b, k] == 0 and modes[b, k] == -1
+                continue
+            lq = om.node_lq(0, nodes["dt"][k], x[b, k], u[b, k], x[b, k + 1], nodes["xref"][k], nodes["mode"][k], nodes["zref"][k], nodes["zdref"][k])
+            assert rows[b, k] == lq["nc"] and modes[b, k] == nodes["mode"][k]
+            assert np.abs(v[b, k, :lq["nc"]] - np.asarray(lq["e"])[:lq["nc"]]).max() < 1e-10
+            seen.add(int(modes[b, k]))
+    assert seen >= {0, 1, 2} and np.all(rows[:, n:] == 0)
