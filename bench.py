@@ -63,6 +63,8 @@ def parse_args():
                          "openloong = the reference's own 12-joint robot")
     ap.add_argument("--gait", default=None, help="gait template of the trot workload (default: trot; g1: standing_trot = \"walk\")")
     ap.add_argument("--no-fused", action="store_true", help="skip the second timed region (fused solve mode)")
+    ap.add_argument("--gather", default="all", choices=["all", "root"],
+                    help="collective of the solved trajectories per step: all-gather (every rank holds every block) or gather to rank 0")
     ap.add_argument("--chunks", type=int, default=0, help="horizon chunks of the linearise/project || Riccati pipeline (0 = library default, 1 = off)")
     return ap.parse_args()
 
@@ -169,7 +171,7 @@ def main():
     n_intermediate_total = int(inter_of_grid[p_grid].sum())     # node linearisations per launch on this rank
 
     with torch.cuda.stream(s):
-        gather = bd.TrajectoryGather(capacity, max_nodes, nx, nu, torch.device("cuda", device))
+        gather = bd.TrajectoryGather(capacity, max_nodes, nx, nu, torch.device("cuda", device), mode=args.gather)
     if capacity != B:       # a short shard exports into the head of its block: x and u sub-blocks of B problems are contiguous only together with
         x_dst = torch.zeros(B * (max_nodes + 1) * nx, dtype=torch.float64, device="cuda")   # the padding, so go through a staging copy
         u_dst = torch.zeros(B * max_nodes * nu, dtype=torch.float64, device="cuda")
@@ -186,9 +188,12 @@ def main():
             gather.u_local[:B].copy_(u_dst.view(B, max_nodes, nu))
         gather.launch()
 
-    def fence():
+    def fence(barrier=True):
+        """Opening bracket of a timed region: every rank idle and aligned.  Closing bracket (barrier=False): this rank's work drained - the
+        clock is read per rank and the MAX over ranks is taken afterwards, so no collective sits inside the timed region beyond the
+        per-step gather itself."""
         gather.drain()
-        if use_dist:
+        if use_dist and barrier:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -202,7 +207,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        fence()
+        fence(barrier=False)
         elapsed = time.perf_counter() - t0
         if use_dist:
             elapsed = float(bd.reduce_stats([elapsed], op="max")[0])
@@ -232,11 +237,12 @@ def main():
             report = [float(v) for v in bd.reduce_stats(report).tolist()]
             # every rank holds everybody's result: rank 0's copy of the last rank's block must be what that rank computed
             probe = torch.zeros(2, dtype=torch.float64)
-            xb, ub = gather.block(world - 1)
             if rank == world - 1:
                 probe = torch.tensor([float(gather.x_local.sum()), float(gather.u_local.sum())], dtype=torch.float64)
             probe = bd.reduce_stats(probe.tolist())
-            gathered_ok = gathered_ok and float(xb.sum()) == float(probe[0]) and float(ub.sum()) == float(probe[1])
+            if args.gather == "all" or rank == 0:       # (gather to root: only rank 0 holds the other ranks' blocks)
+                xb, ub = gather.block(world - 1)
+                gathered_ok = gathered_ok and float(xb.sum()) == float(probe[0]) and float(ub.sum()) == float(probe[1])
         ktimes = {k: mpc.kernel_time(k, reset=False) for k in KERNEL_CLASSES}
         # ---- second timed region: the fused solve mode, same problems, same number of steps, no kernel carries an event pair
         fused = None
@@ -249,7 +255,7 @@ def main():
             tf0 = time.perf_counter()
             for _ in range(args.steps):
                 step()
-            fence()
+            fence(barrier=False)
             f_elapsed = time.perf_counter() - tf0
             if use_dist:
                 f_elapsed = float(bd.reduce_stats([f_elapsed], op="max")[0])
@@ -300,7 +306,8 @@ def main():
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": wl, "global_batch": total, "problems_on_rank0": B, "shooting_nodes": n_nodes,
                           "node_linearizations_per_step": int(report[4]), "nx": nx, "nu": nu,
-                          "parallelism": "problem-sharded x%d, one all-gather of trajectories per solve (%s), overlapped with the next solve" % (world, backend if use_dist else "none at N = 1"),
+                          "parallelism": "problem-sharded x%d, one %s of trajectories per solve (%s), overlapped with the next solve" % (
+                              world, "all-gather" if args.gather == "all" else "gather to rank 0", backend if use_dist else "none at N = 1"),
                           "accepted_steps_rank0": ok,
                           "job_report": {"merit_sum": report[0], "dynamics_sse_sum": report[1], "equality_sse_sum": report[2], "failures": int(report[3]),
                                          "gather_consistent": bool(gathered_ok)}},

@@ -30,7 +30,13 @@ class TrajectoryGather:
     (`with torch.cuda.stream(s)`), so that the collective is ordered after the export that fills the block and the next export is
     ordered after `drain()` - torch.distributed orders a collective only against the CURRENT stream."""
 
-    def __init__(self, capacity, nodes, nx, nu, device, group=None, dtype=torch.float64):
+    def __init__(self, capacity, nodes, nx, nu, device, group=None, dtype=torch.float64, mode="all"):
+        """mode "all": all-gather, every rank ends up with every rank's block (default; 7 x 18 MB received per GPU and solve at
+        BASELINE.json configs[2]); mode "root": gather to rank 0 only - what the north-star's "final gather" needs at the least -, the
+        other ranks only send their block."""
+        if mode not in ("all", "root"):
+            raise ValueError("gather mode is 'all' or 'root'")
+        self.mode = mode
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -38,7 +44,9 @@ class TrajectoryGather:
         self.n_x = self.capacity * (self.nodes + 1) * self.nx
         self.n_u = self.capacity * self.nodes * self.nu
         self.local = torch.zeros(self.n_x + self.n_u, dtype=dtype, device=device)
-        self.gathered = torch.zeros(self.world * (self.n_x + self.n_u), dtype=dtype, device=device) if self.world > 1 or dist.is_initialized() else self.local
+        holds_all = mode == "all" or self.rank == 0
+        self.gathered = (torch.zeros(self.world * (self.n_x + self.n_u), dtype=dtype, device=device) if holds_all else None) \
+            if self.world > 1 or dist.is_initialized() else self.local
         self.pending = []
 
     # views of this rank's block (the solver exports straight into them)
@@ -52,8 +60,14 @@ class TrajectoryGather:
 
     def launch(self):
         """Start the all-gather of the local block (no-op without a process group)."""
-        if dist.is_initialized():
+        if not dist.is_initialized():
+            return
+        if self.mode == "all":
             self.pending.append(dist.all_gather_into_tensor(self.gathered, self.local, group=self.group, async_op=True))
+        else:
+            blk = self.n_x + self.n_u
+            parts = [self.gathered[r * blk:(r + 1) * blk] for r in range(self.world)] if self.rank == 0 else None
+            self.pending.append(dist.gather(self.local, parts, dst=0, group=self.group, async_op=True))
 
     def drain(self):
         """Make the current stream (GPU) / the caller (CPU) wait for every collective in flight: afterwards the local block may be
@@ -62,7 +76,9 @@ class TrajectoryGather:
             self.pending.pop().wait()
 
     def block(self, rank):
-        """(x, u) views of the gathered block of `rank`."""
+        """(x, u) views of the gathered block of `rank` (mode "root": on rank 0 only)."""
+        if self.gathered is None:
+            raise RuntimeError("gather mode 'root': only rank 0 holds the gathered trajectories")
         base = rank * (self.n_x + self.n_u)
         flat = self.gathered[base:base + self.n_x + self.n_u]
         return flat[:self.n_x].view(self.capacity, self.nodes + 1, self.nx), flat[self.n_x:].view(self.capacity, self.nodes, self.nu)
@@ -77,7 +93,9 @@ class TrajectoryGather:
         return torch.cat(xs), torch.cat(us)
 
     def own_block_consistent(self):
-        """The gathered copy of this rank's block equals what it sent."""
+        """The gathered copy of this rank's block equals what it sent (mode "root": checked where the copy exists, rank 0)."""
+        if self.gathered is None:
+            return True
         base = self.rank * (self.n_x + self.n_u)
         return bool(torch.equal(self.gathered[base:base + self.n_x + self.n_u], self.local))
 

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, n_intervals, out_dir):
+def _worker(rank, world, port, total, n_intervals, out_dir, mode="all"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,7 +32,7 @@ def _worker(rank, world, port, total, n_intervals, out_dir):
     prob = scenarios.trot_problem(itf, batch=hi - lo, n_intervals=n_intervals, offset=lo)
     sols = [ob.oracle_solve_like(prob, b) for b in range(hi - lo)]
     nodes = sols[0][0].shape[0] - 1
-    g = bd.TrajectoryGather(bd.shard_capacity(total, world), nodes, itf.stateDim, itf.inputDim, torch.device("cpu"))
+    g = bd.TrajectoryGather(bd.shard_capacity(total, world), nodes, itf.stateDim, itf.inputDim, torch.device("cpu"), mode=mode)
     # two "solves" in a row, as the timed loop of bench.py issues them: launch, (next solve), drain, overwrite, launch
     for scale in (2.0, 1.0):
         g.drain()
@@ -42,7 +42,11 @@ def _worker(rank, world, port, total, n_intervals, out_dir):
         g.launch()
     g.drain()
     assert g.own_block_consistent()
-    x_all, u_all = g.assemble(total)
+    if mode == "root" and rank != 0:       # gather to rank 0: the others only sent their block
+        assert g.gathered is None
+        x_all, u_all = torch.zeros(0), torch.zeros(0)
+    else:
+        x_all, u_all = g.assemble(total)
     stats = bd.reduce_stats([float(hi - lo), float(sum(s[0].sum() for s in sols))])
     tmax = bd.reduce_stats([float(rank)], op="max")
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x_all.numpy(), u=u_all.numpy(), stats=stats.numpy(), tmax=tmax.numpy())
@@ -80,6 +84,23 @@ def test_ranks_gather_trajectories(tmp_path, world, total):
         xo, uo, _, _ = ob.oracle_solve_like(prob, b)
         assert np.array_equal(res[0]["x"][b], xo) and np.array_equal(res[0]["u"][b], uo)
     assert res[0]["stats"][0] == total and res[0]["tmax"][0] == world - 1
+
+
+@pytest.mark.timeout(600)
+def test_ranks_gather_trajectories_to_root(tmp_path):
+    """TrajectoryGather(mode="root") - bench.py --gather root: the same blocks, collected on rank 0 only (uneven shards 2 + 2 + 1)."""
+    world, total, n_int = 3, 5, 6
+    mp.spawn(_worker, args=(world, _free_port(), total, n_int, str(tmp_path), "root"), nprocs=world, join=True)
+    res = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    assert res[1]["x"].size == 0 and res[2]["x"].size == 0
+    from bipedal_control_amd import scenarios
+    from tests import oracle_bridge as ob
+    itf = scenarios.h1_interface()
+    prob = scenarios.trot_problem(itf, batch=total, n_intervals=n_int)
+    for b in range(total):
+        xo, uo, _, _ = ob.oracle_solve_like(prob, b)
+        assert np.array_equal(res[0]["x"][b], xo) and np.array_equal(res[0]["u"][b], uo)
+    assert res[0]["stats"][0] == total
 
 
 def test_bench_self_launch_command():

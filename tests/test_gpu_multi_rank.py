@@ -45,5 +45,8 @@ def test_two_ranks_weak_and_strong():
 def test_three_ranks_uneven_shards_and_rccl_single_rank():
     s3 = _bench("--gpus", "3", "--scaling", "strong", "--global-batch", "50", "--intervals", "30")     # shards 17 + 17 + 16: the short one is padded
     assert s3["config"]["job_report"]["gather_consistent"] and s3["config"]["problems_on_rank0"] == 17
+    g3 = _bench("--gpus", "3", "--scaling", "strong", "--global-batch", "50", "--intervals", "30", "--gather", "root")   # the same job, gathered to rank 0 only
+    assert g3["config"]["job_report"]["gather_consistent"] and "gather to rank 0" in g3["config"]["parallelism"]
+    assert g3["config"]["job_report"]["merit_sum"] == s3["config"]["job_report"]["merit_sum"]
     r1 = _bench("--gpus", "1", "--batch", "16", "--intervals", "30", env_extra={"BPMPC_BENCH_FORCE_DIST": "1", "BPMPC_BENCH_ONE_DEVICE": "0"})   # RCCL itself, one rank
     assert r1["config"]["job_report"]["gather_consistent"] and "nccl" in r1["config"]["parallelism"]
