@@ -19,6 +19,10 @@ struct RiccatiFastIO {
   RiccatiIO base;            // same views as the reference kernel (Kt/kt unused; At .. rt unused: the projected model comes packed)
   const double *Wt, *Qp, *Mt; // per node PackedLq<NJ>::W_SIZE, Q_SIZE, M_SIZE: [At | bt | Bt], [Qt | qt], [Pt | rt | Rt] (project_node.h)
   const double* Vt;          // per node NJ * PackedLq<NJ>::WP: the joint rows of [Px | Pe | Pu], packed (project_lu_s.h); base.Pe: its Pe column incl. the force rows
+  // folded change of variables (riccati_fold8.h): what the lineariser left of the node's LQ model (per node nx*nx, nx*nu, nx, nx, nu, kQrdStride),
+  // the interval lengths of the problem's grid, the model constants
+  const double *lqA, *lqB, *lqb, *lqq, *lqr, *qrd, *gdt;
+  const DeviceModel* model;
   const double* zero_one;    // {0.0, 1.0} in global memory (what a loader lane loads for the zeros and ones of the generated force rows)
   const int* mode;           // per node: contact mode of the stage (its low two bits), from which the force rows of [Px | Pe | Pu] are generated
   double *Acl, *bcl;         // per node NX*NX, NX

@@ -433,3 +433,24 @@ def test_structured_and_dense_change_of_variables_agree(ctx, robot, gait, monkey
             for a, d in pairs:
                 worst = max(worst, _rel(a, d))
     assert worst < 1e-12, worst
+
+
+@pytest.mark.parametrize("gait", ["trot", "standing_trot", "flying_trot"])
+def test_folded_change_of_variables_matches_the_kernel_pipeline(ctx, gait, monkeypatch):
+    """riccati_fold8.h (experimental, BPMPC_FOLD=1): the sweep's own workgroup computes the projected model of every node in LDS instead
+    of reading it from HBM.  Same solves as the default pipeline (elimination kernel -> change-of-variables kernel -> sweep) to rounding,
+    and against the oracle at the tolerance of the other solve tests; all contact modes incl. double stance (three block columns)."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=5, n_intervals=45, gait=gait)
+    out = {}
+    for fold in ("0", "1"):
+        monkeypatch.setenv("BPMPC_FOLD", fold)
+        mpc = bp.BatchedSqpMpc(itf, max_batch=5, max_nodes=72, sqp_iterations=2, return_gains=True)
+        out[fold] = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    (t, x, u, K, st), (_, x1, u1, K1, st1) = out["0"], out["1"]
+    n = st[0].n_nodes
+    assert [s.step_size for s in st] == [s.step_size for s in st1]
+    assert rel_x(x1[:, :n + 1], x[:, :n + 1]) < 1e-11 and rel_u(u1[:, :n], u[:, :n]) < 1e-11 and rel_K(K1[:, :n], K[:, :n]) < 1e-10
+    for b in (0, 4):
+        xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
+        assert rel_x(x1[b, :n + 1], xo) < 1e-11 and rel_u(u1[b, :n], uo) < 1e-11 and rel_K(K1[b, :n], Ko) < 1e-10
