@@ -118,7 +118,10 @@ struct PwVtLoader {
   const double2* gV;
   const double* gPe;
   const double* zero_one;                       // {0.0, 1.0} in global memory
-  int vo[SV], fo[SF], fc[SF], fr[SF];           // LDS element offset of the pair (-1: none); force rows: first column, component
+  int vo[SV], fo[SF];                           // LDS element offset of the pair (-1: none)
+  // force-row pairs, decided once for the whole sweep: pe_off >= 0: the pair opens at column nx (its first value is Pe of that component);
+  // ux / uy: bit m set = under contact mode code m the first / second value of the pair is the 1 of a stance component
+  int pe_off[SF], ux[SF], uy[SF];
   int tl;
   __device__ __forceinline__ void init(const RiccatiFastIO& io, int tl_, bool loader, size_t k) {
     tl = tl_;
@@ -129,19 +132,28 @@ struct PwVtLoader {
 #pragma unroll
     for (int e = 0; e < SV; ++e) { const int p = tp + e * NLD; vo[e] = p < NPV ? (12 + p / HW) * LDW + 2 * (p % HW) : -1; }
 #pragma unroll
-    for (int e = 0; e < SF; ++e) { const int p = tp + e * NLD; fo[e] = p < NPF ? (p / HW) * LDW + 2 * (p % HW) : -1; fc[e] = 2 * (p % HW); fr[e] = p < NPF ? p / HW : 0; }
+    for (int e = 0; e < SF; ++e) {
+      const int p = tp + e * NLD, c = p < NPF ? p / HW : 0, col = 2 * (p % HW);
+      fo[e] = p < NPF ? (p / HW) * LDW + 2 * (p % HW) : -1;
+      pe_off[e] = col == NX ? c : -1;
+      ux[e] = 0; uy[e] = 0;
+#pragma unroll
+      for (int m = 1; m <= 3; ++m) {               // modes with stance components: LF (0..5), RF (6..11), STANCE (all)
+        const int c0s = m == 2 ? 6 : 0, nsf = m == 3 ? 12 : 6;
+        const int s = c - c0s, ucol = (s >= 0 && s < nsf) ? BC + s : -1;
+        ux[e] |= (col == ucol ? 1 : 0) << m;
+        uy[e] |= (col + 1 == ucol ? 1 : 0) << m;
+      }
+    }
   }
   // the stage the pointers stand on (contact mode code `mode`: 0..3, kModeEvent for an event node), then one stage down
   __device__ __forceinline__ void prefetch(int mode) {
-    const int c0s = mode == 2 ? 6 : 0, nsf = mode == 3 ? 12 : ((mode == 0 || mode >= kModeEvent) ? 0 : 6);
 #pragma unroll
     for (int e = 0; e < SV; ++e) { const double2 v = gV[vo[e] >= 0 ? e * NLD : -tl]; vx[e] = v.x; vy[e] = v.y; }     // (a lane without a pair re-reads pair 0 of the node)
 #pragma unroll
     for (int e = 0; e < SF; ++e) {
-      const int s = fr[e] - c0s;                                       // position among the stance components
-      const int ucol = (s >= 0 && s < nsf) ? BC + s : -1;
-      fx[e] = *(fc[e] == NX ? gPe + fr[e] : zero_one + (fc[e] == ucol ? 1 : 0));
-      fy[e] = fc[e] + 1 == ucol ? 1.0 : 0.0;
+      fx[e] = *(pe_off[e] >= 0 ? gPe + pe_off[e] : zero_one + ((ux[e] >> mode) & 1));
+      fy[e] = ((uy[e] >> mode) & 1) ? 1.0 : 0.0;
     }
     gV -= (NJ * WP) / 2; gPe -= NU;
   }
