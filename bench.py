@@ -39,7 +39,9 @@ HBM_PEAK_GBS = 8000.0              # /opt/skills/guides/MI355X_MICROARCH.md: HBM
 FP64_PEAK_TFLOPS = 78.6
 FP64_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9      # FP64 VALU lane-operations per second at full issue rate
 ROBOT_LABEL = {"h1": "Unitree H1", "openloong": "OpenLoong (nx = nu = 24)", "g1": "Unitree G1 (nx = nu = 24; self-defined configuration, not reference parity)",
-               "hunter": "Hunter (the reference's configuration with positionErrorGain 20)"}
+               "hunter": "Hunter (the reference's configuration with positionErrorGain 20)",
+               "h1:hard": "Unitree H1 with useHardFrictionConeConstraint (cones as inequality constraints, sqp.inequalityConstraintMu / Delta)",
+               "hunter:hard": "Hunter with useHardFrictionConeConstraint"}
 KERNEL_CLASSES = ("linearize", "project_lu", "project", "riccati", "linesearch")
 
 
@@ -58,7 +60,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not wrap kernels in HIP events")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class inside the timed region (default: the linearisation kernel only)")
-    ap.add_argument("--robot", default="h1", choices=["h1", "openloong", "g1", "hunter"],
+    ap.add_argument("--robot", default="h1", choices=["h1", "openloong", "g1", "hunter", "h1:hard", "hunter:hard"],
                     help="h1 = the headline workload (nx = nu = 22); g1 = BASELINE.json configs[3] (nx = nu = 24, self-defined configuration); "
                          "openloong = the reference's own 12-joint robot")
     ap.add_argument("--gait", default=None, help="gait template of the trot workload (default: trot; g1: standing_trot = \"walk\")")
@@ -301,7 +303,7 @@ def main():
                 "BASELINE.json configs[1]" if headline and scaling == "weak" and args.batch == 256 else
                 "BASELINE.json configs[2]" if headline and scaling == "strong" and total == 4096 else
                 "BASELINE.json configs[3]" if (args.robot, gait, NI) == ("g1", "standing_trot", 100) else "not the headline workload")
-        out = {"metric": "MPC solves/s (%s, horizon=%d)" % ({"h1": "H1", "g1": "G1"}.get(args.robot, args.robot), NI), "value": round(value, 2), "unit": "solves/s", "n_gpus": world,
+        out = {"metric": "MPC solves/s (%s, horizon=%d)" % ({"h1": "H1", "g1": "G1", "h1:hard": "H1 hard cones"}.get(args.robot, args.robot), NI), "value": round(value, 2), "unit": "solves/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": wl, "global_batch": total, "problems_on_rank0": B, "shooting_nodes": n_nodes,
@@ -340,7 +342,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_sweep(itf, cp, min(args.cpu_sample, 16), x, stats, args.robot)
             else:
                 out["cpu_baseline"] = cpu_baseline(prob, min(args.cpu_sample, B), x, u, stats, args.robot)
-                out["cpu_baseline_analytic"] = cpu_baseline_analytic(prob, min(args.cpu_sample, B), x, stats, args.robot)
+                if ":" not in args.robot:       # (the lane-emulation build of the test tier loads the soft-cone model)
+                    out["cpu_baseline_analytic"] = cpu_baseline_analytic(prob, min(args.cpu_sample, B), x, stats, args.robot)
         print(json.dumps(out), flush=True)
     if use_dist:
         assert gathered_ok, "gathered trajectories differ from the local result"

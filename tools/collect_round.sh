@@ -1,10 +1,11 @@
 #!/bin/bash
 # Everything a round's evidence is made of, in ONE call on the GPU box (boxes of the pool differ in clocks, so numbers that are compared
 # must come from the same box):   gpurun --timeout 2400 -- 'bash tools/collect_round.sh <tag>'
-# Writes gpurun_out/<tag>/: GPU tests, bench lines (headline, G1 = configs[3], gait sweep = configs[4], batch 4096 = configs[2], two ranks on
-# one device), batch-1 latency, and gpurun_out/<tag>_*: rocprofv3 kernel stats, PMC traffic, SQ counters.  Copy what is judged into profiles/.
+# Writes gpurun_out/<tag>/: GPU tests, bench lines (headline, G1 = configs[3], gait sweep = configs[4], batch 4096 = configs[2] on one GPU,
+# batch 512 = its per-GPU share), batch-1 latency, WBC, and gpurun_out/<tag>_*: rocprofv3 kernel stats + PMC traffic for the headline and the
+# three large shapes, SQ counters.  Copy what is judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp PYTHONPATH=.
 O=gpurun_out/$TAG
 mkdir -p $O
@@ -13,10 +14,18 @@ timeout 600 python bench.py > $O/bench_h1.json 2> $O/bench_h1.err
 timeout 600 python bench.py --robot g1 --batch 1024 --cpu-sample 16 > $O/bench_g1.json 2>> $O/bench_h1.err
 timeout 600 python bench.py --workload gait-sweep --batch 4096 --cpu-sample 16 > $O/bench_sweep.json 2>> $O/bench_h1.err
 timeout 600 python bench.py --batch 4096 --cpu-sample 0 > $O/bench_4096.json 2>> $O/bench_h1.err
-BPMPC_BENCH_ONE_DEVICE=1 BPMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --batch 128 --cpu-sample 0 > $O/bench_2rank.json 2>> $O/bench_h1.err
+timeout 600 python bench.py --batch 512 --cpu-sample 0 > $O/bench_512.json 2>> $O/bench_h1.err
+timeout 600 python bench.py --robot hunter --cpu-sample 16 > $O/bench_hunter.json 2>> $O/bench_h1.err
+timeout 600 python bench.py --robot h1:hard --cpu-sample 16 > $O/bench_h1_hard.json 2>> $O/bench_h1.err
 timeout 300 python tools/latency_probe.py > $O/latency.log 2>&1
 timeout 300 python tools/wbc_probe.py > $O/wbc.log 2>&1
 bash tools/collect_profiles.sh $TAG > $O/profiles.log 2>&1
+bash tools/collect_profiles.sh ${TAG}_b4096 --batch 4096 > $O/profiles_b4096.log 2>&1
+bash tools/collect_profiles.sh ${TAG}_g1 --robot g1 --batch 1024 > $O/profiles_g1.log 2>&1
+bash tools/collect_profiles.sh ${TAG}_sweep --workload gait-sweep --batch 4096 > $O/profiles_sweep.log 2>&1
 bash tools/collect_counters.sh $TAG > $O/counters.log 2>&1
-bash tools/collect_counters.sh ${TAG}_g1 --robot g1 --batch 1024 > $O/counters_g1.log 2>&1
-cat $O/pytest.log; tail -n 2 $O/latency.log; for f in h1 g1 sweep 4096 2rank; do tail -c 400 $O/bench_$f.json | head -c 400; echo; done
+cat $O/pytest.log; tail -n 2 $O/latency.log; for f in h1 g1 sweep 4096 512 hunter h1_hard; do python -c "
+import json,sys
+try:
+    d=json.loads(open('$O/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], (d.get('fused') or {}).get('value'), d['kernel_ms_per_step'])
+except Exception as e: print('$f', 'FAILED', e)"; done
