@@ -170,7 +170,9 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
   }
 }
 
-template <int NJ>
+// PK: [Px | Pe | Pu] arrives as the packed joint rows of the structured elimination (in.Vt; the force rows are generated from in.mode)
+// instead of as Px, Pu, Pe - a compile-time choice: both paths in one kernel cost nx = 24 its third wave per SIMD.
+template <int NJ, bool PK = false>
 __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
                                                    double dt_over_mass, const double* Qc, const double* Rc, double reg = 0.0) {
   using WS = ProjectMfmaWorkspace<NJ>;
@@ -187,7 +189,7 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
       out.Wt[i * WP + j] = j < NX ? (i == j ? 1.0 : 0.0) : (j == NX ? in.b[i] : 0.0);
       out.Qp[i * QP + j] = (i == j) ? reg : 0.0;
     }
-    if (out.Vt)
+    if (!PK && out.Vt)
       for (int idx = l; idx < NJ * 48; idx += kWave) out.Vt[(idx / 48) * WP + idx % 48] = 0.0;
     return;
   }
@@ -195,7 +197,32 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   const int nbc = (BC + nut + 15) >> 4;                // block columns (and rows) of the packed width nx + 1 + nut
 
   // ---- X to LDS (coalesced reads), padding zeroed; the workgroup is this one wave
-  {
+  if constexpr (PK) {
+    // after the structured elimination: the joint rows come packed (complete rows of 48 columns, zeros beyond the reduced inputs), the
+    // force rows are generated - zero except Pe_c in column nx and a single 1 for a stance component (project_lu_s.h)
+    constexpr int WP = PackedLq<NJ>::WP, NV = NJ * 48, IT = (NV + kWave - 1) / kWave;
+    double vv[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {                  // all loads in flight before the first LDS write
+      const int idx = l + it * kWave;
+      vv[it] = idx < NV ? in.Vt[(idx / 48) * WP + idx % 48] : 0.0;
+    }
+    const double pev = l < 12 ? out.Pe[l] : 0.0;
+    for (int idx = l; idx < 12 * LDW; idx += kWave) (&ws.X[0][0])[idx] = 0.0;                          // force rows
+    for (int idx = l; idx < NJ * (LDW - 48); idx += kWave) ws.X[12 + idx / (LDW - 48)][48 + idx % (LDW - 48)] = 0.0;   // padding columns of the joint rows
+    lds_wave_sync();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = l + it * kWave;
+      if (idx < NV) ws.X[12 + idx / 48][idx % 48] = vv[it];
+    }
+    if (l < 12) {
+      const int mode = in.mode, c0s = mode == 2 ? 6 : 0, nsf = mode == 3 ? 12 : (mode == 0 ? 0 : 6);
+      ws.X[l][NX] = pev;
+      const int sidx = l - c0s;
+      if (sidx >= 0 && sidx < nsf && BC + sidx < LDW) ws.X[l][BC + sidx] = 1.0;
+    }
+  } else {
     constexpr int IT = (NU * NX + kWave - 1) / kWave;
     double vx[IT], vu[IT];
 #pragma unroll
@@ -210,12 +237,12 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
       const int idx = l + it * kWave;
       if (idx < NU * NX) { ws.X[idx / NX][idx % NX] = vx[it]; if (BC + idx % NX < WC) ws.X[idx / NX][BC + idx % NX] = vu[it]; }
     }
+    if (l < NU) ws.X[l][NX] = out.Pe[l];
+    for (int idx = l; idx < NU * (LDW - WC); idx += kWave) ws.X[idx / (LDW - WC)][WC + idx % (LDW - WC)] = 0.0;   // columns beyond [Px Pe Pu]
   }
-  if (l < NU) ws.X[l][NX] = out.Pe[l];
   for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
-  for (int idx = l; idx < NU * (LDW - WC); idx += kWave) ws.X[idx / (LDW - WC)][WC + idx % (LDW - WC)] = 0.0;   // columns beyond [Px Pe Pu]
 
-  if (out.Vt) {                                        // joint rows of X in the packed layout the sweep's loaders read (columns < 16 nbc)
+  if (!PK && out.Vt) {                                 // joint rows of X in the packed layout the sweep's loaders read (columns < 16 nbc)
     constexpr int WP = PackedLq<NJ>::WP;
     lds_wave_sync();
     for (int idx = l; idx < NJ * WP; idx += kWave) {

@@ -406,8 +406,15 @@ def test_structured_and_dense_change_of_variables_agree(ctx, robot, gait, monkey
     B, N = 3, 64
     prob = sc.trot_problem(itf, batch=B, n_intervals=45, gait=gait)
     got = {}
-    for dense in ("0", "1"):
-        monkeypatch.setenv("BPMPC_DENSE_PROJECT", dense)
+    # "1": FullPivLU-format elimination outputs (Px, Pu, Pe) + dense kernel;  "0": structured elimination (packed joint rows) + the kernel the
+    # solver picks for the regime (nx = 22 at this batch: project_struct.h; nx = 24: project_mfma.h reading the packed rows);
+    # "s": the structured kernel forced (covers it on nx = 24 as well)
+    for dense in ("0", "1", "s"):
+        monkeypatch.setenv("BPMPC_DENSE_PROJECT", "1" if dense == "1" else "0")
+        if dense == "s":
+            monkeypatch.setenv("BPMPC_STRUCT_PROJECT", "1")
+        else:
+            monkeypatch.delenv("BPMPC_STRUCT_PROJECT", raising=False)
         mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=N)
         lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
         mpc.enqueue(); mpc.synchronize()                                  # away from the cold start
@@ -423,15 +430,16 @@ def test_structured_and_dense_change_of_variables_agree(ctx, robot, gait, monkey
     Q = {d: got[d]["Qp"].reshape(B, N, nx, 32)[:, :n] for d in got}
     M = {d: got[d]["Mt"].reshape(B, N, nx, wp)[:, :n] for d in got}
     worst = 0.0
-    for b in range(B):
-        for k in range(n):
-            nt = nut[b, k]
-            cend = 16 * ((nx + 1 + nt + 15) // 16) if kind[k] == 0 else 32
-            pairs = [(W["0"][b, k, :, :cend], W["1"][b, k, :, :cend]), (Q["0"][b, k, :, :nx + 1], Q["1"][b, k, :, :nx + 1])]
-            if kind[k] == 0:
-                pairs.append((M["0"][b, k, :nt, :cend], M["1"][b, k, :nt, :cend]))
-            for a, d in pairs:
-                worst = max(worst, _rel(a, d))
+    for other in ("0", "s"):
+        for b in range(B):
+            for k in range(n):
+                nt = nut[b, k]
+                cend = 16 * ((nx + 1 + nt + 15) // 16) if kind[k] == 0 else 32
+                pairs = [(W[other][b, k, :, :cend], W["1"][b, k, :, :cend]), (Q[other][b, k, :, :nx + 1], Q["1"][b, k, :, :nx + 1])]
+                if kind[k] == 0:
+                    pairs.append((M[other][b, k, :nt, :cend], M["1"][b, k, :nt, :cend]))
+                for a, d in pairs:
+                    worst = max(worst, _rel(a, d))
     assert worst < 1e-12, worst
 
 
