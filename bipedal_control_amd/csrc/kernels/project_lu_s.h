@@ -187,10 +187,10 @@ __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, 
     // packed joint rows: two passes of 24 columns through the tile (rows = joints)
     constexpr int WP = PackedLq<NJ>::WP, BC = NX + 1, PW = 24;
     static_assert(NJ <= (12 + NJ) / 2 && PW <= 12 + NJ + 2 && 2 * PW <= WP, "the tile holds nj rows of 24 columns");
-    // complete rows of 48 columns (three block columns, what the change of variables keeps: project_struct.h NBC_MAX), zeros beyond the
-    // reduced inputs: the readers load them without a mask (a mask is two instructions per pair on the sweep's critical path) and every
-    // row is three whole 128-byte lines
-    constexpr int cend = 2 * PW;
+    // columns below the first unwritten block column (whole 128-byte lines; zeros between the reduced inputs and the block boundary); the
+    // readers mask the rest where it costs nothing: the sweeps' loaders by the address they load from, a stage ahead (PwVtLoader)
+    const int cend_ = 16 * ((BC + nut + 15) >> 4);
+    const int cend = cend_ < 2 * PW ? cend_ : 2 * PW;      // the change of variables keeps three block columns (project_mfma.h NBC_MAX)
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int c0 = pass * PW;

@@ -198,14 +198,16 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
 
   // ---- X to LDS (coalesced reads), padding zeroed; the workgroup is this one wave
   if constexpr (PK) {
-    // after the structured elimination: the joint rows come packed (complete rows of 48 columns, zeros beyond the reduced inputs), the
+    // after the structured elimination: the joint rows come packed (columns below the first unwritten block column), the
     // force rows are generated - zero except Pe_c in column nx and a single 1 for a stance component (project_lu_s.h)
     constexpr int WP = PackedLq<NJ>::WP, NV = NJ * 48, IT = (NV + kWave - 1) / kWave;
     double vv[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {                  // all loads in flight before the first LDS write
       const int idx = l + it * kWave;
-      vv[it] = idx < NV ? in.Vt[(idx / 48) * WP + idx % 48] : 0.0;
+      // (the elimination kernel wrote the columns < 16 nbc; beyond them a zero is loaded: an unconditional load with a selected ADDRESS,
+      //  where a conditional load is a branch and a wait for everything in flight)
+      vv[it] = *((idx < NV && idx % 48 < 16 * nbc) ? in.Vt + (idx / 48) * WP + idx % 48 : in.zero);
     }
     const double pev = l < 12 ? out.Pe[l] : 0.0;
     for (int idx = l; idx < 12 * LDW; idx += kWave) (&ws.X[0][0])[idx] = 0.0;                          // force rows

@@ -21,6 +21,7 @@ struct ProjectIn {
   const double *A, *B, *b, *Q, *R, *P, *q, *r;
   const double* qrd = nullptr;    // compact node-dependent part of Q, R (linearize_fast.h kQrdStride), fast kernels only
   int mode = 3;                   // contact mode of the node (fast kernels after the structured elimination: the force rows of [Px | Pe | Pu] are generated from it)
+  const double* zero = nullptr;   // a 0.0 in global memory (masked loads by address)
   const double* Vt = nullptr;     // joint rows of the packed [Px | Pe | Pu] (project_lu_s.h, row stride PackedLq::WP), structured fast path only
 };
 struct ProjectOut {

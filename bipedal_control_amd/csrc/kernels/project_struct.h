@@ -219,7 +219,7 @@ __device__ __forceinline__ void project_apply_struct(ProjectStructWorkspace<NJ>&
 #pragma unroll
     for (int it = 0; it < IT; ++it) {                  // all loads in flight before the first LDS write
       const int idx = l + it * kWave;
-      vv[it] = (idx < NV && idx % WP < 16 * WS::NBC_MAX) ? in.Vt[idx] : 0.0;      // complete rows: zeros beyond the reduced inputs
+      vv[it] = (idx < NV && idx % WP < 16 * (nbc < WS::NBC_MAX ? nbc : WS::NBC_MAX)) ? in.Vt[idx] : 0.0;      // the columns the elimination kernel wrote
     }
 #pragma unroll
     for (int it = 0; it < IB; ++it) {

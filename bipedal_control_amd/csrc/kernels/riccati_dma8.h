@@ -205,7 +205,7 @@ __device__ __forceinline__ void riccati_dma8(RiccatiDma8Workspace<NJ>& ws, const
     dma.template issue<(P == 0 ? 0 : (P == 1 ? J1 : J2)), (P == 0 ? J1 : (P == 1 ? J2 : DMA::JMAX))>(io, (size_t)k, nt, zero_page, ldsW0 + kWBytes * (unsigned)(k % 3), ldsQ0 + kQBytes * (unsigned)(k & 1),
               ldsM0 + kMBytes * (unsigned)(k & 1));
   };
-  if (role_l && k_top >= io.k_lo) { const int n0 = io.base.nut[k_top]; pw.prefetch(n0 > 0 ? (io.mode[k_top] & 3) : kModeEvent); }
+  if (role_l && k_top >= io.k_lo) { const int n0 = io.base.nut[k_top]; pw.prefetch(n0, n0 > 0 ? (io.mode[k_top] & 3) : kModeEvent); }
   using Part0 = std::integral_constant<int, 0>; using Part1 = std::integral_constant<int, 1>; using Part2 = std::integral_constant<int, 2>;
   if (role_d && k_top >= io.k_lo) {                                        // (the LDS copy of nut may not be visible yet)
     const int nt0 = io.base.nut[k_top];
@@ -300,7 +300,7 @@ __device__ __forceinline__ void riccati_dma8(RiccatiDma8Workspace<NJ>& ws, const
     lds_barrier();                     // B0
     // ---- P1: SW = sym(S) W, s added to the b column: up to six blocks on C0..C3, F, E
     //      L: the requests of the next stage (their buffers were last read in P3 of the stage before this one); wave 5 keeps r~, q~
-    if (role_l && k > io.k_lo) pw.prefetch(ws.mode[k - 1]);                              // never beyond the chunk: earlier stages may not be projected yet
+    if (role_l && k > io.k_lo) pw.prefetch(ws.nut[k - 1], ws.mode[k - 1]);                              // never beyond the chunk: earlier stages may not be projected yet
     const bool ahead = role_d && k > io.k_lo;                              // wave 4 issues the requests of stage k - 1, a third here, a third in P2, a third in P3:
     const int nt_next = k > io.k_lo ? ws.nut[k - 1] : 0;                   // all of them at once kept it ~3 k cycles and the barrier B1 waited for it (0.385 ms)
     if (ahead) issue_part(k - 1, nt_next, Part0{});

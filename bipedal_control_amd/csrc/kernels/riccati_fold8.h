@@ -79,12 +79,14 @@ struct FoldLoader {
   __device__ __forceinline__ int f_col(int e) const { return 2 * ((tl + e * NLD) % HW); }
   __device__ __forceinline__ int f_row(int e) const { const int p = tl + e * NLD; return p < NPF ? p / HW : 0; }
   // requests of node j of the problem (mode: 0..3 or kModeEvent)
-  __device__ __forceinline__ void prefetch(const RiccatiFastIO& io, size_t j, int mode) {
+  __device__ __forceinline__ void prefetch(const RiccatiFastIO& io, size_t j, int nt, int mode) {
     const int c0s = mode == 2 ? 6 : 0, nsf = mode == 3 ? 12 : ((mode == 0 || mode >= kModeEvent) ? 0 : 6);
     const double2* gV = reinterpret_cast<const double2*>(io.Vt + j * (NJ * WP));
+    const double2* zero2 = reinterpret_cast<const double2*>(io.zero_one + 2);
     const double* gPe = io.base.Pe + j * NU;
+    const int cend = 16 * ((BC + nt + 15) >> 4);       // the elimination kernel wrote the columns below this one
 #pragma unroll
-    for (int e = 0; e < SV; ++e) { const double2 v = gV[v_off(e) >= 0 ? tl + e * NLD : 0]; vx[e] = v.x; vy[e] = v.y; }
+    for (int e = 0; e < SV; ++e) { const int p = tl + e * NLD; const double2 v = *((p < NPV && 2 * (p % HW) < cend) ? gV + p : zero2); vx[e] = v.x; vy[e] = v.y; }
 #pragma unroll
     for (int e = 0; e < SF; ++e) {
       const int s = f_row(e) - c0s, fc = f_col(e);
@@ -395,7 +397,7 @@ __device__ __forceinline__ void riccati_fold8(RiccatiFold8Workspace<NJ>& ws, con
   int wide_mask = 0;                        // W buffers (k mod 3) that last held three block columns
   double p_dt = 0.0;                        // dt of the node whose data is in LDS
   auto stage_node = [&](int j) { fl.stage(ws, ws.PW[j % 3]); p_dt = fl.dt; };
-  auto request_node = [&](int j, int mode) { fl.prefetch(io, (size_t)j, mode); };
+  auto request_node = [&](int j, int nt, int mode) { fl.prefetch(io, (size_t)j, nt, mode); };
   // part one (P2 of the chain's stage): everything up to the stores
   auto project_part1 = [&](int j) {
     const int nt = ws.nut[j], mode = ws.mode[j];
@@ -429,11 +431,11 @@ __device__ __forceinline__ void riccati_fold8(RiccatiFold8Workspace<NJ>& ws, con
     }
   };
   // prologue: node k_top completely, the requests of node k_top - 1
-  if (role_p && k_top >= io.k_lo) { const int n0 = io.base.nut[k_top]; request_node(k_top, n0 > 0 ? (io.mode[k_top] & 3) : kModeEvent); }
+  if (role_p && k_top >= io.k_lo) { const int n0 = io.base.nut[k_top]; request_node(k_top, n0, n0 > 0 ? (io.mode[k_top] & 3) : kModeEvent); }
   __syncthreads();
   if (role_p && k_top >= io.k_lo) {
     stage_node(k_top);
-    if (k_top > io.k_lo) request_node(k_top - 1, ws.mode[k_top - 1]);
+    if (k_top > io.k_lo) request_node(k_top - 1, ws.nut[k_top - 1], ws.mode[k_top - 1]);
   }
   __syncthreads();
   if (role_p && k_top >= io.k_lo) project_part1(k_top);
@@ -532,7 +534,7 @@ __device__ __forceinline__ void riccati_fold8(RiccatiFold8Workspace<NJ>& ws, con
     FP_BEGIN();
     if (ahead) {
       stage_node(k - 1);
-      if (k - 1 > io.k_lo) request_node(k - 2, ws.mode[k - 2]);
+      if (k - 1 > io.k_lo) request_node(k - 2, ws.nut[k - 2], ws.mode[k - 2]);
     }
     if (role_p) FP_END(0);
     if (role_f) {

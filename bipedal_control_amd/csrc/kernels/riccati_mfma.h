@@ -117,12 +117,13 @@ struct PwVtLoader {
   double vx[SV], vy[SV], fx[SF], fy[SF];
   const double2* gV;
   const double* gPe;
-  const double* zero_one;                       // {0.0, 1.0} in global memory
+  const double* zero_one;                       // {0.0, 1.0, 0.0, 0.0} in global memory
   int vo[SV], fo[SF];                           // LDS element offset of the pair (-1: none)
   // force-row pairs, decided once for the whole sweep: pe_off >= 0: the pair opens at column nx (its first value is Pe of that component);
   // ux / uy: bit m set = under contact mode code m the first / second value of the pair is the 1 of a stance component
   int pe_off[SF], ux[SF], uy[SF];
   int tl;
+  __device__ __forceinline__ int vc(int e) const { return 2 * ((tl + e * NLD) % HW); }      // first column of the joint-row pair of slot e
   __device__ __forceinline__ void init(const RiccatiFastIO& io, int tl_, bool loader, size_t k) {
     tl = tl_;
     const int tp = loader ? tl : 0;
@@ -146,10 +147,15 @@ struct PwVtLoader {
       }
     }
   }
-  // the stage the pointers stand on (contact mode code `mode`: 0..3, kModeEvent for an event node), then one stage down
-  __device__ __forceinline__ void prefetch(int mode) {
+  // the stage the pointers stand on (nt reduced inputs; contact mode code `mode`: 0..3, kModeEvent for an event node), then one stage down
+  __device__ __forceinline__ void prefetch(int nt, int mode) {
+    const int cend = 16 * ((BC + nt + 15) >> 4);       // the elimination kernel wrote the columns below this one
+    const double2* zero2 = reinterpret_cast<const double2*>(zero_one + 2);
 #pragma unroll
-    for (int e = 0; e < SV; ++e) { const double2 v = gV[vo[e] >= 0 ? e * NLD : -tl]; vx[e] = v.x; vy[e] = v.y; }     // (a lane without a pair re-reads pair 0 of the node)
+    for (int e = 0; e < SV; ++e) {                     // a pair beyond the written columns (or a lane without a pair) loads zeros: masked by the ADDRESS, nothing to do when it is staged
+      const double2 v = *((vo[e] >= 0 && vc(e) < cend) ? gV + e * NLD : zero2);
+      vx[e] = v.x; vy[e] = v.y;
+    }
 #pragma unroll
     for (int e = 0; e < SF; ++e) {
       fx[e] = *(pe_off[e] >= 0 ? gPe + pe_off[e] : zero_one + ((ux[e] >> mode) & 1));
@@ -216,7 +222,7 @@ struct PackedStageLoader {
     for (int e = 0; e < SQ; ++e) if ((e + 1) * NLD <= NPQ || qo[e] >= 0) { const int p = tl + e * NLD; const double2 v = gQ[(p / HQU) * HQ + p % HQU]; qx[e] = v.x; qy[e] = v.y; }
 #pragma unroll
     for (int e = 0; e < SM; ++e) if (((e + 1) * NLD <= NPM || mo[e] >= 0) && mr[e] < nt && mc[e] < cend) { const double2 v = gM[e * NLD]; mx[e] = v.x; my[e] = v.y; }
-    pw.prefetch(mode);
+    pw.prefetch(nt, mode);
     gW -= PL::W_SIZE / 2; gQ -= PL::Q_SIZE / 2; gM -= PL::M_SIZE / 2;
   }
   // registers -> LDS: W = [A~ | b~ | B~], Qq = [Q~ | q~], M = [P~ | r~ | R~] (MR rows), PW = [Px | Pe | Pu], r~ also to rvec
