@@ -336,7 +336,7 @@ def main():
             roofline["bound"] = top if fr[top] >= 0.5 else "latency"
             roofline["bound_fracs"] = fr
             roofline["bound_note"] = ("`frac` stays achieved / HBM peak (the roof the north-star names); fp64-issue / mfma fractions use executed-instruction "
-                                      "counts from profiles/r02_sq_counters.json (builder run) at this run's kernel time")
+                                      "counts from profiles/r03_sq_counters.json (builder run) at this run's kernel time")
         if world == 1 and args.cpu_sample > 0:
             if sweep:
                 out["cpu_baseline"] = cpu_baseline_sweep(itf, cp, min(args.cpu_sample, 16), x, stats, args.robot)
@@ -422,14 +422,14 @@ def roofline_fp64(robot, kernel_ms, n_lin_nodes, n_nodes_total, n_stages_total, 
       restatement_flops    operation count of the CPU restatement for the work of one launch (profiles/flop_counts.json: instrumented
                            scalar for the lineariser, standard dense-algebra counts behind it) - NOT a bound for the lineariser: the
                            restatement differentiates in forward mode over 44 directions, the kernel uses analytic derivatives
-      executed             from the committed SQ counter passes of this same command (profiles/r02_sq_counters.json): VALU
+      executed             from the committed SQ counter passes of this same command (profiles/r03_sq_counters.json): VALU
                            lane-operations (SQ_INSTS_VALU x 64) and FP64 MFMAs (x 2048 flop) per launch
       issue_frac           executed lane-operations / launch time / the FP64 issue rate (16 lanes per clock and SIMD): the fraction of
                            the vector pipe's FP64 issue slots the kernel fills - an upper bound of its FP64 utilisation, since every
                            VALU instruction is counted as one FP64 slot
       mfma_frac            MFMA flop / launch time / 78.6 TFLOP/s
     Durations are this run's HIP-event times; the counter file only applies to the headline workload."""
-    cpath, fpath = os.path.join(ROOT, "profiles", "r02_sq_counters.json"), os.path.join(ROOT, "profiles", "flop_counts.json")
+    cpath, fpath = os.path.join(ROOT, "profiles", "r03_sq_counters.json"), os.path.join(ROOT, "profiles", "flop_counts.json")
     if not (os.path.exists(cpath) and os.path.exists(fpath)):
         return None
     try:
@@ -442,7 +442,7 @@ def roofline_fp64(robot, kernel_ms, n_lin_nodes, n_nodes_total, n_stages_total, 
                "riccati": ("k_riccati_fast", flops["riccati_stage"] * n_stages_total),
                "linesearch": ("k_trial_fast", 2 * flops["flow_map"] * n_nodes_total + flops["ee_kinematics"] * n_nodes_total)}
     out = {"peak_tflops": FP64_PEAK_TFLOPS, "note": "restatement_flops = CPU restatement's operation count (forward-mode AD for the lineariser: not a bound); "
-                                                     "issue_frac = executed VALU lane-ops / time / FP64 issue rate; counters from profiles/r02_sq_counters.json"}
+                                                     "issue_frac = executed VALU lane-ops / time / FP64 issue rate; counters from profiles/r03_sq_counters.json"}
     for cls, (prefix, rflops) in classes.items():
         ms = kernel_ms.get(cls)
         if not ms:
