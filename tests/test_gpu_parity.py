@@ -462,3 +462,27 @@ def test_folded_change_of_variables_matches_the_kernel_pipeline(ctx, gait, monke
     for b in (0, 4):
         xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
         assert rel_x(x1[b, :n + 1], xo) < 1e-11 and rel_u(u1[b, :n], uo) < 1e-11 and rel_K(K1[b, :n], Ko) < 1e-10
+
+
+@pytest.mark.parametrize("robot,gait", [("h1", "trot"), ("h1", "standing_trot"), ("h1", "flying_trot"), ("g1", "standing_trot"), ("hunter", "trot")])
+def test_wave_per_problem_sweep_matches_the_workgroup_sweep(ctx, robot, gait, monkeypatch):
+    """riccati_wave.h (one wavefront owns a problem: batches larger than the chip) against the workgroup-per-problem sweep of the same
+    solver, same solves to rounding (the wave kernel reads S transposed instead of symmetrising it), and against the oracle at the
+    tolerance of the other solve tests.  All contact modes incl. event nodes; two iterations so that the second starts from the first's step."""
+    bp, sc, ob = ctx["bp"], ctx["sc"], ctx["ob"]
+    itf = sc.interface(robot)
+    prob = sc.trot_problem(itf, batch=5, n_intervals=45, gait=gait)
+    out = {}
+    for wave in ("0", "2"):
+        monkeypatch.setenv("BPMPC_RICCATI_WAVE", wave)
+        mpc = bp.BatchedSqpMpc(itf, max_batch=5, max_nodes=72, sqp_iterations=2, return_gains=True)
+        out[wave] = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    (t, x, u, K, st), (_, x1, u1, K1, st1) = out["0"], out["2"]
+    n = st[0].n_nodes
+    assert all(s.status == 0 for s in st1)
+    assert [s.step_size for s in st] == [s.step_size for s in st1]
+    assert rel_x(x1[:, :n + 1], x[:, :n + 1]) < 1e-11 and rel_u(u1[:, :n], u[:, :n]) < 1e-11 and rel_K(K1[:, :n], K[:, :n]) < 1e-10
+    if robot == "h1":
+        for b in (0, 4):
+            xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
+            assert rel_x(x1[b, :n + 1], xo) < 1e-11 and rel_u(u1[b, :n], uo) < 1e-11 and rel_K(K1[b, :n], Ko) < 1e-10

@@ -1,0 +1,65 @@
+import os, sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import bipedal_control_amd as bp
+from bipedal_control_amd import scenarios as sc
+robot, gait = sys.argv[1], sys.argv[2]
+itf = sc.interface(robot)
+nx = itf.stateDim
+B, NN = 3, 72
+prob = sc.trot_problem(itf, batch=B, n_intervals=45, gait=gait)
+out = {}
+for wave in ("0", "2", "ref"):
+    os.environ["BPMPC_RICCATI_WAVE"] = wave if wave != "ref" else "0"
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN, return_gains=True, reference_kernels=(wave == "ref"))
+    lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    mpc.enqueue(); mpc.synchronize()
+    for st in ("linearize", "project", "riccati"):
+        mpc.stage(st)
+    mpc.synchronize()
+    out[wave] = {k: mpc.read(k) for k in (("K", "dx", "du", "nut") if wave == "ref" else ("K", "Acl", "dx", "du", "nut", "g_mode", "g_kind"))}
+    n = lay["n_nodes_max"]
+a, b = out["0"], out["2"]
+nut = a["nut"].reshape(B, NN)[:, :n]
+K0 = a["K"].reshape(B, NN, nx, nx)[:, :n]; K1 = b["K"].reshape(B, NN, nx, nx)[:, :n]
+A0 = a["Acl"].reshape(B, NN, nx, nx)[:, :n]; A1 = b["Acl"].reshape(B, NN, nx, nx)[:, :n]
+print("nut", nut[0])
+for k in range(n - 1, -1, -1):
+    eK = np.abs(K0[0, k] - K1[0, k]); eA = np.abs(A0[0, k] - A1[0, k])
+    print(k, int(nut[0, k]), "K err %.2e at %s (scale %.2e)  Acl err %.2e at %s" % (eK.max(), np.unravel_index(eK.argmax(), eK.shape), np.abs(K0[0, k]).max(), eA.max(), np.unravel_index(eA.argmax(), eA.shape)))
+np.set_printoptions(linewidth=250, precision=1)
+k = n - 1
+print("K err pattern (log10) stage", k)
+e = np.abs(K0[0, k] - K1[0, k]); print(np.where(e > 0, np.log10(e + 1e-300), -99).astype(int))
+e = np.abs(A0[0, k] - A1[0, k]); print("Acl"); print(np.where(e > 0, np.log10(e + 1e-300), -99).astype(int))
+
+KR = out["ref"]["K"].reshape(B, NN, nx, nx)[:, :n]
+for k in (n - 1, n - 2, n - 12, 0):
+    print("stage", k, "K: 8-wave vs ref %.2e   wave vs ref %.2e   (scale %.2e)" % (np.abs(K0[0, k] - KR[0, k]).max(), np.abs(K1[0, k] - KR[0, k]).max(), np.abs(KR[0, k]).max()))
+# host check of the first swept stage (S = 0): Y = H^-1 [G g], K_J = Vx - Vu Y
+os.environ["BPMPC_RICCATI_WAVE"] = "0"
+mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN, return_gains=True)
+lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+mpc.enqueue(); mpc.synchronize()
+for st in ("linearize", "project"):
+    mpc.stage(st)
+mpc.synchronize()
+wp = ((2 * nx + 1 + 15) // 16) * 16
+nj = nx - 12
+Mt = mpc.read("Mt").reshape(B, NN, nx, wp)[0, n - 1]
+Vt = mpc.read("Vt").reshape(B, NN, nj, wp)[0, n - 1]
+nt = int(nut[0, n - 1]); bc = nx + 1
+H = Mt[:nt, bc:bc + nt]; Gg = Mt[:nt, :bc]
+print("H asym", np.abs(H - H.T).max(), "cond", np.linalg.cond(H))
+Y = np.linalg.solve(H, Gg)
+KJ = Vt[:, :nx] - Vt[:, bc:bc + nt] @ Y[:, :nx]
+print("host vs 8-wave %.2e   host vs wave %.2e" % (np.abs(KJ - K0[0, n - 1][12:]).max(), np.abs(KJ - K1[0, n - 1][12:]).max()))
+print("Vt cols beyond nt:", np.abs(Vt[:, bc + nt:]).max(), " Mt cols beyond:", np.abs(Mt[:nt, bc + nt:]).max(), "Mt rows beyond", np.abs(Mt[nt:, :]).max())
+dK = K1[0, n - 1][12:] - K0[0, n - 1][12:]
+Vu = Vt[:, bc:bc + nt]
+dY = -np.linalg.lstsq(Vu, dK, rcond=None)[0]
+E_ = H @ dY
+np.set_printoptions(linewidth=250, precision=2)
+print("dY row norms", np.abs(dY).max(axis=1))
+print("H dY row max", np.abs(E_).max(axis=1))
+print("H dY col max", np.abs(E_).max(axis=0))
+print("G row max", np.abs(Gg).max(axis=1))
