@@ -39,7 +39,8 @@ struct RiccatiWaveWorkspace {
   alignas(16) double oA[NX * NX];          // outputs of the stage in their HBM layout
   alignas(16) double oK[NU * NX];
   double ob[NX], ok[NU], om[NX + 2];
-  alignas(16) double Zt[16][34], Yn[16][34];   // pivot rows of the elimination before / after their division (columns <= nx; nx + 2 .. spare)
+  alignas(16) double Zt[16][34];           // Zt and Yn stay adjacent: together they are the 32-row tile of the symmetrisation of S
+  alignas(16) double Yn[16][34];   // pivot rows of the elimination before / after their division (columns <= nx; nx + 2 .. spare)
   unsigned char nut[kMaxRiccatiStages];    // reduced input dimensions and contact modes of all stages (a global load per stage would make
   unsigned char mode[kMaxRiccatiStages];   // the wave wait for every operand load in flight)
   double rv[16];                           // r~ (column nx of Mt as loaded)
@@ -453,6 +454,29 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
       }
     RWPROF(5);
     if (more) load_late(k - 1, nt_n, mode_n);
+    // S <- (S + S') / 2 through LDS (the tiles of Z and Yn are free: their operands are in registers).  The next stage reads S(k, i) for
+    // S(i, k); without this step the rounding asymmetry of a hundred stages shows at the 24-state robot (2e-10 against the other sweeps
+    // after three iterations, 1e-11 with it).
+    {
+      double (*St)[34] = ws.Zt;                                       // 32 rows: Zt and Yn are adjacent
+#pragma unroll
+      for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) St[16 * bi + lk + 4 * r][16 * bj + li] = S[bi][bj][r];
+      lds_wave_sync();
+#pragma unroll
+      for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * bi + lk + 4 * r, col = 16 * bj + li;
+            const double t = St[col < NX ? col : 0][row < NX ? row : 0];
+            if (row < NX && col < NX) S[bi][bj][r] = 0.5 * (S[bi][bj][r] + t);
+          }
+    }
     // outputs into their HBM layout
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
@@ -501,6 +525,8 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
 }
 
 // Roll-out, step norms and the opening of the line search after riccati_wave: the routine of the workgroup kernels on its own.
+static_assert(offsetof(RiccatiWaveWorkspace<10>, Yn) == offsetof(RiccatiWaveWorkspace<10>, Zt) + sizeof(double) * 16 * 34, "Zt, Yn adjacent");
+
 template <int NJ>
 struct RiccatiRolloutWorkspace {
   static constexpr int NX = 12 + NJ;

@@ -152,3 +152,19 @@ def test_g1_full_size_properties(ctx):
     xo, uo, _, _ = ob.oracle_solve_like(prob2, 1, iterations=3, robot=ROBOT)
     nn = st2[1].n_nodes
     assert rel_x(x2[1, :nn + 1], xo) < 1e-11 and rel_u(u2[1, :nn], uo) < 1e-11
+
+
+@pytest.mark.parametrize("batch", [260, 530])
+def test_g1_batches_larger_than_the_chip_match_oracle(ctx, batch):
+    """More problems than CUs: the sweep changes kernel (four-wave workgroups with Gauss-Jordan up to two problems per CU, riccati_wave.h - a
+    wavefront per problem, forward elimination and back substitution - beyond).  The 24-state robot is the hard case for both: its reduced
+    Hessian has a condition number of 2.6e5 and gains of 6e3.  First and last problem of the batch against the oracle."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=batch, n_intervals=45, gait=WALK)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=batch, max_nodes=72, sqp_iterations=2, return_gains=True)
+    t, x, u, K, stats = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    n = stats[0].n_nodes
+    assert all(s.status == 0 for s in stats)
+    for b in (0, batch - 1):
+        xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2, robot=ROBOT)
+        assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11 and rel_K(K[b, :n], Ko) < 1e-10
