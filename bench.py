@@ -64,6 +64,8 @@ def parse_args():
                     help="h1 = the headline workload (nx = nu = 22); g1 = BASELINE.json configs[3] (nx = nu = 24, self-defined configuration); "
                          "openloong = the reference's own 12-joint robot")
     ap.add_argument("--gait", default=None, help="gait template of the trot workload (default: trot; g1: standing_trot = \"walk\")")
+    ap.add_argument("--gait-start", type=float, default=-1.225,
+                    help="time at which the gait template of the trot workload is inserted (default: t0 = 0 falls mid-swing; 0 = SURVEY 8(d) config 2 to the letter)")
     ap.add_argument("--no-fused", action="store_true", help="skip the second timed region (fused solve mode)")
     ap.add_argument("--gather", default="all", choices=["all", "root"],
                     help="collective of the solved trajectories per step: all-gather (every rank holds every block) or gather to rank 0")
@@ -146,7 +148,7 @@ def main():
             capacity = args.batch
         B = hi - lo
         scaling = args.scaling
-        prob = scenarios.trot_problem(itf, batch=B, n_intervals=NI, offset=lo, gait=gait)
+        prob = scenarios.trot_problem(itf, batch=B, n_intervals=NI, offset=lo, gait=gait, gait_start=args.gait_start)
         max_nodes = NI + 16
     if B < 1:
         raise SystemExit("rank %d owns no problems (more ranks than work units)" % rank)

@@ -253,10 +253,18 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
     double2* K2 = reinterpret_cast<double2*>(io.Kfull + (size_t)hk * NXU);
     const double2* a2 = reinterpret_cast<const double2*>(ws.oA);
     const double2* k2 = reinterpret_cast<const double2*>(ws.oK);
+    // all LDS reads first (read - wait - store per chunk exposes the LDS latency eight times), the last chunk clamped instead of predicated
+    constexpr int NIT = (NXX / 2 + kWave - 1) / kWave;
+    double2 ta[NIT], tk[NIT];
 #pragma unroll
-    for (int it = 0; it < (NXX / 2 + kWave - 1) / kWave; ++it) {
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = l + it * kWave, ic = idx < NXX / 2 ? idx : NXX / 2 - 1;
+      ta[it] = a2[ic]; tk[it] = k2[ic];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
       const int idx = l + it * kWave;
-      if (idx < NXX / 2) { A2[idx] = a2[idx]; K2[idx] = k2[idx]; }
+      if (it + 1 < NIT || idx < NXX / 2) { A2[idx] = ta[it]; K2[idx] = tk[it]; }
     }
     if (l < NX) {
       io.bcl[(size_t)hk * NX + l] = ws.ob[l];
@@ -298,15 +306,6 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
     // ---- outputs of the stage above, then the first loads of the stage below
     if (k < k_top) flush(k + 1);
     if (more) load_W(nW, k - 1, nt_n);
-    // r~ and q~ as loaded (m = q~ - Y' r~ below)
-    if (li == XR) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        ws.rv[lk + 4 * r] = cM[1][r];
-        ws.qv[lk + 4 * r] = cQ[0][1][r];
-        ws.qv[16 + lk + 4 * r] = cQ[1][1][r];
-      }
-    }
     RWPROF(0);
     // ---- P1: SW = S' W, s added to the b column
     v4d sw[2][NB];
@@ -330,6 +329,16 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
         sw[bi][bj] = acc;
       }
     RWPROF(1);
+    // r~ and q~ as loaded (m = q~ - Y' r~ below).  Here, not at the top of the stage: a use of a loaded register is a wait, and at the top
+    // the loads issued at the end of the stage above are still on their way.
+    if (li == XR) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ws.rv[lk + 4 * r] = cM[1][r];
+        ws.qv[lk + 4 * r] = cQ[0][1][r];
+        ws.qv[16 + lk + 4 * r] = cQ[1][1][r];
+      }
+    }
     // ---- P2: [G | g | H] = [P | r | R] + B' SW
     v4d m[NB];
 #pragma unroll
@@ -353,6 +362,7 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
 #pragma unroll
       for (int bj = 0; bj < 2; ++bj) {
         v4d acc = cQ[bi][bj];
+        if (bi == 1 && bj == 0) { sn[bi][bj] = acc; continue; }     // block (1, 0) of S is the transpose of block (0, 1): mirrored below
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bi == 0 ? cW[ks][0] : cWT[ks], sw[ks >> 2][bj][ks & 3], acc, 0, 0, 0);      // A(4 ks + lk, 16 bi + li)
@@ -425,15 +435,15 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj) yb[ks][bj] = (ks < ksn) ? -ws.Mx[4 * ks + lk][16 * bj + li] : 0.0;   // rows >= nt of the tile are zero
+      for (int bj = 0; bj < 2; ++bj) yb[ks][bj] = -ws.Mx[4 * ks + lk][16 * bj + li];   // unconditional (a select on ksn compiles to a branch and a full LDS wait per read); k-steps >= ksn are not issued, rows >= nt of the tile are zero
     double zA[2][4], yn[4][2];                                         // -Z' in the A-operand (Z(4 ks + lk, 16 bi + li)), Yn in the B-operand
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int b2 = 0; b2 < 2; ++b2) {
-        const double z = (ks < ksn) ? -ws.Zt[4 * ks + lk][16 * b2 + li] : 0.0;
+        const double z = -ws.Zt[4 * ks + lk][16 * b2 + li];
         zA[b2][ks] = (b2 == 0 || li < XR) ? z : 0.0;
-        yn[ks][b2] = (ks < ksn) ? ws.Yn[4 * ks + lk][16 * b2 + li] : 0.0;
+        yn[ks][b2] = ws.Yn[4 * ks + lk][16 * b2 + li];
       }
     v4d acl[2][2], kf[2][2];
 #pragma unroll
@@ -446,7 +456,7 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
           if (ks < ksn) {
-            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zA[bi][ks], yn[ks][bj], a0, 0, 0, 0);
+            if (!(bi == 1 && bj == 0)) a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zA[bi][ks], yn[ks][bj], a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cBt[bi][ks], yb[ks][bj], a1, 0, 0, 0);
             a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cPu[bi][ks], yb[ks][bj], a2, 0, 0, 0);
           }
@@ -454,9 +464,10 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
       }
     RWPROF(5);
     if (more) load_late(k - 1, nt_n, mode_n);
-    // S <- (S + S') / 2 through LDS (the tiles of Z and Yn are free: their operands are in registers).  The next stage reads S(k, i) for
-    // S(i, k); without this step the rounding asymmetry of a hundred stages shows at the 24-state robot (2e-10 against the other sweeps
-    // after three iterations, 1e-11 with it).
+    // S made symmetric through LDS (the tiles of Z and Yn are free: their operands are in registers): the diagonal blocks become
+    // (S + S') / 2, block (1, 0) - never computed: 9 matrix-core instructions less per stage - is the transpose of block (0, 1).  The
+    // next stage reads S(k, i) for S(i, k); without this step the rounding asymmetry of a hundred stages shows at the 24-state robot
+    // (2e-10 against the other sweeps after three iterations, 1e-11 with it).
     {
       double (*St)[34] = ws.Zt;                                       // 32 rows: Zt and Yn are adjacent
 #pragma unroll
@@ -472,9 +483,12 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
         for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            if (bi == 0 && bj == 1) continue;                         // kept as computed (its mirror image is block (1, 0))
             const int row = 16 * bi + lk + 4 * r, col = 16 * bj + li;
+            if (16 * bi + 4 * r >= NX) continue;
             const double t = St[col < NX ? col : 0][row < NX ? row : 0];
-            if (row < NX && col < NX) S[bi][bj][r] = 0.5 * (S[bi][bj][r] + t);
+            if (bi == 1 && bj == 0) S[bi][bj][r] = row < NX ? t : 0.0;
+            else if (row < NX && col < NX) S[bi][bj][r] = 0.5 * (S[bi][bj][r] + t);
           }
     }
     // outputs into their HBM layout
@@ -484,10 +498,16 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
       for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          if (16 * bi + 4 * r >= NX) continue;                        // (whole registers beyond the matrix: decided at compile time)
           const int row = 16 * bi + lk + 4 * r, col = 16 * bj + li;
-          if (row < NX) {
-            if (col < NX) { ws.oA[row * NX + col] = acl[bi][bj][r]; ws.oK[row * NX + col] = kf[bi][bj][r]; }
-            else if (col == NX) { ws.ob[row] = acl[bi][bj][r]; ws.ok[row] = kf[bi][bj][r]; }
+          const bool rin = 16 * bi + 4 * r + 3 < NX || row < NX;
+          if (bj == 0) {
+            if (rin) { ws.oA[row * NX + col] = acl[bi][bj][r]; ws.oK[row * NX + col] = kf[bi][bj][r]; }
+          } else if (rin && li <= XR) {
+            // column nx is the vector column: bcl / kff
+            double* da = li < XR ? &ws.oA[row * NX + col] : &ws.ob[row];
+            double* dk = li < XR ? &ws.oK[row * NX + col] : &ws.ok[row];
+            *da = acl[bi][bj][r]; *dk = kf[bi][bj][r];
           }
         }
     lds_wave_sync();

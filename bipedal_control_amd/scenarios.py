@@ -68,11 +68,13 @@ def stance_problem(itf, n_intervals=20):
     return dict(t0=0.0, x0=x0, schedule=sched, targets=[TargetTrajectories(np.array([0.0, horizon]), xs)], horizon=horizon)
 
 
-def trot_problem(itf, batch, n_intervals=100, cmd_vel=(0.3, 0.0, 0.0, 0.0), gait="trot", seed=SEED, offset=0):
-    """Config 2/3: H1 trot, horizon N*dt, `batch` perturbed initial states starting at problem index `offset`."""
+def trot_problem(itf, batch, n_intervals=100, cmd_vel=(0.3, 0.0, 0.0, 0.0), gait="trot", seed=SEED, offset=0, gait_start=GAIT_START):
+    """Config 2/3: H1 trot, horizon N*dt, `batch` perturbed initial states starting at problem index `offset`.
+    gait_start: time at which the gait template is inserted.  The default puts t0 = 0 in the middle of a swing phase (steady state);
+    gait_start = 0.0 is SURVEY.md section 8(d) config 2 to the letter ("template tiled from t = 0": the solve starts on a mode switch)."""
     horizon = n_intervals * DT
     x0 = perturbed_initial_states(itf, offset + batch, seed)[offset:]
-    sched = gait_schedule(itf, gait, 0.0, horizon)
+    sched = gait_schedule(itf, gait, 0.0, horizon, start=gait_start)
     targets = [itf.cmdVelToTargetTrajectories(cmd_vel, 0.0, x0[b], horizon) for b in range(batch)]
     return dict(t0=0.0, x0=x0, schedule=sched, targets=targets, horizon=horizon)
 

@@ -486,3 +486,17 @@ def test_wave_per_problem_sweep_matches_the_workgroup_sweep(ctx, robot, gait, mo
         for b in (0, 4):
             xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
             assert rel_x(x1[b, :n + 1], xo) < 1e-11 and rel_u(u1[b, :n], uo) < 1e-11 and rel_K(K1[b, :n], Ko) < 1e-10
+
+
+def test_config2_with_the_template_tiled_from_zero(ctx):
+    """SURVEY.md section 8(d) config 2 to the letter: the trot template is inserted at t = 0, so the solve starts ON a mode switch (the
+    scenarios default inserts it 3.5 half periods earlier, t0 mid-swing).  Same comparison as the other solve tests."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=4, n_intervals=60, gait_start=0.0)
+    assert abs(prob["schedule"].eventTimes[np.searchsorted(prob["schedule"].eventTimes, -1e-9)]) < 1e-12      # a switch at t0 = 0
+    mpc = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=80, sqp_iterations=2, return_gains=True)
+    t, x, u, K, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    n = st[0].n_nodes
+    for b in (0, 3):
+        xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
+        assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11 and rel_K(K[b, :n], Ko) < 1e-10
