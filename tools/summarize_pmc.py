@@ -39,7 +39,8 @@ def main(fetch_dir, write_dir, out, extra=""):
     # class runs once per step except the two linearisers, which split the steps between them
     lin = next((k for k in kernels if k.startswith("k_linearize_fast") and k.endswith("true>")), None) or next((k for k in kernels if k.startswith("k_linearize_fast")), None)
     lin_f = next((k for k in kernels if k.startswith("k_linearize_fast") and k.endswith("false>")), None)
-    ric = next((k for k in kernels if k.startswith("k_riccati_fast")), None)
+    # the sweep: k_riccati_fast* (workgroup per problem) or k_riccati_wave (wavefront per problem; its roll-out k_riccati_rollout is a launch of its own)
+    ric = next((k for k in kernels if k.startswith("k_riccati_fast") or k.startswith("k_riccati_wave")), None)
     steps = kernels[ric]["launches"] if ric else 0
     per_step_common = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in kernels.items() if not k.startswith("k_linearize_fast") and not k.startswith("k_prepare")) / max(1, steps)
     import re
