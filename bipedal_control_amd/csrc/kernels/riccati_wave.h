@@ -1,27 +1,32 @@
-// Riccati sweep for batches larger than the chip: ONE wavefront owns a problem from the terminal stage down (HIP only; same mathematics
-// as riccati_mfma.h, which shares a problem among four or eight waves).
+// Riccati sweep for batches of more than two problems per CU: ONE wavefront owns a problem from the terminal stage down (HIP only; same
+// mathematics as riccati_mfma.h / riccati_mfma8.h, which share a problem among four or eight waves).
 //
-// With more problems than CUs the sweep is a throughput problem, and the workgroup-per-problem kernels spend it badly: 66 KB of LDS per
-// problem allow two workgroups per CU, every stage crosses five workgroup barriers, and a stage costs ~6.8 k cycles of a CU per problem
-// against ~1.8 k of matrix-core time (114 v_mfma_f64_16x16x4_f64 over four SIMDs).  Loads, the elimination and the barriers' skew are
-// not what binds there (measured at batch 4096: no prefetch 4.41 ms, no elimination 4.56 ms, no stores 3.67 ms against 4.56 ms).
-// Here a wave runs alone on its SIMD with the whole register file (512 VGPRs), four problems per CU, no workgroup barrier anywhere:
+// With that many problems the sweep is a throughput problem, and the workgroup-per-problem kernels spend it badly: 66 KB of LDS per problem
+// allow two workgroups per CU, every stage crosses five workgroup barriers, and a stage costs ~6.8 k cycles of a CU per problem against
+// ~1.8 k of matrix-core time (114 v_mfma_f64_16x16x4_f64 over four SIMDs).  Loads, the elimination and HBM are not what binds there
+// (measured at batch 4096: no prefetch 4.41 ms, no elimination 4.56 ms, no stores 3.67 ms against 4.56 ms; 3.2 TB/s).
+// Here a wave runs alone on its SIMD with the whole register file (428 of 512 registers), four problems per CU, no workgroup barrier:
 //   * the value function [S | s], the stage operands and all products live in REGISTERS in the accumulator layout of the matrix core
 //     (lane l, register r <-> row (l / 16) + 4 r, column l % 16 of a 16x16 block).  That layout is at the same time the B-operand
 //     layout of the block for four k-steps (k = row) and the A-operand layout of its transpose, so
-//         SW = S' W  (+ s in the b column)      A: S blocks (S is symmetric up to rounding)   B: W as loaded
+//         SW = S W  (+ s in the b column)       A: S blocks (S is kept symmetric)              B: W as loaded
 //         M += B' SW                            A: the B~ columns of W as loaded              B: SW as computed
 //         Sn = Qq + A' SW                       A: W as loaded                                B: SW as computed
 //     need no transposition and no LDS at all; only Acl = [A b] - B Y and [K kff] = [Px Pe] - Pu Y want B~ and Pu row-major in the
 //     A-operand - those are loaded from HBM a second time in that orientation (2 KB per stage, L2 hits);
-//   * LDS (15 KB per problem) carries the one change of layout a stage needs - [G g | H] from the accumulator layout to one column per
-//     lane for the Gauss-Jordan elimination (riccati_fast.h) and Y back - and the output tiles: Acl, K, bcl, kff, m are assembled in
-//     their HBM layout and leave as 16-byte chunks of consecutive addresses at the top of the NEXT stage (stores retire in order with
-//     the loads: a store issued at the end of a stage would put its latency in front of the next stage's operands);
-//   * every operand is loaded straight into the registers it is used from, one stage ahead, and re-loaded immediately after its last
-//     use (only W, which is needed from the first to the last product of a stage, is double buffered): the loads of stage k-1 are
-//     spread over stage k and are consumed in the order they were issued;
+//   * the elimination of [H | G g] is forward elimination + back substitution in the column-per-lane layouts of riccati_fast.h /
+//     riccati_mfma8.h (Gauss-Jordan lost 1e-9 of K per stage on the 24-state robot); its pivot rows Z (before) and Yn (after the division)
+//     give S = Sn - Z' Yn, and S is made symmetric through LDS every stage (block (1, 0) is never computed: it is the mirror of (0, 1));
+//   * LDS (25 KB per problem) carries those changes of layout and the output tiles: Acl, K, bcl, kff, m are assembled in their HBM
+//     layout and leave as 16-byte chunks of consecutive addresses at the top of the NEXT stage (stores retire in order with the loads: a
+//     store issued at the end of a stage would put its latency in front of the next stage's operands);
+//   * every operand is BUFFER-loaded straight into the registers it is used from, one stage ahead, masked by its offset, and re-loaded
+//     immediately after its last use (only W, which is needed from the first to the last product of a stage, is double buffered): the
+//     loads of stage k-1 are spread over stage k and are consumed in the order they were issued;
 //   * the force rows of [Px | Pe | Pu] are generated from the contact mode of the stage as in riccati_mfma.h (PwVtLoader).
+// What a stage costs: a lone wave issues an instruction every ~5 cycles whatever it is, and the FP64 matrix instructions share their pipe
+// with the FP64 VALU, so (instructions x 5) + (matrix instructions x 64) = 17 k cycles (tools/riccati_wave_phase_profile.py).  Every select
+// around a load that the compiler turns into a branch with a full wait shows directly: keep loads unconditional, mask by address.
 // The roll-out runs as a second launch (k_riccati_rollout, the routine of riccati_mfma.h): the status travels in the carry record.
 #pragma once
 #include <hip/hip_runtime.h>
