@@ -154,10 +154,10 @@ def test_g1_full_size_properties(ctx):
     assert rel_x(x2[1, :nn + 1], xo) < 1e-11 and rel_u(u2[1, :nn], uo) < 1e-11
 
 
-@pytest.mark.parametrize("batch", [260, 530])
+@pytest.mark.parametrize("batch", [260, 530, 1100])
 def test_g1_batches_larger_than_the_chip_match_oracle(ctx, batch):
     """More problems than CUs: the sweep changes kernel (four-wave workgroups with Gauss-Jordan up to two problems per CU, riccati_wave.h - a
-    wavefront per problem, forward elimination and back substitution - beyond).  The 24-state robot is the hard case for both: its reduced
+    wavefront per problem, forward elimination and back substitution - up to four, riccati_wave2.h - two such waves per SIMD - beyond).  The 24-state robot is the hard case for both: its reduced
     Hessian has a condition number of 2.6e5 and gains of 6e3.  First and last problem of the batch against the oracle."""
     bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
     prob = sc.trot_problem(itf, batch=batch, n_intervals=45, gait=WALK)

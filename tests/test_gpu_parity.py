@@ -501,3 +501,18 @@ def test_config2_with_the_template_tiled_from_zero(ctx):
     for b in (0, 3):
         xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
         assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11 and rel_K(K[b, :n], Ko) < 1e-10
+
+
+def test_h1_batch_beyond_four_problems_per_cu_matches_oracle(ctx):
+    """Batch 1100 on the 256-CU chip: the sweep runs riccati_wave2.h (two wavefronts per SIMD, one per problem).  First, middle and last
+    problem against the oracle; every problem reports success."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    B = 1100
+    prob = sc.trot_problem(itf, batch=B, n_intervals=45)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=72, sqp_iterations=2, return_gains=True)
+    t, x, u, K, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    n = st[0].n_nodes
+    assert all(s.status == 0 for s in st)
+    for b in (0, 550, B - 1):
+        xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
+        assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11 and rel_K(K[b, :n], Ko) < 1e-10
