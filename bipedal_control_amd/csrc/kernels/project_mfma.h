@@ -46,6 +46,9 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
   using WS = ProjectMfmaWorkspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, KR = WS::KR, KS = KR / 4, BC = NX + 1, WP = PackedLq<NJ>::WP, QP = PackedLq<NJ>::QP;
   const int l = threadIdx.x, li = l & 15, lk = l >> 4;
+  // RAW loads first, every one of them, and only then the arithmetic on what they returned (shift, dt, identity rows, masks): a select
+  // or a product on a loaded value makes the wave wait for that load, and interleaved with the loads it serialised the node's memory
+  // latency four times over (three `s_waitcnt vmcnt(0)` in the middle of the load stream).
   const double shift = in.qrd[0];
   // A-operands from HBM: rows 16 bi + li of R and of B, k = 4 ks + lk (out-of-range lanes read element 0 and are masked)
   double aR[2][KS], aB[2][KS];
@@ -64,11 +67,8 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
       // rest is regenerated from the model constants (cache resident) with the lineariser's own expressions - 7 KB less HBM
       // read per node than fetching Q and R
       const bool r_block = ok && row < 12 && kk < 12 && row / 3 == kk / 3;
-      const double rv = *(r_block ? in.qrd + 1 + 3 * kk + row % 3 : Rc + (ok ? row * NU + kk : 0));
-      const double bv = in.B[dense ? row * NU + kk : 3 * NU];
-      aR[bi][ks] = ok ? (r_block ? rv : dt * (row == kk ? rv + shift : rv)) : 0.0;
-      const double synth = row < 3 ? ((kk < 12 && kk % 3 == row) ? dt_over_mass : 0.0) : (kk == row ? dt : 0.0);
-      aB[bi][ks] = dense ? bv : (ok ? synth : 0.0);
+      aR[bi][ks] = *(r_block ? in.qrd + 1 + 3 * kk + row % 3 : Rc + (ok ? row * NU + kk : 0));
+      aB[bi][ks] = in.B[dense ? row * NU + kk : 3 * NU];
     }
   // accumulator initial values in the D layout: [A | b | 0] (2 x NBC blocks), [Q | q | 0] (block row 0 and, for rows < nx, 1),
   // r for the b column of R X
@@ -79,16 +79,46 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
     for (int r = 0; r < 4; ++r) {
       const int rr = 16 * bi + lk + 4 * r;
       const bool rin = rr < NX;
-      const double rv = in.r[rin ? rr : 0];
-      cR[bi][r] = (li == NX - 16 && rin) ? rv : 0.0;             // column nx lives in block column 1 (nx in 16..31)
+      cR[bi][r] = in.r[rin ? rr : 0];
 #pragma unroll
       for (int bj = 0; bj < NBC; ++bj) {
         const int col = 16 * bj + li;
         const bool in_m = rin && col < NX, in_v = rin && col == NX;
         const bool a_dense = in_m && rr >= 3 && rr < 12;
-        double av = *(a_dense ? in.A + rr * NX + col : (in_v ? in.b + rr : in.A + 3 * NX));
+        cA[bi][bj][r] = *(a_dense ? in.A + rr * NX + col : (in_v ? in.b + rr : in.A + 3 * NX));
+        cQ[bi][bj][r] = *(in_m ? Qc + rr * NX + col : (in_v ? in.q + rr : in.q));
+      }
+    }
+  }
+  // ---- the arithmetic on the loaded values
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int row = 16 * bi + li, kk = 4 * ks + lk;
+      const bool ok = row < NU && kk < NU;
+      const bool dense = ok && row >= 3 && row < 12;
+      const bool r_block = ok && row < 12 && kk < 12 && row / 3 == kk / 3;
+      const double rv = aR[bi][ks];
+      aR[bi][ks] = ok ? (r_block ? rv : dt * (row == kk ? rv + shift : rv)) : 0.0;
+      const double synth = row < 3 ? ((kk < 12 && kk % 3 == row) ? dt_over_mass : 0.0) : (kk == row ? dt : 0.0);
+      aB[bi][ks] = dense ? aB[bi][ks] : (ok ? synth : 0.0);
+    }
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 16 * bi + lk + 4 * r;
+      const bool rin = rr < NX;
+      cR[bi][r] = (li == NX - 16 && rin) ? cR[bi][r] : 0.0;      // column nx lives in block column 1 (nx in 16..31)
+#pragma unroll
+      for (int bj = 0; bj < NBC; ++bj) {
+        const int col = 16 * bj + li;
+        const bool in_m = rin && col < NX, in_v = rin && col == NX;
+        const bool a_dense = in_m && rr >= 3 && rr < 12;
+        double av = cA[bi][bj][r];
         if (in_m && !a_dense) av = (rr == col) ? 1.0 : 0.0;          // identity rows of A
-        double qv = *(in_m ? Qc + rr * NX + col : (in_v ? in.q + rr : in.q));
+        double qv = cQ[bi][bj][r];
         if (in_m) qv = dt * (rr == col ? qv + shift : qv);
         cA[bi][bj][r] = (in_m || in_v) ? av : 0.0;
         cQ[bi][bj][r] = (in_m || in_v) ? qv : 0.0;
