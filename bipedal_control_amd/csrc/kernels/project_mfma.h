@@ -40,41 +40,63 @@ struct ProjectMfmaWorkspace {
 // The three products for a compile-time number of block columns NBC (packed width nx + 1 + nut <= 16 NBC).  Everything
 // that is read from HBM (operands, accumulator initial values) is loaded before the first output store: vmcnt retires in
 // order, a load issued behind a store would wait for that store to reach memory.
-template <int NJ, int NBC>
+template <int NJ, int NBC, class IssueX, class WriteX>
 __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
-                                                     double dt_over_mass, const double* Qc, const double* Rc, double reg, int nut) {
+                                                     double dt_over_mass, const double* Qc, const double* Rc, double reg, int nut,
+                                                     IssueX&& issue_x, WriteX&& write_x) {
   using WS = ProjectMfmaWorkspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, KR = WS::KR, KS = KR / 4, BC = NX + 1, WP = PackedLq<NJ>::WP, QP = PackedLq<NJ>::QP;
   const int l = threadIdx.x, li = l & 15, lk = l >> 4;
-  // RAW loads first, every one of them, and only then the arithmetic on what they returned (shift, dt, identity rows, masks): a select
-  // or a product on a loaded value makes the wave wait for that load, and interleaved with the loads it serialised the node's memory
-  // latency four times over (three `s_waitcnt vmcnt(0)` in the middle of the load stream).
+  // The memory latency of a node is paid in as few round trips as the registers allow:
+  //   (1) the loads of X (the caller's issue_x) together with the RAW operands of the first product, [A | b | 0] + B X;
+  //   (2) X goes to LDS (write_x), the RAW operands of the other two products are issued behind it and arrive under the first product.
+  // RAW: the arithmetic on a loaded value (shift, dt, identity rows, masks) comes after the loads of its group - a select or a product
+  // on a loaded value makes the wave wait for that load, and interleaved with the loads it serialised the latency several times over.
+  issue_x();
   const double shift = in.qrd[0];
   // A-operands from HBM: rows 16 bi + li of R and of B, k = 4 ks + lk (out-of-range lanes read element 0 and are masked)
   double aR[2][KS], aB[2][KS];
+  // accumulator initial values in the D layout: [A | b | 0] (2 x NBC blocks), [Q | q | 0] (block row 0 and, for rows < nx, 1),
+  // r for the b column of R X
+  v4d cA[2][NBC], cQ[2][NBC], cR[2];
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
+  for (int bi = 0; bi < 2; ++bi) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int row = 16 * bi + li, kk = 4 * ks + lk;
+      // Only the rows 3..11 of the discretised centroidal dynamics are dense (linearize_fast.h writes the others as
+      //   A: identity rows;   B rows 0..2: dt/m on the matching component of the four contact forces;   B rows 12..: dt on the
+      // joint velocity), so those are generated here instead of being read (a fifth of this kernel's HBM reads).
+      const bool dense = row < NU && kk < NU && row >= 3 && row < 12;
+      aB[bi][ks] = in.B[dense ? row * NU + kk : 3 * NU];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 16 * bi + lk + 4 * r;
+      const bool rin = rr < NX;
+#pragma unroll
+      for (int bj = 0; bj < NBC; ++bj) {
+        const int col = 16 * bj + li;
+        const bool in_m = rin && col < NX, in_v = rin && col == NX;
+        const bool a_dense = in_m && rr >= 3 && rr < 12;
+        cA[bi][bj][r] = *(a_dense ? in.A + rr * NX + col : (in_v ? in.b + rr : in.A + 3 * NX));
+      }
+    }
+  }
+  write_x();
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int row = 16 * bi + li, kk = 4 * ks + lk;
       const bool ok = row < NU && kk < NU;
-      // Only the rows 3..11 of the discretised centroidal dynamics are dense (linearize_fast.h writes the others as
-      //   A: identity rows;   B rows 0..2: dt/m on the matching component of the four contact forces;   B rows 12..: dt on the
-      // joint velocity), so those are generated here instead of being read (a fifth of this kernel's HBM reads).
-      const bool dense = ok && row >= 3 && row < 12;
       // R and Q of the node are dt x (constant weight) except on the diagonal (Hessian shift of the relaxed barriers) and in the
       // four 3x3 force blocks of R (cone Hessians), linearize_fast.h: those come from the node's compact record (320 B), the
       // rest is regenerated from the model constants (cache resident) with the lineariser's own expressions - 7 KB less HBM
       // read per node than fetching Q and R
       const bool r_block = ok && row < 12 && kk < 12 && row / 3 == kk / 3;
       aR[bi][ks] = *(r_block ? in.qrd + 1 + 3 * kk + row % 3 : Rc + (ok ? row * NU + kk : 0));
-      aB[bi][ks] = in.B[dense ? row * NU + kk : 3 * NU];
     }
-  // accumulator initial values in the D layout: [A | b | 0] (2 x NBC blocks), [Q | q | 0] (block row 0 and, for rows < nx, 1),
-  // r for the b column of R X
-  v4d cA[2][NBC], cQ[2][NBC], cR[2];
-#pragma unroll
-  for (int bi = 0; bi < 2; ++bi) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 16 * bi + lk + 4 * r;
@@ -84,33 +106,25 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
       for (int bj = 0; bj < NBC; ++bj) {
         const int col = 16 * bj + li;
         const bool in_m = rin && col < NX, in_v = rin && col == NX;
-        const bool a_dense = in_m && rr >= 3 && rr < 12;
-        cA[bi][bj][r] = *(a_dense ? in.A + rr * NX + col : (in_v ? in.b + rr : in.A + 3 * NX));
         cQ[bi][bj][r] = *(in_m ? Qc + rr * NX + col : (in_v ? in.q + rr : in.q));
       }
     }
   }
-  // ---- the arithmetic on the loaded values
+  // ---- the arithmetic on the operands of the first product
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
+  for (int bi = 0; bi < 2; ++bi) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int row = 16 * bi + li, kk = 4 * ks + lk;
       const bool ok = row < NU && kk < NU;
       const bool dense = ok && row >= 3 && row < 12;
-      const bool r_block = ok && row < 12 && kk < 12 && row / 3 == kk / 3;
-      const double rv = aR[bi][ks];
-      aR[bi][ks] = ok ? (r_block ? rv : dt * (row == kk ? rv + shift : rv)) : 0.0;
       const double synth = row < 3 ? ((kk < 12 && kk % 3 == row) ? dt_over_mass : 0.0) : (kk == row ? dt : 0.0);
       aB[bi][ks] = dense ? aB[bi][ks] : (ok ? synth : 0.0);
     }
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi) {
-#pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 16 * bi + lk + 4 * r;
       const bool rin = rr < NX;
-      cR[bi][r] = (li == NX - 16 && rin) ? cR[bi][r] : 0.0;      // column nx lives in block column 1 (nx in 16..31)
 #pragma unroll
       for (int bj = 0; bj < NBC; ++bj) {
         const int col = 16 * bj + li;
@@ -118,15 +132,12 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
         const bool a_dense = in_m && rr >= 3 && rr < 12;
         double av = cA[bi][bj][r];
         if (in_m && !a_dense) av = (rr == col) ? 1.0 : 0.0;          // identity rows of A
-        double qv = cQ[bi][bj][r];
-        if (in_m) qv = dt * (rr == col ? qv + shift : qv);
         cA[bi][bj][r] = (in_m || in_v) ? av : 0.0;
-        cQ[bi][bj][r] = (in_m || in_v) ? qv : 0.0;
       }
     }
   }
   static_assert(NX >= 16 && NX < 32, "column nx sits in block column 1");
-  lds_wave_sync();                                     // X is in LDS (written by the caller)
+  lds_wave_sync();                                     // X is in LDS (write_x)
 
   // Every HBM load of this node has been issued by now, so results may leave as soon as they exist.
   // ---- [At | bt | Bt] = [A | b | 0] + B X, stored at once (frees the B operands and these accumulators)
@@ -146,6 +157,32 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
       for (int r = 0; r < 4; ++r)
         if (16 * bi + lk + 4 * r < NX) wrow[4 * r * WP] = acc[r];
     }
+  // ---- the arithmetic on the operands of the other two products (their loads travelled under the first one)
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int row = 16 * bi + li, kk = 4 * ks + lk;
+      const bool ok = row < NU && kk < NU;
+      const bool r_block = ok && row < 12 && kk < 12 && row / 3 == kk / 3;
+      const double rv = aR[bi][ks];
+      aR[bi][ks] = ok ? (r_block ? rv : dt * (row == kk ? rv + shift : rv)) : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 16 * bi + lk + 4 * r;
+      const bool rin = rr < NX;
+      cR[bi][r] = (li == NX - 16 && rin) ? cR[bi][r] : 0.0;      // column nx lives in block column 1 (nx in 16..31)
+#pragma unroll
+      for (int bj = 0; bj < NBC; ++bj) {
+        const int col = 16 * bj + li;
+        const bool in_m = rin && col < NX, in_v = rin && col == NX;
+        double qv = cQ[bi][bj][r];
+        if (in_m) qv = dt * (rr == col ? qv + shift : qv);
+        cQ[bi][bj][r] = (in_m || in_v) ? qv : 0.0;
+      }
+    }
+  }
   // ---- per block column bj:  RX(:, bj) = R X(:, bj) + [0 | r | 0]  ->  LDS,  then  X' RX(:, bj) + [Q | q | 0 ; 0](:, bj)
   //      -> Qt, qt (rows < nx);  Pt, rt, Rt (rows > nx)
 #pragma unroll
@@ -226,65 +263,75 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
   const int nut = out.nut[0];
   const int nbc = (BC + nut + 15) >> 4;                // block columns (and rows) of the packed width nx + 1 + nut
 
-  // ---- X to LDS (coalesced reads), padding zeroed; the workgroup is this one wave
+  // ---- X to LDS (coalesced reads), padding zeroed; the workgroup is this one wave.  Split in two: the loads are issued together with the
+  //      first operand loads of the products (project_apply_blocks), the LDS writes follow once those are in flight.
   if constexpr (PK) {
     // after the structured elimination: the joint rows come packed (columns below the first unwritten block column), the
     // force rows are generated - zero except Pe_c in column nx and a single 1 for a stance component (project_lu_s.h)
     constexpr int WP = PackedLq<NJ>::WP, NV = NJ * 48, IT = (NV + kWave - 1) / kWave;
     double vv[IT];
+    double pev = 0.0;
+    auto issue_x = [&]() {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {                  // all loads in flight before the first LDS write
-      const int idx = l + it * kWave;
-      // (the elimination kernel wrote the columns < 16 nbc; beyond them a zero is loaded: an unconditional load with a selected ADDRESS,
-      //  where a conditional load is a branch and a wait for everything in flight)
-      vv[it] = *((idx < NV && idx % 48 < 16 * nbc) ? in.Vt + (idx / 48) * WP + idx % 48 : in.zero);
-    }
-    const double pev = l < 12 ? out.Pe[l] : 0.0;
-    for (int idx = l; idx < 12 * LDW; idx += kWave) (&ws.X[0][0])[idx] = 0.0;                          // force rows
-    for (int idx = l; idx < NJ * (LDW - 48); idx += kWave) ws.X[12 + idx / (LDW - 48)][48 + idx % (LDW - 48)] = 0.0;   // padding columns of the joint rows
-    lds_wave_sync();
+      for (int it = 0; it < IT; ++it) {
+        const int idx = l + it * kWave;
+        // (the elimination kernel wrote the columns < 16 nbc; beyond them a zero is loaded: an unconditional load with a selected ADDRESS,
+        //  where a conditional load is a branch and a wait for everything in flight)
+        vv[it] = *((idx < NV && idx % 48 < 16 * nbc) ? in.Vt + (idx / 48) * WP + idx % 48 : in.zero);
+      }
+      pev = *(l < 12 ? out.Pe + l : in.zero);
+    };
+    auto write_x = [&]() {
+      for (int idx = l; idx < 12 * LDW; idx += kWave) (&ws.X[0][0])[idx] = 0.0;                          // force rows
+      for (int idx = l; idx < NJ * (LDW - 48); idx += kWave) ws.X[12 + idx / (LDW - 48)][48 + idx % (LDW - 48)] = 0.0;   // padding columns of the joint rows
+      for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
+      lds_wave_sync();
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int idx = l + it * kWave;
-      if (idx < NV) ws.X[12 + idx / 48][idx % 48] = vv[it];
-    }
-    if (l < 12) {
-      const int mode = in.mode, c0s = mode == 2 ? 6 : 0, nsf = mode == 3 ? 12 : (mode == 0 ? 0 : 6);
-      ws.X[l][NX] = pev;
-      const int sidx = l - c0s;
-      if (sidx >= 0 && sidx < nsf && BC + sidx < LDW) ws.X[l][BC + sidx] = 1.0;
-    }
+      for (int it = 0; it < IT; ++it) {
+        const int idx = l + it * kWave;
+        if (idx < NV) ws.X[12 + idx / 48][idx % 48] = vv[it];
+      }
+      if (l < 12) {
+        const int mode = in.mode, c0s = mode == 2 ? 6 : 0, nsf = mode == 3 ? 12 : (mode == 0 ? 0 : 6);
+        ws.X[l][NX] = pev;
+        const int sidx = l - c0s;
+        if (sidx >= 0 && sidx < nsf && BC + sidx < LDW) ws.X[l][BC + sidx] = 1.0;
+      }
+    };
+    if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x);
+    else project_apply_blocks<NJ, WS::NBC_MAX>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x);
   } else {
-    constexpr int IT = (NU * NX + kWave - 1) / kWave;
-    double vx[IT], vu[IT];
+    auto issue_x = [&]() {                             // (test path, FullPivLU-format inputs: staged in one go)
+      constexpr int IT = (NU * NX + kWave - 1) / kWave;
+      double vx[IT], vu[IT];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {                  // all loads in flight before the first LDS write
-      const int idx = l + it * kWave;
-      const bool ok = idx < NU * NX;
-      vx[it] = ok ? out.Px[idx] : 0.0;
-      vu[it] = (ok && idx % NX < nut) ? out.Pu[idx] : 0.0;     // columns >= nut of Pu are zero: not read
-    }
+      for (int it = 0; it < IT; ++it) {                  // all loads in flight before the first LDS write
+        const int idx = l + it * kWave;
+        const bool ok = idx < NU * NX;
+        vx[it] = ok ? out.Px[idx] : 0.0;
+        vu[it] = (ok && idx % NX < nut) ? out.Pu[idx] : 0.0;     // columns >= nut of Pu are zero: not read
+      }
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int idx = l + it * kWave;
-      if (idx < NU * NX) { ws.X[idx / NX][idx % NX] = vx[it]; if (BC + idx % NX < WC) ws.X[idx / NX][BC + idx % NX] = vu[it]; }
-    }
-    if (l < NU) ws.X[l][NX] = out.Pe[l];
-    for (int idx = l; idx < NU * (LDW - WC); idx += kWave) ws.X[idx / (LDW - WC)][WC + idx % (LDW - WC)] = 0.0;   // columns beyond [Px Pe Pu]
+      for (int it = 0; it < IT; ++it) {
+        const int idx = l + it * kWave;
+        if (idx < NU * NX) { ws.X[idx / NX][idx % NX] = vx[it]; if (BC + idx % NX < WC) ws.X[idx / NX][BC + idx % NX] = vu[it]; }
+      }
+      if (l < NU) ws.X[l][NX] = out.Pe[l];
+      for (int idx = l; idx < NU * (LDW - WC); idx += kWave) ws.X[idx / (LDW - WC)][WC + idx % (LDW - WC)] = 0.0;   // columns beyond [Px Pe Pu]
+      for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
+      if (out.Vt) {                                      // joint rows of X in the packed layout the sweep's loaders read (columns < 16 nbc)
+        constexpr int WP = PackedLq<NJ>::WP;
+        lds_wave_sync();
+        for (int idx = l; idx < NJ * WP; idx += kWave) {
+          const int r = idx / WP, c = idx % WP;
+          if (c < 48) out.Vt[idx] = ws.X[12 + r][c];       // complete rows of three block columns (X is zero padded)
+        }
+      }
+    };
+    auto write_x = []() {};
+    if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x);
+    else project_apply_blocks<NJ, WS::NBC_MAX>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x);
   }
-  for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
-
-  if (!PK && out.Vt) {                                 // joint rows of X in the packed layout the sweep's loaders read (columns < 16 nbc)
-    constexpr int WP = PackedLq<NJ>::WP;
-    lds_wave_sync();
-    for (int idx = l; idx < NJ * WP; idx += kWave) {
-      const int r = idx / WP, c = idx % WP;
-      if (c < 48) out.Vt[idx] = ws.X[12 + r][c];         // complete rows of three block columns (X is zero padded)
-    }
-  }
-  if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
-  else project_apply_blocks<NJ, WS::NBC_MAX>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut);
-
 }
 
 }  // namespace bpmpc
