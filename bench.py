@@ -372,8 +372,11 @@ def committed_traffic(robot, gait, sweep, batch, intervals):
             if k.startswith(prefix) and k.endswith(suffix):
                 return v.get("hbm_bytes_per_launch")
         return None
+    def pick_sum(prefix):          # the sweep is one launch (k_riccati_fast*) or two (k_riccati_wave*, k_riccati_rollout) per step
+        vals = [v.get("hbm_bytes_per_launch") for k, v in ks.items() if k.startswith(prefix) and v.get("hbm_bytes_per_launch")]
+        return sum(vals) if vals else None
     kernels = {"linearize_materialised": pick("k_linearize_fast", "true>"), "linearize_fused": pick("k_linearize_fast", "false>"),
-               "project_lu": pick("k_project_lu"), "project": pick("k_project_fast"), "riccati": pick("k_riccati_fast"), "linesearch": pick("k_trial_fast")}
+               "project_lu": pick("k_project_lu"), "project": pick("k_project_fast"), "riccati": pick_sum("k_riccati"), "linesearch": pick("k_trial_fast")}
     return {"source": "profiles/%s (builder run of the same command under rocprofv3 --pmc; not measured in this process)" % name, "kernels": kernels,
             "materialised_hbm_bytes_per_step": tj.get("materialised_hbm_bytes_per_step"), "fused_hbm_bytes_per_step": tj.get("fused_hbm_bytes_per_step")}
 
