@@ -10,6 +10,7 @@ export TMPDIR=/tmp PYTHONPATH=.
 O=gpurun_out/$TAG
 mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/pytest.log
+timeout 300 python bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-fused > /dev/null 2>&1    # warm-up: the first bench after the test suite runs ~2 % slow (clocks)
 timeout 600 python bench.py > $O/bench_h1.json 2> $O/bench_h1.err
 timeout 600 python bench.py --robot g1 --batch 1024 --cpu-sample 16 > $O/bench_g1.json 2>> $O/bench_h1.err
 timeout 600 python bench.py --workload gait-sweep --batch 4096 --cpu-sample 16 > $O/bench_sweep.json 2>> $O/bench_h1.err
