@@ -143,6 +143,49 @@ class BipedalRobotInterface:
         v = self.get("sqp")
         return dict(dt=v[0], sqpIteration=int(v[1]), deltaTol=v[2], g_max=v[3], g_min=v[4])
 
+    _IPM_FIELDS = ("dt", "ipmIteration", "deltaTol", "g_max", "g_min", "computeLagrangeMultipliers", "useFeedbackPolicy", "initialBarrierParameter",
+                   "targetBarrierParameter", "barrierLinearDecreaseFactor", "barrierSuperlinearDecreasePower", "barrierReductionCostTol",
+                   "barrierReductionConstraintTol", "fractionToBoundaryMargin", "usePrimalStepSizeForDual", "initialSlackLowerBound",
+                   "initialDualLowerBound", "initialSlackMarginRate", "initialDualMarginRate", "nThreads", "threadPriority")
+    _DDP_FIELDS = ("algorithm", "maxNumIterations", "minRelCost", "constraintTolerance", "AbsTolODE", "RelTolODE", "timeStep", "maxNumStepsPerSecond",
+                   "backwardPassIntegratorType", "constraintPenaltyInitialValue", "constraintPenaltyIncreaseRate", "preComputeRiccatiTerms",
+                   "useFeedbackPolicy", "strategy", "lineSearch.minStepLength", "lineSearch.maxStepLength", "lineSearch.hessianCorrectionStrategy",
+                   "lineSearch.hessianCorrectionMultiple", "nThreads", "threadPriority")
+    _DDP_ENUMS = {"algorithm": ("SLQ", "ILQR"), "strategy": ("LINE_SEARCH", "LEVENBERG_MARQUARDT"),
+                  "backwardPassIntegratorType": ("ODE45", "EULER", "ODE45_OCS2", "ADAMS_BASHFORTH", "BULIRSCH_STOER", "MODIFIED_MIDPOINT", "RK4", "RK5_VARIABLE",
+                                                 "ADAMS_BASHFORTH_MOULTON"),
+                  "lineSearch.hessianCorrectionStrategy": ("DIAGONAL_SHIFT", "CHOLESKY_MODIFICATION", "EIGENVALUE_MODIFICATION", "GERSHGORIN_MODIFICATION")}
+    _INT_FIELDS = {"ipmIteration", "nThreads", "threadPriority", "maxNumIterations", "maxNumStepsPerSecond"}
+    _BOOL_FIELDS = {"computeLagrangeMultipliers", "useFeedbackPolicy", "usePrimalStepSizeForDual", "preComputeRiccatiTerms"}
+
+    def _settings(self, block, fields, enums=()):
+        v = self.get(block)
+        out = {}
+        for name, x in zip(fields, v):
+            if name in enums:
+                out[name] = enums[name][int(x)]
+            elif name in self._BOOL_FIELDS:
+                out[name] = bool(x)
+            elif name in self._INT_FIELDS:
+                out[name] = int(x)
+            else:
+                out[name] = float(x)
+        return out
+
+    def ipmSettings(self):
+        """The `ipm` block of task.info as the reference loads it (BipedalRobotInterface.cpp:100, accessor BipedalRobotInterface.h:80).
+        The reference constructs no IPM solver; neither does this engine: the settings are loaded and exposed, nothing consumes them."""
+        return self._settings("ipm", self._IPM_FIELDS)
+
+    def ddpSettings(self):
+        """The `ddp` block of task.info (BipedalRobotInterface.cpp:98); consumed in the reference by the stand-alone DDP node
+        (BipedalRobotDdpMpcNode.cpp:70-74), a solver this engine does not have."""
+        return self._settings("ddp", self._DDP_FIELDS, self._DDP_ENUMS)
+
+    def rolloutSettings(self):
+        v = self.get("rollout")
+        return dict(AbsTolODE=v[0], RelTolODE=v[1], timeStep=v[2], maxNumStepsPerSecond=int(v[3]))
+
     def mpcSettings(self):
         return dict(timeHorizon=float(self.get("time_horizon")[0]))
 

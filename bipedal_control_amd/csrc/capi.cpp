@@ -107,6 +107,22 @@ int bpmpc_model_get(const bpmpc_model* m, const char* name, double* out, int cap
     if (n == "swing") return list({r.swing.lift_off_velocity, r.swing.touch_down_velocity, r.swing.swing_height, r.swing.swing_time_scale});
     if (n == "rollout") return list({r.rollout.abs_tol, r.rollout.rel_tol, r.rollout.time_step, (double)r.rollout.max_steps_per_second, r.mrt_frequency, r.mpc_frequency});
     if (n == "sqp") return list({r.sqp.dt, (double)r.sqp.sqp_iteration, r.sqp.delta_tol, r.sqp.g_max, r.sqp.g_min});
+    // settings blocks the reference loads beside sqp (BipedalRobotInterface.cpp:98-100); field order documented in include/bpmpc.h
+    if (n == "ipm") {
+      const IpmConfig& p = r.ipm;
+      return list({p.dt, (double)p.ipm_iteration, p.delta_tol, p.g_max, p.g_min, (double)p.compute_lagrange_multipliers, (double)p.use_feedback_policy,
+                   p.initial_barrier_parameter, p.target_barrier_parameter, p.barrier_linear_decrease_factor, p.barrier_superlinear_decrease_power,
+                   p.barrier_reduction_cost_tol, p.barrier_reduction_constraint_tol, p.fraction_to_boundary_margin, (double)p.use_primal_step_size_for_dual,
+                   p.initial_slack_lower_bound, p.initial_dual_lower_bound, p.initial_slack_margin_rate, p.initial_dual_margin_rate,
+                   (double)p.n_threads, (double)p.thread_priority});
+    }
+    if (n == "ddp") {
+      const DdpConfig& d = r.ddp;
+      return list({(double)d.algorithm, (double)d.max_num_iterations, d.min_rel_cost, d.constraint_tolerance, d.abs_tol_ode, d.rel_tol_ode, d.time_step,
+                   (double)d.max_num_steps_per_second, (double)d.backward_pass_integrator, d.constraint_penalty_initial_value, d.constraint_penalty_increase_rate,
+                   (double)d.pre_compute_riccati_terms, (double)d.use_feedback_policy, (double)d.strategy, d.ls_min_step_length, d.ls_max_step_length,
+                   (double)d.ls_hessian_correction_strategy, d.ls_hessian_correction_multiple, (double)d.n_threads, (double)d.thread_priority});
+    }
     throw std::invalid_argument("bpmpc_model_get: unknown name " + n);
   });
 }

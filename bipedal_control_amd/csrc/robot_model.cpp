@@ -214,6 +214,42 @@ RobotModel load_robot_model(const std::string& urdf_path, const std::string& tas
   task->get("mpc.timeHorizon", &m.time_horizon);
   task->get("mpc.mrtDesiredFrequency", &m.mrt_frequency);
   task->get("mpc.mpcDesiredFrequency", &m.mpc_frequency);
+  // ipm / ddp blocks: optional, as every ocs2 loadSettings (missing entries keep the defaults)
+  {
+    auto flag = [&](const std::string& path, int* out) { std::string v; if (task->get(path, &v)) *out = (v == "true" || v == "1") ? 1 : 0; };
+    auto choice = [&](const std::string& path, std::initializer_list<const char*> names, int* out) {
+      std::string v;
+      if (!task->get(path, &v)) return;
+      int i = 0;
+      for (const char* n : names) { if (v == n) { *out = i; return; } ++i; }
+      throw std::runtime_error("task.info: unknown value '" + v + "' of " + path);
+    };
+    IpmConfig& p = m.ipm;
+    task->get("ipm.dt", &p.dt); task->get("ipm.ipmIteration", &p.ipm_iteration); task->get("ipm.deltaTol", &p.delta_tol);
+    task->get("ipm.g_max", &p.g_max); task->get("ipm.g_min", &p.g_min); task->get("ipm.nThreads", &p.n_threads); task->get("ipm.threadPriority", &p.thread_priority);
+    flag("ipm.computeLagrangeMultipliers", &p.compute_lagrange_multipliers); flag("ipm.useFeedbackPolicy", &p.use_feedback_policy);
+    task->get("ipm.initialBarrierParameter", &p.initial_barrier_parameter); task->get("ipm.targetBarrierParameter", &p.target_barrier_parameter);
+    task->get("ipm.barrierLinearDecreaseFactor", &p.barrier_linear_decrease_factor); task->get("ipm.barrierSuperlinearDecreasePower", &p.barrier_superlinear_decrease_power);
+    task->get("ipm.barrierReductionCostTol", &p.barrier_reduction_cost_tol); task->get("ipm.barrierReductionConstraintTol", &p.barrier_reduction_constraint_tol);
+    task->get("ipm.fractionToBoundaryMargin", &p.fraction_to_boundary_margin); flag("ipm.usePrimalStepSizeForDual", &p.use_primal_step_size_for_dual);
+    task->get("ipm.initialSlackLowerBound", &p.initial_slack_lower_bound); task->get("ipm.initialDualLowerBound", &p.initial_dual_lower_bound);
+    task->get("ipm.initialSlackMarginRate", &p.initial_slack_margin_rate); task->get("ipm.initialDualMarginRate", &p.initial_dual_margin_rate);
+    DdpConfig& d = m.ddp;
+    choice("ddp.algorithm", {"SLQ", "ILQR"}, &d.algorithm);
+    task->get("ddp.nThreads", &d.n_threads); task->get("ddp.threadPriority", &d.thread_priority); task->get("ddp.maxNumIterations", &d.max_num_iterations);
+    task->get("ddp.minRelCost", &d.min_rel_cost); task->get("ddp.constraintTolerance", &d.constraint_tolerance);
+    task->get("ddp.AbsTolODE", &d.abs_tol_ode); task->get("ddp.RelTolODE", &d.rel_tol_ode); task->get("ddp.timeStep", &d.time_step);
+    task->get("ddp.maxNumStepsPerSecond", &d.max_num_steps_per_second);
+    choice("ddp.backwardPassIntegratorType", {"ODE45", "EULER", "ODE45_OCS2", "ADAMS_BASHFORTH", "BULIRSCH_STOER", "MODIFIED_MIDPOINT", "RK4", "RK5_VARIABLE", "ADAMS_BASHFORTH_MOULTON"},
+           &d.backward_pass_integrator);
+    task->get("ddp.constraintPenaltyInitialValue", &d.constraint_penalty_initial_value); task->get("ddp.constraintPenaltyIncreaseRate", &d.constraint_penalty_increase_rate);
+    flag("ddp.preComputeRiccatiTerms", &d.pre_compute_riccati_terms); flag("ddp.useFeedbackPolicy", &d.use_feedback_policy);
+    choice("ddp.strategy", {"LINE_SEARCH", "LEVENBERG_MARQUARDT"}, &d.strategy);
+    task->get("ddp.lineSearch.minStepLength", &d.ls_min_step_length); task->get("ddp.lineSearch.maxStepLength", &d.ls_max_step_length);
+    choice("ddp.lineSearch.hessianCorrectionStrategy", {"DIAGONAL_SHIFT", "CHOLESKY_MODIFICATION", "EIGENVALUE_MODIFICATION", "GERSHGORIN_MODIFICATION"},
+           &d.ls_hessian_correction_strategy);
+    task->get("ddp.lineSearch.hessianCorrectionMultiple", &d.ls_hessian_correction_multiple);
+  }
   task->get("rollout.AbsTolODE", &m.rollout.abs_tol);
   task->get("rollout.RelTolODE", &m.rollout.rel_tol);
   task->get("rollout.timeStep", &m.rollout.time_step);

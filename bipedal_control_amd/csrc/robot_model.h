@@ -33,6 +33,32 @@ struct SqpConfig { double dt = 0.015; int sqp_iteration = 1; double delta_tol = 
 // rollout block of task.info (TimeTriggeredRollout, ODE45)
 struct RolloutConfig { double abs_tol = 1e-5, rel_tol = 1e-3, time_step = 0.015; int max_steps_per_second = 10000; };
 
+// ipm block of task.info: the reference LOADS these settings (src/BipedalRobotInterface.cpp:100, accessor ipmSettings(),
+// include/ocs2_bipedal_robot/BipedalRobotInterface.h:80) and constructs no IPM solver anywhere; the same here - loaded, exposed, unused.
+// Defaults [OCS2-upstream, recalled]: ocs2_ipm/IpmSettings.h.
+struct IpmConfig {
+  double dt = 0.01; int ipm_iteration = 10; double delta_tol = 1e-6, g_max = 1e-2, g_min = 1e-6;
+  int compute_lagrange_multipliers = 1, use_feedback_policy = 1, n_threads = 4, thread_priority = 50;
+  double initial_barrier_parameter = 1e-2, target_barrier_parameter = 1e-4, barrier_linear_decrease_factor = 0.2,
+         barrier_superlinear_decrease_power = 1.5, barrier_reduction_cost_tol = 1e-3, barrier_reduction_constraint_tol = 1e-3;
+  double fraction_to_boundary_margin = 0.995; int use_primal_step_size_for_dual = 1;
+  double initial_slack_lower_bound = 1e-4, initial_dual_lower_bound = 1e-4, initial_slack_margin_rate = 1e-2, initial_dual_margin_rate = 1e-2;
+};
+// ddp block of task.info: loaded at src/BipedalRobotInterface.cpp:98 and consumed by the stand-alone DDP node
+// (ocs2_bipedal_robot_ros/src/BipedalRobotDdpMpcNode.cpp:70-74, GaussNewtonDDP_MPC) - a solver this engine does not have.
+struct DdpConfig {
+  int algorithm = 0;                       // 0 SLQ, 1 ILQR
+  int n_threads = 1, thread_priority = 99, max_num_iterations = 15;
+  double min_rel_cost = 1e-3, constraint_tolerance = 1e-3;
+  double abs_tol_ode = 1e-9, rel_tol_ode = 1e-6, time_step = 1e-2; int max_num_steps_per_second = 10000;
+  int backward_pass_integrator = 0;        // 0 ODE45 (index into kIntegratorNames)
+  double constraint_penalty_initial_value = 2.0, constraint_penalty_increase_rate = 2.0;
+  int pre_compute_riccati_terms = 1, use_feedback_policy = 0;
+  int strategy = 0;                        // 0 LINE_SEARCH, 1 LEVENBERG_MARQUARDT
+  double ls_min_step_length = 0.05, ls_max_step_length = 1.0; int ls_hessian_correction_strategy = 0;   // 0 DIAGONAL_SHIFT, 1 CHOLESKY_MODIFICATION, 2 EIGENVALUE_MODIFICATION, 3 GERSHGORIN_MODIFICATION
+  double ls_hessian_correction_multiple = 1e-6;
+};
+
 struct RobotModel {
   int nj = 0, nx = 0, nu = 0;
   std::vector<std::string> joint_names, contact_names;
@@ -57,6 +83,8 @@ struct RobotModel {
   SwingConfig swing;
   SqpConfig sqp;
   RolloutConfig rollout;
+  IpmConfig ipm;
+  DdpConfig ddp;
   double mrt_frequency = 400, mpc_frequency = 50;
   ModeSchedule initial_mode_schedule;
   ModeTemplate default_template;

@@ -58,7 +58,22 @@ int bpmpc_model_dims(const bpmpc_model* model, int* nx, int* nu, int* n_contacts
  * "com_height", "body_mass", "body_com", "body_inertia", "joint_parent", "joint_rotation", "joint_offset", "joint_axis",
  * "contact_body", "contact_offset", "cone" (mu, regularization, gripper force, hessian shift, barrier mu, barrier delta),
  * "swing" (liftOffVelocity, touchDownVelocity, swingHeight, swingTimeScale), "sqp" (dt, sqpIteration, deltaTol, g_max, g_min),
- * "time_horizon", "position_error_gain", "phase_transition_stance_time". */
+ * "time_horizon", "position_error_gain", "phase_transition_stance_time", "hard_cone" (flag, sqp.inequalityConstraintMu, Delta),
+ * "rollout" (AbsTolODE, RelTolODE, timeStep, maxNumStepsPerSecond, mrt frequency, mpc frequency).
+ * The other two solver-settings blocks the reference loads beside `sqp` (src/BipedalRobotInterface.cpp:98-100; accessors ddpSettings(),
+ * ipmSettings(), include/ocs2_bipedal_robot/BipedalRobotInterface.h:78-80) are loaded and exposed; NO solver of this library consumes
+ * them (the reference constructs no IPM solver either; its DDP solver lives in one stand-alone node, BipedalRobotDdpMpcNode.cpp:70-74):
+ *   "ipm": dt, ipmIteration, deltaTol, g_max, g_min, computeLagrangeMultipliers, useFeedbackPolicy, initialBarrierParameter,
+ *          targetBarrierParameter, barrierLinearDecreaseFactor, barrierSuperlinearDecreasePower, barrierReductionCostTol,
+ *          barrierReductionConstraintTol, fractionToBoundaryMargin, usePrimalStepSizeForDual, initialSlackLowerBound,
+ *          initialDualLowerBound, initialSlackMarginRate, initialDualMarginRate, nThreads, threadPriority          (booleans as 0 / 1)
+ *   "ddp": algorithm (0 SLQ, 1 ILQR), maxNumIterations, minRelCost, constraintTolerance, AbsTolODE, RelTolODE, timeStep,
+ *          maxNumStepsPerSecond, backwardPassIntegratorType (0 ODE45, 1 EULER, 2 ODE45_OCS2, 3 ADAMS_BASHFORTH, 4 BULIRSCH_STOER,
+ *          5 MODIFIED_MIDPOINT, 6 RK4, 7 RK5_VARIABLE, 8 ADAMS_BASHFORTH_MOULTON), constraintPenaltyInitialValue,
+ *          constraintPenaltyIncreaseRate, preComputeRiccatiTerms, useFeedbackPolicy, strategy (0 LINE_SEARCH, 1 LEVENBERG_MARQUARDT),
+ *          lineSearch.minStepLength, lineSearch.maxStepLength, lineSearch.hessianCorrectionStrategy (0 DIAGONAL_SHIFT,
+ *          1 CHOLESKY_MODIFICATION, 2 EIGENVALUE_MODIFICATION, 3 GERSHGORIN_MODIFICATION), lineSearch.hessianCorrectionMultiple,
+ *          nThreads, threadPriority */
 int bpmpc_model_get(const bpmpc_model* model, const char* name, double* out, int capacity);
 /* joint name j (DFS order = state order); returns length or negative status */
 int bpmpc_model_joint_name(const bpmpc_model* model, int j, char* out, int capacity);
