@@ -465,7 +465,7 @@ def test_folded_change_of_variables_matches_the_kernel_pipeline(ctx, gait, monke
 
 
 @pytest.mark.parametrize("robot,gait", [("h1", "trot"), ("h1", "standing_trot"), ("h1", "flying_trot"), ("g1", "standing_trot"), ("hunter", "trot")])
-@pytest.mark.parametrize("variant", ["2", "4"])
+@pytest.mark.parametrize("variant", ["2", "4", "5"])
 def test_wave_per_problem_sweep_matches_the_workgroup_sweep(ctx, robot, gait, variant, monkeypatch):
     """riccati_wave.h (one wavefront owns a problem: batches larger than the chip) against the workgroup-per-problem sweep of the same
     solver, same solves to rounding (the wave kernel reads S transposed instead of symmetrising it), and against the oracle at the
@@ -474,7 +474,7 @@ def test_wave_per_problem_sweep_matches_the_workgroup_sweep(ctx, robot, gait, va
     itf = sc.interface(robot)
     prob = sc.trot_problem(itf, batch=5, n_intervals=45, gait=gait)
     out = {}
-    for wave in ("0", variant):              # "2": riccati_wave.h (one wave per SIMD), "4": riccati_wave2.h (two) - forced at this small batch
+    for wave in ("0", variant):              # "2": riccati_wave.h (one wave per SIMD), "4": riccati_wave2.h (two), "5": riccati_pair.h (two waves per problem) - forced at this small batch
         monkeypatch.setenv("BPMPC_RICCATI_WAVE", wave)
         mpc = bp.BatchedSqpMpc(itf, max_batch=5, max_nodes=72, sqp_iterations=2, return_gains=True)
         out[wave] = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)

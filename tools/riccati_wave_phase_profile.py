@@ -16,7 +16,9 @@ mpc.synchronize()
 mpc.stage("riccati"); mpc.synchronize()
 r = mpc.read("rprof").reshape(B, 8)
 n = lay["n_nodes_max"]
-if variant == "2":
+if variant == "5":
+    print("riccati_pair.h, wave 0, cycles per stage (products + tile + loads, wait B1, elimination, wait B2, updates + LDS writes, wait B3, S read):")
+elif variant == "2":
     print("riccati_wave.h, cycles per stage by phase (top: stores + W loads, S W, B' SW + loads, A' SW + loads, tile + elimination, updates, outputs + loads):")
 else:
     print("riccati_wave2.h, cycles per stage by phase (output stores, products by block column, tile + elimination, S update + symmetrisation, Acl, loads 1 + force rows of Pu, K, loads 2):")
