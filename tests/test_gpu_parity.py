@@ -516,3 +516,29 @@ def test_h1_batch_beyond_four_problems_per_cu_matches_oracle(ctx):
     for b in (0, 550, B - 1):
         xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
         assert rel_x(x[b, :n + 1], xo) < 1e-11 and rel_u(u[b, :n], uo) < 1e-11 and rel_K(K[b, :n], Ko) < 1e-10
+
+
+def test_batch_4096_full_size_matches_small_batches_and_oracle(ctx):
+    """configs[2] on one GPU at its full size (4096 problems, horizon 100): the sweep runs riccati_wave2.h, sixteen problems per CU.  A
+    problem's solution does not depend on its batch: first, middle and last problem against the same three solved as a batch of their own
+    (eight-wave sweep, one problem per CU) to rounding, one of them against the oracle; every problem reports success and the
+    violation of every problem goes down."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    B, N, NN = 4096, 100, 116
+    prob = sc.trot_problem(itf, batch=B, n_intervals=N)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN, sqp_iterations=2)
+    t, x, u, _, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    assert all(s.status == 0 for s in st)
+    v0 = np.array([np.sqrt(s.dynamics_sse_before + s.equality_sse_before) for s in st])
+    v1 = np.array([np.sqrt(s.dynamics_sse_after + s.equality_sse_after) for s in st])
+    assert np.all(v1 <= v0 + 1e-12) and np.median(v1) < 0.2 * np.median(v0)
+    sub = [0, 2047, 4095]
+    prob2 = dict(prob, x0=prob["x0"][sub], targets=[prob["targets"][i] for i in sub])
+    mpc2 = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=NN, sqp_iterations=2)
+    _, x2, u2, _, st2 = mpc2.run(prob2["t0"], prob2["x0"], prob2["schedule"], prob2["targets"], horizon=prob2["horizon"])
+    n = st2[0].n_nodes
+    for j, i in enumerate(sub):
+        assert st[i].step_size == st2[j].step_size
+        assert rel_x(x[i, :n + 1], x2[j, :n + 1]) < 1e-10 and rel_u(u[i, :n], u2[j, :n]) < 1e-10
+    xo, uo, _, _ = ob.oracle_solve_like(prob2, 2, iterations=2)
+    assert rel_x(x[4095, :n + 1], xo) < 1e-11 and rel_u(u[4095, :n], uo) < 1e-11
