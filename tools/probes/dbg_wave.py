@@ -1,3 +1,7 @@
+# Debugging aid of the wave-per-problem sweeps: runs linearise / project / riccati once with two sweep kernels (BPMPC_RICCATI_WAVE = 0 and 2)
+# and with the reference kernels, prints the per-stage difference of K and Acl, the error pattern of the first swept stage and a host check of
+# that stage (S = 0: Y = H^-1 [G g], K_J = Vx - Vu Y).  It found the 1e-9-per-stage loss of the first elimination on the 24-state robot.
+# usage (GPU box, repository root): python tools/probes/dbg_wave.py g1 standing_trot
 import os, sys, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import bipedal_control_amd as bp
