@@ -239,7 +239,6 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
     // load in flight).
     asm volatile("" : "+v"(l));
     li = l & 15; lk = l >> 4; lx = li < XR; lxe = li <= XR;
-    if (k < k_top) flush(k + 1);
     RW2PROF(0);
     // ---- the products of the stage, one block column at a time
     double Sa1[KS];                                                     // S(4 ks + lk, 16 + li), state columns only
@@ -285,6 +284,9 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
         sn01 = a; sn11 = b;
       }
     }
+    // the outputs of the stage above leave here, behind the products (whose operand loads they would otherwise queue behind) and before
+    // the tiles they lie over are written again
+    if (k < k_top) flush(k + 1);
     RW2PROF(1);
     // the registers of W are the initial values of [Acl | bcl]
     v4d acl[2][2];
