@@ -542,3 +542,30 @@ def test_batch_4096_full_size_matches_small_batches_and_oracle(ctx):
         assert rel_x(x[i, :n + 1], x2[j, :n + 1]) < 1e-10 and rel_u(u[i, :n], u2[j, :n]) < 1e-10
     xo, uo, _, _ = ob.oracle_solve_like(prob2, 2, iterations=2)
     assert rel_x(x[4095, :n + 1], xo) < 1e-11 and rel_u(u[4095, :n], uo) < 1e-11
+
+
+@pytest.mark.parametrize("variant", ["2", "4", "5"])
+def test_wave_sweeps_chunked_horizon_and_handle_reuse(ctx, variant, monkeypatch):
+    """The sweeps that give a problem one or two wavefronts of its own (riccati_wave.h "2", riccati_wave2.h "4", riccati_pair.h "5", forced at
+    this small batch): (1) the chunked horizon pipeline hands [S | s] and the status from launch to launch through the carry record -
+    every chunk count gives the same bits, also with grids of different lengths; (2) a handle that has seen wider reduced inputs at a node
+    gives the same bits on a narrower problem as a fresh one (block columns and rows beyond nx + 1 + nut are neither loaded nor used)."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    monkeypatch.setenv("BPMPC_RICCATI_WAVE", variant)
+    gaits = ["stance", "trot", "standing_trot", "flying_trot"]
+    prob = sc.gait_sweep_problem(itf, gaits, [(0.3, 0.0), (-0.2, 0.3)], n_intervals=60)
+    results = []
+    for chunks in (1, 3, 7):
+        mpc = bp.BatchedSqpMpc(itf, max_batch=8, max_nodes=96, sqp_iterations=2, return_gains=True, pipeline_chunks=chunks)
+        results.append(mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"]))
+    for r in results[1:]:
+        assert np.array_equal(r[1], results[0][1]) and np.array_equal(r[2], results[0][2]) and np.array_equal(r[3], results[0][3])
+        assert [s.step_size for s in r[4]] == [s.step_size for s in results[0][4]]
+    trot = sc.trot_problem(itf, batch=4, n_intervals=60)
+    stance = sc.trot_problem(itf, batch=4, n_intervals=60, gait="stance")
+    reused = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=80, sqp_iterations=2, return_gains=True)
+    for p in (trot, stance, trot):
+        last = reused.run(p["t0"], p["x0"], p["schedule"], p["targets"], horizon=p["horizon"])
+    fresh = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=80, sqp_iterations=2, return_gains=True)
+    ref = fresh.run(trot["t0"], trot["x0"], trot["schedule"], trot["targets"], horizon=trot["horizon"])
+    assert np.array_equal(last[1], ref[1]) and np.array_equal(last[2], ref[2]) and np.array_equal(last[3], ref[3])
