@@ -569,3 +569,22 @@ def test_wave_sweeps_chunked_horizon_and_handle_reuse(ctx, variant, monkeypatch)
     fresh = bp.BatchedSqpMpc(itf, max_batch=4, max_nodes=80, sqp_iterations=2, return_gains=True)
     ref = fresh.run(trot["t0"], trot["x0"], trot["schedule"], trot["targets"], horizon=trot["horizon"])
     assert np.array_equal(last[1], ref[1]) and np.array_equal(last[2], ref[2]) and np.array_equal(last[3], ref[3])
+
+
+@pytest.mark.parametrize("variant", ["0", "2", "4", "5"])
+def test_indefinite_hessian_is_reported_by_every_sweep(ctx, variant, monkeypatch, tmp_path):
+    """Fail loudly: with a NEGATIVE input weight the reduced Hessian of a stage has a non-positive pivot; every sweep kernel has to report
+    the numerical failure (status 2, bpmpc.h) for the problem instead of returning numbers - the eight-wave sweep ("0" at this batch) and
+    the sweeps with one or two wavefronts per problem, forced."""
+    bp, sc = ctx["bp"], ctx["sc"]
+    monkeypatch.setenv("BPMPC_RICCATI_WAVE", variant)
+    text = open(sc.H1["task"]).read()
+    a = text.index("\nR\n{")
+    bad = tmp_path / "task_negative_R.info"
+    bad.write_text(text[:a] + text[a:].replace("scaling 1e-3", "scaling -1e-3", 1))
+    itf = bp.BipedalRobotInterface(str(bad), sc.H1["urdf"], sc.H1["reference"])
+    itf.gaitFile = sc.H1["gait"]
+    prob = sc.trot_problem(itf, batch=3, n_intervals=30)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=48, sqp_iterations=1)
+    t, x, u, _, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    assert all(s.status == 2 for s in st), [s.status for s in st]
