@@ -170,8 +170,7 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bool in = 4 * ks + lk < nt;
-#pragma unroll
-      for (int bi = 0; bi < 2; ++bi) cBt[bi][ks] = bload(rw, in ? oBt[bi] + 32u * ks : kOut);
+      cBt[0][ks] = bload(rw, in ? oBt[0] + 32u * ks : kOut);        // (rows 16.. of B~ row-major are not needed: Acl rows 3..11 only)
     }
   };
   auto load_pu = [&](int k, int nt) {         // Pu row-major (joint rows), [Px | Pe]
@@ -200,10 +199,11 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = l + it * kWave;
-      if (it + 1 < NIT || idx < NXX / 2) { A2[idx] = a2[idx]; K2[idx] = k2[idx]; }
+      if (it + 1 < NIT || idx < NXX / 2) K2[idx] = k2[idx];
+      if (idx >= 3 * NX / 2 && idx < 12 * NX / 2) A2[idx] = a2[idx];       // rows 3..11 of Acl
     }
     if (l < NX) {
-      io.bcl[(size_t)hk * NX + l] = ws.ob[l];
+      if (l >= 3 && l < 12) io.bcl[(size_t)hk * NX + l] = ws.ob[l];
       io.kff[(size_t)hk * NU + l] = ws.ok[l];
       io.mvec[(size_t)hk * NX + l] = ws.om[l];
     }
@@ -289,11 +289,11 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
     if (k < k_top) flush(k + 1);
     RW2PROF(1);
     // the registers of W are the initial values of [Acl | bcl]
-    v4d acl[2][2];
+    v4d acl[2];                                                         // first block row only (rows 3..11 are what the roll-out reads)
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { acl[0][bj][r] = cW[bj][r]; acl[1][bj][r] = (4 + r < KS) ? cW[bj][(4 + r < KS) ? 4 + r : 0] : 0.0; }
+      for (int r = 0; r < 4; ++r) acl[bj][r] = cW[bj][r];
     // ---- elimination (riccati_wave.h): [G g H] through the tile, forward elimination + back substitution, Z / Yn for the update of S
     load_bt(k, nt);
     if (nt > 0) {
@@ -391,27 +391,25 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
       lds_wave_sync();
     }
     RW2PROF(3);
-    // [Acl | bcl] = [A | b] - B Y  -> LDS (over the tiles of the elimination)
+    // [Acl | bcl] = [A | b] - B Y  -> LDS (over the tiles of the elimination): rows 3..11 only - the first block row, registers 0..2 -
+    // riccati_rollout_sparse derives the other rows of the closed-loop dynamics from du
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
+    for (int bj = 0; bj < 2; ++bj) {
+      v4d a = acl[bj];
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj) {
-        v4d a = acl[bi][bj];
+      for (int ks = 0; ks < 4; ++ks)
+        if (ks < ksn) a = __builtin_amdgcn_mfma_f64_16x16x4f64(cBt[0][ks], yb[ks][bj], a, 0, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          if (ks < ksn) a = __builtin_amdgcn_mfma_f64_16x16x4f64(cBt[bi][ks], yb[ks][bj], a, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (16 * bi + 4 * r >= NX) continue;
-          const int row = 16 * bi + lk + 4 * r, col = 16 * bj + li;
-          const bool rin = 16 * bi + 4 * r + 3 < NX || row < NX;
-          if (bj == 0) { if (rin) oA[row * NX + col] = a[r]; }
-          else {
-            if (rin && lx) oA[row * NX + col] = a[r];
-            if (rin && li == XR) ws.ob[row] = a[r];
-          }
+      for (int r = 0; r < 3; ++r) {
+        const int row = lk + 4 * r, col = 16 * bj + li;
+        const bool ain = r > 0 || lk == 3;
+        if (bj == 0) { if (ain) oA[row * NX + col] = a[r]; }
+        else {
+          if (ain && lx) oA[row * NX + col] = a[r];
+          if (ain && li == XR) ws.ob[row] = a[r];
         }
       }
+    }
     RW2PROF(4);
     // [K | kff] = [Px | Pe] - Pu Y  -> LDS; the force rows of Pu are generated from the contact mode
     {
