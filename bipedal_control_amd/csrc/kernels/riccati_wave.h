@@ -560,7 +560,7 @@ struct RiccatiRolloutWorkspace {
   static constexpr int NX = 12 + NJ;
   static constexpr int kCap = 152;                                                   // stages of history per pass
   static constexpr int kDoubles = (kCap + 4 + 8) * NX + kStepNormsScratch * kRiccatiThreads / kWave;
-  static constexpr int kCapSparse = (kDoubles - 256 - 4 * NX) / (2 * NX);          // riccati_rollout_sparse: dx and du histories of a pass
+  static constexpr int kCapSparse = (kDoubles - 200 - 64 - 4 * NX) / (2 * NX);          // riccati_rollout_sparse: dx and du histories of a pass
   alignas(16) double hist[kDoubles];
 };
 // Roll-out that reads 5.9 instead of 8.3 KB per stage.  The roll-out of riccati_mfma.h walks dx+ = Acl dx + bcl and computes du = K dx + kff
@@ -577,7 +577,15 @@ __device__ __forceinline__ void riccati_rollout_sparse(double* lds /* (cap + 4) 
   const int N = io.base.N;
   double* const hist = lds;                               // dx_0 .. dx_cap (+ slack), row stride nx
   double* const duh = lds + (size_t)(cap + 4) * NX;       // du of the pass, row stride nu
-  double* const scratch = duh + (size_t)cap * NU;         // line-search opening (3 * 64 + 5 doubles)
+  double* const scratch = duh + (size_t)cap * NU;         // line-search opening (3 * 64 + 5 doubles), then the stance table (<= 512 bytes)
+  // which force components are stance components, per stage: a component without contact has K = 0 (and kff = Pe) - its row is not
+  // read, the lane loads a row of zeros instead (same instructions, another address: the loads stay unconditional)
+  unsigned char* const stance_tab = reinterpret_cast<unsigned char*>(scratch + 200);
+  for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) {
+    const int m = io.base.nut[idx] > 0 ? (io.mode[idx] & 3) : 0;
+    stance_tab[idx] = (unsigned char)m;                   // bit 0: components 0..5, bit 1: components 6..11
+  }
+  const double* const zero_row_ptr = io.zero_one + 4;
   const double dt_over_m_factor = 1.0 / io.model->robot_mass;
   if (tid < NX) hist[tid] = io.base.dx0[tid];
   if (tid >= kWave && tid < kWave + NX) io.base.dx[tid - kWave] = io.base.dx0[tid - kWave];
@@ -592,7 +600,9 @@ __device__ __forceinline__ void riccati_rollout_sparse(double* lds /* (cap + 4) 
       int nA, nB, nC;
       auto load = [&](double (&r)[NX], double& sv, double& bv, double& dv, int& nv, int k) {
         const int kc = k < N ? k : N - 1;               // beyond the end: a valid, unused stage
-        const double* p = (is_a ? io.Acl + (size_t)kc * NXX : io.Kfull + (size_t)kc * NXU) + (size_t)ri * NX;
+        const int m = stance_tab[kc];
+        const bool zero_row = is_k && l < 12 && !((m >> (l >= 6 ? 1 : 0)) & 1);      // force component without contact: K row = 0
+        const double* p = zero_row ? zero_row_ptr : (is_a ? io.Acl + (size_t)kc * NXX : io.Kfull + (size_t)kc * NXU) + (size_t)ri * NX;
 #pragma unroll
         for (int c = 0; c < NX; ++c) r[c] = p[c];
         sv = *(is_a ? io.bcl + (size_t)kc * NX + ri : io.kff + (size_t)kc * NU + ri);
