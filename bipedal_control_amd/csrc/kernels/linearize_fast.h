@@ -66,7 +66,7 @@ struct LinFastNodeLds {
   double x[C::NX], u[C::NU], zref[FULL ? kNumContacts : 1], zdref[FULL ? kNumContacts : 1];   // value-only: swing references straight from HBM
   double xh2[9];                 // normalised momentum and base position of the second RK2 stage (the first stage reads x[0..8])
   union {                        // chain tables (dead after the walks)  <->  second-stage block
-    double T[NJ][12];            // joint-local transform of joint g-6: E (9) | pfix (3)
+    double T[NJ][9];             // joint-local rotation E of joint g-6 (its fixed offset is a model constant: LinFastShared::pfix)
     double a2[9][12];            // rows 3..11, x columns 0..11 of the stage-two Jacobian
   };
   union {
@@ -190,7 +190,6 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
     double E[9];
     mat3_mul(sh.Rfix[lb.body], rot, E);
     for (int i = 0; i < 9; ++i) nl.T[g - 6][i] = E[i];
-    for (int i = 0; i < 3; ++i) nl.T[g - 6][9 + i] = sh.pfix[lb.body][i];
   }
   lds_wave_sync();
   double R[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
@@ -203,7 +202,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
     const int gj = on ? path[d] - 1 : 0;   // joint index (0-based) of the d-th body on the chain
     double Ej[9], pj[3], t[3], Rn[9];
     for (int i = 0; i < 9; ++i) Ej[i] = nl.T[gj][i];
-    for (int i = 0; i < 3; ++i) pj[i] = nl.T[gj][9 + i];
+    for (int i = 0; i < 3; ++i) pj[i] = sh.pfix[gj + 1][i];
     mat3_vec(R, pj, t);
     mat3_mul(R, Ej, Rn);
     for (int i = 0; i < 3; ++i) o[i] = on ? o[i] + t[i] : o[i];
