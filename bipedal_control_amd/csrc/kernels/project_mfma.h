@@ -23,7 +23,7 @@
 
 namespace bpmpc {
 
-template <int NJ>
+template <int NJ, bool PK = false>
 struct ProjectMfmaWorkspace {
   static constexpr int NX = 12 + NJ, NU = 12 + NJ;
   static constexpr int KR = ((NX + 3) / 4) * 4;                  // rows used as the k index (nx rounded up to the k-step)
@@ -33,18 +33,21 @@ struct ProjectMfmaWorkspace {
   static constexpr int NBC_MAX = 3;
   static constexpr int WC = (NX + 1 + NU < 16 * NBC_MAX) ? NX + 1 + NU : 16 * NBC_MAX;     // columns of [Px | Pe | Pu] that are kept
   static constexpr int LDW = 16 * NBC_MAX + 2;
-  alignas(16) double X[KR][LDW];        // [Px | Pe | Pu], zero padded
-  alignas(16) double RX[KR][16 + 2];    // one block column of R X + [0 | r | 0] at a time (13 KB of LDS per wave in total: 12 waves per CU)
+  // PK (after the structured elimination): the force rows 0..11 of X hold Pe in column nx and a single 1 per stance component and are
+  // generated in registers where they are used; LDS holds the joint rows only - 8.3 KB per wave instead of 13 KB: 16 waves per CU, not 12
+  static constexpr int X0 = PK ? 12 : 0;                         // first row of X that lives in LDS
+  alignas(16) double X[KR - X0][LDW];   // [Px | Pe | Pu], zero padded
+  alignas(16) double RX[KR][16 + 2];    // one block column of R X + [0 | r | 0] at a time
 };
 
 // The three products for a compile-time number of block columns NBC (packed width nx + 1 + nut <= 16 NBC).  Everything
 // that is read from HBM (operands, accumulator initial values) is loaded before the first output store: vmcnt retires in
 // order, a load issued behind a store would wait for that store to reach memory.
-template <int NJ, int NBC, class IssueX, class WriteX>
-__device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
+template <int NJ, int NBC, bool PK, class IssueX, class WriteX>
+__device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ, PK>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
                                                      double dt_over_mass, const double* Qc, const double* Rc, double reg, int nut,
-                                                     IssueX&& issue_x, WriteX&& write_x) {
-  using WS = ProjectMfmaWorkspace<NJ>;
+                                                     IssueX&& issue_x, WriteX&& write_x, const double& pev) {
+  using WS = ProjectMfmaWorkspace<NJ, PK>;
   constexpr int NX = WS::NX, NU = WS::NU, KR = WS::KR, KS = KR / 4, BC = NX + 1, WP = PackedLq<NJ>::WP, QP = PackedLq<NJ>::QP;
   const int l = threadIdx.x, li = l & 15, lk = l >> 4;
   // The memory latency of a node is paid in as few round trips as the registers allow:
@@ -138,6 +141,28 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
   }
   static_assert(NX >= 16 && NX < 32, "column nx sits in block column 1");
   lds_wave_sync();                                     // X is in LDS (write_x)
+  // PK: element (4 ks + lk, col) of the force rows, ks < 3: Pe in column nx, a 1 in column nx + 1 + (row - first stance component) of a stance
+  // component, zero elsewhere - in particular in the whole block column 0, whose k-steps 0..2 are skipped (exact zeros either way)
+  constexpr int KF = PK ? 3 : 0;                        // k-steps that cover the force rows
+  double pe_k[3] = {0.0, 0.0, 0.0};
+  int one_k[3] = {-1, -1, -1};
+  if constexpr (PK) {
+    const int mode = in.mode, c0s = mode == 2 ? 6 : 0, nsf = mode == 3 ? 12 : (mode == 0 ? 0 : 6);
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      pe_k[ks] = __shfl(pev, 4 * ks + lk);
+      const int sidx = 4 * ks + lk - c0s;
+      one_k[ks] = (sidx >= 0 && sidx < nsf) ? BC + sidx : -1;
+    }
+  }
+  // operand element X(4 ks + lk, 16 blk + li)
+  auto x_elem = [&](int ks, int blk) -> double {
+    if (ks < KF) {
+      const int col = 16 * blk + li;
+      return col == NX ? pe_k[ks] : (col == one_k[ks] ? 1.0 : 0.0);
+    }
+    return ws.X[4 * ks + lk - WS::X0][16 * blk + li];
+  };
 
   // Every HBM load of this node has been issued by now, so results may leave as soon as they exist.
   // ---- [At | bt | Bt] = [A | b | 0] + B X, stored at once (frees the B operands and these accumulators)
@@ -147,10 +172,10 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
     for (int bj = 0; bj < NBC; ++bj) {
       double b[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) b[ks] = ws.X[4 * ks + lk][16 * bj + li];
+      for (int ks = 0; ks < KS; ++ks) b[ks] = x_elem(ks, bj);
       v4d acc = cA[bi][bj];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aB[bi][ks], b[ks], acc, 0, 0, 0);
+      for (int ks = (bj == 0 ? KF : 0); ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aB[bi][ks], b[ks], acc, 0, 0, 0);
       // packed layout (PackedLq): the block is 16 aligned row segments of Wt; columns beyond nx + 1 + nut hold exact zeros (B x 0)
       double* wrow = out.Wt + (16 * bi + lk) * WP + 16 * bj + li;
 #pragma unroll
@@ -191,13 +216,13 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
     {
       double b[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) b[ks] = ws.X[4 * ks + lk][col];
+      for (int ks = 0; ks < KS; ++ks) b[ks] = x_elem(ks, bj);
 #pragma unroll
       for (int bi = 0; bi < 2; ++bi) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         if (bj == 1) acc = cR[bi];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[bi][ks], b[ks], acc, 0, 0, 0);
+        for (int ks = (bj == 0 ? KF : 0); ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aR[bi][ks], b[ks], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rr = 16 * bi + lk + 4 * r;
@@ -216,11 +241,11 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
       if (bi == 0 && bj >= 2) continue;
       double a[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) a[ks] = ws.X[4 * ks + lk][16 * bi + li];         // X'(i, k)
+      for (int ks = 0; ks < KS; ++ks) a[ks] = x_elem(ks, bi);         // X'(i, k)
       v4d acc = {0.0, 0.0, 0.0, 0.0};
       if (bi < 2) acc = cQ[bi < 2 ? bi : 0][bj];         // rows >= nx of cQ are zero
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+      for (int ks = (bi == 0 ? KF : 0); ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = 16 * bi + lk + 4 * r;
@@ -240,9 +265,9 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ>& w
 // PK: [Px | Pe | Pu] arrives as the packed joint rows of the structured elimination (in.Vt; the force rows are generated from in.mode)
 // instead of as Px, Pu, Pe - a compile-time choice: both paths in one kernel cost nx = 24 its third wave per SIMD.
 template <int NJ, bool PK = false>
-__device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
+__device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ, PK>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
                                                    double dt_over_mass, const double* Qc, const double* Rc, double reg = 0.0) {
-  using WS = ProjectMfmaWorkspace<NJ>;
+  using WS = ProjectMfmaWorkspace<NJ, PK>;
   constexpr int NX = WS::NX, NU = WS::NU, LDW = WS::LDW, KR = WS::KR, BC = NX + 1, WC = WS::WC;
   static_assert(NX == NU, "packed layout assumes nx == nu");
   const int l = threadIdx.x;
@@ -281,25 +306,17 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
       }
       pev = *(l < 12 ? out.Pe + l : in.zero);
     };
-    auto write_x = [&]() {
-      for (int idx = l; idx < 12 * LDW; idx += kWave) (&ws.X[0][0])[idx] = 0.0;                          // force rows
-      for (int idx = l; idx < NJ * (LDW - 48); idx += kWave) ws.X[12 + idx / (LDW - 48)][48 + idx % (LDW - 48)] = 0.0;   // padding columns of the joint rows
-      for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU][0])[idx] = 0.0;                 // rows nu..
-      lds_wave_sync();
+    auto write_x = [&]() {                               // LDS rows: joint rows 12.. of X (the force rows are generated, project_apply_blocks)
+      for (int idx = l; idx < NJ * (LDW - 48); idx += kWave) ws.X[idx / (LDW - 48)][48 + idx % (LDW - 48)] = 0.0;   // padding columns of the joint rows
+      for (int idx = l; idx < (KR - NU) * LDW; idx += kWave) (&ws.X[NU - 12][0])[idx] = 0.0;            // rows nu..
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
         const int idx = l + it * kWave;
-        if (idx < NV) ws.X[12 + idx / 48][idx % 48] = vv[it];
-      }
-      if (l < 12) {
-        const int mode = in.mode, c0s = mode == 2 ? 6 : 0, nsf = mode == 3 ? 12 : (mode == 0 ? 0 : 6);
-        ws.X[l][NX] = pev;
-        const int sidx = l - c0s;
-        if (sidx >= 0 && sidx < nsf && BC + sidx < LDW) ws.X[l][BC + sidx] = 1.0;
+        if (idx < NV) ws.X[idx / 48][idx % 48] = vv[it];
       }
     };
-    if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x);
-    else project_apply_blocks<NJ, WS::NBC_MAX>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x);
+    if (nbc <= 2) project_apply_blocks<NJ, 2, true>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, pev);
+    else project_apply_blocks<NJ, WS::NBC_MAX, true>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, pev);
   } else {
     auto issue_x = [&]() {                             // (test path, FullPivLU-format inputs: staged in one go)
       constexpr int IT = (NU * NX + kWave - 1) / kWave;
@@ -329,8 +346,9 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ>& ws,
       }
     };
     auto write_x = []() {};
-    if (nbc <= 2) project_apply_blocks<NJ, 2>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x);
-    else project_apply_blocks<NJ, WS::NBC_MAX>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x);
+    const double no_pe = 0.0;
+    if (nbc <= 2) project_apply_blocks<NJ, 2, false>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, no_pe);
+    else project_apply_blocks<NJ, WS::NBC_MAX, false>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, no_pe);
   }
 }
 
