@@ -402,7 +402,13 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #ifdef BPMPC_RICCATI_PROFILE
     const long long tr0 = clock64();
 #endif
+#if BPMPC_ROLLOUT_SPARSE
+    constexpr int kCapSparse = ((int)(offsetof(WS, status) / sizeof(double)) - 264 - 4 * NX) / (2 * NX);
+    static_assert(kCapSparse >= 64, "roll-out history");
+    riccati_rollout_sparse<NJ, NT>(reinterpret_cast<double*>(&ws), kCapSparse, st, io);
+#else
     riccati_rollout_deep<NJ, NT>(reinterpret_cast<double*>(&ws), kHistCap, st, io);
+#endif
 #ifdef BPMPC_RICCATI_PROFILE
     if (BPMPC_RICCATI_PROFILE == 1 && io.prof && tid == 0) io.prof[5] = (double)(clock64() - tr0);     // roll-out + step norms, whole horizon
 #endif

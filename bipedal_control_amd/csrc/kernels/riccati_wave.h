@@ -563,121 +563,7 @@ struct RiccatiRolloutWorkspace {
   static constexpr int kCapSparse = (kDoubles - 200 - 64 - 4 * NX) / (2 * NX);          // riccati_rollout_sparse: dx and du histories of a pass
   alignas(16) double hist[kDoubles];
 };
-// Roll-out that reads 5.9 instead of 8.3 KB per stage.  The roll-out of riccati_mfma.h walks dx+ = Acl dx + bcl and computes du = K dx + kff
-// for all stages afterwards: Acl AND K, 3.9 KB each.  But 13 of the nx rows of the discretised dynamics are structural - rows 0..2:
-// dx+ = dx + b + (dt / m) (sum of the force inputs of that component), joint rows: dx+ = dx + b + dt du - so with du in hand only the rows
-// 3..11 of Acl are needed.  Here K is read INSIDE the recurrence (one row per lane, lanes 0..nx-1), the nine dense rows of Acl by lanes
-// 32..40, three stages in flight as before; dx and du stay in LDS for the norms and leave in coalesced passes.  Same mathematics
-// (dx+ = A dx + B du + b), results equal to the other roll-out to rounding.  At batch 4096 the roll-out is a streaming kernel (5.2 TB/s).
-template <int NJ, int NT = kRiccatiThreads>
-__device__ __forceinline__ void riccati_rollout_sparse(double* lds /* (cap + 4) nx + cap nu + 256 doubles */, int cap, int status, const RiccatiFastIO& io) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ, NXX = NX * NX, NXU = NX * NU;
-  static_assert(NX <= 32 && 9 <= 32, "lanes 0..nx-1: rows of K; lanes 32..40: rows 3..11 of Acl");
-  const int tid = threadIdx.x, l = tid & 63;
-  const int N = io.base.N;
-  double* const hist = lds;                               // dx_0 .. dx_cap (+ slack), row stride nx
-  double* const duh = lds + (size_t)(cap + 4) * NX;       // du of the pass, row stride nu
-  double* const scratch = duh + (size_t)cap * NU;         // line-search opening (3 * 64 + 5 doubles), then the stance table (<= 512 bytes)
-  // which force components are stance components, per stage: a component without contact has K = 0 (and kff = Pe) - its row is not
-  // read, the lane loads a row of zeros instead (same instructions, another address: the loads stay unconditional)
-  unsigned char* const stance_tab = reinterpret_cast<unsigned char*>(scratch + 200);
-  for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) {
-    const int m = io.base.nut[idx] > 0 ? (io.mode[idx] & 3) : 0;
-    stance_tab[idx] = (unsigned char)m;                   // bit 0: components 0..5, bit 1: components 6..11
-  }
-  const double* const zero_row_ptr = io.zero_one + 4;
-  const double dt_over_m_factor = 1.0 / io.model->robot_mass;
-  if (tid < NX) hist[tid] = io.base.dx0[tid];
-  if (tid >= kWave && tid < kWave + NX) io.base.dx[tid - kWave] = io.base.dx0[tid - kWave];
-  __syncthreads();
-  double acc_arm = 0.0, acc_x = 0.0, acc_u = 0.0;
-  for (int k0 = 0; k0 < N; k0 += cap) {
-    const int nk = N - k0 < cap ? N - k0 : cap;
-    if (tid < kWave) {
-      const bool is_k = l < NX, is_a = l >= 32 && l < 32 + 9;
-      const int ri = is_k ? l : (is_a ? 3 + (l - 32) : 0);                     // row of K / of Acl
-      double rA[NX], rB[NX], rC[NX], sA, sB, sC, bA, bB, bC, dA, dB, dC;
-      int nA, nB, nC;
-      auto load = [&](double (&r)[NX], double& sv, double& bv, double& dv, int& nv, int k) {
-        const int kc = k < N ? k : N - 1;               // beyond the end: a valid, unused stage
-        const int m = stance_tab[kc];
-        const bool zero_row = is_k && l < 12 && !((m >> (l >= 6 ? 1 : 0)) & 1);      // force component without contact: K row = 0
-        const double* p = zero_row ? zero_row_ptr : (is_a ? io.Acl + (size_t)kc * NXX : io.Kfull + (size_t)kc * NXU) + (size_t)ri * NX;
-#pragma unroll
-        for (int c = 0; c < NX; ++c) r[c] = p[c];
-        sv = *(is_a ? io.bcl + (size_t)kc * NX + ri : io.kff + (size_t)kc * NU + ri);
-        bv = io.lqb[(size_t)kc * NX + ri];
-        dv = io.gdt[kc];
-        nv = io.base.nut[kc];
-      };
-      auto step = [&](const double (&r)[NX], double sv, double bv, double dv, int nv, int j) {      // j: stage index inside this pass
-        const double* cur = hist + j * NX;
-        double t0 = sv, t1 = 0.0;
-#pragma unroll
-        for (int c = 0; c < NX; c += 2) { t0 += r[c] * cur[c]; t1 += r[c + 1] * cur[c + 1]; }
-        const double t = t0 + t1;
-        const double du = (is_k && nv > 0) ? t : 0.0;                          // event node: no input
-        // force inputs of the component l % 3 (lanes 0..2): du_l + du_(l+3) + du_(l+6) + du_(l+9)
-        const double f4 = du + __shfl(du, (l + 3) & 63) + __shfl(du, (l + 6) & 63) + __shfl(du, (l + 9) & 63);
-        const double own = cur[is_k ? l : 0];
-        double nxt;
-        if (is_a) nxt = t;                                                      // rows 3..11: [Acl | bcl]
-        else if (l < 3) nxt = own + bv + dv * dt_over_m_factor * f4;
-        else nxt = own + bv + dv * du;                                          // joint rows (lanes 12..nx-1)
-        if (is_a || l < 3 || (l >= 12 && l < NX)) hist[(j + 1) * NX + ri] = nxt;
-        if (is_k) duh[j * NU + l] = du;
-        lds_wave_sync();
-      };
-      load(rA, sA, bA, dA, nA, k0); load(rB, sB, bB, dB, nB, k0 + 1); load(rC, sC, bC, dC, nC, k0 + 2);
-      for (int j = 0; j < nk; j += 3) {                 // steps past nk write history rows that are never read (cap + 4 rows; du: see below)
-        step(rA, sA, bA, dA, nA, j);     load(rA, sA, bA, dA, nA, k0 + j + 3);
-        if (j + 1 < nk) step(rB, sB, bB, dB, nB, j + 1);
-        load(rB, sB, bB, dB, nB, k0 + j + 4);
-        if (j + 2 < nk) step(rC, sC, bC, dC, nC, j + 2);
-        load(rC, sC, bC, dC, nC, k0 + j + 5);
-      }
-    } else if (k0 == 0 && io.with_ls && tid < 2 * kWave) {
-      linesearch_begin_wave<NJ>(scratch, io.ls, tid - kWave);
-    }
-    __syncthreads();
-    // outputs of the pass (coalesced) and its share of the norms
-    for (int idx = tid; idx < nk * NX; idx += NT) {
-      const double d = hist[idx];                        // dx_(k0 + idx / nx): the Armijo metric and |dx| run over the stages 0..N-1 here, dx_N below
-      const double dn = hist[NX + idx];
-      io.base.dx[(size_t)(k0 + 1) * NX + idx] = dn;
-      const double u = duh[idx];                         // nu == nx
-      io.base.du[(size_t)k0 * NU + idx] = u;
-      acc_u += u * u;
-      acc_x += d * d;
-      acc_arm += io.mvec[(size_t)k0 * NX + idx] * d;
-      if (idx % NX == 0) acc_arm += io.mscal[k0 + idx / NX];
-    }
-    __syncthreads();
-    if (tid < NX) {
-      const double dl = hist[nk * NX + tid];             // the last state of the pass
-      if (k0 + nk < N) hist[tid] = dl;                   // input of the next pass
-      else acc_x += dl * dl;                             // dx_N
-    }
-    __syncthreads();
-  }
-  __shared__ double red3s[3][NT / kWave];
-  for (int off = kWave / 2; off >= 1; off >>= 1) {
-    acc_arm += __shfl_down(acc_arm, off);
-    acc_x += __shfl_down(acc_x, off);
-    acc_u += __shfl_down(acc_u, off);
-  }
-  if ((tid & (kWave - 1)) == 0) { red3s[0][tid / kWave] = acc_arm; red3s[1][tid / kWave] = acc_x; red3s[2][tid / kWave] = acc_u; }
-  __syncthreads();
-  if (tid == 0) {
-    double a = 0.0, x2 = 0.0, u2 = 0.0;
-    for (int w = 0; w < NT / kWave; ++w) { a += red3s[0][w]; x2 += red3s[1][w]; u2 += red3s[2][w]; }
-    io.base.summary[0] = a;
-    io.base.summary[1] = x2;
-    io.base.summary[2] = u2;
-    io.base.summary[3] = (double)status;
-  }
-}
-
+// (riccati_rollout_sparse: riccati_mfma.h)
 template <int NJ>
 __device__ __forceinline__ void riccati_rollout_only(RiccatiRolloutWorkspace<NJ>& ws, const RiccatiFastIO& io) {
   constexpr int NX = 12 + NJ, NXX = NX * NX;
