@@ -65,11 +65,13 @@ struct LinFastNodeLds {
   // node inputs, staged once so that nothing is loaded from global memory after the first output store
   double x[C::NX], u[C::NU], zref[FULL ? kNumContacts : 1], zdref[FULL ? kNumContacts : 1];   // value-only: swing references straight from HBM
   double xh2[9];                 // normalised momentum and base position of the second RK2 stage (the first stage reads x[0..8])
-  union {                        // chain tables (dead after the walks)  <->  second-stage block
-    double T[NJ][9];             // joint-local rotation E of joint g-6 (its fixed offset is a model constant: LinFastShared::pfix)
-    double a2[9][12];            // rows 3..11, x columns 0..11 of the stage-two Jacobian
-  };
+  // One storage for five tables that are never alive together (all within one wavefront, program order): the chain rotations (eval_lane,
+  // dead after the walks) -> per-body composites -> per-body momenta (both inside eval_lane) -> after both evaluations the second-stage
+  // block a2 -> after the rows of A and B the cost vectors.  864 bytes per node less than two unions: the value-only kernels fit four
+  // (nx = 22) / three (nx = 24) workgroups per CU instead of three / two.
   union {
+    double T[NJ][9];             // joint-local rotation E of joint g-6 (its fixed offset is a model constant: LinFastShared::pfix)
+    double a2[FULL ? 9 : 1][12]; // rows 3..11, x columns 0..11 of the stage-two Jacobian
     double comp[C::NB][10];      // per body mass / first moment / inertia about o0
     double hb[C::NB][6];         // per body momentum about o0
     struct { double dx[C::NX], du[C::NU]; };   // cost vectors (both evaluations are done by then)
