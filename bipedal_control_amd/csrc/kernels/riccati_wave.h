@@ -571,5 +571,23 @@ __device__ __forceinline__ void riccati_rollout_only(RiccatiRolloutWorkspace<NJ>
   __syncthreads();
   riccati_rollout_sparse<NJ>(ws.hist, RiccatiRolloutWorkspace<NJ>::kCapSparse, st, io);
 }
+// The same roll-out in workgroups of TWO waves (recurrence; opening of the line search) on a quarter of a CU's LDS: the recurrence is a
+// chain of ~1 600 cycles per stage in which the SIMD idles, so what a batch of problems needs is more recurrences in flight - four per CU
+// instead of two.  The history holds ~100 stages; a longer horizon takes another pass (riccati_rollout_sparse).
+constexpr int kRolloutPairThreads = 2 * kWave;
+template <int NJ>
+struct RiccatiRolloutPairWorkspace {
+  static constexpr int NX = 12 + NJ;
+  static constexpr int kDoubles = 5040;                                              // 39.4 KB: four workgroups per CU
+  static constexpr int kCapSparse = (kDoubles - 200 - 64 - 4 * NX) / (2 * NX);       // 106 stages at nx = 22, 97 at nx = 24
+  alignas(16) double hist[kDoubles];
+};
+template <int NJ>
+__device__ __forceinline__ void riccati_rollout_pair(RiccatiRolloutPairWorkspace<NJ>& ws, const RiccatiFastIO& io) {
+  constexpr int NX = 12 + NJ, NXX = NX * NX;
+  const int st = (int)io.carry[NXX + NX];
+  __syncthreads();
+  riccati_rollout_sparse<NJ, kRolloutPairThreads>(ws.hist, RiccatiRolloutPairWorkspace<NJ>::kCapSparse, st, io);
+}
 
 }  // namespace bpmpc
