@@ -35,6 +35,30 @@ __device__ __constant__ unsigned char kForceRow[4][12] = {{0, 1, 2, 4, 5, 6, 8, 
                                                            {0, 1, 2, 4, 5, 6, 255, 255, 255, 255, 255, 255},
                                                            {255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255}};
 
+// The same two tables packed into registers, five bits per entry (31 = none): a table in constant memory costs the node a memory round trip
+// between knowing its mode and issuing its loads
+__device__ __forceinline__ constexpr unsigned long long lus_pack(const unsigned char (&t)[12]) {
+  unsigned long long v = 0;
+  for (int i = 11; i >= 0; --i) v = (v << 5) | (unsigned long long)(t[i] == 255 ? 31 : t[i]);
+  return v;
+}
+constexpr unsigned char kVelRowH[4][12] = {{3, 7, 11, 15, 255, 255, 255, 255, 255, 255, 255, 255},
+                                           {0, 1, 2, 3, 4, 5, 9, 13, 255, 255, 255, 255},
+                                           {3, 7, 8, 9, 10, 11, 12, 13, 255, 255, 255, 255},
+                                           {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11}};
+constexpr unsigned char kForceRowH[4][12] = {{0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14},
+                                             {255, 255, 255, 255, 255, 255, 6, 7, 8, 10, 11, 12},
+                                             {0, 1, 2, 4, 5, 6, 255, 255, 255, 255, 255, 255},
+                                             {255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255}};
+__device__ __forceinline__ unsigned long long lus_vel_rows(int mode) {
+  constexpr unsigned long long p0 = lus_pack(kVelRowH[0]), p1 = lus_pack(kVelRowH[1]), p2 = lus_pack(kVelRowH[2]), p3 = lus_pack(kVelRowH[3]);
+  return mode == 0 ? p0 : (mode == 1 ? p1 : (mode == 2 ? p2 : p3));
+}
+__device__ __forceinline__ unsigned long long lus_force_rows(int mode) {
+  constexpr unsigned long long p0 = lus_pack(kForceRowH[0]), p1 = lus_pack(kForceRowH[1]), p2 = lus_pack(kForceRowH[2]), p3 = lus_pack(kForceRowH[3]);
+  return mode == 0 ? p0 : (mode == 1 ? p1 : (mode == 2 ? p2 : p3));
+}
+
 template <int NJ>
 struct ProjectLuSLds {                       // per node
   union {
@@ -113,24 +137,36 @@ __device__ __forceinline__ void lu_s_step(LuSLane& s, int j) {
 // reader generates from the contact mode (project_struct.h, riccati_mfma.h), 2.6 KB per node instead of 7.9.
 template <int NJ, int RM, bool PK = false>
 __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, int mode, const double* D, const double* C, const double* e, double* Px,
-                                             double* Pu, double* Pe, int* nut_out, int sub, int j, double* Vt = nullptr) {
+                                             double* Pu, double* Pe, int* nut_out, int sub, int j, double* Vt = nullptr, double* prof = nullptr) {
+#ifdef BPMPC_LUS_PROFILE
+  long long tprev = clock64();
+  int pslot = 0;
+#define LUSPROF() do { const long long tn_ = clock64(); if (prof) prof[pslot] = (double)(tn_ - tprev); ++pslot; tprev = tn_; } while (0)
+#else
+#define LUSPROF() ((void)0)
+#endif
   constexpr int NX = 12 + NJ, NU = 12 + NJ, R = 12;
   static_assert(NJ <= 16 && NX + 1 <= 32, "lane layout");
   const bool has_d = j < NJ, has_c1 = j < NX - 16, is_e = j == NX - 16;
   const int nvr = !valid ? 0 : (mode == 3 ? 12 : (mode == 0 ? 4 : 8));
   LuSLane st;
+  const unsigned long long vel_rows = lus_vel_rows(mode);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int orow = (r < RM && r < nvr) ? kVelRow[mode][r] : 255;
-    const bool rv = orow != 255;
+    const int orow = (r < RM && r < nvr) ? (int)((vel_rows >> (5 * r)) & 31) : 31;
+    const bool rv = orow != 31;
     const int ro = rv ? orow : 0;
     st.vd[r] = (rv && has_d) ? D[ro * NU + 12 + j] : 0.0;
     st.vr0[r] = rv ? C[ro * NX + j] : 0.0;
     st.vr1[r] = (rv && has_c1) ? C[ro * NX + 16 + j] : ((rv && is_e) ? e[ro] : 0.0);
   }
+#ifdef BPMPC_LUS_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  LUSPROF();     // 0: loads
   // swing forces: du_F = -F; read before anything is written
   double pe_force = 0.0;
-  if (valid && j < 12) { const int fr = kForceRow[mode][j]; if (fr != 255) pe_force = -e[fr]; }
+  if (valid && j < 12) { const int fr = (int)((lus_force_rows(mode) >> (5 * j)) & 31); if (fr != 31) pe_force = -e[fr]; }
   const int size = nvr < NJ ? nvr : NJ;              // min(rows, cols)
   st.maxpiv = 0.0; st.cpos = has_d ? j : 64; st.size = size; st.nonzero = size; st.done = !has_d; st.alive = size > 0;
   int smax = __builtin_amdgcn_readlane(size, 0);
@@ -144,6 +180,7 @@ __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, 
   BP_LUS_STEP(0) BP_LUS_STEP(1) BP_LUS_STEP(2) BP_LUS_STEP(3) BP_LUS_STEP(4) BP_LUS_STEP(5)
   BP_LUS_STEP(6) BP_LUS_STEP(7) BP_LUS_STEP(8) BP_LUS_STEP(9) BP_LUS_STEP(10) BP_LUS_STEP(11)
 #undef BP_LUS_STEP
+  LUSPROF();     // 1: elimination steps
   double (&vd)[12] = st.vd, (&vr0)[12] = st.vr0, (&vr1)[12] = st.vr1;
   const int cpos = st.cpos;
   // ---- U11 by position, column permutation, rank, reciprocal diagonal
@@ -158,6 +195,7 @@ __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, 
   const int rank = __popc((unsigned)(big >> (kLuLanes * sub)) & 0xffffu);
   if (j < NJ) nl.idiag[j] = j < rank ? 1.0 / ujj : 0.0;
   lds_wave_sync();
+  LUSPROF();     // 2: U, rank
   // ---- back substitution in place: the columns of this lane are right-hand sides ([c | e], and U12 where the D column is free)
 #pragma unroll
   for (int i = R - 1; i >= 0; --i) {
@@ -176,6 +214,7 @@ __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, 
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  LUSPROF();     // 3: back substitution
   // ---- outputs through the LDS tile, half of the rows at a time (row = input index: 0..11 forces, 12.. joints)
   const int nsf = mode == 3 ? 12 : (mode == 0 ? 0 : 6);      // free stance-force components = the first reduced inputs
   const int nut = nsf + NJ - rank;
@@ -290,6 +329,10 @@ __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, 
     }
   }
   }
+#ifdef BPMPC_LUS_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  LUSPROF();     // 4: outputs
   if (valid && j == 0) nut_out[0] = nut;
 }
 
