@@ -588,3 +588,28 @@ def test_indefinite_hessian_is_reported_by_every_sweep(ctx, variant, monkeypatch
     mpc = bp.BatchedSqpMpc(itf, max_batch=3, max_nodes=48, sqp_iterations=1)
     t, x, u, _, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
     assert all(s.status == 2 for s in st), [s.status for s in st]
+
+
+@pytest.mark.parametrize("parts,wave", [("2", None), ("3", None), ("3", "4")])
+def test_batch_split_over_streams_gives_the_same_bits(ctx, parts, wave, monkeypatch):
+    """BPMPC_BATCH_PARTS: the batch split into parts that run their SQP iterations on streams of their own (solver.hip run_iterations,
+    Launch::b0).  The problems are independent, so states, inputs, gains and step sizes are the bits of the unsplit solve - mixed gaits (grids of
+    different lengths), a batch that does not divide evenly (part boundaries fall on multiples of 16), two iterations, and the sweep with
+    two waves per SIMD forced."""
+    bp, sc, itf = ctx["bp"], ctx["sc"], ctx["itf"]
+    if wave:
+        monkeypatch.setenv("BPMPC_RICCATI_WAVE", wave)
+    gaits = ["stance", "trot", "standing_trot", "flying_trot"]
+    prob = sc.gait_sweep_problem(itf, gaits, [(0.3, 0.0), (-0.2, 0.3), (0.1, -0.1)] * 9, n_intervals=40)      # 4 x 27 = 108 problems
+    nb = prob["x0"].shape[0]
+    results = []
+    for p in ("1", parts):
+        monkeypatch.setenv("BPMPC_BATCH_PARTS", p)
+        mpc = bp.BatchedSqpMpc(itf, max_batch=nb, max_nodes=64, sqp_iterations=2, return_gains=True)
+        results.append(mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"]))
+        # a second solve on the same handle (warm handle state, streams re-joined)
+        results.append(mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"]))
+    ref = results[0]
+    for r in results[1:]:
+        assert np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3])
+        assert [s.step_size for s in r[4]] == [s.step_size for s in ref[4]]

@@ -1,0 +1,13 @@
+export TMPDIR=/tmp PYTHONPATH=.
+O=gpurun_out/r03j; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "batch_split" 2>&1 | tail -8 > $O/pytest_split.log
+cat $O/pytest_split.log
+timeout 300 python bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-fused >/dev/null 2>&1
+for P in 1 2 3 4 6 8; do
+  for B in 256 4096; do
+    BPMPC_BATCH_PARTS=$P timeout 300 python bench.py --batch $B --cpu-sample 0 > $O/b${B}_p$P.json 2>$O/err.log
+    python -c "
+import json
+d=json.loads(open('$O/b${B}_p$P.json').read().strip().splitlines()[-1]); print('parts $P batch $B', d['value'], d['ms_per_step'], (d.get('fused') or {}).get('value'), d['kernel_ms_per_step'])" 2>&1 | tail -1
+  done
+done
