@@ -106,6 +106,14 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #define BPMPC_RICCATI8_LOADERS 3     // loader waves 4 .. : L4, L5 and F (with the packed stage loader three are 1 % faster than two)
 #endif
   const bool role_c = w < 4, role_l = w >= 4 && w < 4 + BPMPC_RICCATI8_LOADERS, role_f = w == 6, role_e = w == 7;
+#ifndef BPMPC_RICCATI8_PRIO_CHAIN
+#define BPMPC_RICCATI8_PRIO_CHAIN 0    // s_setprio of the chain waves C0..C3 / of the elimination wave E over the loader waves that share their SIMDs
+#endif
+#ifndef BPMPC_RICCATI8_PRIO_E
+#define BPMPC_RICCATI8_PRIO_E 0
+#endif
+  if (BPMPC_RICCATI8_PRIO_CHAIN > 0 && role_c) __builtin_amdgcn_s_setprio(BPMPC_RICCATI8_PRIO_CHAIN);
+  if (BPMPC_RICCATI8_PRIO_E > 0 && role_e) __builtin_amdgcn_s_setprio(BPMPC_RICCATI8_PRIO_E);
 
   const int k_top = (io.k_hi < N ? io.k_hi : N) - 1;
   const bool resumed = io.k_hi < N;
