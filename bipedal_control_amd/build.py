@@ -1,32 +1,64 @@
-"""Build libbpmpc.so (HIP, gfx950) in-tree.  `python -m bipedal_control_amd.build`"""
+"""Build libbpmpc.so (HIP, gfx950) in-tree.  `python -m bipedal_control_amd.build [--force]`
+
+One translation unit per kernel family (csrc/k_*.hip) plus the host code; they compile in parallel into csrc/build/*.o and are
+re-compiled only when a source they depend on (conservatively: any header, or the unit itself) is newer than the object.
+"""
+import concurrent.futures
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libbpmpc.so")
-SOURCES = ["solver.hip", "wbc.hip", "capi.cpp", "info_tree.cpp", "urdf_tree.cpp", "robot_model.cpp", "reference_gen.cpp", "device_model.cpp"]
+SOURCES = ["k_node.hip", "k_project.hip", "k_riccati.hip", "k_riccati_wave.hip", "solver.hip", "wbc.hip", "capi.cpp", "info_tree.cpp", "urdf_tree.cpp",
+           "robot_model.cpp", "reference_gen.cpp", "device_model.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def _newest_header():
+    newest = os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "bpmpc.h"))
+    for root, dirs, files in os.walk(CSRC):
+        if os.path.basename(root) == "build":
+            continue
+        for f in files:
+            if f.endswith(".h"):
+                newest = max(newest, os.path.getmtime(os.path.join(root, f)))
+    return newest
 
 
 def _newest_source():
-    newest = 0.0
-    for root, _, files in os.walk(CSRC):
-        for f in files:
-            newest = max(newest, os.path.getmtime(os.path.join(root, f)))
-    newest = max(newest, os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "bpmpc.h")))
-    return newest
+    return max([_newest_header()] + [os.path.getmtime(os.path.join(CSRC, s)) for s in SOURCES])
 
 
 def build(force=False, verbose=False):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", LIB]
-    cmd += os.environ.get("BPMPC_EXTRA_FLAGS", "").split()      # e.g. -DBPMPC_PROJECT_PROFILE for tools/*_phase_profile.py
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("BPMPC_EXTRA_FLAGS", "").split()      # e.g. -DBPMPC_LINFAST_PROFILE for tools/*_phase_profile.py
+    tag = hashlib.sha1(" ".join(extra).encode()).hexdigest()[:8] if extra else "default"
+    objdir = os.path.join(OBJ, tag)
+    os.makedirs(objdir, exist_ok=True)
+    headers = _newest_header()
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(headers, os.path.getmtime(path)):
+            return obj
+        cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 

@@ -1,0 +1,348 @@
+// Per-node kernels in the lane-per-coordinate mapping (kernels/linearize_fast.h), line search, warm start, policy rollout.
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+
+#include "kernel_launchers.h"
+#include "launch.h"
+#include "kernels/rollout.h"
+
+namespace bpmpc {
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_prepare(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  const int s = blockIdx.x, b = s / L.N, k = s % L.N;
+  const int g = L.buf.p_grid[b];
+  const int n = L.buf.g_nodes[g];
+  if (k >= n) { if (threadIdx.x == 0) L.buf.n_info[s] = 0; return; }
+  const size_t gs = (size_t)g * L.N + k;
+  if (threadIdx.x == 0) L.buf.n_info[s] = 8 | ((L.buf.g_mode[gs] & 3) << 1) | (L.buf.g_kind[gs] == 1 ? 1 : 0);
+  prepare_node<NJ>(*L.model, L.buf.g_kind[gs], L.buf.g_mode[gs], L.buf.g_start[gs], L.cold != 0, k == n - 1, L.buf.p_tgt_n[b],
+                   L.buf.p_tgt_t + (size_t)b * kMaxTargetPoints, L.buf.p_tgt_x + (size_t)b * kMaxTargetPoints * NX, L.buf.p_x0 + (size_t)b * NX,
+                   L.buf.xref + (size_t)s * NX, L.buf.x + ((size_t)b * (L.N + 1) + k) * NX, L.buf.u + (size_t)s * NU,
+                   L.buf.x + ((size_t)b * (L.N + 1) + k + 1) * NX);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ NodeWorkspace<NJ> ws;
+  const int sidx = blockIdx.x, b = sidx / L.N, k = sidx % L.N;
+  if (!L.buf.active[b]) return;
+  if (k >= L.buf.g_nodes[L.buf.p_grid[b]]) return;
+  const size_t s = sidx;
+  const NodeInputs in = node_inputs<NJ>(L, b, k);
+  NodeLQOut out;
+  out.A = L.buf.A + s * NX * NX; out.B = L.buf.B + s * NX * NU; out.b = L.buf.b + s * NX;
+  out.Q = L.buf.Q + s * NX * NX; out.R = L.buf.R + s * NU * NU; out.P = L.buf.P + s * NU * NX;
+  out.q = L.buf.q + s * NX; out.r = L.buf.r + s * NU; out.c = L.buf.c + s;
+  out.C = L.buf.C + s * kMaxEqRows * NX; out.D = L.buf.D + s * kMaxEqRows * NU; out.e = L.buf.e + s * kMaxEqRows;
+  out.nc = L.buf.nc + s; out.perf = L.buf.perf + s * 3;
+  out.prof = (b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
+  linearize_node<NJ>(*L.model, ws, in, out);
+}
+
+constexpr int kTrialWaves = 4; // same for the value-only trial kernel (smaller per-node LDS: four waves, 8 waves per CU)
+// wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS.  Four: 74.3 KB at nx = 22, 79.1 KB
+// at nx = 24 (a wave serves four nodes of 4.2 KB each, packed lanes, LinFastCfg) - two workgroups, eight waves per CU
+#ifndef BPMPC_LIN_WAVES
+#define BPMPC_LIN_WAVES 4      // five (two workgroups = ten waves per CU fit since the node tables share one storage): 0.302 against 0.223 ms at batch
+#endif                        // 256, 4.22 against 3.20 at 4096 - the kernel is not short of waves
+template <int NJ> constexpr int lin_waves() { return BPMPC_LIN_WAVES; }
+#ifndef BPMPC_LIN_WPE
+#define BPMPC_LIN_WPE __attribute__((amdgpu_waves_per_eu(2, BPMPC_LIN_WAVES > 4 ? 3 : 2)))
+#endif
+template <int NJ, bool MAT>
+__global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linearize_fast(Launch L) {
+  using C = LinFastCfg<NJ, true>;
+  constexpr int LPN = C::LPN, NPW = C::NPW, kLinWaves = lin_waves<NJ>();
+  __shared__ LinFastNodeLds<NJ> lds[kLinWaves * NPW];
+  __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
+  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kLinWaves * kWave);
+  __syncthreads();
+  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;       // sub: node slot of the workgroup
+  const int widx = blockIdx.x * (kLinWaves * NPW) + sub;          // batch * max_nodes < 2^31 is checked at creation
+  bool valid = widx < L.batch * L.klen;
+  const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
+  const int act = L.buf.active[b], grid = L.buf.p_grid[b];           // unconditional loads: two round trips to the node's facts, not four
+  const int n_nodes = L.buf.g_nodes[grid];
+  const NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
+  valid = valid && act != 0 && k < n_nodes;
+  const size_t s = valid ? (size_t)b * L.N + k : 0;
+  LinFastOut out;
+  out.A = L.buf.A; out.B = L.buf.B; out.b = L.buf.b; out.Q = L.buf.Q; out.R = L.buf.R; out.q = L.buf.q; out.r = L.buf.r; out.c = L.buf.c;
+  out.C = L.buf.C; out.D = L.buf.D; out.e = L.buf.e; out.perf = L.buf.perf; out.nc = L.buf.nc;
+  out.park = L.buf.lin_park;
+  out.qrd = L.buf.qrd;
+  out.s = s;
+  out.prof = (valid && b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
+  linearize_fast<NJ, MAT, C>(*L.model, shared, lds[sub], valid, in, out, g);      // g: lane inside the node's group
+}
+
+// Warm start of a receding-horizon solve from the previous solution, one wavefront per (problem, node).  [OCS2-upstream, recalled]
+// SqpSolver::initializeStateInputTrajectories with a non-empty PrimalSolution: for an intermediate node with
+// intervalStart <= second-to-last and intervalEnd <= last time of the previous solution,
+//     u_i = uff(t) + K(t) x_i  (LinearController, sqp.useFeedbackPolicy true, task.info:80;  uff_j = u_j - K_j x_j, inputs and
+//           gains of pre-event nodes and of the terminal node repeat the previous one: multiple_shooting::toPrimalSolution),
+//     x_{i+1} = LinearInterpolation(intervalEnd, previous states);
+// otherwise BipedalRobotInitializer::compute (already written by k_prepare) and x_{i+1} = x_i; event nodes copy the state.
+// The state guess of node i is therefore the interpolation at the end of the last interpolating node before it (or the measured
+// state), which every node finds on its own - no sequential sweep (the first version, one wavefront per problem walking the
+// horizon, took 0.53 ms at batch 256 and was the longest kernel of a closed-loop tick).
+// Oracle: oracle/reference_py.py warm_start_from_previous.
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_warm_shift(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ double xi[NX];
+  __shared__ double Ks[2][NU * NX];
+  const int b = blockIdx.x / L.N, i = blockIdx.x % L.N, l = threadIdx.x;
+  const int N = L.N;
+  const int g = L.buf.p_grid[b], n = L.buf.g_nodes[g];
+  if (i >= n) return;
+  const int gp = L.buf.tp_grid[b], np = L.buf.tp_nodes[gp];
+  if (np < 1) return;
+  const double* tp = L.buf.tp_time + (size_t)gp * (N + 1);
+  const int* kp = L.buf.tp_kind + (size_t)gp * N;
+  const double* xp = L.buf.x_prev + (size_t)b * (N + 1) * NX;
+  const double* up = L.buf.u_prev + (size_t)b * N * NU;
+  const double* Kp = L.buf.K_prev + (size_t)b * N * NU * NX;
+  double* x = L.buf.x + (size_t)b * (N + 1) * NX;
+  double* u = L.buf.u + (size_t)b * N * NU;
+  const double state_till = tp[np], input_till = tp[np - 1];
+  auto effective = [&](int j) { while (j > 0 && (j == np || kp[j] == 1)) --j; return j; };   // repeated input / gain
+  auto interpolates = [&](int k) {
+    const size_t gs = (size_t)g * N + k;
+    if (L.buf.g_kind[gs] != 0) return false;
+    const double t = L.buf.g_start[gs], tn = t + L.buf.g_dt[gs];
+    return !(t > input_till || tn > state_till);
+  };
+  auto state_after = [&](int k, int c) {            // component c of the guess of x_{k+1} for an interpolating node k
+    const size_t gs = (size_t)g * N + k;
+    int j2;
+    double a2;
+    time_segment(tp, np + 1, L.buf.g_start[gs] + L.buf.g_dt[gs], &j2, &a2);
+    return a2 * xp[(size_t)j2 * NX + c] + (1.0 - a2) * xp[(size_t)(j2 + 1) * NX + c];
+  };
+  int src = i - 1;
+  while (src >= 0 && !interpolates(src)) --src;
+  const bool mine = interpolates(i);
+  if (l < NX) {
+    const double v = src < 0 ? L.buf.p_x0[(size_t)b * NX + l] : state_after(src, l);
+    xi[l] = v;
+    if (i == 0) x[l] = v;
+    x[(size_t)(i + 1) * NX + l] = mine ? state_after(i, l) : v;
+  }
+  if (!mine) return;
+  int j;
+  double a;
+  time_segment(tp, np + 1, L.buf.g_start[(size_t)g * N + i], &j, &a);
+  const int e0 = effective(j), e1 = effective(j + 1);
+  for (int idx = l; idx < NU * NX; idx += kWave) {
+    Ks[0][idx] = Kp[(size_t)e0 * NU * NX + idx];
+    Ks[1][idx] = Kp[(size_t)e1 * NU * NX + idx];
+  }
+  __syncthreads();
+  if (l < NU) {
+    double uff0 = up[(size_t)e0 * NU + l], uff1 = up[(size_t)e1 * NU + l], kx = 0.0;
+    for (int c = 0; c < NX; ++c) {
+      const double k0 = Ks[0][l * NX + c], k1 = Ks[1][l * NX + c];
+      uff0 -= k0 * xp[(size_t)j * NX + c];
+      uff1 -= k1 * xp[(size_t)(j + 1) * NX + c];
+      kx += (a * k0 + (1.0 - a) * k1) * xi[c];
+    }
+    u[(size_t)i * NU + l] = a * uff0 + (1.0 - a) * uff1 + kx;
+  }
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_ls_begin(Launch L) {
+  __shared__ double partial[3 * kWave + 5];
+  linesearch_begin<NJ>(partial, problem_ls<NJ>(L, blockIdx.x));
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_trial(Launch L) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ TrialWorkspace<NJ> ws;
+  const int sidx = blockIdx.x, b = sidx / L.N, k = sidx % L.N;
+  if (L.buf.done[b]) return;
+  if (k >= L.buf.g_nodes[L.buf.p_grid[b]]) return;
+  const NodeInputs in = node_inputs<NJ>(L, b, k);
+  const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
+  trial_node<NJ>(*L.model, ws, in, L.buf.alpha[b], dx, L.buf.du + (size_t)sidx * NU, dx + NX, L.buf.trial_perf + (size_t)sidx * 3);
+}
+
+// Waves per SIMD of the value-only kernel (144 registers at nx = 22, 170 at nx = 24 when left alone; the LDS fits four / three workgroups
+// per CU since the node tables share one storage).  nx = 24: three (168 registers) - line search 0.492 -> 0.404 ms on G1 / 1024, 0.152 ->
+// 0.129 at batch 256.  nx = 22: four (128 registers) pays once the launch has several rounds of workgroups (1.18 -> 1.13 ms at batch 4096),
+// is neutral at batch 512 and loses at 256 (0.108 -> 0.112): chosen per launch, WIDE.
+template <int NJ, bool WIDE>
+__global__ __launch_bounds__(kTrialWaves * kWave) __attribute__((amdgpu_waves_per_eu(NJ <= 10 ? (WIDE ? 4 : 3) : 3, NJ <= 10 ? (WIDE ? 4 : 3) : 3)))
+void k_trial_fast(Launch L) {
+  using C = LinFastCfg<NJ, true>;
+  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
+  __shared__ LinFastNodeLds<NJ, false> lds[kTrialWaves * NPW];
+  __shared__ LinFastShared<NJ, false> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
+  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
+  __syncthreads();
+  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
+  const int widx = blockIdx.x * (kTrialWaves * NPW) + sub;
+  bool valid = widx < L.batch * L.klen;
+  const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
+  const int fin = L.buf.done[b], grid = L.buf.p_grid[b];
+  const double alpha = L.buf.alpha[b];
+  const int n_nodes = L.buf.g_nodes[grid];
+  const NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
+  valid = valid && fin == 0 && k < n_nodes;
+  const size_t s = valid ? (size_t)b * L.N + k : 0;
+  const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
+  trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, alpha, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
+}
+
+// Values of the active equality rows at the CURRENT iterate (after a solve: the solution), per node in registration order: the value-only
+// evaluation of the line search with a zero step and one more output (linearize_fast.h trial_fast<.., EQV>).
+template <int NJ>
+__global__ __launch_bounds__(kTrialWaves * kWave) void k_constraint_values(Launch L, double* eqv) {
+  using C = LinFastCfg<NJ, true>;
+  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
+  __shared__ LinFastNodeLds<NJ, false> lds[kTrialWaves * NPW];
+  __shared__ LinFastShared<NJ, false> shared;
+  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
+  __syncthreads();
+  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
+  const int widx = blockIdx.x * (kTrialWaves * NPW) + sub;
+  bool valid = widx < L.batch * L.klen;
+  const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
+  const int grid = L.buf.p_grid[b];
+  valid = valid && k < L.buf.g_nodes[grid] && L.buf.g_kind[(size_t)grid * L.N + k] == 0;
+  const size_t s = valid ? (size_t)b * L.N + k : 0;
+  const NodeInputs in = node_inputs<NJ>(L, b, k);
+  const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
+  double perf[3];
+  trial_fast<NJ, C, true>(*L.model, shared, lds[sub], valid, in, 0.0, dx, L.buf.du + s * NU, dx + NX, perf, g, eqv + s * kMaxEqRows);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_rollout(const DeviceModel* model, RolloutArgs a) {
+  __shared__ RolloutLds<NJ> w;
+  load_shared_model<NJ>(*model, w.shared, threadIdx.x, kWave);
+  __syncthreads();
+  rollout_policy<NJ>(*model, w, a);
+}
+
+constexpr int kDecideThreads = 256;
+template <int NJ>
+__global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L) {
+  __shared__ double partial[3 * kDecideThreads + 5];
+  linesearch_decide<NJ, kDecideThreads>(partial, problem_ls<NJ>(L, blockIdx.x), L.ls);
+}
+
+// Back-tracking rounds after the first one, entirely on the device: a workgroup per problem that has not accepted yet (normally
+// none: the block exits at once) evaluates its own trial nodes, thirty-two at a time, and decides, until the problem accepts or gives
+// up.  The host never reads a flag back inside a solve, so consecutive solves queue without a gap.  The few problems that back-track
+// are alone on their CUs and what they cost is the latency of their rounds: eight waves walk the horizon in half the chunks of four
+// (the sums are the ones of k_ls_decide term by term while the horizon has at most kDecideThreads nodes).
+constexpr int kTailThreads = 512;
+template <int NJ>
+__global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int max_trials) {
+  using C = LinFastCfg<NJ, true>;
+  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW, CHUNK = (kTailThreads / kWave) * NPW;
+  const int b = blockIdx.x;
+  if (L.buf.done[b]) return;
+  __shared__ LinFastNodeLds<NJ, false> lds[CHUNK];
+  __shared__ LinFastShared<NJ, false> shared;
+  __shared__ double partial[3 * kTailThreads + 5];
+  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTailThreads);
+  __syncthreads();
+  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
+  const int n = L.buf.g_nodes[L.buf.p_grid[b]];
+  const ProblemLS p = problem_ls<NJ>(L, b);
+  volatile const int* done = L.buf.done + b;
+  volatile const double* alpha = L.buf.alpha + b;
+  for (int round = 1; round < max_trials; ++round) {
+    const double al = *alpha;
+    for (int k0 = 0; k0 < n; k0 += CHUNK) {
+      const int k = k0 + sub;
+      const bool valid = k < n;
+      const int kk = valid ? k : 0;
+      const size_t s = (size_t)b * L.N + kk;
+      const NodeInputs in = node_inputs<NJ>(L, b, kk);
+      const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + kk) * NX;
+      trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, al, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
+    }
+    __threadfence();
+    __syncthreads();
+    linesearch_decide<NJ, kTailThreads>(partial, p, L.ls);
+    __threadfence();
+    __syncthreads();
+    if (*done) break;
+  }
+}
+
+// One launch instead of several driver copies / fills (each costs a dispatch gap of a few microseconds between kernels):
+// copies two pairs of double arrays and optionally re-arms the per-problem flags.
+__global__ __launch_bounds__(256) void k_copy_pairs(const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb,
+                                                     int* iterations, int* active, int batch) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  const double2* a2 = reinterpret_cast<const double2*>(a_src);
+  const double2* b2 = reinterpret_cast<const double2*>(b_src);
+  double2* ad = reinterpret_cast<double2*>(a_dst);
+  double2* bd = reinterpret_cast<double2*>(b_dst);
+  for (size_t i = i0; i < na / 2; i += stride) ad[i] = a2[i];
+  for (size_t i = i0; i < nb / 2; i += stride) bd[i] = b2[i];
+  if (i0 == 0) { if (na & 1) a_dst[na - 1] = a_src[na - 1]; if (nb & 1) b_dst[nb - 1] = b_src[nb - 1]; }
+  if (iterations) for (size_t i = i0; i < (size_t)batch; i += stride) { iterations[i] = 0; active[i] = 1; }
+}
+
+#define KL_NJ(nj, ...)                                                          \
+  do {                                                                          \
+    if ((nj) == 10) { constexpr int NJ = 10; __VA_ARGS__; }                     \
+    else if ((nj) == 12) { constexpr int NJ = 12; __VA_ARGS__; }                \
+    else throw std::runtime_error("unsupported joint count");                   \
+  } while (0)
+
+namespace kl {
+
+void prepare(int nj, int slots, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_prepare<NJ>, dim3(slots), dim3(kWave), 0, st, L)); }
+void linearize_reference(int nj, int slots, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_linearize<NJ>, dim3(slots), dim3(kWave), 0, st, L)); }
+void linearize_fast(int nj, bool materialise, int nodes, hipStream_t st, const Launch& L) {
+  KL_NJ(nj, {
+    constexpr int per_wg = lin_waves<NJ>() * LinFastCfg<NJ, true>::NPW;
+    const int grid = (nodes + per_wg - 1) / per_wg;
+    if (materialise) hipLaunchKernelGGL((k_linearize_fast<NJ, true>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
+    else hipLaunchKernelGGL((k_linearize_fast<NJ, false>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
+  });
+}
+void warm_shift(int nj, int slots, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_warm_shift<NJ>, dim3(slots), dim3(kWave), 0, st, L)); }
+void ls_begin(int nj, int batch, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_ls_begin<NJ>, dim3(batch), dim3(kWave), 0, st, L)); }
+void trial_reference(int nj, int slots, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_trial<NJ>, dim3(slots), dim3(kWave), 0, st, L)); }
+int trial_fast_workgroups(int nj, int nodes) {
+  const int per_wg = kTrialWaves * (nj == 10 ? LinFastCfg<10, true>::NPW : LinFastCfg<12, true>::NPW);
+  return (nodes + per_wg - 1) / per_wg;
+}
+void trial_fast(int nj, bool wide, int nodes, hipStream_t st, const Launch& L) {
+  const int grid = trial_fast_workgroups(nj, nodes);
+  KL_NJ(nj, {
+    if (wide && NJ <= 10) hipLaunchKernelGGL((k_trial_fast<NJ, true>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
+    else hipLaunchKernelGGL((k_trial_fast<NJ, false>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
+  });
+}
+void ls_decide(int nj, int batch, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, st, L)); }
+void ls_tail(int nj, int batch, hipStream_t st, const Launch& L, int max_trials) {
+  KL_NJ(nj, hipLaunchKernelGGL(k_ls_tail<NJ>, dim3(batch), dim3(kTailThreads), 0, st, L, max_trials));
+}
+void constraint_values(int nj, int nodes, hipStream_t st, const Launch& L, double* eqv) {
+  const int grid = trial_fast_workgroups(nj, nodes);
+  KL_NJ(nj, hipLaunchKernelGGL(k_constraint_values<NJ>, dim3(grid), dim3(kTrialWaves * kWave), 0, st, L, eqv));
+}
+void rollout(int nj, int batch, hipStream_t st, const DeviceModel* model, const RolloutArgs& a) {
+  KL_NJ(nj, hipLaunchKernelGGL(k_rollout<NJ>, dim3((batch + LinFastCfg<NJ>::NPW - 1) / LinFastCfg<NJ>::NPW), dim3(kWave), 0, st, model, a));
+}
+void copy_pairs(int grid, hipStream_t st, const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb,
+                int* iterations, int* active, int batch) {
+  hipLaunchKernelGGL(k_copy_pairs, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, a_src, a_dst, na, b_src, b_dst, nb, iterations, active, batch);
+}
+
+}  // namespace kl
+}  // namespace bpmpc

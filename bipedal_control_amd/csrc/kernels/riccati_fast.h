@@ -265,6 +265,7 @@ __device__ __forceinline__ double quad_swap_pairs(double v) {       // value of 
 #ifndef BPMPC_STEP_NORMS_STAGED
 #define BPMPC_STEP_NORMS_STAGED 1
 #endif
+constexpr int kMaxRiccatiStages = 512;            // longest horizon of a solver handle (node tables of the sweeps, bpmpc_solver_create)
 constexpr int kStepNormsScratch = 32 * 26;     // doubles of LDS per wave (StepNormsTile)
 template <int NJ>
 struct StepNormsTile {

@@ -35,7 +35,6 @@
 namespace bpmpc {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int kMaxRiccatiStages = 512;
 
 // DB: the staged operands are double buffered (stage k-1 is staged while the updates of stage k still read theirs, which
 // saves a barrier per stage).  At nx = 22 that costs 98 KB of LDS (one workgroup per CU) against 66 KB single buffered (two

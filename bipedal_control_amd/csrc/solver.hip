@@ -24,23 +24,8 @@
 #include "../../include/bpmpc.h"
 #include "capi_internal.h"
 #include "device_model.h"
-#include "kernels/linesearch.h"
-#include "kernels/node_lq.h"
-#include "kernels/linearize_fast.h"
-#include "kernels/project_node.h"
-#include "kernels/project_lu4.h"
-#include "kernels/project_lu_s.h"
-#include "kernels/riccati.h"
-#include "kernels/riccati_fast.h"
-#include "kernels/riccati_mfma.h"
-#include "kernels/riccati_mfma8.h"
-#include "kernels/riccati_dma8.h"
-#include "kernels/riccati_fold8.h"
-#include "kernels/riccati_wave.h"
-#include "kernels/riccati_wave2.h"
-#include "kernels/riccati_pair.h"
-#include "kernels/project_mfma.h"
-#include "kernels/project_struct.h"
+#include "launch.h"
+#include "kernel_launchers.h"
 #include "reference_gen.h"
 #include "kernels/reference_device.h"
 #include "kernels/rollout.h"
@@ -55,741 +40,12 @@ namespace bpmpc {
 
 struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
 
-// ------------------------------------------------------------------------------------------------ device views
-struct Buffers {
-  // grids
-  int *g_kind, *g_mode, *g_nodes;
-  double *g_dt, *g_start, *g_zref, *g_zdref;
-  // problems
-  int* p_grid;
-  double *p_x0, *p_tgt_t, *p_tgt_x;
-  int* p_tgt_n;
-  // iterate
-  double *x, *u, *x_init, *u_init, *xref;
-  // LQ
-  double *A, *B, *b, *Q, *R, *P, *q, *r, *c, *C, *D, *e, *perf;
-  int* nc;
-  // projection
-  double *Px, *Pu, *Pe, *At, *Bt, *bt, *Qt, *Rt, *Pt, *qt, *rt;
-  double *Wt, *Qp, *Mt;   // the projected model in the packed layout of the fast kernels (PackedLq, project_node.h)
-  double* Vt;             // the joint rows of [Px | Pe | Pu], packed (project_lu_s.h); the force rows are generated by the readers
-  int* nut;
-  int* n_info;         // per (problem, node): 0 = beyond the problem's grid, else 8 | mode << 1 | kind (written once per setup by k_prepare):
-                       // what a per-node kernel needs to know before it can address its data, one load away instead of three
-  double* lin_park;    // per node 15 doubles per lane: scratch of the linearisation kernel
-  double* qrd;         // per node kQrdStride doubles: node-dependent part of Q, R in compact form (linearize_fast.h)
-  // riccati
-  double *Kt, *kt, *dx, *du, *K, *summary, *dx0;
-  double *Acl, *bcl, *kff, *mvec, *mscal, *rprof;
-  // previous solution, kept for the receding-horizon warm start (k_warm_shift)
-  double *x_prev, *u_prev, *K_prev, *tp_time;
-  int *tp_kind, *tp_nodes, *tp_grid;
-  // batched policy rollout (kernels/rollout.h)
-  double *roll_t, *roll_x0, *roll_x, *roll_u;
-  int *roll_steps, *roll_status;
-  // device-side reference generation (kernels/reference_device.h)
-  double *g_time, *rg_t0, *rg_start, *p_t0, *p_cmd, *lib_d;
-  int *rg_gait, *rg_status, *rg_rows, *lib_i;
-  double* ric_carry;   // per problem NX*NX + NX + 1: value function and status handed from one horizon chunk to the next
-  double* zero_page;   // 16 bytes of zeros: source of every LDS-DMA chunk that must read as zero (riccati_dma8.h)
-  // line search
-  double *trial_perf, *base, *alpha, *stats;
-  int *done, *active, *iterations, *remaining;
-};
-
-struct Launch {
-  const DeviceModel* model;
-  Buffers buf;
-  int batch, N;  // N = node stride (max_nodes); batch = problems of THIS launch
-  int b0;        // ... which start at problem b0 (0 unless the batch is split over streams, bpmpc_solver::run_iterations)
-  int k0, klen;  // node range [k0, k0 + klen) of this launch (fast kernels; the horizon is pipelined in chunks)
-  int cold;
-  LineSearchSettings ls;
-  double reg_prim;
-};
-
-template <int NJ>
-__global__ __launch_bounds__(kWave) void k_prepare(Launch L) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  const int s = blockIdx.x, b = s / L.N, k = s % L.N;
-  const int g = L.buf.p_grid[b];
-  const int n = L.buf.g_nodes[g];
-  if (k >= n) { if (threadIdx.x == 0) L.buf.n_info[s] = 0; return; }
-  const size_t gs = (size_t)g * L.N + k;
-  if (threadIdx.x == 0) L.buf.n_info[s] = 8 | ((L.buf.g_mode[gs] & 3) << 1) | (L.buf.g_kind[gs] == 1 ? 1 : 0);
-  prepare_node<NJ>(*L.model, L.buf.g_kind[gs], L.buf.g_mode[gs], L.buf.g_start[gs], L.cold != 0, k == n - 1, L.buf.p_tgt_n[b],
-                   L.buf.p_tgt_t + (size_t)b * kMaxTargetPoints, L.buf.p_tgt_x + (size_t)b * kMaxTargetPoints * NX, L.buf.p_x0 + (size_t)b * NX,
-                   L.buf.xref + (size_t)s * NX, L.buf.x + ((size_t)b * (L.N + 1) + k) * NX, L.buf.u + (size_t)s * NU,
-                   L.buf.x + ((size_t)b * (L.N + 1) + k + 1) * NX);
-}
-
-template <int NJ>
-__device__ __forceinline__ NodeInputs node_inputs(const Launch& L, int b, int k) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  const int g = L.buf.p_grid[b];
-  const size_t gs = (size_t)g * L.N + k, s = (size_t)b * L.N + k;
-  NodeInputs in;
-  in.kind = L.buf.g_kind[gs];
-  in.mode = L.buf.g_mode[gs];
-  in.dt = L.buf.g_dt[gs];
-  in.x = L.buf.x + ((size_t)b * (L.N + 1) + k) * NX;
-  in.xnext = in.x + NX;
-  in.u = L.buf.u + s * NU;
-  in.xref = L.buf.xref + s * NX;
-  in.zref = L.buf.g_zref + gs * 4;
-  in.zdref = L.buf.g_zdref + gs * 4;
-  return in;
-}
-
-// The same with the problem's grid already in hand (the fast kernels load it next to the problem's flags: one memory round trip less
-// between the start of a wave and its first data load)
-template <int NJ>
-__device__ __forceinline__ NodeInputs node_inputs_on_grid(const Launch& L, int b, int k, int g) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  const size_t gs = (size_t)g * L.N + k, s = (size_t)b * L.N + k;
-  NodeInputs in;
-  in.kind = L.buf.g_kind[gs];
-  in.mode = L.buf.g_mode[gs];
-  in.dt = L.buf.g_dt[gs];
-  in.x = L.buf.x + ((size_t)b * (L.N + 1) + k) * NX;
-  in.xnext = in.x + NX;
-  in.u = L.buf.u + s * NU;
-  in.xref = L.buf.xref + s * NX;
-  in.zref = L.buf.g_zref + gs * 4;
-  in.zdref = L.buf.g_zdref + gs * 4;
-  return in;
-}
-
-template <int NJ>
-__global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ NodeWorkspace<NJ> ws;
-  const int sidx = blockIdx.x, b = sidx / L.N, k = sidx % L.N;
-  if (!L.buf.active[b]) return;
-  if (k >= L.buf.g_nodes[L.buf.p_grid[b]]) return;
-  const size_t s = sidx;
-  const NodeInputs in = node_inputs<NJ>(L, b, k);
-  NodeLQOut out;
-  out.A = L.buf.A + s * NX * NX; out.B = L.buf.B + s * NX * NU; out.b = L.buf.b + s * NX;
-  out.Q = L.buf.Q + s * NX * NX; out.R = L.buf.R + s * NU * NU; out.P = L.buf.P + s * NU * NX;
-  out.q = L.buf.q + s * NX; out.r = L.buf.r + s * NU; out.c = L.buf.c + s;
-  out.C = L.buf.C + s * kMaxEqRows * NX; out.D = L.buf.D + s * kMaxEqRows * NU; out.e = L.buf.e + s * kMaxEqRows;
-  out.nc = L.buf.nc + s; out.perf = L.buf.perf + s * 3;
-  out.prof = (b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
-  linearize_node<NJ>(*L.model, ws, in, out);
-}
-
-constexpr int kTrialWaves = 4; // same for the value-only trial kernel (smaller per-node LDS: four waves, 8 waves per CU)
-// wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS.  Four: 74.3 KB at nx = 22, 79.1 KB
-// at nx = 24 (a wave serves four nodes of 4.2 KB each, packed lanes, LinFastCfg) - two workgroups, eight waves per CU
-#ifndef BPMPC_LIN_WAVES
-#define BPMPC_LIN_WAVES 4      // five (two workgroups = ten waves per CU fit since the node tables share one storage): 0.302 against 0.223 ms at batch
-#endif                        // 256, 4.22 against 3.20 at 4096 - the kernel is not short of waves
-template <int NJ> constexpr int lin_waves() { return BPMPC_LIN_WAVES; }
-#ifndef BPMPC_LIN_WPE
-#define BPMPC_LIN_WPE __attribute__((amdgpu_waves_per_eu(2, BPMPC_LIN_WAVES > 4 ? 3 : 2)))
-#endif
-template <int NJ, bool MAT>
-__global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linearize_fast(Launch L) {
-  using C = LinFastCfg<NJ, true>;
-  constexpr int LPN = C::LPN, NPW = C::NPW, kLinWaves = lin_waves<NJ>();
-  __shared__ LinFastNodeLds<NJ> lds[kLinWaves * NPW];
-  __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kLinWaves * kWave);
-  __syncthreads();
-  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;       // sub: node slot of the workgroup
-  const int widx = blockIdx.x * (kLinWaves * NPW) + sub;          // batch * max_nodes < 2^31 is checked at creation
-  bool valid = widx < L.batch * L.klen;
-  const int b = valid ? L.b0 + widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
-  const int act = L.buf.active[b], grid = L.buf.p_grid[b];           // unconditional loads: two round trips to the node's facts, not four
-  const int n_nodes = L.buf.g_nodes[grid];
-  const NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
-  valid = valid && act != 0 && k < n_nodes;
-  const size_t s = valid ? (size_t)b * L.N + k : 0;
-  LinFastOut out;
-  out.A = L.buf.A; out.B = L.buf.B; out.b = L.buf.b; out.Q = L.buf.Q; out.R = L.buf.R; out.q = L.buf.q; out.r = L.buf.r; out.c = L.buf.c;
-  out.C = L.buf.C; out.D = L.buf.D; out.e = L.buf.e; out.perf = L.buf.perf; out.nc = L.buf.nc;
-  out.park = L.buf.lin_park;
-  out.qrd = L.buf.qrd;
-  out.s = s;
-  out.prof = (valid && b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
-  linearize_fast<NJ, MAT, C>(*L.model, shared, lds[sub], valid, in, out, g);      // g: lane inside the node's group
-}
-
-template <int NJ>
-__global__ __launch_bounds__(kWave) void k_project(Launch L) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ ProjectWorkspace<NJ> ws;
-  const int sidx = blockIdx.x, b = sidx / L.N, k = sidx % L.N;
-  if (!L.buf.active[b]) return;
-  const int g = L.buf.p_grid[b];
-  if (k >= L.buf.g_nodes[g]) return;
-  const size_t s = sidx;
-  ProjectIn in;
-  in.kind = L.buf.g_kind[(size_t)g * L.N + k];
-  in.nc = L.buf.nc[s];
-  in.C = L.buf.C + s * kMaxEqRows * NX; in.D = L.buf.D + s * kMaxEqRows * NU; in.e = L.buf.e + s * kMaxEqRows;
-  in.A = L.buf.A + s * NX * NX; in.B = L.buf.B + s * NX * NU; in.b = L.buf.b + s * NX;
-  in.Q = L.buf.Q + s * NX * NX; in.R = L.buf.R + s * NU * NU; in.P = L.buf.P + s * NU * NX; in.q = L.buf.q + s * NX; in.r = L.buf.r + s * NU;
-  ProjectOut out;
-  out.Px = L.buf.Px + s * NU * NX; out.Pu = L.buf.Pu + s * NU * NU; out.Pe = L.buf.Pe + s * NU; out.nut = L.buf.nut + s;
-  out.At = L.buf.At + s * NX * NX; out.Bt = L.buf.Bt + s * NX * NU; out.bt = L.buf.bt + s * NX;
-  out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
-  out.rt = L.buf.rt + s * NU;
-  project_node<NJ>(ws, in, out);
-}
-
-template <int NJ, int RM>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_project_lu(Launch L) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ ProjectLuLds<NJ> lds[kLuNodes];
-  const int sub = threadIdx.x / kLuLanes, j = threadIdx.x % kLuLanes;
-  const int widx = blockIdx.x * kLuNodes + sub;
-  bool valid = widx < L.batch * L.klen;
-  const int b = valid ? L.b0 + widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
-  const int g = L.buf.p_grid[b];
-  valid = valid && L.buf.active[b] && k < L.buf.g_nodes[g];
-  const size_t s = valid ? (size_t)b * L.N + k : 0;
-  double* Px = L.buf.Px + s * NU * NX;
-  double* Pu = L.buf.Pu + s * NU * NU;
-  double* Pe = L.buf.Pe + s * NU;
-  if (valid && L.buf.g_kind[(size_t)g * L.N + k] == 1) {   // event node: no input
-    for (int idx = j; idx < NU * NX; idx += kLuLanes) { Px[idx] = 0.0; Pu[idx] = 0.0; }
-    for (int idx = j; idx < NU; idx += kLuLanes) Pe[idx] = 0.0;
-    if (j == 0) L.buf.nut[s] = 0;
-    valid = false;
-  }
-  project_lu4<NJ, RM>(lds[sub], valid, L.buf.nc[s], L.buf.D + s * kMaxEqRows * NU, L.buf.C + s * kMaxEqRows * NX, L.buf.e + s * kMaxEqRows, Px, Pu, Pe,
-                  L.buf.nut + s, sub, j);
-}
-
-#ifndef BPMPC_RICCATI_WAVES8
-#define BPMPC_RICCATI_WAVES8 1     // one problem per CU (batch <= CUs): the eight-wave sweep with the gains off the critical path (riccati_mfma8.h)
-#endif
-#ifndef BPMPC_STRUCTURED_LU
-#define BPMPC_STRUCTURED_LU 1      // constraint elimination through the block structure of D (project_lu_s.h); 0: FullPivLU on the whole D
-#endif
-#ifndef BPMPC_LUS_WPE
-#define BPMPC_LUS_WPE __attribute__((amdgpu_waves_per_eu(4, 4)))     // 68 registers, 9 KB of LDS per wave: four waves per SIMD, 0.107 -> 0.095 ms (five: the same)
-#endif
-template <int NJ, int RM, bool PK>
-__global__ __launch_bounds__(kWave) BPMPC_LUS_WPE void k_project_lu_s(Launch L) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ, WP = PackedLq<NJ>::WP;
-  __shared__ ProjectLuSLds<NJ> lds[kLuNodes];
-  const int sub = threadIdx.x / kLuLanes, j = threadIdx.x % kLuLanes;
-  const int widx = blockIdx.x * kLuNodes + sub;
-  bool valid = widx < L.batch * L.klen;
-  const int b = valid ? L.b0 + widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
-  // the node's facts one memory round trip away (n_info, written by k_prepare): a wave of this kernel lives ~40 k cycles and every
-  // dependent load before its data loads costs it ~5 k
-  const int act = L.buf.active[b];
-  const int info = L.buf.n_info[(size_t)b * L.N + k];
-  const int kind = info & 1, gmode = (info >> 1) & 3;
-  valid = valid && act != 0 && info != 0;
-  const size_t s = valid ? (size_t)b * L.N + k : 0;
-  double* Px = L.buf.Px + s * NU * NX;
-  double* Pu = L.buf.Pu + s * NU * NU;
-  double* Pe = L.buf.Pe + s * NU;
-  double* Vt = L.buf.Vt + s * NJ * WP;
-  if (valid && kind == 1) {   // event node: no input
-    if constexpr (PK) {
-      for (int idx = j; idx < NJ * 32; idx += kLuLanes) Vt[(idx >> 5) * WP + (idx & 31)] = 0.0;      // the first two block columns: what a reader with nut = 0 loads
-    } else {
-      for (int idx = j; idx < NU * NX; idx += kLuLanes) { Px[idx] = 0.0; Pu[idx] = 0.0; }
-    }
-    for (int idx = j; idx < NU; idx += kLuLanes) Pe[idx] = 0.0;
-    if (j == 0) L.buf.nut[s] = 0;
-    valid = false;
-  }
-  const int mode = valid ? (gmode & 3) : 3;
-  project_lu_s<NJ, RM, PK>(lds[sub], valid, mode, L.buf.D + s * kMaxEqRows * NU, L.buf.C + s * kMaxEqRows * NX, L.buf.e + s * kMaxEqRows, Px, Pu, Pe,
-                           L.buf.nut + s, sub, j, Vt,
-                           (threadIdx.x == 0 && blockIdx.x < (unsigned)L.batch) ? L.buf.rprof + 8 * blockIdx.x : nullptr);
-}
-
-// (amdgpu_waves_per_eu(3): 168 registers and 60 B of scratch instead of 186 registers, three waves per SIMD instead of two - measured
-//  slower, 0.272 against 0.255 ms on the same box)
-#ifndef BPMPC_PROJECT_WPE
-#define BPMPC_PROJECT_WPE 3
-#endif
-template <int NJ, bool PK>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PK ? BPMPC_PROJECT_WPE : 2, 4))) void k_project_fast(Launch L) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ ProjectMfmaWorkspace<NJ, PK> ws;
-  const int b = L.b0 + blockIdx.x / L.klen, k = L.k0 + blockIdx.x % L.klen;
-  if (!L.buf.active[b]) return;
-  const int g = L.buf.p_grid[b];
-  if (k >= L.buf.g_nodes[g]) return;
-  const size_t s = (size_t)b * L.N + k;
-  ProjectIn in;
-  in.kind = L.buf.g_kind[(size_t)g * L.N + k];
-  in.nc = L.buf.nc[s];
-  in.C = L.buf.C + s * kMaxEqRows * NX; in.D = L.buf.D + s * kMaxEqRows * NU; in.e = L.buf.e + s * kMaxEqRows;
-  in.A = L.buf.A + s * NX * NX; in.B = L.buf.B + s * NX * NU; in.b = L.buf.b + s * NX;
-  in.Q = L.buf.Q + s * NX * NX; in.R = L.buf.R + s * NU * NU; in.P = L.buf.P + s * NU * NX; in.q = L.buf.q + s * NX; in.r = L.buf.r + s * NU;
-  ProjectOut out;
-  out.Px = L.buf.Px + s * NU * NX; out.Pu = L.buf.Pu + s * NU * NU; out.Pe = L.buf.Pe + s * NU; out.nut = L.buf.nut + s;
-  out.At = L.buf.At + s * NX * NX; out.Bt = L.buf.Bt + s * NX * NU; out.bt = L.buf.bt + s * NX;
-  out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
-  out.rt = L.buf.rt + s * NU;
-  in.qrd = L.buf.qrd + s * kQrdStride;
-  const double dt = L.buf.g_dt[(size_t)g * L.N + k];
-  out.Wt = L.buf.Wt + s * PackedLq<NJ>::W_SIZE; out.Qp = L.buf.Qp + s * PackedLq<NJ>::Q_SIZE; out.Mt = L.buf.Mt + s * PackedLq<NJ>::M_SIZE;
-  if constexpr (PK) { in.zero = L.buf.zero_page; in.Vt = L.buf.Vt + s * NJ * PackedLq<NJ>::WP; in.mode = L.buf.g_mode[(size_t)g * L.N + k] & 3; }   // written by the structured elimination
-  else out.Vt = L.buf.Vt + s * NJ * PackedLq<NJ>::WP;   // FullPivLU elimination (Px, Pu, Pe): this kernel packs the joint rows for the sweep's loaders
-  project_apply_mfma<NJ, PK>(ws, in, out, dt, dt * (1.0 / L.model->robot_mass), L.model->Q, L.model->R, L.reg_prim);   // as written by linearize_fast
-}
-
-// The same change of variables through the block structure of [Px | Pe | Pu], B and R (project_struct.h): the default of the fast path.
-#ifndef BPMPC_STRUCTURED_PROJECT
-#define BPMPC_STRUCTURED_PROJECT 1
-#endif
-#ifndef BPMPC_PROJECT_STRUCT_WPE
-#define BPMPC_PROJECT_STRUCT_WPE __attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
-template <int NJ>
-__global__ __launch_bounds__(kWave) BPMPC_PROJECT_STRUCT_WPE void k_project_struct(Launch L) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ ProjectStructWorkspace<NJ> ws;
-  const int b = L.b0 + blockIdx.x / L.klen, k = L.k0 + blockIdx.x % L.klen;
-  if (!L.buf.active[b]) return;
-  const int g = L.buf.p_grid[b];
-  if (k >= L.buf.g_nodes[g]) return;
-  const size_t s = (size_t)b * L.N + k, gs = (size_t)g * L.N + k;
-  ProjectIn in;
-  in.kind = L.buf.g_kind[gs];
-  in.nc = 0;
-  in.C = in.D = in.e = in.Q = in.R = in.P = nullptr;
-  in.A = L.buf.A + s * NX * NX; in.B = L.buf.B + s * NX * NU; in.b = L.buf.b + s * NX; in.q = L.buf.q + s * NX; in.r = L.buf.r + s * NU;
-  in.qrd = L.buf.qrd + s * kQrdStride;
-  in.Vt = L.buf.Vt + s * NJ * PackedLq<NJ>::WP;
-  ProjectOut out;
-  out.Px = L.buf.Px + s * NU * NX; out.Pu = L.buf.Pu + s * NU * NU; out.Pe = L.buf.Pe + s * NU; out.nut = L.buf.nut + s;
-  out.At = out.Bt = out.bt = out.Qt = out.Rt = out.Pt = out.qt = out.rt = nullptr;
-  out.Wt = L.buf.Wt + s * PackedLq<NJ>::W_SIZE; out.Qp = L.buf.Qp + s * PackedLq<NJ>::Q_SIZE; out.Mt = L.buf.Mt + s * PackedLq<NJ>::M_SIZE;
-  const double dt = L.buf.g_dt[gs];
-  project_apply_struct<NJ>(ws, in, out, L.buf.g_mode[gs] & 3, dt, dt * (1.0 / L.model->robot_mass), L.model->Q, L.model->R, L.reg_prim);
-}
-
-template <int NJ>
-__global__ __launch_bounds__(kRiccatiThreads) void k_riccati(Launch L) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ RiccatiWorkspace<NJ> ws;
-  const int b = blockIdx.x;
-  if (!L.buf.active[b]) return;
-  const size_t s0 = (size_t)b * L.N;
-  // dx0 = x_measured - x_0
-  double* dx0 = L.buf.dx0 + (size_t)b * NX;
-  if (threadIdx.x < NX) dx0[threadIdx.x] = L.buf.p_x0[(size_t)b * NX + threadIdx.x] - L.buf.x[(size_t)b * (L.N + 1) * NX + threadIdx.x];
-  __syncthreads();
-  RiccatiIO io;
-  io.N = L.buf.g_nodes[L.buf.p_grid[b]];
-  io.nut = L.buf.nut + s0;
-  io.At = L.buf.At + s0 * NX * NX; io.Bt = L.buf.Bt + s0 * NX * NU; io.bt = L.buf.bt + s0 * NX;
-  io.Qt = L.buf.Qt + s0 * NX * NX; io.Rt = L.buf.Rt + s0 * NU * NU; io.Pt = L.buf.Pt + s0 * NU * NX; io.qt = L.buf.qt + s0 * NX;
-  io.rt = L.buf.rt + s0 * NU;
-  io.Px = L.buf.Px + s0 * NU * NX; io.Pu = L.buf.Pu + s0 * NU * NU; io.Pe = L.buf.Pe + s0 * NU;
-  io.dx0 = dx0;
-  io.Kt = L.buf.Kt + s0 * NU * NX; io.kt = L.buf.kt + s0 * NU;
-  io.dx = L.buf.dx + (size_t)b * (L.N + 1) * NX; io.du = L.buf.du + s0 * NU;
-  io.K = L.buf.K ? L.buf.K + s0 * NU * NX : nullptr;
-  io.summary = L.buf.summary + (size_t)b * 4;
-  riccati_problem<NJ>(ws, io);
-}
-
-template <int NJ>
-__device__ __forceinline__ ProblemLS problem_ls(const Launch& L, int b) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  ProblemLS p;
-  const size_t s0 = (size_t)b * L.N;
-  p.n_nodes = L.buf.g_nodes[L.buf.p_grid[b]];
-  p.node_perf = L.buf.perf + s0 * 3;
-  p.trial_perf = L.buf.trial_perf + s0 * 3;
-  p.x0 = L.buf.p_x0 + (size_t)b * NX;
-  p.x = L.buf.x + (size_t)b * (L.N + 1) * NX;
-  p.u = L.buf.u + s0 * NU;
-  p.dx = L.buf.dx + (size_t)b * (L.N + 1) * NX;
-  p.du = L.buf.du + s0 * NU;
-  p.summary = L.buf.summary + (size_t)b * 4;
-  p.base = L.buf.base + (size_t)b * 3;
-  p.alpha = L.buf.alpha + b;
-  p.done = L.buf.done + b;
-  p.active = L.buf.active + b;
-  p.iterations = L.buf.iterations + b;
-  p.stats = L.buf.stats + (size_t)b * kStatsStride;
-  p.remaining = L.buf.remaining;
-  return p;
-}
-
-template <int NJ>
-__device__ __forceinline__ bool riccati_fast_io(const Launch& L, RiccatiFastIO& io, double* lds_scratch /* 3 * 64 + 5 doubles: the kernel's workspace */) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  const int b = L.b0 + blockIdx.x;
-  const int tid_ = threadIdx.x;
-  io.with_ls = L.k0 == 0;                                  // the launch that sweeps down to stage 0 (and rolls out) also opens the line search
-  if (io.with_ls) io.ls = problem_ls<NJ>(L, b);
-  if (!L.buf.active[b]) {                                  // a finished problem: only its line-search flags (done = 1)
-    if (io.with_ls && tid_ < kWave) linesearch_begin_wave<NJ>(lds_scratch, io.ls, tid_);
-    return false;
-  }
-  const size_t s0 = (size_t)b * L.N;
-  double* dx0 = L.buf.dx0 + (size_t)b * NX;
-  if (tid_ < NX) dx0[tid_] = L.buf.p_x0[(size_t)b * NX + tid_] - L.buf.x[(size_t)b * (L.N + 1) * NX + tid_];
-  __syncthreads();
-  io.base.N = L.buf.g_nodes[L.buf.p_grid[b]];
-  io.base.nut = L.buf.nut + s0;
-  io.base.At = L.buf.At + s0 * NX * NX; io.base.Bt = L.buf.Bt + s0 * NX * NU; io.base.bt = L.buf.bt + s0 * NX;
-  io.base.Qt = L.buf.Qt + s0 * NX * NX; io.base.Rt = L.buf.Rt + s0 * NU * NU; io.base.Pt = L.buf.Pt + s0 * NU * NX;
-  io.base.qt = L.buf.qt + s0 * NX; io.base.rt = L.buf.rt + s0 * NU;
-  io.Wt = L.buf.Wt + s0 * PackedLq<NJ>::W_SIZE; io.Qp = L.buf.Qp + s0 * PackedLq<NJ>::Q_SIZE; io.Mt = L.buf.Mt + s0 * PackedLq<NJ>::M_SIZE;
-  io.base.Px = L.buf.Px + s0 * NU * NX; io.base.Pu = L.buf.Pu + s0 * NU * NU; io.base.Pe = L.buf.Pe + s0 * NU;
-  io.Vt = L.buf.Vt + s0 * NJ * PackedLq<NJ>::WP;
-  io.mode = L.buf.g_mode + (size_t)L.buf.p_grid[b] * L.N;
-  io.zero_one = L.buf.zero_page;
-  io.lqA = L.buf.A + s0 * NX * NX; io.lqB = L.buf.B + s0 * NX * NU; io.lqb = L.buf.b + s0 * NX; io.lqq = L.buf.q + s0 * NX; io.lqr = L.buf.r + s0 * NU;
-  io.qrd = L.buf.qrd + s0 * kQrdStride; io.gdt = L.buf.g_dt + (size_t)L.buf.p_grid[b] * L.N;
-  io.model = L.model;
-  io.base.dx0 = dx0;
-  io.base.Kt = nullptr; io.base.kt = nullptr;
-  io.base.dx = L.buf.dx + (size_t)b * (L.N + 1) * NX; io.base.du = L.buf.du + s0 * NU;
-  io.base.K = nullptr;
-  io.base.summary = L.buf.summary + (size_t)b * 4;
-  io.Acl = L.buf.Acl + s0 * NX * NX; io.bcl = L.buf.bcl + s0 * NX; io.kff = L.buf.kff + s0 * NU;
-  io.mvec = L.buf.mvec + s0 * NX; io.mscal = L.buf.mscal + s0;
-  io.Kfull = L.buf.K + s0 * NU * NX;
-  io.prof = L.buf.rprof ? L.buf.rprof + (size_t)b * 8 : nullptr;
-  io.k_lo = L.k0;
-  io.k_hi = L.k0 + L.klen;
-  io.carry = L.buf.ric_carry + (size_t)b * (NX * NX + NX + 2);
-  io.reg = L.reg_prim;
-  return true;
-}
-
-// The single-buffered variant is meant to run two workgroups per CU: cap its registers at 256 (VGPR + AGPR).
-template <int NJ, bool DB>
-__global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu(DB ? 1 : 2, DB ? 8 : 2))) void k_riccati_fast(Launch L) {
-  __shared__ RiccatiMfmaWorkspace<NJ, DB> ws;
-  RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
-  riccati_mfma<NJ, DB>(ws, io);
-}
-
-// Batches larger than the chip (riccati_wave.h): one wavefront per problem, alone on its SIMD with the whole register file; the roll-out is
-// a launch of its own.
-#ifndef BPMPC_WAVE_WPE
-#define BPMPC_WAVE_WPE 1
-#endif
-#ifndef BPMPC_ROLLOUT_PAIR
-#define BPMPC_ROLLOUT_PAIR 1       // roll-out behind the wave sweeps in two-wave workgroups, four per CU (0: four-wave workgroups, two per CU)
-#endif
-#ifndef BPMPC_RICCATI_WAVE_DEFAULT
-#define BPMPC_RICCATI_WAVE_DEFAULT 1     // BPMPC_RICCATI_WAVE unset: 1 = batches larger than the chip use the wave-per-problem sweep
-#endif
-template <int NJ>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BPMPC_WAVE_WPE, 2))) void k_riccati_wave(Launch L) {
-  __shared__ RiccatiWaveWorkspace<NJ> ws;
-  RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
-  riccati_wave<NJ>(ws, io);
-}
-// the same sweep arranged for two waves per SIMD (riccati_wave2.h)
-template <int NJ>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_riccati_wave2(Launch L) {
-  __shared__ RiccatiWave2Workspace<NJ> ws;
-  RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io, ws.T)) return;
-  riccati_wave2<NJ>(ws, io);
-}
-// two waves per problem, each owning block columns (riccati_pair.h): between two and eight problems per CU
-// (Measured and NOT the default anywhere - BPMPC_RICCATI_WAVE=5 selects it: 10.2 k cycles per stage with a CU to itself, but 12.5 k at two
-//  problems per CU and 14.6 k at four (tools/riccati_wave_phase_profile.py <batch> h1 5): 0.71 against 0.61 ms of the four-wave kernel at
-//  batch 512, 0.96 against 0.98 ms of riccati_wave.h at 1024, 3.9 against 3.2 ms of riccati_wave2.h at 4096.  Two problems per four-wave
-//  workgroup, so that the four waves are certain to sit on four SIMDs, were slower still (13.2 k at batch 512): every barrier then waits
-//  for the slowest of four waves.)
-template <int NJ>
-__global__ __launch_bounds__(kRiccatiPairThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_riccati_pair(Launch L) {
-  __shared__ RiccatiPairWorkspace<NJ> ws;
-  RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io, &ws.Mx[0][0])) return;
-  riccati_pair<NJ>(ws, io, __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave)));
-}
-template <int NJ>
-__global__ __launch_bounds__(kRiccatiThreads) void k_riccati_rollout(Launch L) {
-  __shared__ RiccatiRolloutWorkspace<NJ> ws;
-  RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io, ws.hist)) return;
-  riccati_rollout_only<NJ>(ws, io);
-}
-
-template <int NJ>
-__global__ __launch_bounds__(kRolloutPairThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_riccati_rollout_pair(Launch L) {
-  __shared__ RiccatiRolloutPairWorkspace<NJ> ws;
-  RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io, ws.hist)) return;
-  riccati_rollout_pair<NJ>(ws, io);
-}
-
-// Eight waves per problem with fixed roles (riccati_mfma8.h): one workgroup per CU.
-template <int NJ>
-__global__ __launch_bounds__(kRiccati8Threads) void k_riccati_fast8(Launch L) {
-  __shared__ RiccatiMfma8Workspace<NJ> ws;
-  RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
-  riccati_mfma8<NJ>(ws, io);
-}
-
-// The same sweep with the stage data staged by LDS-DMA into triple buffers (riccati_dma8.h): nx = 22 only (151 KB of LDS).
-// MEASURED AND REJECTED (round 3, tools/ab_variants.sh on one box, batch 256): 0.358 ms against 0.333 ms of riccati_mfma8.h.  With the
-// requests switched off (wrong results) the triple-buffered structure runs at 0.318 ms - register staging was costing ~0.3 k cycles of the
-// stage, not the 1.2 k its phase profile suggested - and the requests themselves add ~0.9 k cycles per stage whoever issues them (one
-// wave 0.358, two waves 0.425, three 0.428): an LDS-DMA piece occupies the LDS write port for ~60 cycles per KB (16 B/clk, the guide's
-// "issue cost"), eight times what the forty ds_write_b128 of the register path take, and the chain's operand reads wait behind it.
-// Kept behind the macro as the record of the experiment.
-#ifndef BPMPC_RICCATI8_DMA
-#define BPMPC_RICCATI8_DMA 0
-#endif
-template <int NJ>
-__global__ __launch_bounds__(kRiccati8Threads) void k_riccati_dma8(Launch L) {
-  __shared__ RiccatiDma8Workspace<NJ> ws;
-  RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
-  riccati_dma8<NJ>(ws, io, L.buf.zero_page);
-}
-// The sweep with the change of variables folded in (riccati_fold8.h): the projected model never goes through HBM; nx = 22 (157 KB of LDS).
-#ifndef BPMPC_FOLD_PROJECTION
-#define BPMPC_FOLD_PROJECTION 1
-#endif
-template <int NJ>
-__global__ __launch_bounds__(kRiccati8Threads) void k_riccati_fold8(Launch L) {
-  __shared__ RiccatiFold8Workspace<NJ> ws;
-  RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
-  riccati_fold8<NJ>(ws, io);
-}
-template <int NJ> constexpr bool riccati_fold8_fits() { return BPMPC_FOLD_PROJECTION && sizeof(RiccatiFold8Workspace<NJ>) <= 160 * 1024; }
-template <int NJ> constexpr bool riccati_dma8_fits() { return BPMPC_RICCATI8_DMA && sizeof(RiccatiDma8Workspace<NJ>) <= 160 * 1024; }
-
-// Warm start of a receding-horizon solve from the previous solution, one wavefront per (problem, node).  [OCS2-upstream, recalled]
-// SqpSolver::initializeStateInputTrajectories with a non-empty PrimalSolution: for an intermediate node with
-// intervalStart <= second-to-last and intervalEnd <= last time of the previous solution,
-//     u_i = uff(t) + K(t) x_i  (LinearController, sqp.useFeedbackPolicy true, task.info:80;  uff_j = u_j - K_j x_j, inputs and
-//           gains of pre-event nodes and of the terminal node repeat the previous one: multiple_shooting::toPrimalSolution),
-//     x_{i+1} = LinearInterpolation(intervalEnd, previous states);
-// otherwise BipedalRobotInitializer::compute (already written by k_prepare) and x_{i+1} = x_i; event nodes copy the state.
-// The state guess of node i is therefore the interpolation at the end of the last interpolating node before it (or the measured
-// state), which every node finds on its own - no sequential sweep (the first version, one wavefront per problem walking the
-// horizon, took 0.53 ms at batch 256 and was the longest kernel of a closed-loop tick).
-// Oracle: oracle/reference_py.py warm_start_from_previous.
-template <int NJ>
-__global__ __launch_bounds__(kWave) void k_warm_shift(Launch L) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ double xi[NX];
-  __shared__ double Ks[2][NU * NX];
-  const int b = blockIdx.x / L.N, i = blockIdx.x % L.N, l = threadIdx.x;
-  const int N = L.N;
-  const int g = L.buf.p_grid[b], n = L.buf.g_nodes[g];
-  if (i >= n) return;
-  const int gp = L.buf.tp_grid[b], np = L.buf.tp_nodes[gp];
-  if (np < 1) return;
-  const double* tp = L.buf.tp_time + (size_t)gp * (N + 1);
-  const int* kp = L.buf.tp_kind + (size_t)gp * N;
-  const double* xp = L.buf.x_prev + (size_t)b * (N + 1) * NX;
-  const double* up = L.buf.u_prev + (size_t)b * N * NU;
-  const double* Kp = L.buf.K_prev + (size_t)b * N * NU * NX;
-  double* x = L.buf.x + (size_t)b * (N + 1) * NX;
-  double* u = L.buf.u + (size_t)b * N * NU;
-  const double state_till = tp[np], input_till = tp[np - 1];
-  auto effective = [&](int j) { while (j > 0 && (j == np || kp[j] == 1)) --j; return j; };   // repeated input / gain
-  auto interpolates = [&](int k) {
-    const size_t gs = (size_t)g * N + k;
-    if (L.buf.g_kind[gs] != 0) return false;
-    const double t = L.buf.g_start[gs], tn = t + L.buf.g_dt[gs];
-    return !(t > input_till || tn > state_till);
-  };
-  auto state_after = [&](int k, int c) {            // component c of the guess of x_{k+1} for an interpolating node k
-    const size_t gs = (size_t)g * N + k;
-    int j2;
-    double a2;
-    time_segment(tp, np + 1, L.buf.g_start[gs] + L.buf.g_dt[gs], &j2, &a2);
-    return a2 * xp[(size_t)j2 * NX + c] + (1.0 - a2) * xp[(size_t)(j2 + 1) * NX + c];
-  };
-  int src = i - 1;
-  while (src >= 0 && !interpolates(src)) --src;
-  const bool mine = interpolates(i);
-  if (l < NX) {
-    const double v = src < 0 ? L.buf.p_x0[(size_t)b * NX + l] : state_after(src, l);
-    xi[l] = v;
-    if (i == 0) x[l] = v;
-    x[(size_t)(i + 1) * NX + l] = mine ? state_after(i, l) : v;
-  }
-  if (!mine) return;
-  int j;
-  double a;
-  time_segment(tp, np + 1, L.buf.g_start[(size_t)g * N + i], &j, &a);
-  const int e0 = effective(j), e1 = effective(j + 1);
-  for (int idx = l; idx < NU * NX; idx += kWave) {
-    Ks[0][idx] = Kp[(size_t)e0 * NU * NX + idx];
-    Ks[1][idx] = Kp[(size_t)e1 * NU * NX + idx];
-  }
-  __syncthreads();
-  if (l < NU) {
-    double uff0 = up[(size_t)e0 * NU + l], uff1 = up[(size_t)e1 * NU + l], kx = 0.0;
-    for (int c = 0; c < NX; ++c) {
-      const double k0 = Ks[0][l * NX + c], k1 = Ks[1][l * NX + c];
-      uff0 -= k0 * xp[(size_t)j * NX + c];
-      uff1 -= k1 * xp[(size_t)(j + 1) * NX + c];
-      kx += (a * k0 + (1.0 - a) * k1) * xi[c];
-    }
-    u[(size_t)i * NU + l] = a * uff0 + (1.0 - a) * uff1 + kx;
-  }
-}
-
-template <int NJ>
-__global__ __launch_bounds__(kWave) void k_ls_begin(Launch L) {
-  __shared__ double partial[3 * kWave + 5];
-  linesearch_begin<NJ>(partial, problem_ls<NJ>(L, blockIdx.x));
-}
-
-template <int NJ>
-__global__ __launch_bounds__(kWave) void k_trial(Launch L) {
-  constexpr int NX = 12 + NJ, NU = 12 + NJ;
-  __shared__ TrialWorkspace<NJ> ws;
-  const int sidx = blockIdx.x, b = sidx / L.N, k = sidx % L.N;
-  if (L.buf.done[b]) return;
-  if (k >= L.buf.g_nodes[L.buf.p_grid[b]]) return;
-  const NodeInputs in = node_inputs<NJ>(L, b, k);
-  const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
-  trial_node<NJ>(*L.model, ws, in, L.buf.alpha[b], dx, L.buf.du + (size_t)sidx * NU, dx + NX, L.buf.trial_perf + (size_t)sidx * 3);
-}
-
-// Waves per SIMD of the value-only kernel (144 registers at nx = 22, 170 at nx = 24 when left alone; the LDS fits four / three workgroups
-// per CU since the node tables share one storage).  nx = 24: three (168 registers) - line search 0.492 -> 0.404 ms on G1 / 1024, 0.152 ->
-// 0.129 at batch 256.  nx = 22: four (128 registers) pays once the launch has several rounds of workgroups (1.18 -> 1.13 ms at batch 4096),
-// is neutral at batch 512 and loses at 256 (0.108 -> 0.112): chosen per launch, WIDE.
-template <int NJ, bool WIDE>
-__global__ __launch_bounds__(kTrialWaves * kWave) __attribute__((amdgpu_waves_per_eu(NJ <= 10 ? (WIDE ? 4 : 3) : 3, NJ <= 10 ? (WIDE ? 4 : 3) : 3)))
-void k_trial_fast(Launch L) {
-  using C = LinFastCfg<NJ, true>;
-  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
-  __shared__ LinFastNodeLds<NJ, false> lds[kTrialWaves * NPW];
-  __shared__ LinFastShared<NJ, false> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
-  __syncthreads();
-  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
-  const int widx = blockIdx.x * (kTrialWaves * NPW) + sub;
-  bool valid = widx < L.batch * L.klen;
-  const int b = valid ? L.b0 + widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
-  const int fin = L.buf.done[b], grid = L.buf.p_grid[b];
-  const double alpha = L.buf.alpha[b];
-  const int n_nodes = L.buf.g_nodes[grid];
-  const NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
-  valid = valid && fin == 0 && k < n_nodes;
-  const size_t s = valid ? (size_t)b * L.N + k : 0;
-  const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
-  trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, alpha, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
-}
-
-// Values of the active equality rows at the CURRENT iterate (after a solve: the solution), per node in registration order: the value-only
-// evaluation of the line search with a zero step and one more output (linearize_fast.h trial_fast<.., EQV>).
-template <int NJ>
-__global__ __launch_bounds__(kTrialWaves * kWave) void k_constraint_values(Launch L, double* eqv) {
-  using C = LinFastCfg<NJ, true>;
-  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
-  __shared__ LinFastNodeLds<NJ, false> lds[kTrialWaves * NPW];
-  __shared__ LinFastShared<NJ, false> shared;
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
-  __syncthreads();
-  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
-  const int widx = blockIdx.x * (kTrialWaves * NPW) + sub;
-  bool valid = widx < L.batch * L.klen;
-  const int b = valid ? L.b0 + widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
-  const int grid = L.buf.p_grid[b];
-  valid = valid && k < L.buf.g_nodes[grid] && L.buf.g_kind[(size_t)grid * L.N + k] == 0;
-  const size_t s = valid ? (size_t)b * L.N + k : 0;
-  const NodeInputs in = node_inputs<NJ>(L, b, k);
-  const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
-  double perf[3];
-  trial_fast<NJ, C, true>(*L.model, shared, lds[sub], valid, in, 0.0, dx, L.buf.du + s * NU, dx + NX, perf, g, eqv + s * kMaxEqRows);
-}
-
-template <int NJ>
-__global__ __launch_bounds__(kWave) void k_rollout(const DeviceModel* model, RolloutArgs a) {
-  __shared__ RolloutLds<NJ> w;
-  load_shared_model<NJ>(*model, w.shared, threadIdx.x, kWave);
-  __syncthreads();
-  rollout_policy<NJ>(*model, w, a);
-}
-
-constexpr int kDecideThreads = 256;
-template <int NJ>
-__global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L) {
-  __shared__ double partial[3 * kDecideThreads + 5];
-  linesearch_decide<NJ, kDecideThreads>(partial, problem_ls<NJ>(L, L.b0 + blockIdx.x), L.ls);
-}
-
-// Back-tracking rounds after the first one, entirely on the device: a workgroup per problem that has not accepted yet (normally
-// none: the block exits at once) evaluates its own trial nodes, thirty-two at a time, and decides, until the problem accepts or gives
-// up.  The host never reads a flag back inside a solve, so consecutive solves queue without a gap.  The few problems that back-track
-// are alone on their CUs and what they cost is the latency of their rounds: eight waves walk the horizon in half the chunks of four
-// (the sums are the ones of k_ls_decide term by term while the horizon has at most kDecideThreads nodes).
-constexpr int kTailThreads = 512;
-template <int NJ>
-__global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int max_trials) {
-  using C = LinFastCfg<NJ, true>;
-  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW, CHUNK = (kTailThreads / kWave) * NPW;
-  const int b = L.b0 + blockIdx.x;
-  if (L.buf.done[b]) return;
-  __shared__ LinFastNodeLds<NJ, false> lds[CHUNK];
-  __shared__ LinFastShared<NJ, false> shared;
-  __shared__ double partial[3 * kTailThreads + 5];
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTailThreads);
-  __syncthreads();
-  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
-  const int n = L.buf.g_nodes[L.buf.p_grid[b]];
-  const ProblemLS p = problem_ls<NJ>(L, b);
-  volatile const int* done = L.buf.done + b;
-  volatile const double* alpha = L.buf.alpha + b;
-  for (int round = 1; round < max_trials; ++round) {
-    const double al = *alpha;
-    for (int k0 = 0; k0 < n; k0 += CHUNK) {
-      const int k = k0 + sub;
-      const bool valid = k < n;
-      const int kk = valid ? k : 0;
-      const size_t s = (size_t)b * L.N + kk;
-      const NodeInputs in = node_inputs<NJ>(L, b, kk);
-      const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + kk) * NX;
-      trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, al, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
-    }
-    __threadfence();
-    __syncthreads();
-    linesearch_decide<NJ, kTailThreads>(partial, p, L.ls);
-    __threadfence();
-    __syncthreads();
-    if (*done) break;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ solver object
 struct KernelTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double total_ms = 0.0;
   int launches = 0;
 };
-
-// One launch instead of several driver copies / fills (each costs a dispatch gap of a few microseconds between kernels):
-// copies two pairs of double arrays and optionally re-arms the per-problem flags.
-__global__ __launch_bounds__(256) void k_copy_pairs(const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb,
-                                                     int* iterations, int* active, int batch) {
-  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-  const double2* a2 = reinterpret_cast<const double2*>(a_src);
-  const double2* b2 = reinterpret_cast<const double2*>(b_src);
-  double2* ad = reinterpret_cast<double2*>(a_dst);
-  double2* bd = reinterpret_cast<double2*>(b_dst);
-  for (size_t i = i0; i < na / 2; i += stride) ad[i] = a2[i];
-  for (size_t i = i0; i < nb / 2; i += stride) bd[i] = b2[i];
-  if (i0 == 0) { if (na & 1) a_dst[na - 1] = a_src[na - 1]; if (nb & 1) b_dst[nb - 1] = b_src[nb - 1]; }
-  if (iterations) for (size_t i = i0; i < (size_t)batch; i += stride) { iterations[i] = 0; active[i] = 1; }
-}
 
 }  // namespace bpmpc
 
@@ -836,17 +92,16 @@ struct bpmpc_solver {
   int nx = 0, nu = 0;
   int batch = 0, n_grids = 0, n_nodes_max = 0;
   int num_cus = 256;                                        // compute units of the device
-  // One Riccati workgroup per problem: double buffered staging (one workgroup per CU) while every problem gets its own CU,
-  // the leaner single-buffered variant (two workgroups per CU at nx = 22) for larger batches.
-  // change of variables through the block structure (project_struct.h): needs the structured elimination (its layout of Px, Pu, Pe) and an
-  // input weight without force / joint-velocity cross terms (checked when the solver is created; BipedalRobotInterface.cpp:239-271 builds it so)
+  // change of variables reading the packed joint rows of the structured elimination: needs an input weight without force / joint-velocity
+  // cross terms (checked when the solver is created; BipedalRobotInterface.cpp:239-271 builds it so).  BPMPC_DENSE_PROJECT=1 switches it off.
   bool structured_project = false;
-  int riccati_wave = 0;                                     // BPMPC_RICCATI_WAVE=1: batches larger than the chip sweep with one wavefront per problem (riccati_wave.h); 2: every batch (tests)
+  // Riccati sweep by regime: eight waves with fixed roles while every problem has a CU to itself; four-wave workgroups up to two problems per CU;
+  // beyond that one wavefront per problem (riccati_wave.h at one wave per SIMD up to four problems per CU, riccati_wave2.h at two beyond).
+  // BPMPC_RICCATI_WAVE: 0 never a wave per problem; 1 (default) as described; 2 riccati_wave.h at every batch size, 4 riccati_wave2.h at every
+  // batch size (tests); 3 riccati_wave2.h whenever a wave per problem is used
+  int riccati_wave = 1;
   int trial_wide_from = 16;                                 // workgroups per CU from which the value-only kernel runs at one more wave per SIMD (BPMPC_TRIAL_WIDE_FROM)
-  int split_whole = 0;                                      // the whole batch while its parts are being launched (the kernels of a regime are chosen for what the chip sees)
-  int regime_batch() const { return split_whole > 0 ? split_whole : batch; }
-  bool riccati8_always = false;                             // experiment: BPMPC_RICCATI8_ALWAYS=1 runs the eight-wave sweep (one workgroup per CU) at every batch size
-  bool riccati_double_buffered() const { return riccati_wave != 2 && riccati_wave != 4 && riccati_wave != 5 && (riccati8_always || regime_batch() <= num_cus); }
+  bool riccati_double_buffered() const { return riccati_wave != 2 && riccati_wave != 4 && batch <= num_cus; }
   bool has_solution = false;                               // a solve has completed on the current setup
   bool has_rollout = false;                                // roll_x holds the end states of a rollout
   bool rollout_unchecked = false;                          // ... whose status flags have not been read back yet
@@ -859,14 +114,6 @@ struct bpmpc_solver {
   hipStream_t producer_stream = nullptr;                   // linearisation + projection of the pipelined horizon chunks
   hipEvent_t ev_go = nullptr;
   std::vector<hipEvent_t> ev_chunk;
-  // The batch split over streams (BPMPC_BATCH_PARTS, run_iterations): the problems are independent, so each part runs its whole SQP
-  // iteration on a stream of its own.  What it buys: the last, partly filled round of workgroups of one part's kernels overlaps the next
-  // kernel of another part, and a part's latency-bound sweep the other parts' streaming kernels.  Results are bit-identical.
-  int batch_parts = 1;
-  int part_b0 = 0;                                         // first problem of the part being launched (Launch::b0)
-  std::vector<hipStream_t> part_streams;
-  std::vector<hipEvent_t> ev_part, ev_skew;
-  bool batch_skew = false;                                 // BPMPC_BATCH_SKEW=1
   Buffers buf{};
   std::vector<void*> allocations;
   std::map<std::string, std::pair<void*, size_t>> named;   // name -> (device ptr, element count)  (doubles unless in int_named)
@@ -892,7 +139,6 @@ struct bpmpc_solver {
     L.model = d_model;
     L.buf = buf;
     L.batch = batch;
-    L.b0 = part_b0;
     L.N = settings.max_nodes;
     L.k0 = 0;
     // node range of a launch: the longest grid of the current setup, not the solver's capacity - the per-node kernels map their
@@ -937,148 +183,93 @@ struct bpmpc_solver {
     }
   }
 
-  template <int NJ> void stage_prepare();
-  template <int NJ> void stage_linearize();
-  template <int NJ> void stage_project();
-  template <int NJ> void stage_riccati();
-  template <int NJ> void launch_riccati8(const Launch& L);
-  template <int NJ> void launch_riccati_big(const Launch& L);
-  // the eight-wave sweep with the change of variables folded in replaces the projection kernel: structured elimination, the eight-wave
-  // regime (one problem per CU), no horizon pipelining (the chunks hand S over; the folded sweep supports it but the producer stream is pointless)
-  // Which change-of-variables kernel follows the structured elimination (both read its packed joint rows).  Measured on one box
-  // (BPMPC_STRUCT_PROJECT=1 / 0): the DENSE kernel wins everywhere once it reads the packed rows - 157 registers instead of 162, three
-  // waves per SIMD - although it issues 120 matrix-core instructions per node where project_struct.h issues 42: batch 256 0.169 against
-  // 0.179 ms, batch 4096 2.43 against 2.75 ms, nx = 24 / batch 1024 0.85 against 1.27 ms.  Neither is bound by the matrix core: they wait
-  // for HBM and for their own stores.  The structured kernel stays as the reference of the folded sweep (riccati_fold8.h) and in the tests.
-  int struct_project_choice = -1;                          // BPMPC_STRUCT_PROJECT=1: the structured kernel; default / 0: the dense one
-  template <int NJ> bool use_struct_project() const { return structured_project && struct_project_choice == 1; }
-  bool fold_projection = false;
-  bool explicit_stage = false;                             // inside bpmpc_solver_stage
-  template <int NJ> bool folds_projection() const;
-  template <int NJ> void stage_linesearch();
-  template <int NJ> void pipelined_backward();
-  template <int NJ> void run_iterations();
+  void stage_prepare();
+  void stage_linearize();
+  void stage_project();
+  void stage_riccati();
+  void launch_project(hipStream_t on, const Launch& L, int nodes);
+  void launch_riccati(const Launch& L);
+  void stage_linesearch();
+  void pipelined_backward();
+  void run_iterations();
+  int nj() const { return rm.nj; }
 };
 
-#define TIMED_LAUNCH_ON(on, cls, kernel, grid, block, L)                            \
+// One launch (or a short sequence of launches) bracketed by the events of its kernel class
+#define TIMED_ON(on, cls, ...)                                                      \
   do {                                                                              \
     hipEvent_t ev_a_, ev_b_;                                                        \
     time_begin(cls, &ev_a_, &ev_b_, on);                                            \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, on, L);                  \
+    __VA_ARGS__;                                                                    \
     time_end(cls, ev_a_, ev_b_, on);                                                \
     HIP_CHECK(hipGetLastError());                                                   \
   } while (0)
-#define TIMED_LAUNCH(cls, kernel, grid, block, L) TIMED_LAUNCH_ON(stream, cls, kernel, grid, block, L)
+#define TIMED(cls, ...) TIMED_ON(stream, cls, __VA_ARGS__)
 
-template <int NJ> void bpmpc_solver::stage_prepare() {
+void bpmpc_solver::stage_prepare() {
   const Launch L = launch_params();
-  TIMED_LAUNCH("prepare", k_prepare<NJ>, batch * settings.max_nodes, kWave, L);
+  TIMED("prepare", kl::prepare(nj(), batch * settings.max_nodes, stream, L));
 }
-template <int NJ> void bpmpc_solver::stage_linearize() {
+void bpmpc_solver::stage_linearize() {
   const Launch L = launch_params();
-  if (settings.reference_kernels) {
-    TIMED_LAUNCH("linearize", k_linearize<NJ>, batch * settings.max_nodes, kWave, L);
-  } else {
-    constexpr int NPW = LinFastCfg<NJ, true>::NPW, kLinWaves = lin_waves<NJ>();
-    const int grid = (batch * L.klen + kLinWaves * NPW - 1) / (kLinWaves * NPW);
-    if (settings.materialize_lq) TIMED_LAUNCH("linearize", (k_linearize_fast<NJ, true>), grid, kLinWaves * kWave, L);
-    else TIMED_LAUNCH("linearize", (k_linearize_fast<NJ, false>), grid, kLinWaves * kWave, L);
-  }
+  if (settings.reference_kernels) TIMED("linearize", kl::linearize_reference(nj(), batch * settings.max_nodes, stream, L));
+  else TIMED("linearize", kl::linearize_fast(nj(), settings.materialize_lq != 0, batch * L.klen, stream, L));
 }
-template <int NJ> void bpmpc_solver::stage_project() {
+// constraint elimination + change of variables of `nodes` node slots (the fast kernels)
+void bpmpc_solver::launch_project(hipStream_t on, const Launch& L, int nodes) {
+  // packed joint rows of [Px | Pe | Pu] when the input weight allows the change of variables to generate the force rows; Px, Pu, Pe for the
+  // general one (which packs the joint rows for the sweeps' loaders itself)
+  TIMED_ON(on, "project_lu", kl::project_lu_s(nj(), max_vel_rows, structured_project, nodes, on, L));
+  TIMED_ON(on, "project", kl::project_fast(nj(), structured_project, nodes, on, L));
+}
+void bpmpc_solver::stage_project() {
   const Launch L = launch_params();
-  if (settings.reference_kernels) TIMED_LAUNCH("project", k_project<NJ>, batch * settings.max_nodes, kWave, L);
-  else {
-    const int lu_grid = (batch * L.klen + kLuNodes - 1) / kLuNodes;
-    if (BPMPC_STRUCTURED_LU) {
-      // packed joint rows of [Px | Pe | Pu] when the structured change of variables follows; Px, Pu, Pe for the dense one (which packs them itself)
-      if (structured_project) {
-        if (max_vel_rows <= 8) TIMED_LAUNCH("project_lu", (k_project_lu_s<NJ, 8, true>), lu_grid, kWave, L);
-        else TIMED_LAUNCH("project_lu", (k_project_lu_s<NJ, 12, true>), lu_grid, kWave, L);
-      } else {
-        if (max_vel_rows <= 8) TIMED_LAUNCH("project_lu", (k_project_lu_s<NJ, 8, false>), lu_grid, kWave, L);
-        else TIMED_LAUNCH("project_lu", (k_project_lu_s<NJ, 12, false>), lu_grid, kWave, L);
-      }
-    } else
-    if (max_rows <= 12) TIMED_LAUNCH("project_lu", (k_project_lu<NJ, 12>), lu_grid, kWave, L);
-    else if (max_rows <= 14) TIMED_LAUNCH("project_lu", (k_project_lu<NJ, 14>), lu_grid, kWave, L);
-    else TIMED_LAUNCH("project_lu", (k_project_lu<NJ, 16>), lu_grid, kWave, L);
-    if (folds_projection<NJ>() && !explicit_stage) return;      // the sweep projects the nodes itself (riccati_fold8.h); an explicit
-                                                                // bpmpc_solver_stage("project") still materialises the packed model (tests)
-    if (use_struct_project<NJ>()) TIMED_LAUNCH("project", k_project_struct<NJ>, batch * L.klen, kWave, L);
-    else if (structured_project) TIMED_LAUNCH("project", (k_project_fast<NJ, true>), batch * L.klen, kWave, L);
-    else TIMED_LAUNCH("project", (k_project_fast<NJ, false>), batch * L.klen, kWave, L);
-  }
+  if (settings.reference_kernels) TIMED("project", kl::project_reference(nj(), batch * settings.max_nodes, stream, L));
+  else launch_project(stream, L, batch * L.klen);
 }
-template <int NJ> bool bpmpc_solver::folds_projection() const {
-  return riccati_fold8_fits<NJ>() && fold_projection && structured_project && !settings.reference_kernels && riccati_double_buffered() && BPMPC_RICCATI_WAVES8 &&
-         settings.pipeline_chunks <= 1;
-}
-template <int NJ> void bpmpc_solver::stage_riccati() {
-  const Launch L = launch_params();
-  if (settings.reference_kernels) TIMED_LAUNCH("riccati", k_riccati<NJ>, batch, kRiccatiThreads, L);
-  else if (riccati_double_buffered() && BPMPC_RICCATI_WAVES8) launch_riccati8<NJ>(L);
-  else if (riccati_double_buffered()) TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, true>), batch, kRiccatiThreads, L);
-  else launch_riccati_big<NJ>(L);
-}
-template <int NJ> void bpmpc_solver::launch_riccati_big(const Launch& L) {
+void bpmpc_solver::launch_riccati(const Launch& L) {
+  if (riccati_double_buffered()) { TIMED("riccati", kl::riccati_fast8(nj(), batch, stream, L)); return; }
   // up to two problems per CU the four-wave workgroups finish in one round (0.61 against 0.91 ms at batch 512); beyond that a wave per
   // problem, four per CU, wins (G1 / 1024: 1.30 against 1.54 ms; 4096: 4.07 against 4.53 ms)
-  // BPMPC_RICCATI_WAVE: 0 never; 1 (default) a wave per problem beyond two problems per CU, riccati_wave.h or riccati_wave2.h by batch size;
-  // 2 riccati_wave.h at every batch size, 4 riccati_wave2.h at every batch size (tests); 3 riccati_wave2.h whenever a wave per problem is used
-  const bool wave_regime = regime_batch() > 2 * num_cus;
-  if (!(riccati_wave == 2 || riccati_wave == 4 || riccati_wave == 5 || ((riccati_wave == 1 || riccati_wave == 3) && wave_regime))) {
-    TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, false>), batch, kRiccatiThreads, L);
+  const bool wave_regime = batch > 2 * num_cus;
+  if (!(riccati_wave == 2 || riccati_wave == 4 || ((riccati_wave == 1 || riccati_wave == 3) && wave_regime))) {
+    TIMED("riccati", kl::riccati_fast(nj(), false, batch, stream, L));
     return;
   }
-  hipEvent_t ev_a, ev_b;
-  time_begin("riccati", &ev_a, &ev_b);
   // two waves per SIMD (riccati_wave2.h) need eight problems per CU to fill the chip - the dispatcher packs a CU before it opens the next
   // one, 1024 problems would occupy half of the CUs - and win from the first batch that takes riccati_wave.h a second round: beyond four
   // problems per CU (batch 1024: 0.98 against 1.27 ms; 4096: 3.75 against 3.22 ms)
-  const bool two_per_simd = riccati_wave >= 3 || (riccati_wave == 1 && regime_batch() > 4 * num_cus);
-  if (riccati_wave == 5) hipLaunchKernelGGL(k_riccati_pair<NJ>, dim3(batch), dim3(kRiccatiPairThreads), 0, stream, L);      // 5: riccati_pair.h at every batch size
-  else if (two_per_simd) hipLaunchKernelGGL(k_riccati_wave2<NJ>, dim3(batch), dim3(kWave), 0, stream, L);
-  else hipLaunchKernelGGL(k_riccati_wave<NJ>, dim3(batch), dim3(kWave), 0, stream, L);
-#if BPMPC_ROLLOUT_PAIR
-  if (L.k0 == 0) hipLaunchKernelGGL(k_riccati_rollout_pair<NJ>, dim3(batch), dim3(kRolloutPairThreads), 0, stream, L);
-#else
-  if (L.k0 == 0) hipLaunchKernelGGL(k_riccati_rollout<NJ>, dim3(batch), dim3(kRiccatiThreads), 0, stream, L);
-#endif
-  time_end("riccati", ev_a, ev_b);
-  HIP_CHECK(hipGetLastError());
+  const bool two_per_simd = riccati_wave >= 3 || (riccati_wave == 1 && batch > 4 * num_cus);
+  TIMED("riccati", { kl::riccati_wave(nj(), two_per_simd, batch, stream, L); if (L.k0 == 0) kl::riccati_rollout(nj(), batch, stream, L); });
 }
-template <int NJ> void bpmpc_solver::launch_riccati8(const Launch& L) {
-  if constexpr (riccati_fold8_fits<NJ>()) {
-    if (folds_projection<NJ>()) { TIMED_LAUNCH("riccati", k_riccati_fold8<NJ>, batch, kRiccati8Threads, L); return; }
-  }
-  if constexpr (riccati_dma8_fits<NJ>()) TIMED_LAUNCH("riccati", k_riccati_dma8<NJ>, batch, kRiccati8Threads, L);
-  else TIMED_LAUNCH("riccati", k_riccati_fast8<NJ>, batch, kRiccati8Threads, L);
+void bpmpc_solver::stage_riccati() {
+  const Launch L = launch_params();
+  if (settings.reference_kernels) TIMED("riccati", kl::riccati_reference(nj(), batch, stream, L));
+  else launch_riccati(L);
 }
-template <int NJ> void bpmpc_solver::stage_linesearch() {
+void bpmpc_solver::stage_linesearch() {
   const Launch L = launch_params();
   if (settings.reference_kernels) HIP_CHECK(hipMemsetAsync(buf.remaining, 0, sizeof(int), stream));   // only the host loop below reads the counter
   hipEvent_t ev_a, ev_b;
   time_begin("linesearch", &ev_a, &ev_b);
-  if (settings.reference_kernels) hipLaunchKernelGGL(k_ls_begin<NJ>, dim3(batch), dim3(kWave), 0, stream, L);   // fast path: done inside the Riccati kernel
+  if (settings.reference_kernels) kl::ls_begin(nj(), batch, stream, L);   // fast path: done inside the Riccati kernel
   // alpha = 1, 1/2, ... >= alpha_min  ([OCS2-upstream] SqpSolver::takeStep do-while)
   int max_trials = 0;
   for (double a = 1.0; a >= ls.alpha_min; a *= ls.alpha_decay) ++max_trials;
   if (!settings.reference_kernels) {
     // first round for everybody, later rounds per problem on the device (k_ls_tail): no read-back inside a solve
-    constexpr int NPW = LinFastCfg<NJ, true>::NPW;
-    const int trial_grid = (batch * L.klen + kTrialWaves * NPW - 1) / (kTrialWaves * NPW);
-    if (NJ <= 10 && (long long)trial_grid * regime_batch() / batch > (long long)trial_wide_from * num_cus) hipLaunchKernelGGL((k_trial_fast<NJ, true>), dim3(trial_grid), dim3(kTrialWaves * kWave), 0, stream, L);   // > 4 rounds of 4 per CU
-    else hipLaunchKernelGGL((k_trial_fast<NJ, false>), dim3(trial_grid), dim3(kTrialWaves * kWave), 0, stream, L);
-    hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L);
-    hipLaunchKernelGGL(k_ls_tail<NJ>, dim3(batch), dim3(kTailThreads), 0, stream, L, max_trials);
+    const int nodes = batch * L.klen;
+    const bool wide = (long long)kl::trial_fast_workgroups(nj(), nodes) > (long long)trial_wide_from * num_cus;   // > 4 rounds of 4 per CU (nx = 22 only)
+    kl::trial_fast(nj(), wide, nodes, stream, L);
+    kl::ls_decide(nj(), batch, stream, L);
+    kl::ls_tail(nj(), batch, stream, L, max_trials);
     HIP_CHECK(hipGetLastError());
     time_end("linesearch", ev_a, ev_b);
     return;
   }
   for (int t = 0; t < max_trials; ++t) {
-    hipLaunchKernelGGL(k_trial<NJ>, dim3(batch * settings.max_nodes), dim3(kWave), 0, stream, L);
-    hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, stream, L);
+    kl::trial_reference(nj(), batch * settings.max_nodes, stream, L);
+    kl::ls_decide(nj(), batch, stream, L);
     HIP_CHECK(hipGetLastError());
     // one 4-byte read-back per trial round: stop as soon as every problem has accepted (or given up)
     HIP_CHECK(hipMemcpyAsync(h_remaining, buf.remaining, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1090,8 +281,7 @@ template <int NJ> void bpmpc_solver::stage_linesearch() {
 // Linearisation, projection and Riccati sweep of one SQP iteration with the horizon cut into chunks: the producers
 // (linearise, LU, change of variables) of chunk c+1 run on their own stream while the latency-bound Riccati sweep of
 // chunk c occupies one workgroup per problem.  Only stream/event ordering is used, no device-side waiting.
-template <int NJ> void bpmpc_solver::pipelined_backward() {
-  constexpr int NPW = LinFastCfg<NJ, true>::NPW, kLinWaves = lin_waves<NJ>();
+void bpmpc_solver::pipelined_backward() {
   const int chunks = settings.pipeline_chunks;
   const int n = n_nodes_max;
   HIP_CHECK(hipEventRecord(ev_go, stream));
@@ -1104,83 +294,30 @@ template <int NJ> void bpmpc_solver::pipelined_backward() {
     L.k0 = lo;
     L.klen = hi - lo;
     const int nodes = batch * L.klen;
-    if (settings.materialize_lq) TIMED_LAUNCH_ON(producer_stream, "linearize", (k_linearize_fast<NJ, true>), (nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW), kLinWaves * kWave, L);
-    else TIMED_LAUNCH_ON(producer_stream, "linearize", (k_linearize_fast<NJ, false>), (nodes + kLinWaves * NPW - 1) / (kLinWaves * NPW), kLinWaves * kWave, L);
-    if (BPMPC_STRUCTURED_LU) {
-      if (structured_project) {
-        if (max_vel_rows <= 8) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu_s<NJ, 8, true>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
-        else TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu_s<NJ, 12, true>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
-      } else {
-        if (max_vel_rows <= 8) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu_s<NJ, 8, false>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
-        else TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu_s<NJ, 12, false>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
-      }
-    } else
-    if (max_rows <= 12) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 12>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
-    else if (max_rows <= 14) TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 14>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
-    else TIMED_LAUNCH_ON(producer_stream, "project_lu", (k_project_lu<NJ, 16>), (nodes + kLuNodes - 1) / kLuNodes, kWave, L);
-    if (use_struct_project<NJ>()) TIMED_LAUNCH_ON(producer_stream, "project", k_project_struct<NJ>, nodes, kWave, L);
-    else if (structured_project) TIMED_LAUNCH_ON(producer_stream, "project", (k_project_fast<NJ, true>), nodes, kWave, L);
-    else TIMED_LAUNCH_ON(producer_stream, "project", (k_project_fast<NJ, false>), nodes, kWave, L);
+    TIMED_ON(producer_stream, "linearize", kl::linearize_fast(nj(), settings.materialize_lq != 0, nodes, producer_stream, L));
+    launch_project(producer_stream, L, nodes);
     HIP_CHECK(hipEventRecord(ev_chunk[c], producer_stream));
     HIP_CHECK(hipStreamWaitEvent(stream, ev_chunk[c], 0));
     if (c == 0) { L.klen = settings.max_nodes - lo; }   // problems on longer grids than n_nodes_max do not exist; keep k_hi >= N
-    if (riccati_double_buffered() && BPMPC_RICCATI_WAVES8) launch_riccati8<NJ>(L);
-    else if (riccati_double_buffered()) TIMED_LAUNCH("riccati", (k_riccati_fast<NJ, true>), batch, kRiccatiThreads, L);
-    else launch_riccati_big<NJ>(L);
+    launch_riccati(L);
   }
 }
 
-template <int NJ> void bpmpc_solver::run_iterations() {
+void bpmpc_solver::run_iterations() {
+  if (rm.nj != 10 && rm.nj != 12) throw std::runtime_error("unsupported joint count");
   const int iters = ls.max_iterations;
-  // parts of at least 32 problems, boundaries on multiples of 16; the reference kernels, the horizon pipeline and an explicit stage keep one part
-  const int parts = (settings.reference_kernels || settings.pipeline_chunks > 1) ? 1 : std::min(batch_parts, batch / 32);
-  if (parts > 1) {
-    const int whole = batch;
-    hipStream_t const main_stream = stream;
-    HIP_CHECK(hipEventRecord(ev_go, main_stream));
-    struct Restore { bpmpc_solver* s; int batch; hipStream_t stream; ~Restore() { s->batch = batch; s->stream = stream; s->part_b0 = 0; s->split_whole = 0; } } restore{this, whole, main_stream};
-    split_whole = whole;
-    for (int p = 0; p < parts; ++p) HIP_CHECK(hipStreamWaitEvent(part_streams[p], ev_go, 0));
-    for (int it = 0; it < iters; ++it) {
-      for (int p = 0; p < parts; ++p) {
-        const int lo = (int)((long long)whole * p / parts) & ~15, hi = p + 1 == parts ? whole : (int)((long long)whole * (p + 1) / parts) & ~15;
-        part_b0 = lo; batch = hi - lo; stream = part_streams[p];
-        // skew: a part starts linearising when the part before it has its projected model - its streaming kernels then run under that
-        // part's latency-bound sweep instead of beside the same kernels of the other parts
-        if (batch_skew && p > 0) HIP_CHECK(hipStreamWaitEvent(stream, ev_skew[p - 1], 0));
-        stage_linearize<NJ>();
-        stage_project<NJ>();
-        if (batch_skew && p + 1 < parts) HIP_CHECK(hipEventRecord(ev_skew[p], stream));
-        stage_riccati<NJ>();
-        stage_linesearch<NJ>();
-      }
-    }
-    for (int p = 0; p < parts; ++p) {
-      HIP_CHECK(hipEventRecord(ev_part[p], part_streams[p]));
-      HIP_CHECK(hipStreamWaitEvent(main_stream, ev_part[p], 0));
-    }
-    has_solution = true;
-    return;
-  }
   for (int it = 0; it < iters; ++it) {
     if (!settings.reference_kernels && settings.pipeline_chunks > 1) {
-      pipelined_backward<NJ>();
+      pipelined_backward();
     } else {
-      stage_linearize<NJ>();
-      stage_project<NJ>();
-      stage_riccati<NJ>();
+      stage_linearize();
+      stage_project();
+      stage_riccati();
     }
-    stage_linesearch<NJ>();
+    stage_linesearch();
   }
   has_solution = true;
 }
-
-#define DISPATCH_NJ(self, call)                                        \
-  do {                                                                 \
-    if ((self)->rm.nj == 10) (self)->template call<10>();              \
-    else if ((self)->rm.nj == 12) (self)->template call<12>();         \
-    else throw std::runtime_error("unsupported joint count");          \
-  } while (0)
 
 namespace {
 
@@ -1267,8 +404,7 @@ void upload_pinned(bpmpc_solver* s, T* dst, const std::vector<T>& src) { upload_
 void copy_pairs(bpmpc_solver* s, const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb, bool rearm) {
   const size_t work = (na > nb ? na : nb) / 2;
   const int grid = (int)std::min<size_t>((work + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_copy_pairs, dim3(grid > 0 ? grid : 1), dim3(256), 0, s->stream, a_src, a_dst, na, b_src, b_dst, nb,
-                     rearm ? s->buf.iterations : nullptr, s->buf.active, s->batch);
+  kl::copy_pairs(grid, s->stream, a_src, a_dst, na, b_src, b_dst, nb, rearm ? s->buf.iterations : nullptr, s->buf.active, s->batch);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1298,11 +434,10 @@ void finish_setup(bpmpc_solver* s, int batch, const double* warm_x, const double
     HIP_CHECK(hipMemcpyAsync(bf.x, warm_x, (size_t)batch * (N + 1) * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_CHECK(hipMemcpyAsync(bf.u, warm_u, (size_t)batch * N * NU * sizeof(double), hipMemcpyHostToDevice, s->stream));
   }
-  DISPATCH_NJ(s, stage_prepare);
+  s->stage_prepare();
   if (from_previous) {
     const Launch L = s->launch_params();
-    if (s->rm.nj == 10) hipLaunchKernelGGL(k_warm_shift<10>, dim3(batch * L.N), dim3(kWave), 0, s->stream, L);
-    else hipLaunchKernelGGL(k_warm_shift<12>, dim3(batch * L.N), dim3(kWave), 0, s->stream, L);
+    kl::warm_shift(s->rm.nj, batch * L.N, s->stream, L);
     HIP_CHECK(hipGetLastError());
   }
   copy_pairs(s, bf.x, bf.x_init, (size_t)batch * (N + 1) * NX, bf.u, bf.u_init, (size_t)batch * N * NU, true);
@@ -1563,8 +698,7 @@ void rollout(bpmpc_solver* s, const double* t_start, const double* x_start, doub
   a.duration = duration; a.abs_tol = s->rm.rollout.abs_tol; a.rel_tol = s->rm.rollout.rel_tol; a.time_step = s->rm.rollout.time_step;
   a.max_steps = (int)(s->rm.rollout.max_steps_per_second * std::max(1.0, duration));
   a.x_end = bf.roll_x; a.u_end = bf.roll_u; a.steps = bf.roll_steps; a.status = bf.roll_status;
-  if (s->rm.nj == 10) hipLaunchKernelGGL(k_rollout<10>, dim3((B + LinFastCfg<10>::NPW - 1) / LinFastCfg<10>::NPW), dim3(kWave), 0, s->stream, s->d_model, a);
-  else hipLaunchKernelGGL(k_rollout<12>, dim3((B + LinFastCfg<12>::NPW - 1) / LinFastCfg<12>::NPW), dim3(kWave), 0, s->stream, s->d_model, a);
+  kl::rollout(s->rm.nj, B, s->stream, s->d_model, a);
   HIP_CHECK(hipGetLastError());
   s->has_rollout = true;
   if (!x_end && !u_end && !steps) {                 // nothing to hand back: stay asynchronous; the status is looked at by the next
@@ -1646,29 +780,13 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     HIP_CHECK(hipSetDevice(settings->device));
     { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, settings->device)); s->num_cus = prop.multiProcessorCount; }
     { const char* e = std::getenv("BPMPC_TRIAL_WIDE_FROM"); if (e) s->trial_wide_from = std::max(0, std::atoi(e)); }
-    { const char* e = std::getenv("BPMPC_RICCATI8_ALWAYS"); s->riccati8_always = e && e[0] == '1'; }
-    { const char* e = std::getenv("BPMPC_RICCATI_WAVE"); s->riccati_wave = e ? std::atoi(e) : BPMPC_RICCATI_WAVE_DEFAULT; }
+    { const char* e = std::getenv("BPMPC_RICCATI_WAVE"); s->riccati_wave = e ? std::atoi(e) : 1; }
     {
       bool block_diagonal = true;
       for (int c = 0; c < 12; ++c)
         for (int j = 12; j < s->nu; ++j) block_diagonal = block_diagonal && s->dm.R[c * s->nu + j] == 0.0 && s->dm.R[j * s->nu + c] == 0.0;
       const char* e = std::getenv("BPMPC_DENSE_PROJECT");
-      s->structured_project = BPMPC_STRUCTURED_PROJECT && BPMPC_STRUCTURED_LU && block_diagonal && !(e && e[0] == '1');
-      // the folded sweep additionally assumes a diagonal state weight and a force block of R that is block diagonal per contact (what
-      // task.info holds for every shipped robot); other weights run the unfused path
-      bool simple_weights = true;
-      for (int i = 0; i < s->nx; ++i)
-        for (int j = 0; j < s->nx; ++j) simple_weights = simple_weights && (i == j || s->dm.Q[i * s->nx + j] == 0.0);
-      for (int c = 0; c < 12; ++c)
-        for (int c2 = 0; c2 < 12; ++c2) simple_weights = simple_weights && (c / 3 == c2 / 3 || s->dm.R[c * s->nu + c2] == 0.0);
-      // MEASURED, NOT THE DEFAULT (round 3): correct (same parity tests) but slower at batch 256 - 0.684 ms against 0.344 + 0.185 ms of
-      // sweep + projection kernel.  The two projector waves need ~2.0 / 5.0 / 4.9 k cycles of own work in the phases P1 / P2 / P3 of a
-      // stage (tools/fold_phase_profile.py) where the chain leaves them 1.3 / 0.95 / 2.3 k: a lone wave beside a busy chain wave issues
-      // an instruction every 10-20 cycles and nothing hides its LDS round trips, and the kernel is at the register limit (256 VGPRs,
-      // 124 B of scratch).  Opt in with BPMPC_FOLD=1 (tests/test_gpu_parity.py keeps the path honest).
-      { const char* sp = std::getenv("BPMPC_STRUCT_PROJECT"); s->struct_project_choice = (sp && sp[0] == '1') ? 1 : ((sp && sp[0] == '0') ? 0 : -1); }
-      const char* f = std::getenv("BPMPC_FOLD");
-      s->fold_projection = BPMPC_FOLD_PROJECTION && simple_weights && (f && f[0] == '1');
+      s->structured_project = block_diagonal && !(e && e[0] == '1');
     }
     if (settings->stream) { s->stream = static_cast<hipStream_t>(settings->stream); }
     else { HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
@@ -1677,14 +795,6 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     HIP_CHECK(hipStreamCreateWithFlags(&s->producer_stream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_go, hipEventDisableTiming));
     s->ev_chunk.resize(s->settings.pipeline_chunks);
-    { const char* bp = std::getenv("BPMPC_BATCH_PARTS"); s->batch_parts = bp ? std::max(1, std::min(16, std::atoi(bp))) : 1; }
-    s->part_streams.resize(s->batch_parts > 1 ? s->batch_parts : 0);
-    for (auto& st : s->part_streams) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    s->ev_part.resize(s->part_streams.size());
-    for (auto& e : s->ev_part) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    s->ev_skew.resize(s->part_streams.size());
-    for (auto& e : s->ev_skew) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    { const char* sk = std::getenv("BPMPC_BATCH_SKEW"); s->batch_skew = sk && sk[0] == '1'; }
     for (auto& e : s->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s->d_model), sizeof(DeviceModel)));
     HIP_CHECK(hipMemcpy(s->d_model, &s->dm, sizeof(DeviceModel), hipMemcpyHostToDevice));
@@ -1710,9 +820,6 @@ void bpmpc_solver_destroy(bpmpc_solver* s) {
   if (s->producer_stream) { (void)hipStreamSynchronize(s->producer_stream); (void)hipStreamDestroy(s->producer_stream); }
   if (s->ev_go) (void)hipEventDestroy(s->ev_go);
   for (hipEvent_t e : s->ev_chunk) if (e) (void)hipEventDestroy(e);
-  for (hipStream_t st : s->part_streams) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-  for (hipEvent_t e : s->ev_part) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : s->ev_skew) if (e) (void)hipEventDestroy(e);
   for (void* p : s->allocations) (void)hipFree(p);
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->h_remaining) (void)hipHostFree(s->h_remaining);
@@ -1742,7 +849,7 @@ int bpmpc_solver_setup_from_previous(bpmpc_solver* s, int batch, double horizon,
 }
 int bpmpc_solver_reset(bpmpc_solver* s) { API_GUARD(s, reset(s)) }
 int bpmpc_solver_run(bpmpc_solver* s) {
-  API_GUARD(s, { if (s->batch < 1) throw std::invalid_argument("bpmpc_solver_run before bpmpc_solver_setup"); DISPATCH_NJ(s, run_iterations); })
+  API_GUARD(s, { if (s->batch < 1) throw std::invalid_argument("bpmpc_solver_run before bpmpc_solver_setup"); s->run_iterations(); })
 }
 int bpmpc_solver_sync(bpmpc_solver* s) { API_GUARD(s, { HIP_CHECK(hipStreamSynchronize(s->stream)); s->collect_timers(); }) }
 int bpmpc_solver_fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double* out_K, bpmpc_stats* stats) {
@@ -1771,7 +878,7 @@ int bpmpc_solve_batch(bpmpc_solver* s, int batch, double horizon, const double* 
                       double* out_u, double* out_K, bpmpc_stats* stats) {
   API_GUARD(s, {
     setup(s, batch, horizon, t0, x0, schedules, n_schedules, targets, warm_x, warm_u);
-    DISPATCH_NJ(s, run_iterations);
+    s->run_iterations();
     fetch(s, out_t, out_x, out_u, out_K, stats);
     s->collect_timers();
   })
@@ -1782,10 +889,10 @@ int bpmpc_solver_stage(bpmpc_solver* s, const char* stage) {
     const std::string n(stage);
     // an explicit stage request always applies to every problem of the batch
     HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)s->buf.active, 1, s->batch, s->stream));
-    if (n == "linearize") DISPATCH_NJ(s, stage_linearize);
-    else if (n == "project") { s->explicit_stage = true; try { DISPATCH_NJ(s, stage_project); } catch (...) { s->explicit_stage = false; throw; } s->explicit_stage = false; }
-    else if (n == "riccati") DISPATCH_NJ(s, stage_riccati);
-    else if (n == "linesearch") DISPATCH_NJ(s, stage_linesearch);
+    if (n == "linearize") s->stage_linearize();
+    else if (n == "project") s->stage_project();
+    else if (n == "riccati") s->stage_riccati();
+    else if (n == "linesearch") s->stage_linesearch();
     else throw std::invalid_argument("unknown stage " + n);
   })
 }
@@ -1856,13 +963,7 @@ int bpmpc_solver_constraint_values(bpmpc_solver* s, double* values, int* rows, i
     try {
       HIP_CHECK(hipMemsetAsync(d_eqv, 0, S * kMaxEqRows * sizeof(double), s->stream));
       const Launch L = s->launch_params();
-      if (s->rm.nj == 10) {
-        constexpr int NPW = LinFastCfg<10, true>::NPW;
-        hipLaunchKernelGGL(k_constraint_values<10>, dim3((s->batch * L.klen + kTrialWaves * NPW - 1) / (kTrialWaves * NPW)), dim3(kTrialWaves * kWave), 0, s->stream, L, d_eqv);
-      } else {
-        constexpr int NPW = LinFastCfg<12, true>::NPW;
-        hipLaunchKernelGGL(k_constraint_values<12>, dim3((s->batch * L.klen + kTrialWaves * NPW - 1) / (kTrialWaves * NPW)), dim3(kTrialWaves * kWave), 0, s->stream, L, d_eqv);
-      }
+      kl::constraint_values(s->rm.nj, s->batch * L.klen, s->stream, L, d_eqv);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipMemcpyAsync(values, d_eqv, S * kMaxEqRows * sizeof(double), hipMemcpyDeviceToHost, s->stream));
       HIP_CHECK(hipStreamSynchronize(s->stream));

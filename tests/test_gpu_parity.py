@@ -396,8 +396,8 @@ def test_reg_prim_setting_matches_oracle(ctx):
 @pytest.mark.parametrize("robot,gait", [("h1", "trot"), ("h1", "standing_trot"), ("h1", "flying_trot"), ("hunter", "trot"), ("g1", "standing_trot"),
                                          ("openloong", "flying_trot")])
 def test_structured_and_dense_change_of_variables_agree(ctx, robot, gait, monkeypatch):
-    """project_struct.h (inner dimension = joint rows only, force rows assembled: 42 matrix-core instructions per node) against
-    project_mfma.h (dense, 120): the packed projected model Wt = [At | bt | Bt], Qp = [Qt | qt], Mt = [Pt | rt | Rt] of every node, in
+    """The change of variables behind the structured elimination (packed joint rows Vt, force rows generated in registers) against the
+    same kernel behind the general elimination outputs (Px, Pu, Pe written in full, BPMPC_DENSE_PROJECT=1): the packed projected model Wt = [At | bt | Bt], Qp = [Qt | qt], Mt = [Pt | rt | Rt] of every node, in
     the region the sweep reads (block columns < nbc, rows < nut of Mt), on all four contact modes, after one accepted step."""
     bp, sc = ctx["bp"], ctx["sc"]
     itf = sc.interface(robot)
@@ -406,15 +406,9 @@ def test_structured_and_dense_change_of_variables_agree(ctx, robot, gait, monkey
     B, N = 3, 64
     prob = sc.trot_problem(itf, batch=B, n_intervals=45, gait=gait)
     got = {}
-    # "1": FullPivLU-format elimination outputs (Px, Pu, Pe) + dense kernel;  "0": structured elimination (packed joint rows) + the kernel the
-    # solver picks for the regime (nx = 22 at this batch: project_struct.h; nx = 24: project_mfma.h reading the packed rows);
-    # "s": the structured kernel forced (covers it on nx = 24 as well)
-    for dense in ("0", "1", "s"):
-        monkeypatch.setenv("BPMPC_DENSE_PROJECT", "1" if dense == "1" else "0")
-        if dense == "s":
-            monkeypatch.setenv("BPMPC_STRUCT_PROJECT", "1")
-        else:
-            monkeypatch.delenv("BPMPC_STRUCT_PROJECT", raising=False)
+    # "1": elimination outputs Px, Pu, Pe in full + k_project_fast<.., false>;  "0" (default): packed joint rows + k_project_fast<.., true>
+    for dense in ("0", "1"):
+        monkeypatch.setenv("BPMPC_DENSE_PROJECT", dense)
         mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=N)
         lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
         mpc.enqueue(); mpc.synchronize()                                  # away from the cold start
@@ -430,7 +424,7 @@ def test_structured_and_dense_change_of_variables_agree(ctx, robot, gait, monkey
     Q = {d: got[d]["Qp"].reshape(B, N, nx, 32)[:, :n] for d in got}
     M = {d: got[d]["Mt"].reshape(B, N, nx, wp)[:, :n] for d in got}
     worst = 0.0
-    for other in ("0", "s"):
+    for other in ("0",):
         for b in range(B):
             for k in range(n):
                 nt = nut[b, k]
@@ -443,29 +437,8 @@ def test_structured_and_dense_change_of_variables_agree(ctx, robot, gait, monkey
     assert worst < 1e-12, worst
 
 
-@pytest.mark.parametrize("gait", ["trot", "standing_trot", "flying_trot"])
-def test_folded_change_of_variables_matches_the_kernel_pipeline(ctx, gait, monkeypatch):
-    """riccati_fold8.h (experimental, BPMPC_FOLD=1): the sweep's own workgroup computes the projected model of every node in LDS instead
-    of reading it from HBM.  Same solves as the default pipeline (elimination kernel -> change-of-variables kernel -> sweep) to rounding,
-    and against the oracle at the tolerance of the other solve tests; all contact modes incl. double stance (three block columns)."""
-    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
-    prob = sc.trot_problem(itf, batch=5, n_intervals=45, gait=gait)
-    out = {}
-    for fold in ("0", "1"):
-        monkeypatch.setenv("BPMPC_FOLD", fold)
-        mpc = bp.BatchedSqpMpc(itf, max_batch=5, max_nodes=72, sqp_iterations=2, return_gains=True)
-        out[fold] = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
-    (t, x, u, K, st), (_, x1, u1, K1, st1) = out["0"], out["1"]
-    n = st[0].n_nodes
-    assert [s.step_size for s in st] == [s.step_size for s in st1]
-    assert rel_x(x1[:, :n + 1], x[:, :n + 1]) < 1e-11 and rel_u(u1[:, :n], u[:, :n]) < 1e-11 and rel_K(K1[:, :n], K[:, :n]) < 1e-10
-    for b in (0, 4):
-        xo, uo, Ko, _ = ob.oracle_solve_like(prob, b, iterations=2)
-        assert rel_x(x1[b, :n + 1], xo) < 1e-11 and rel_u(u1[b, :n], uo) < 1e-11 and rel_K(K1[b, :n], Ko) < 1e-10
-
-
 @pytest.mark.parametrize("robot,gait", [("h1", "trot"), ("h1", "standing_trot"), ("h1", "flying_trot"), ("g1", "standing_trot"), ("hunter", "trot")])
-@pytest.mark.parametrize("variant", ["2", "4", "5"])
+@pytest.mark.parametrize("variant", ["2", "4"])
 def test_wave_per_problem_sweep_matches_the_workgroup_sweep(ctx, robot, gait, variant, monkeypatch):
     """riccati_wave.h (one wavefront owns a problem: batches larger than the chip) against the workgroup-per-problem sweep of the same
     solver, same solves to rounding (the wave kernel reads S transposed instead of symmetrising it), and against the oracle at the
@@ -474,7 +447,7 @@ def test_wave_per_problem_sweep_matches_the_workgroup_sweep(ctx, robot, gait, va
     itf = sc.interface(robot)
     prob = sc.trot_problem(itf, batch=5, n_intervals=45, gait=gait)
     out = {}
-    for wave in ("0", variant):              # "2": riccati_wave.h (one wave per SIMD), "4": riccati_wave2.h (two), "5": riccati_pair.h (two waves per problem) - forced at this small batch
+    for wave in ("0", variant):              # "2": riccati_wave.h (one wave per SIMD), "4": riccati_wave2.h (two) - forced at this small batch
         monkeypatch.setenv("BPMPC_RICCATI_WAVE", wave)
         mpc = bp.BatchedSqpMpc(itf, max_batch=5, max_nodes=72, sqp_iterations=2, return_gains=True)
         out[wave] = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
@@ -544,9 +517,9 @@ def test_batch_4096_full_size_matches_small_batches_and_oracle(ctx):
     assert rel_x(x[4095, :n + 1], xo) < 1e-11 and rel_u(u[4095, :n], uo) < 1e-11
 
 
-@pytest.mark.parametrize("variant", ["2", "4", "5"])
+@pytest.mark.parametrize("variant", ["2", "4"])
 def test_wave_sweeps_chunked_horizon_and_handle_reuse(ctx, variant, monkeypatch):
-    """The sweeps that give a problem one or two wavefronts of its own (riccati_wave.h "2", riccati_wave2.h "4", riccati_pair.h "5", forced at
+    """The sweeps that give a problem one or two wavefronts of its own (riccati_wave.h "2", riccati_wave2.h "4", forced at
     this small batch): (1) the chunked horizon pipeline hands [S | s] and the status from launch to launch through the carry record -
     every chunk count gives the same bits, also with grids of different lengths; (2) a handle that has seen wider reduced inputs at a node
     gives the same bits on a narrower problem as a fresh one (block columns and rows beyond nx + 1 + nut are neither loaded nor used)."""
@@ -571,7 +544,7 @@ def test_wave_sweeps_chunked_horizon_and_handle_reuse(ctx, variant, monkeypatch)
     assert np.array_equal(last[1], ref[1]) and np.array_equal(last[2], ref[2]) and np.array_equal(last[3], ref[3])
 
 
-@pytest.mark.parametrize("variant", ["0", "2", "4", "5"])
+@pytest.mark.parametrize("variant", ["0", "2", "4"])
 def test_indefinite_hessian_is_reported_by_every_sweep(ctx, variant, monkeypatch, tmp_path):
     """Fail loudly: with a NEGATIVE input weight the reduced Hessian of a stage has a non-positive pivot; every sweep kernel has to report
     the numerical failure (status 2, bpmpc.h) for the problem instead of returning numbers - the eight-wave sweep ("0" at this batch) and
@@ -590,26 +563,3 @@ def test_indefinite_hessian_is_reported_by_every_sweep(ctx, variant, monkeypatch
     assert all(s.status == 2 for s in st), [s.status for s in st]
 
 
-@pytest.mark.parametrize("parts,wave", [("2", None), ("3", None), ("3", "4")])
-def test_batch_split_over_streams_gives_the_same_bits(ctx, parts, wave, monkeypatch):
-    """BPMPC_BATCH_PARTS: the batch split into parts that run their SQP iterations on streams of their own (solver.hip run_iterations,
-    Launch::b0).  The problems are independent, so states, inputs, gains and step sizes are the bits of the unsplit solve - mixed gaits (grids of
-    different lengths), a batch that does not divide evenly (part boundaries fall on multiples of 16), two iterations, and the sweep with
-    two waves per SIMD forced."""
-    bp, sc, itf = ctx["bp"], ctx["sc"], ctx["itf"]
-    if wave:
-        monkeypatch.setenv("BPMPC_RICCATI_WAVE", wave)
-    gaits = ["stance", "trot", "standing_trot", "flying_trot"]
-    prob = sc.gait_sweep_problem(itf, gaits, [(0.3, 0.0), (-0.2, 0.3), (0.1, -0.1)] * 9, n_intervals=40)      # 4 x 27 = 108 problems
-    nb = prob["x0"].shape[0]
-    results = []
-    for p in ("1", parts):
-        monkeypatch.setenv("BPMPC_BATCH_PARTS", p)
-        mpc = bp.BatchedSqpMpc(itf, max_batch=nb, max_nodes=64, sqp_iterations=2, return_gains=True)
-        results.append(mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"]))
-        # a second solve on the same handle (warm handle state, streams re-joined)
-        results.append(mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"]))
-    ref = results[0]
-    for r in results[1:]:
-        assert np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3])
-        assert [s.step_size for s in r[4]] == [s.step_size for s in ref[4]]
