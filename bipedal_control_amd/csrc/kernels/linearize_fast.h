@@ -59,29 +59,46 @@ __device__ __forceinline__ void load_shared_model(const DeviceModel& md, LinFast
   for (int i = tid; i < C::NB * NJ; i += nthreads) sh.path[i / NJ][i % NJ] = md.path[i / NJ][i % NJ];
 }
 
-template <int NJ, bool FULL = true>   // FULL = false: value-only evaluation (line search trials), no parked columns
+// Per-node LDS tables.  FULL = false: value-only evaluation (line search trials, policy rollout): no derivative tables.
+// FULL = true (the lineariser): 2.6 KB per node at nx = 22, so that three four-wave workgroups (48 nodes) fit the 160 KB of a CU next to
+// their three copies of the model block.  Tables that are never alive together share storage; everything is accessed by one wavefront
+// in program order (lds_wave_sync between a write and a cross-lane read):
+//   tab:   chain rotations T (eval_lane, dead after the walks) -> per-body composites -> per-body momenta (both inside eval_lane)
+//          -> contact velocities (between the first evaluation and the constraint rows) -> ... second evaluation ... -> the stage-two
+//          block a2 -> after the rows of A and B the cost vectors dx, du
+//   swing references (read by the constraint rows, BEFORE the second evaluation) / stage-two momentum and base position xh2
+//   joint origins og and velocities wv (twist walk of an evaluation) / cone terms (cost phase, after both evaluations)
+// Node-level results that every lane of the node computes identically (flow-map rows 0..5, base velocity, Euler sines / cosines) are
+// parked here by one lane and read back where they are used instead of occupying registers of all lanes across the derivative phases.
+template <int NJ, bool FULL = true>
 struct LinFastNodeLds {
   using C = LinFastCfg<NJ>;
+  static constexpr bool kFull = FULL;
   // node inputs, staged once so that nothing is loaded from global memory after the first output store
-  double x[C::NX], u[C::NU], zref[FULL ? kNumContacts : 1], zdref[FULL ? kNumContacts : 1];   // value-only: swing references straight from HBM
-  double xh2[9];                 // normalised momentum and base position of the second RK2 stage (the first stage reads x[0..8])
-  // One storage for five tables that are never alive together (all within one wavefront, program order): the chain rotations (eval_lane,
-  // dead after the walks) -> per-body composites -> per-body momenta (both inside eval_lane) -> after both evaluations the second-stage
-  // block a2 -> after the rows of A and B the cost vectors.  864 bytes per node less than two unions: the value-only kernels fit four
-  // (nx = 22) / three (nx = 24) workgroups per CU instead of three / two.
+  double x[C::NX], u[C::NU];
+  union {
+    double xh2[9];               // normalised momentum and base position of the second RK2 stage (the first stage reads x[0..8])
+    struct { double zref[FULL ? kNumContacts : 1], zdref[FULL ? kNumContacts : 1]; };   // value-only: swing references straight from HBM
+  };
   union {
     double T[NJ][9];             // joint-local rotation E of joint g-6 (its fixed offset is a model constant: LinFastShared::pfix)
     double a2[FULL ? 9 : 1][12]; // rows 3..11, x columns 0..11 of the stage-two Jacobian
     double comp[C::NB][10];      // per body mass / first moment / inertia about o0
     double hb[C::NB][6];         // per body momentum about o0
+    double cvel_full[FULL ? kNumContacts : 1][3];   // contact point velocities of the first stage (FULL)
     struct { double dx[C::NX], du[C::NU]; };   // cost vectors (both evaluations are done by then)
   };
-  double og[C::G - 3][3];        // joint origins (coordinates 3..)
-  double wv[C::G - 3][3];        // a_g * v_g
-  double cpos[kNumContacts][3], cvel[kNumContacts][3];
-  double cone[FULL ? kNumContacts : 1][FULL ? 13 : 1];   // value-only: the barrier value stays in the lane that computes it
-  // node-level results of the two stages: A_b^{-1} blocks, 1/m, contact points and com
+  union {
+    struct { double og[C::G - 3][3], wv[C::G - 3][3]; };   // joint origins (coordinates 3..), a_g * v_g
+    double cone[FULL ? kNumContacts : 1][FULL ? 13 : 1];   // value-only: the barrier value stays in the lane that computes it
+  };
+  double cpos_v[FULL ? 1 : kNumContacts][3], cvel_v[FULL ? 1 : kNumContacts][3];     // value-only: contact points and velocities of the current evaluation
+  // node-level results of the two stages: A_b^{-1} blocks, contact points, com, flow-map rows 0..5, base linear velocity, Euler sin / cos
   double X12[FULL ? 2 : 1][FULL ? 9 : 1], X22[FULL ? 2 : 1][FULL ? 9 : 1], cps[FULL ? 2 : 1][FULL ? kNumContacts : 1][3], com[FULL ? 2 : 1][3];
+  double fh[FULL ? 2 : 1][FULL ? 6 : 1], vlin[FULL ? 2 : 1][FULL ? 3 : 1], trig[FULL ? 4 : 1];
+  // contact points / velocities of an evaluation (FULL: the stage's own copy, kept for the RK2 combination)
+  __device__ __forceinline__ double (*cpos(int stage))[3] { if constexpr (FULL) return cps[stage]; else return cpos_v; }
+  __device__ __forceinline__ double (*cvel())[3] { if constexpr (FULL) return cvel_full; else return cvel_v; }
 };
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -175,12 +192,14 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
   const bool is_joint = g >= 6 && g < G, is_body = g >= 5 && g < G;
   const double mass_total = md.robot_mass;
   const double* pb = xh + 6;           // base position, read from LDS at every use (registers are the scarce resource here)
+  double (*cpos)[3] = nl.cpos(stage);   // contact points of this evaluation
   // ---- sin/cos of the own angle; Euler sin/cos to everybody
   double sg = 0.0, cg = 1.0;
   if (g >= 3 && g < G) sincos(qg, &sg, &cg);
   const double sy = __shfl(sg, 3 - G0, LPN), cy = __shfl(cg, 3 - G0, LPN), sp = __shfl(sg, 4 - G0, LPN), cp = __shfl(cg, 4 - G0, LPN),
                sr = __shfl(sg, 5 - G0, LPN), cr = __shfl(cg, 5 - G0, LPN);
   kin.sy = sy; kin.cy = cy; kin.sp = sp; kin.cp = cp;
+  if constexpr (NodeLds::kFull) { if (g == G0) { nl.trig[0] = sy; nl.trig[1] = cy; nl.trig[2] = sp; nl.trig[3] = cp; } }
   EVPROF(0);
   // ---- joint-local transforms to LDS, chain walk
   if (is_joint) {
@@ -250,7 +269,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
       if (md.contact_body[i] == lb.body) {
         double t[3];
         mat3_vec(R, md.contact_off[i], t);
-        for (int a = 0; a < 3; ++a) { const double pv = o[a] + t[a]; nl.cpos[i][a] = pv; if constexpr (DERIV) nl.cps[stage][i][a] = pv; }
+        for (int a = 0; a < 3; ++a) cpos[i][a] = o[a] + t[a];
       }
   }
   lds_wave_sync();
@@ -310,20 +329,24 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
     X22[6] = c02 * idet; X22[7] = (M[1] * M[6] - M[0] * M[7]) * idet; X22[8] = (M[0] * M[4] - M[1] * M[3]) * idet;
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) X12[3 * i + j] = -im * (A12[3 * i] * X22[j] + A12[3 * i + 1] * X22[3 + j] + A12[3 * i + 2] * X22[6 + j]);
-    if constexpr (DERIV) { const int ln = g - G0; if (ln < 9) { nl.X12[stage][ln] = X12[ln]; nl.X22[stage][ln] = X22[ln]; } }
+    if constexpr (DERIV) { if (g == G0) for (int i = 0; i < 9; ++i) { nl.X12[stage][i] = X12[i]; nl.X22[stage][i] = X22[i]; } }
     mat3_vec(X22, &rhs[3], th);
     mat3_vec(X12, &rhs[3], pd);
     for (int i = 0; i < 3; ++i) pd[i] += im * rhs[i];
   }
   for (int i = 0; i < 3; ++i) { kin.vb[i] = pd[i]; kin.vb[3 + i] = th[i]; }
+  if constexpr (NodeLds::kFull) { if (g == G0) for (int i = 0; i < 3; ++i) nl.vlin[stage][i] = pd[i]; }
   const double vg = g == 0 ? pd[0] : g == 1 ? pd[1] : g == 2 ? pd[2] : g == 3 ? th[0] : g == 4 ? th[1] : g == 5 ? th[2] : (g < G ? ujg : 0.0);
   ev.vg = vg;
   EVPROF(4);
-  // ---- flow map rows 0..5
+  // ---- flow map rows 0..5 (the derivative kernel re-reads the node's com from LDS from here on: three values less in every lane's registers)
+  if constexpr (DERIV) lds_wave_sync();
+  const double* comn = com;
+  if constexpr (DERIV) comn = nl.com[stage];
   {
     double lin[3] = {0.0, 0.0, -9.81 * mass_total}, ang[3] = {0.0, 0.0, 0.0};
     for (int i = 0; i < kNumContacts; ++i) {
-      const double r[3] = {nl.cpos[i][0] - com[0], nl.cpos[i][1] - com[1], nl.cpos[i][2] - com[2]};
+      const double r[3] = {cpos[i][0] - comn[0], cpos[i][1] - comn[1], cpos[i][2] - comn[2]};
       const double Fi[3] = {nl.u[3 * i], nl.u[3 * i + 1], nl.u[3 * i + 2]};
       lin[0] += Fi[0]; lin[1] += Fi[1]; lin[2] += Fi[2];
       ang[0] += r[1] * Fi[2] - r[2] * Fi[1];
@@ -331,7 +354,8 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
       ang[2] += r[0] * Fi[1] - r[1] * Fi[0];
     }
     const double imt_c = 1.0 / mass_total;             // one division instead of six (an fp64 division is ~25 instructions)
-    for (int i = 0; i < 3; ++i) { ev.fh[i] = lin[i] * imt_c; ev.fh[3 + i] = ang[i] * imt_c; }
+    if constexpr (NodeLds::kFull) { if (g == G0) for (int i = 0; i < 3; ++i) { nl.fh[stage][i] = lin[i] * imt_c; nl.fh[stage][3 + i] = ang[i] * imt_c; } }
+    else for (int i = 0; i < 3; ++i) { ev.fh[i] = lin[i] * imt_c; ev.fh[3 + i] = ang[i] * imt_c; }
   }
   double om[3] = {0.0, 0.0, 0.0}, vo[3] = {pd[0], pd[1], pd[2]};
   if constexpr (TWIST) {
@@ -412,7 +436,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
       cross3(ah, l, al);
       cross3(ah, Lk, aL);
       for (int i = 0; i < 3; ++i) { dl[i] = al[i] - linp[i]; dLk[i] = aL[i] - angp[i]; }
-      const double sc[3] = {o[0] - com[0], o[1] - com[1], o[2] - com[2]};
+      const double sc[3] = {o[0] - comn[0], o[1] - comn[1], o[2] - comn[2]};
       const double jc[3] = {Ac[0] * im, Ac[1] * im, Ac[2] * im};
       double t2[3];
       cross3(sc, dl, t);
@@ -434,7 +458,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
       double jcol[3] = {0.0, 0.0, 0.0};
       if (g < 3) { jcol[0] = g == 0 ? 1.0 : 0.0; jcol[1] = g == 1 ? 1.0 : 0.0; jcol[2] = g == 2 ? 1.0 : 0.0; }
       else if (g < G && (g < 6 || ((md.contact_path[i] >> (g - 5)) & 1u))) {
-        const double r[3] = {nl.cpos[i][0] - o[0], nl.cpos[i][1] - o[1], nl.cpos[i][2] - o[2]};
+        const double r[3] = {cpos[i][0] - o[0], cpos[i][1] - o[1], cpos[i][2] - o[2]};
         cross3(ah, r, jcol);
       }
       const double d[3] = {jcol[0] - jcm[0], jcol[1] - jcm[1], jcol[2] - jcm[2]};
@@ -555,27 +579,29 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     for (int rr = 0; rr < 9; ++rr) pk[rr * LPN + ln] = e1.ar_q[rr];
     for (int rr = 0; rr < 6; ++rr) pk[9 * LPN + rr * LPN + ln] = is_joint ? e1.br_j[rr] : 0.0;   // whole 128-byte lines
   }
-  const double f1h_g = lane_pick6(e1.fh, ln), v1g = e1.vg;
-  const double v1t = ln == 0 ? kin.vb[0] : (ln == 1 ? kin.vb[1] : kin.vb[2]);     // base linear velocity component of the translation role
+  const double v1g = e1.vg;
 
   // =========================== contact part (first stage only) ===========================
+  double (*cpos1)[3] = nl.cps[0];
+  double (*cvel1)[3] = nl.cvel();       // shares storage with the tables of the evaluation, which are dead now
+  lds_wave_sync();
   if (g >= 5 && g < G)
     for (int i = 0; i < kNumContacts; ++i)
       if (md.contact_body[i] == lb.body) {
-        const double r[3] = {nl.cpos[i][0] - kin.og[0], nl.cpos[i][1] - kin.og[1], nl.cpos[i][2] - kin.og[2]};
+        const double r[3] = {cpos1[i][0] - kin.og[0], cpos1[i][1] - kin.og[1], cpos1[i][2] - kin.og[2]};
         double t[3];
         cross3(kin.omg, r, t);
-        for (int a = 0; a < 3; ++a) nl.cvel[i][a] = kin.vog[a] + t[a];
+        for (int a = 0; a < 3; ++a) cvel1[i][a] = kin.vog[a] + t[a];
       }
-  if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(md, &nl.u[3 * ln], true, nl.cone[ln]);
   lds_wave_sync();
+  const double tsy = nl.trig[0], tcy = nl.trig[1], tsp = nl.trig[2], tcp = nl.trig[3];   // Euler sines / cosines of the first stage
   // rows in registration order zeroForce_i, zeroVelocity_i, normalVelocity_i (src/BipedalRobotInterface.cpp:187-191)
   int row = 0;
   double eq_sse = 0.0;
   for (int i = 0; i < kNumContacts; ++i) {
     const bool stance = stance_flag(mode, i);
-    const double cp_i[3] = {nl.cpos[i][0], nl.cpos[i][1], nl.cpos[i][2]};
-    const double cv_i[3] = {nl.cvel[i][0], nl.cvel[i][1], nl.cvel[i][2]};
+    const double cp_i[3] = {cpos1[i][0], cpos1[i][1], cpos1[i][2]};
+    const double cv_i[3] = {cvel1[i][0], cvel1[i][1], cvel1[i][2]};
     // own columns of J_i and d(J_i v)/dq
     double Jc[3] = {0.0, 0.0, 0.0}, DJ[3] = {0.0, 0.0, 0.0};
     if (g < 3) { Jc[0] = g == 0 ? 1.0 : 0.0; Jc[1] = g == 1 ? 1.0 : 0.0; Jc[2] = g == 2 ? 1.0 : 0.0; }
@@ -593,7 +619,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     const double rb[3] = {cp_i[0] - pb[0], cp_i[1] - pb[1], cp_i[2] - pb[2]};
     auto base_part = [&](const double* col6, double* outv) {
       const double th0 = col6[3], th1 = col6[4], th2 = col6[5];
-      const double w[3] = {-kin.sy * th1 + kin.cy * kin.cp * th2, kin.cy * th1 + kin.sy * kin.cp * th2, th0 - kin.sp * th2};
+      const double w[3] = {-tsy * th1 + tcy * tcp * th2, tcy * th1 + tsy * tcp * th2, th0 - tsp * th2};
       double t[3];
       cross3(w, rb, t);
       for (int a = 0; a < 3; ++a) outv[a] = col6[a] + t[a];
@@ -646,13 +672,15 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   LaneEval e2;
   double v2t;                        // base linear velocity component ln of the second stage (translation role)
   {
-    if (ln < 6) nl.xh2[ln] = xh[ln] + dt * lane_pick6(e1.fh, ln);
-    if (ln < 3) nl.xh2[6 + ln] = pb[ln] + dt * v1t;
+    lds_wave_sync();                 // the constraint rows have read the swing references, whose storage becomes xh2
+    if (ln < 6) nl.xh2[ln] = xh[ln] + dt * nl.fh[0][ln];
+    if (ln < 3) nl.xh2[6 + ln] = pb[ln] + dt * nl.vlin[0][ln];
     const double* xh2 = nl.xh2;      // published by the lds_wave_sync at the top of eval_lane
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
     eval_lane<NJ, true, true, LinFastNodeLds<NJ>, LinFastShared<NJ>, C>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
-    v2t = ln == 0 ? kin2.vb[0] : (ln == 1 ? kin2.vb[1] : kin2.vb[2]);
+    lds_wave_sync();
+    v2t = tr ? nl.vlin[1][ln] : 0.0;
   }
   LFPROF(3);
   // A2[rows 3..11][x columns 0..11] to LDS (a2 shares storage with the chain tables, dead now): columns 0..5 are the
@@ -716,18 +744,19 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     dyn_sse += bb * bb;
   }
   if (ln < 6) {
-    const double bb = (ln < 6 ? xh[ln] : 0.0) + hdt * f1h_g + hdt * lane_pick6(e2.fh, ln) - xn_h;
+    const double bb = (ln < 6 ? xh[ln] : 0.0) + hdt * nl.fh[0][ln] + hdt * nl.fh[1][ln] - xn_h;
     (o.b + o.s * (NX))[ln] = bb;
     dyn_sse += bb * bb;
   }
   if (tr) {                          // base position: the same expression as a coordinate lane (q + dt/2 v1 + dt/2 v2 - x_next)
-    const double bb = pb[ln] + hdt * v1t + hdt * v2t - xn_t;
+    const double bb = pb[ln] + hdt * nl.vlin[0][ln] + hdt * v2t - xn_t;
     (o.b + o.s * (NX))[6 + ln] = bb;
     dyn_sse += bb * bb;
   }
   LFPROF(4);
   // =========================== cost ===========================
-  lds_wave_sync();   // a2 is dead: its storage becomes dx / du
+  lds_wave_sync();   // a2 is dead: its storage becomes dx / du; the twist tables are dead: their storage becomes the cone terms
+  if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(md, &nl.u[3 * ln], true, nl.cone[ln]);
   const double pt = tr ? pb[ln] : 0.0;       // read before dx / du overwrite nothing of x (x lives in its own array) - kept for symmetry
   if (g < G) nl.dx[6 + g] = qg - xr_q;
   if (tr) nl.dx[6 + ln] = pt - xr_t;
@@ -851,10 +880,10 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   if (g >= 5 && g < G)
     for (int i = 0; i < kNumContacts; ++i)
       if (md.contact_body[i] == lb.body) {
-        const double r[3] = {nl.cpos[i][0] - kin.og[0], nl.cpos[i][1] - kin.og[1], nl.cpos[i][2] - kin.og[2]};
+        const double r[3] = {nl.cpos_v[i][0] - kin.og[0], nl.cpos_v[i][1] - kin.og[1], nl.cpos_v[i][2] - kin.og[2]};
         double t[3];
         cross3(kin.omg, r, t);
-        for (int a = 0; a < 3; ++a) nl.cvel[i][a] = kin.vog[a] + t[a];
+        for (int a = 0; a < 3; ++a) nl.cvel_v[i][a] = kin.vog[a] + t[a];
       }
   double cone_own[4] = {0.0, 0.0, 0.0, 0.0};          // h, barrier value, first and second derivative of this lane's contact
   if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(md, &nl.u[3 * ln], false, cone_own);
@@ -862,17 +891,17 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   double eq_sse = 0.0;
   int row = 0;
   for (int i = 0; i < kNumContacts; ++i) {
-    const double cz = nl.cpos[i][2];
+    const double cz = nl.cpos_v[i][2];
     if (stance_flag(mode, i)) {
       for (int a = 0; a < 3; ++a) {
-        double ev = nl.cvel[i][a];
+        double ev = nl.cvel_v[i][a];
         if (md.pos_gain != 0.0 && a == 2) ev += md.pos_gain * cz;
         eq_sse += ev * ev;
         if constexpr (EQV) { if (ln == 0) eqv[row] = ev; ++row; }
       }
     } else {
       for (int a = 0; a < 3; ++a) { const double ev = nl.u[3 * i + a]; eq_sse += ev * ev; if constexpr (EQV) { if (ln == 0) eqv[row] = ev; ++row; } }
-      double ev = nl.cvel[i][2] - in.zdref[i];
+      double ev = nl.cvel_v[i][2] - in.zdref[i];
       if (md.pos_gain != 0.0) ev += md.pos_gain * (cz - in.zref[i]);
       eq_sse += ev * ev;
       if constexpr (EQV) { if (ln == 0) eqv[row] = ev; ++row; }
