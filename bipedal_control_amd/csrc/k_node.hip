@@ -59,8 +59,14 @@ __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linea
   constexpr int LPN = C::LPN, NPW = C::NPW, kLinWaves = lin_waves<NJ>();
   __shared__ LinFastNodeLds<NJ> lds[kLinWaves * NPW];
   __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
+#ifdef BPMPC_LIN_TIMELINE                  // per workgroup: start, model staged, end (10 ns ticks) and the hardware id -> tools/lin_timeline.py
+  const long long tl0 = wall_clock64();
+#endif
   load_shared_model<NJ>(*L.model, shared, threadIdx.x, kLinWaves * kWave);
   __syncthreads();
+#ifdef BPMPC_LIN_TIMELINE
+  const long long tl1 = wall_clock64();
+#endif
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;       // sub: node slot of the workgroup
   const int widx = blockIdx.x * (kLinWaves * NPW) + sub;          // batch * max_nodes < 2^31 is checked at creation
   bool valid = widx < L.batch * L.klen;
@@ -74,10 +80,22 @@ __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linea
   out.A = L.buf.A; out.B = L.buf.B; out.b = L.buf.b; out.Q = L.buf.Q; out.R = L.buf.R; out.q = L.buf.q; out.r = L.buf.r; out.c = L.buf.c;
   out.C = L.buf.C; out.D = L.buf.D; out.e = L.buf.e; out.perf = L.buf.perf; out.nc = L.buf.nc;
   out.park = L.buf.lin_park;
+  out.dump = L.buf.lin_dump;
   out.qrd = L.buf.qrd;
   out.s = s;
-  out.prof = (valid && b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
+#ifndef BPMPC_LIN_PROF_PROBLEM
+#define BPMPC_LIN_PROF_PROBLEM 0     // the problem whose first 64 nodes report their phase cycles (-DBPMPC_LINFAST_PROFILE): 0 runs on an empty chip, batch / 2 in steady state
+#endif
+  out.prof = (valid && b == BPMPC_LIN_PROF_PROBLEM && k < 64) ? L.buf.rprof + 8 * k : nullptr;
   linearize_fast<NJ, MAT, C>(*L.model, shared, lds[sub], valid, in, out, g);      // g: lane inside the node's group
+#ifdef BPMPC_LIN_TIMELINE
+  if (threadIdx.x % kWave == 0 && blockIdx.x < 2048) {      // every wave: the workgroup's end is the latest of its waves
+    double* t = L.buf.rprof + 16 * blockIdx.x + 4 * (threadIdx.x / kWave);
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    t[0] = (double)tl0; t[1] = (double)tl1; t[2] = (double)wall_clock64(); t[3] = (double)(hw | ((unsigned long long)(xcc & 15) << 32));
+  }
+#endif
 }
 
 // Warm start of a receding-horizon solve from the previous solution, one wavefront per (problem, node).  [OCS2-upstream, recalled]

@@ -481,6 +481,10 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
 // column 6+g for 16 lanes, rows 6..11 of the joint-velocity column for the joints; layout [row][lane] (coalesced).  They are
 // written before the second evaluation and read after it, by when the stores have long retired.
 constexpr int kLinParkDoublesPerLane = 15;   // times the lanes per node
+// Role stores (RoleSlots below) are issued by every lane of a node; a lane without the role writes into this scratch region instead of
+// being masked out: kLinDumpNodes lines of 16 doubles (the node slot picks the line) plus the largest row offset a store adds.
+constexpr int kLinDumpNodes = 1024, kLinDumpSlack = 1024;
+constexpr size_t kLinDumpDoubles = (size_t)kLinDumpNodes * 16 + kLinDumpSlack;
 // Q and R of a node are dt x (constant weight) except for the Hessian shift on their diagonals and the four 3x3 force blocks of R
 // (cone Hessians).  Besides the full matrices the lineariser leaves exactly that part in a compact record: [shift, block entries
 // (column-major inside the block row: 3 * column + row % 3)], so that the change of variables need not read 7.7 KB of mostly
@@ -491,9 +495,59 @@ struct LinFastOut {
   double *A, *B, *b, *Q, *R, *q, *r, *c, *C, *D, *e, *perf;
   int* nc;
   double* park;      // scratch, 15 * LPN doubles per node: the stage-one Jacobian columns wait here for the RK2 combination
+  double* dump;      // kLinDumpDoubles: where the lanes without a role write (never read)
   double* qrd;       // kQrdStride doubles per node: the node-dependent part of Q and R in compact form (read by project_mfma.h)
   double* prof;      // this node's debug slot or nullptr
   size_t s;          // node slot (problem * max_nodes + node)
+};
+
+// A lane owns up to four columns of the node's matrices ("roles"): x column 6+g (its coordinate), x column 6+ln (base translation: packed
+// layout, lanes 0..2), x column ln (momentum, lanes 0..5), u column ln (force, lanes 0..11), u column 12+(g-6) (joint velocity).  A row of
+// a matrix pair [X-type | U-type] ([A | B], [C | D], [Q | R]; NX = NU doubles per row each) leaves in NS store instructions that ALL lanes
+// issue: roles whose lane sets are disjoint share an instruction (the lane picks pointer and value), and a lane without a role in a slot
+// points into the dump.  No execution mask is touched (a predicated store costs s_and_saveexec / branch / s_or around it - the row loops
+// of this kernel were two thirds bookkeeping), the pointers are formed once per matrix pair and the row offset is an immediate.
+//   16 coordinates (G0 = 0):  slot 0 = coordinate | slot 1 = momentum (lanes 0..5) + joint velocity (6..15) | slot 2 = force (0..11)
+//   packed (G0 = 3):          slot 0 = coordinate (0..14) | slot 1 = translation (0..2) + joint velocity (3..14) | slot 2 = force | slot 3 = momentum
+// The row loops are fully unrolled (compile-time row offsets); without a fence between the rows the scheduler hoists the LDS reads of
+// all of them to the top (hundreds of registers, spills).
+#ifndef BPMPC_LIN_UNROLL_CONTACTS
+#define BPMPC_LIN_UNROLL_CONTACTS 0      // 1: 254 registers + 44 B of scratch, 0.218 against 0.211 ms at batch 256 (the four contacts rolled: 219, none)
+#endif
+#ifndef BPMPC_LIN_ROW_FENCE
+#define BPMPC_LIN_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+template <class Cfg>
+struct RoleSlots {
+  static constexpr bool PACKED = Cfg::G0 > 0;
+  static constexpr int NS = PACKED ? 4 : 3;
+  static_assert(Cfg::LPN == 16 && (PACKED || Cfg::G == 16), "role slots are laid out for sixteen lanes per node");
+  int ln, g;
+  double* dump;      // this lane's word of the node's dump line
+  __device__ __forceinline__ void pointers(double* Xn, double* Un, double* (&p)[NS]) const {
+    if constexpr (!PACKED) {
+      p[0] = Xn + (6 + ln);
+      p[1] = ln < 6 ? Xn + ln : Un + (12 + ln - 6);
+      p[2] = ln < 12 ? Un + ln : dump;
+    } else {
+      p[0] = g < Cfg::G ? Xn + (6 + g) : dump;
+      p[1] = ln < 3 ? Xn + (6 + ln) : (g < Cfg::G ? Un + (12 + g - 6) : dump);
+      p[2] = ln < 12 ? Un + ln : dump;
+      p[3] = ln < 6 ? Xn + ln : dump;
+    }
+  }
+  // values of the roles of this lane (what a lane passes for a role it does not have is never stored where it matters)
+  __device__ __forceinline__ void store(double* const (&p)[NS], int off, double v_coord, double v_trans, double v_mom, double v_force, double v_joint) const {
+    p[0][off] = v_coord;
+    if constexpr (!PACKED) {
+      p[1][off] = ln < 6 ? v_mom : v_joint;
+      p[2][off] = v_force;
+    } else {
+      p[1][off] = ln < 3 ? v_trans : v_joint;
+      p[2][off] = v_force;
+      p[3][off] = v_mom;
+    }
+  }
 };
 
 // MAT = true: the complete per-node LQ model of the reference (A, B, b, Q, R, q, r, c, C, D, e zero padded to 16 rows) is written -
@@ -508,6 +562,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
 #ifdef BPMPC_LINFAST_PROFILE
   long long lf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long lf_prev = clock64();
+  const long long lf_wall0 = wall_clock64(), lf_c0 = lf_prev;      // slots 6, 7: the wave's cycles and its wall time in 10 ns ticks (-> shader clock)
 #define LFPROF(slot) do { const long long tn_ = clock64(); lf_t[slot] += tn_ - lf_prev; lf_prev = tn_; } while (0)
 #else
 #define LFPROF(slot) ((void)0)
@@ -542,6 +597,9 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   const double dt = in.dt, hdt = 0.5 * in.dt;
   const int mode = in.mode;
   const double mass_total = md.robot_mass, imt = 1.0 / md.robot_mass;
+  using Slots = RoleSlots<C>;
+  constexpr int NS = Slots::NS;
+  const Slots slots{ln, g, o.dump + ((o.s & (size_t)(kLinDumpNodes - 1)) * 16 + ln)};
   // ---- stage the node inputs in LDS: after this block nothing is read from global memory except model constants
   for (int idx = ln; idx < NX; idx += LPN) { nl.x[idx] = in.x[idx]; nl.u[idx] = in.u[idx]; }
   // the entries of x_next and x_ref this lane needs later (rows 6+g, ln and - packed lanes 0..2 - 6+ln)
@@ -595,76 +653,92 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
       }
   lds_wave_sync();
   const double tsy = nl.trig[0], tcy = nl.trig[1], tsp = nl.trig[2], tcp = nl.trig[3];   // Euler sines / cosines of the first stage
-  // rows in registration order zeroForce_i, zeroVelocity_i, normalVelocity_i (src/BipedalRobotInterface.cpp:187-191)
-  int row = 0;
+  // rows in registration order zeroForce_i, zeroVelocity_i, normalVelocity_i (src/BipedalRobotInterface.cpp:187-191).  Per contact the
+  // three rows of a stance contact (zero velocity) or of a swing contact (zero force) and, swing only, the normal-velocity row; every
+  // store is issued by all lanes (RoleSlots), the fourth row of a stance contact goes to the dump.
   double eq_sse = 0.0;
-  for (int i = 0; i < kNumContacts; ++i) {
-    const bool stance = stance_flag(mode, i);
-    const double cp_i[3] = {cpos1[i][0], cpos1[i][1], cpos1[i][2]};
-    const double cv_i[3] = {cvel1[i][0], cvel1[i][1], cvel1[i][2]};
-    // own columns of J_i and d(J_i v)/dq
-    double Jc[3] = {0.0, 0.0, 0.0}, DJ[3] = {0.0, 0.0, 0.0};
-    if (g < 3) { Jc[0] = g == 0 ? 1.0 : 0.0; Jc[1] = g == 1 ? 1.0 : 0.0; Jc[2] = g == 2 ? 1.0 : 0.0; }
-    else if (g < G && (g < 6 || ((md.contact_path[i] >> (g - 5)) & 1u))) {
-      const double r[3] = {cp_i[0] - kin.og[0], cp_i[1] - kin.og[1], cp_i[2] - kin.og[2]};
-      cross3(kin.ah, r, Jc);
-      const double dv[3] = {cv_i[0] - kin.vog[0], cv_i[1] - kin.vog[1], cv_i[2] - kin.vog[2]};
-      double t1[3], wa[3], t2[3];
-      cross3(kin.ah, dv, t1);
-      cross3(kin.omg, kin.ah, wa);
-      cross3(wa, r, t2);
-      for (int k = 0; k < 3; ++k) DJ[k] = t1[k] + t2[k];
+  double e_mine = 0.0;                  // lane r keeps e[r]: one coalesced store at the end instead of one word per row
+  int nc;
+  {
+    double* pcd[NS];
+    slots.pointers(o.C + o.s * (kMaxEqRows * NX), o.D + o.s * (kMaxEqRows * NU), pcd);
+    if constexpr (MAT) {                // zero padding of rows 12..15 first (the rows that exist overwrite it: same lane, same address, program order);
+      for (int r = 12; r < kMaxEqRows; ++r) slots.store(pcd, r * NX, 0.0, 0.0, 0.0, 0.0, 0.0);   // the LU kernel reads nc rows only
     }
-    // J_i,base (d v_base / d column) = d(pdot) + d(omega_base) x (p_i - o0),  d(omega_base) = W d(thetadot)
-    const double rb[3] = {cp_i[0] - pb[0], cp_i[1] - pb[1], cp_i[2] - pb[2]};
-    auto base_part = [&](const double* col6, double* outv) {
-      const double th0 = col6[3], th1 = col6[4], th2 = col6[5];
-      const double w[3] = {-tsy * th1 + tcy * tcp * th2, tcy * th1 + tsy * tcp * th2, th0 - tsp * th2};
-      double t[3];
-      cross3(w, rb, t);
-      for (int a = 0; a < 3; ++a) outv[a] = col6[a] + t[a];
-    };
-    double bq[3], bh[3], bj[3], hcol[6];
+    double hcol[6];                     // own momentum column (rows 6..11 of df/dx, lanes 0..5): the same for every contact
     for (int l = 0; l < 6; ++l) hcol[l] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, ln, 3 + l);
-    base_part(&e1.ar_q[3], bq);
-    base_part(hcol, bh);
-    base_part(e1.br_j, bj);
-    const int nrows = stance ? 3 : 4;
-    for (int rr = 0; rr < nrows; ++rr) {
-      const int type = stance ? 1 : (rr < 3 ? 0 : 2);
-      const int a = (type == 2) ? 2 : rr;
-      double vq = 0.0, vh = 0.0, vf = 0.0, vj = 0.0, vt = 0.0, ev;
-      if (type == 0) {
-        vf = (ln == 3 * i + a) ? 1.0 : 0.0;                          // ZeroForceConstraint.cpp:64-72
-        ev = nl.u[3 * i + a];
-      } else {
-        vq = bq[a] + DJ[a];
-        if (md.pos_gain != 0.0 && a == 2) { vq += md.pos_gain * Jc[a]; vt = ln == 2 ? md.pos_gain : 0.0; }   // d p_z / d (base z) = 1
-        vh = bh[a];
-        vj = bj[a] + Jc[a];
-        ev = cv_i[a];
-        if (type == 1) { if (md.pos_gain != 0.0 && a == 2) ev += md.pos_gain * cp_i[2]; }
-        else { ev -= nl.zdref[i]; if (md.pos_gain != 0.0) ev += md.pos_gain * (cp_i[2] - nl.zref[i]); }
+    const double pos_gain = md.pos_gain;
+    int row = 0;
+#if BPMPC_LIN_UNROLL_CONTACTS
+#pragma unroll
+#else
+#pragma nounroll
+#endif
+    for (int i = 0; i < kNumContacts; ++i) {
+      const bool stance = stance_flag(mode, i);
+      const double cp_i[3] = {cpos1[i][0], cpos1[i][1], cpos1[i][2]};
+      const double cv_i[3] = {cvel1[i][0], cvel1[i][1], cvel1[i][2]};
+      // own columns of J_i and d(J_i v)/dq
+      const bool on_path = g >= 3 && g < G && (g < 6 || ((md.contact_path[i] >> (g - 5)) & 1u));
+      double Jc[3], DJ[3];
+      {
+        const double r[3] = {cp_i[0] - kin.og[0], cp_i[1] - kin.og[1], cp_i[2] - kin.og[2]};
+        double jr[3];
+        cross3(kin.ah, r, jr);
+        const double dv[3] = {cv_i[0] - kin.vog[0], cv_i[1] - kin.vog[1], cv_i[2] - kin.vog[2]};
+        double t1[3], wa[3], t2[3];
+        cross3(kin.ah, dv, t1);
+        cross3(kin.omg, kin.ah, wa);
+        cross3(wa, r, t2);
+        for (int k = 0; k < 3; ++k) {
+          Jc[k] = on_path ? jr[k] : ((g == k) ? 1.0 : 0.0);        // base translation g < 3: unit column (no such lane in the packed layout)
+          DJ[k] = on_path ? t1[k] + t2[k] : 0.0;
+        }
       }
-      if (g < G) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + g] = vq;
-      if (tr) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + ln] = vt;       // base translation: the contact velocity does not depend on it
-      if (ln < 6) (o.C + o.s * (kMaxEqRows * NX))[row * NX + ln] = vh;
-      if (ln < 12) (o.D + o.s * (kMaxEqRows * NU))[row * NU + ln] = vf;
-      if (is_joint) (o.D + o.s * (kMaxEqRows * NU))[row * NU + 12 + g - 6] = vj;
-      if (ln == 0) (o.e + o.s * (kMaxEqRows))[row] = ev;
-      eq_sse += ev * ev;
-      ++row;
+      // J_i,base (d v_base / d column) = d(pdot) + d(omega_base) x (p_i - o0),  d(omega_base) = W d(thetadot)
+      const double rb[3] = {cp_i[0] - pb[0], cp_i[1] - pb[1], cp_i[2] - pb[2]};
+      auto base_part = [&](const double* col6, double* outv) {
+        const double th0 = col6[3], th1 = col6[4], th2 = col6[5];
+        const double w[3] = {-tsy * th1 + tcy * tcp * th2, tcy * th1 + tsy * tcp * th2, th0 - tsp * th2};
+        double t[3];
+        cross3(w, rb, t);
+        for (int a = 0; a < 3; ++a) outv[a] = col6[a] + t[a];
+      };
+      double bq[3], bh[3], bj[3];
+      base_part(&e1.ar_q[3], bq);
+      base_part(hcol, bh);
+      base_part(e1.br_j, bj);
+      // velocity row of axis a: zero velocity of a stance contact (a = 0..2), normal velocity of a swing contact (a = 2)
+      double vqa[3], vja[3];
+      for (int a = 0; a < 3; ++a) { vqa[a] = bq[a] + DJ[a]; vja[a] = bj[a] + Jc[a]; }
+      double vt2 = 0.0;
+      if (pos_gain != 0.0) { vqa[2] += pos_gain * Jc[2]; vt2 = ln == 2 ? pos_gain : 0.0; }      // d p_z / d (base z) = 1 (packed layout: translation role)
+      double* pc[NS];
+      for (int k = 0; k < NS; ++k) pc[k] = pcd[k] + row * NX;
+      for (int a = 0; a < 3; ++a) {
+        // stance: zero velocity (ZeroVelocityConstraintCppAd); swing: zero force (ZeroForceConstraint.cpp:64-72)
+        double ev = cv_i[a];
+        if (a == 2 && pos_gain != 0.0) ev += pos_gain * cp_i[2];
+        ev = stance ? ev : nl.u[3 * i + a];
+        slots.store(pc, a * NX, stance ? vqa[a] : 0.0, (a == 2 && stance) ? vt2 : 0.0, stance ? bh[a] : 0.0,
+                    (!stance && ln == 3 * i + a) ? 1.0 : 0.0, stance ? vja[a] : 0.0);
+        e_mine = (ln == row + a) ? ev : e_mine;
+        eq_sse += ev * ev;
+      }
+      {                                 // swing: normal velocity (NormalVelocityConstraintCppAd); stance: no fourth row (stores go to the dump)
+        double ev = cv_i[2] - nl.zdref[i];
+        if (pos_gain != 0.0) ev += pos_gain * (cp_i[2] - nl.zref[i]);
+        double* p3[NS];
+        for (int k = 0; k < NS; ++k) p3[k] = stance ? slots.dump : pc[k];
+        slots.store(p3, 3 * NX, vqa[2], vt2, bh[2], 0.0, vja[2]);
+        e_mine = (!stance && ln == row + 3) ? ev : e_mine;
+        eq_sse = stance ? eq_sse : eq_sse + ev * ev;
+      }
+      row += stance ? 3 : 4;
+      BPMPC_LIN_ROW_FENCE();
     }
-  }
-  const int nc = row;
-  if constexpr (MAT)          // the LU kernel reads nc rows only; the zero padding exists for readers of the materialised model
-  for (; row < kMaxEqRows; ++row) {
-    if (g < G) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + g] = 0.0;
-    if (tr) (o.C + o.s * (kMaxEqRows * NX))[row * NX + 6 + ln] = 0.0;
-    if (ln < 6) (o.C + o.s * (kMaxEqRows * NX))[row * NX + ln] = 0.0;
-    if (ln < 12) (o.D + o.s * (kMaxEqRows * NU))[row * NU + ln] = 0.0;
-    if (is_joint) (o.D + o.s * (kMaxEqRows * NU))[row * NU + 12 + g - 6] = 0.0;
-    if (ln == 0) (o.e + o.s * (kMaxEqRows))[row] = 0.0;
+    nc = row;
+    (o.e + o.s * (kMaxEqRows))[ln] = e_mine;      // all kMaxEqRows = LPN entries: zeros beyond nc
   }
 
   LFPROF(2);
@@ -679,6 +753,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
     eval_lane<NJ, true, true, LinFastNodeLds<NJ>, LinFastShared<NJ>, C>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
+    BPMPC_LIN_ROW_FENCE();           // keeps the loads of the combination phase (parked columns, stage-one blocks) out of the evaluation's registers
     lds_wave_sync();
     v2t = tr ? nl.vlin[1][ln] : 0.0;
   }
@@ -705,36 +780,39 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     c1h[rr] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, ln, rr);
     c1f[rr] = force_col(nl.cps[0], nl.com[0], imt, ln, rr);
   }
-  for (int r = MAT ? 0 : 3; r < (MAT ? NX : 12); ++r) {      // fused mode: the structural rows (0..2, 12..) are regenerated downstream
-    double aq, ah_, bf, bj;
-    if (r < 3 || r >= 12) {
-      aq = (r == 6 + g) ? 1.0 : 0.0;
-      ah_ = (r == ln) ? 1.0 : 0.0;
-      bf = (r < 3 && (ln % 3) == r) ? dt * imt : 0.0;
-      bj = (r >= 12 && r == 12 + g - 6) ? dt : 0.0;
-    } else {
-      const int rr = r - 3;
-      double sq = 0.0, sh = 0.0, sf = 0.0, sj = 0.0;
-      for (int l = 0; l < 9; ++l) {
-        const double a = nl.a2[rr][3 + l];
-        sq += a * c1q[l]; sh += a * c1h[l]; sf += a * c1f[l]; sj += a * c1j[l];
+  {
+    double* pab[NS];
+    slots.pointers(o.A + o.s * (NX * NX), o.B + o.s * (NX * NU), pab);
+#pragma unroll
+    for (int r = MAT ? 0 : 3; r < (MAT ? NX : 12); ++r) {      // fused mode: the structural rows (0..2, 12..) are regenerated downstream
+      double aq, ah_, bf, bj;
+      if (r < 3 || r >= 12) {
+        aq = (r == 6 + g) ? 1.0 : 0.0;
+        ah_ = (r == ln) ? 1.0 : 0.0;
+        bf = (r < 3 && (ln % 3) == r) ? dt * imt : 0.0;
+        bj = (r >= 12 && r == 12 + g - 6) ? dt : 0.0;
+      } else {
+        const int rr = r - 3;
+        double sq = 0.0, sh = 0.0, sf = 0.0, sj = 0.0;
+        for (int l = 0; l < 9; ++l) {
+          const double a = nl.a2[rr][3 + l];
+          sq += a * c1q[l]; sh += a * c1h[l]; sf += a * c1f[l]; sj += a * c1j[l];
+        }
+        // B1 rows 0..2 are (1/m) on the force components, rows 12.. are the identity on the joint velocities
+        sf += nl.a2[rr][ln % 3] * imt;
+        sj += e2.ar_q[rr];
+        const double e2h = momentum_col(nl.X12[1], nl.X22[1], imt, mass_total, ln, rr);
+        const double e2f = force_col(nl.cps[1], nl.com[1], imt, ln, rr);
+        const double e2j = rr < 3 ? 0.0 : e2.br_j[rr - 3];
+        aq = ((r == 6 + g) ? 1.0 : 0.0) + hdt * (c1q[rr] + e2.ar_q[rr] + dt * sq);
+        ah_ = ((r == ln) ? 1.0 : 0.0) + hdt * (c1h[rr] + e2h + dt * sh);
+        bf = hdt * (c1f[rr] + e2f + dt * sf);
+        bj = hdt * (c1j[rr] + e2j + dt * sj);
       }
-      // B1 rows 0..2 are (1/m) on the force components, rows 12.. are the identity on the joint velocities
-      sf += nl.a2[rr][ln % 3] * imt;
-      sj += e2.ar_q[rr];
-      const double e2h = momentum_col(nl.X12[1], nl.X22[1], imt, mass_total, ln, rr);
-      const double e2f = force_col(nl.cps[1], nl.com[1], imt, ln, rr);
-      const double e2j = rr < 3 ? 0.0 : e2.br_j[rr - 3];
-      aq = ((r == 6 + g) ? 1.0 : 0.0) + hdt * (c1q[rr] + e2.ar_q[rr] + dt * sq);
-      ah_ = ((r == ln) ? 1.0 : 0.0) + hdt * (c1h[rr] + e2h + dt * sh);
-      bf = hdt * (c1f[rr] + e2f + dt * sf);
-      bj = hdt * (c1j[rr] + e2j + dt * sj);
+      // base translation (packed layout, lanes 0..2): identity column
+      slots.store(pab, r * NX, aq, (r == 6 + ln) ? 1.0 : 0.0, ah_, bf, bj);
+      BPMPC_LIN_ROW_FENCE();
     }
-    if (g < G) (o.A + o.s * (NX * NX))[r * NX + 6 + g] = aq;
-    if (tr) (o.A + o.s * (NX * NX))[r * NX + 6 + ln] = (r == 6 + ln) ? 1.0 : 0.0;      // base translation: identity column
-    if (ln < 6) (o.A + o.s * (NX * NX))[r * NX + ln] = ah_;
-    if (ln < 12) (o.B + o.s * (NX * NU))[r * NU + ln] = bf;
-    if (is_joint) (o.B + o.s * (NX * NU))[r * NU + 12 + g - 6] = bj;
   }
   // b = x + dt/2 (f1 + f2) - x_next
   double dyn_sse = 0.0;
@@ -770,31 +848,56 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   double cost = 0.0;
   {
     const int cq = 6 + g, ch = ln, cf = ln, cj = 12 + g - 6, ct = 6 + ln;
+    // lanes without a role read row / column 0 of the weights (any valid address) and their sums are dropped
+    const int cqs = g < G ? cq : 0, chs = ln < 6 ? ch : 0, cfs = ln < 12 ? cf : 0, cjs = is_joint ? cj : 0, cts = tr ? ct : 0;
+    const bool cf_stance = ln < 12 && stance_flag(mode, cfs / 3);
     double accq = 0.0, acch = 0.0, accf = 0.0, accj = 0.0, acct = 0.0;
+    double* pqr[NS];
+    if constexpr (MAT) slots.pointers(o.Q + o.s * (NX * NX), o.R + o.s * (NU * NU), pqr);
+#pragma unroll
     for (int r = 0; r < NX; ++r) {
       const double dxr = nl.dx[r], dur = nl.du[r];
       // gradient entries use row c of the weight (as the reference kernel), the written element is (r, c)
-      if (g < G) { accq += sh.Q[cq * NX + r] * dxr; if constexpr (MAT) (o.Q + o.s * (NX * NX))[r * NX + cq] = dt * (sh.Q[r * NX + cq] + (r == cq ? shift : 0.0)); }
-      if (tr) { acct += sh.Q[ct * NX + r] * dxr; if constexpr (MAT) (o.Q + o.s * (NX * NX))[r * NX + ct] = dt * (sh.Q[r * NX + ct] + (r == ct ? shift : 0.0)); }
-      if (ln < 6) { acch += sh.Q[ch * NX + r] * dxr; if constexpr (MAT) (o.Q + o.s * (NX * NX))[r * NX + ch] = dt * (sh.Q[r * NX + ch] + (r == ch ? shift : 0.0)); }
-      if (ln < 12) {
-        accf += sh.R[cf * NU + r] * dur;
-        const bool in_block = r < 12 && r / 3 == cf / 3;
-        if (MAT || in_block) {
-          double w = sh.R[r * NU + cf];
-          if (r == cf) w += shift;
-          if (stance_flag(mode, cf / 3) && in_block) {
-            const double* cn = nl.cone[r / 3];
-            const int a = r % 3, b2 = cf % 3;
-            const int lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
-            const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
-            w += cn[3] * cn[4 + a] * cn[4 + b2] + cn[2] * cn[7 + sidx];
-          }
-          if constexpr (MAT) (o.R + o.s * (NU * NU))[r * NU + cf] = dt * w;
-          if (in_block) (o.qrd + o.s * kQrdStride)[1 + 3 * cf + r % 3] = dt * w;
+      accq += sh.Q[cqs * NX + r] * dxr;
+      if constexpr (PACKED) acct += sh.Q[cts * NX + r] * dxr;
+      acch += sh.Q[chs * NX + r] * dxr;
+      accf += sh.R[cfs * NU + r] * dur;
+      accj += sh.R[cjs * NU + r] * dur;
+      if constexpr (MAT) {
+        double w = sh.R[r * NU + cfs];
+        if (r == cf) w += shift;
+        if (r < 12) {                    // the 3 x 3 block of a stance contact carries the cone Hessian
+          const double* cn = nl.cone[r / 3];
+          const int a = r % 3, b2 = cfs % 3;
+          const int lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
+          const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
+          const double wc = w + (cn[3] * cn[4 + a] * cn[4 + b2] + cn[2] * cn[7 + sidx]);
+          w = (cf_stance && r / 3 == cfs / 3) ? wc : w;
         }
+        slots.store(pqr, r * NX, dt * (sh.Q[r * NX + cqs] + (r == cq ? shift : 0.0)), dt * (sh.Q[r * NX + cts] + (r == ct ? shift : 0.0)),
+                    dt * (sh.Q[r * NX + chs] + (r == ch ? shift : 0.0)), dt * w, dt * (sh.R[r * NU + cjs] + (r == cj ? shift : 0.0)));
       }
-      if (is_joint) { accj += sh.R[cj * NU + r] * dur; if constexpr (MAT) (o.R + o.s * (NU * NU))[r * NU + cj] = dt * (sh.R[r * NU + cj] + (r == cj ? shift : 0.0)); }
+      // the sums are needed behind the loop only: left alone, their multiply-adds sink there and the 88 weights they read wait in registers
+      asm volatile("" : "+v"(accq), "+v"(acch), "+v"(accf), "+v"(accj));
+      if constexpr (PACKED) asm volatile("" : "+v"(acct));
+      BPMPC_LIN_ROW_FENCE();
+    }
+    // the node-dependent part of R in compact form: the three rows of the own 3 x 3 force block (lanes 0..11)
+    if (ln < 12) {
+      const int blk = cf / 3, b2 = cf % 3;
+      const double* cn = nl.cone[blk];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int r = 3 * blk + a;
+        double w = sh.R[r * NU + cf];
+        if (r == cf) w += shift;
+        if (cf_stance) {
+          const int lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
+          const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
+          w += cn[3] * cn[4 + a] * cn[4 + b2] + cn[2] * cn[7 + sidx];
+        }
+        (o.qrd + o.s * kQrdStride)[1 + 3 * cf + a] = dt * w;
+      }
     }
     if (g < G) { (o.q + o.s * (NX))[cq] = dt * accq; cost += 0.5 * nl.dx[cq] * accq; }
     if (tr) { (o.q + o.s * (NX))[ct] = dt * acct; cost += 0.5 * nl.dx[ct] * acct; }
@@ -818,8 +921,10 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   }
   LFPROF(5);
 #ifdef BPMPC_LINFAST_PROFILE
-  if (o.prof && ln == 0)
+  if (o.prof && ln == 0) {
+    lf_t[6] = clock64() - lf_c0; lf_t[7] = wall_clock64() - lf_wall0;
     for (int i = 0; i < 8; ++i) o.prof[i] = (double)lf_t[i];
+  }
 #endif
 #ifdef BPMPC_EVAL_PROFILE
   if (o.prof && ln == 0)

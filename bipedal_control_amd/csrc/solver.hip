@@ -334,6 +334,7 @@ void allocate(bpmpc_solver* s) {
   Buffers& b = s->buf;
   b.qrd = s->alloc<double>("qrd", S * kQrdStride);
   b.lin_park = s->alloc<double>("lin_park", S * kLinParkDoublesPerLane * (s->rm.nj == 10 ? LinFastCfg<10, true>::LPN : LinFastCfg<12, true>::LPN));
+  b.lin_dump = s->alloc<double>(nullptr, kLinDumpDoubles);
   b.x_prev = s->alloc<double>("x_prev", B * (N + 1) * NX); b.u_prev = s->alloc<double>("u_prev", S * NU);
   b.K_prev = s->alloc<double>("K_prev", S * NU * NX);
   b.tp_time = s->alloc<double>("tp_time", B * (N + 1)); b.tp_kind = s->alloc<int>("tp_kind", S, true);
@@ -379,7 +380,7 @@ void allocate(bpmpc_solver* s) {
   b.K = s->alloc<double>("K", S * NU * NX);   // feedback gains (also the forward roll-out operator of the fast Riccati kernel)
   b.Acl = s->alloc<double>("Acl", S * NX * NX); b.bcl = s->alloc<double>(nullptr, S * NX); b.kff = s->alloc<double>(nullptr, S * NU);
   b.mvec = s->alloc<double>(nullptr, S * NX); b.mscal = s->alloc<double>(nullptr, S);
-  b.rprof = s->alloc<double>("rprof", B * 8);
+  b.rprof = s->alloc<double>("rprof", std::max<size_t>(B * 8, 32768));      // debug slots of the profiling builds (phase cycles per problem; workgroup timeline of -DBPMPC_LIN_TIMELINE)
   b.summary = s->alloc<double>("summary", B * 4); b.dx0 = s->alloc<double>(nullptr, B * NX);
   b.trial_perf = s->alloc<double>("trial_perf", S * 3); b.base = s->alloc<double>("base", B * 3); b.alpha = s->alloc<double>("alpha", B);
   b.stats = s->alloc<double>("stats", B * kStatsStride);

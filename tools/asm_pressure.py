@@ -24,6 +24,7 @@ def regs_of(tok):
 def main():
     path, key = sys.argv[1], sys.argv[2]
     step = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    at = int(sys.argv[4]) if len(sys.argv) > 4 else None      # list the live ranges that cover this instruction
     lines = open(path).read().split('\n')
     start = next(i for i, l in enumerate(lines) if re.match(r'^[_A-Za-z0-9]+:', l) and key in l)
     end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end'))
@@ -71,6 +72,13 @@ def main():
             if r not in live or r not in s:
                 live[r] = [i, i]
     ranges += [tuple(v) for v in live.values()]
+    if at is not None:
+        import collections
+        short = lambda l: ' <- '.join(re.findall(r'(\w+\.h:\d+|\w+\.hip:\d+)', l)[:3])
+        by_def = collections.Counter((short(locs[a]), short(locs[b])) for a, b in ranges if a < at <= b)
+        for (d, u), n in sorted(by_def.items(), key=lambda kv: -kv[1])[:60]:
+            print('%3d regs  defined %-60s last use %s' % (n, d, u))
+        return
     for a, b in ranges:
         events[a] += 1
         events[b] -= 1
