@@ -54,6 +54,11 @@ DeviceModel make_device_model(const RobotModel& m) {
     d.cone_shift = 0.0;
     d.cone_gauss_newton = 1;
   }
+  d.serial_legs = (m.nj % 2 == 0) ? 1 : 0;
+  for (int b = 1; b <= m.nj && d.serial_legs; ++b) {
+    const bool head = (b == 1 || b == m.nj / 2 + 1);
+    if (m.parent[b] != (head ? 0 : b - 1)) d.serial_legs = 0;
+  }
   d.pos_gain = m.position_error_gain;
   d.robot_mass = m.robot_mass;
   return d;

@@ -24,6 +24,9 @@ struct DeviceModel {
   // hard friction cone (inequality constraint, penalised by the SQP solver through its LINEAR approximation): barrier_mu / barrier_delta hold
   // sqp.inequalityConstraintMu / Delta, cone_shift is 0 and the second derivative of the cone does not enter the Hessian (Gauss-Newton)
   int cone_gauss_newton;
+  // 1: the joints form two serial legs of nj / 2 joints each in body order (body b hangs on b - 1, the leg heads 1 and nj / 2 + 1 on the base):
+  // the lane-per-coordinate kernels then walk the tree by DPP shifts between neighbouring lanes (linearize_fast.h, CHAIN)
+  int serial_legs;
 };
 
 DeviceModel make_device_model(const RobotModel& m);

@@ -53,11 +53,11 @@ template <int NJ> constexpr int lin_waves() { return BPMPC_LIN_WAVES; }
 #ifndef BPMPC_LIN_WPE
 #define BPMPC_LIN_WPE __attribute__((amdgpu_waves_per_eu(2, BPMPC_LIN_WAVES > 4 ? 3 : 2)))
 #endif
-template <int NJ, bool MAT>
+template <int NJ, bool MAT, bool CHAIN>
 __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linearize_fast(Launch L) {
-  using C = LinFastCfg<NJ, true>;
+  using C = LinFastCfg<NJ, true, CHAIN>;
   constexpr int LPN = C::LPN, NPW = C::NPW, kLinWaves = lin_waves<NJ>();
-  __shared__ LinFastNodeLds<NJ> lds[kLinWaves * NPW];
+  __shared__ LinFastNodeLds<NJ, true, CHAIN> lds[kLinWaves * NPW];
   __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
 #ifdef BPMPC_LIN_TIMELINE                  // per workgroup: start, model staged, end (10 ns ticks) and the hardware id -> tools/lin_timeline.py
   const long long tl0 = wall_clock64();
@@ -328,8 +328,13 @@ void linearize_fast(int nj, bool materialise, int nodes, hipStream_t st, const L
   KL_NJ(nj, {
     constexpr int per_wg = lin_waves<NJ>() * LinFastCfg<NJ, true>::NPW;
     const int grid = (nodes + per_wg - 1) / per_wg;
-    if (materialise) hipLaunchKernelGGL((k_linearize_fast<NJ, true>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
-    else hipLaunchKernelGGL((k_linearize_fast<NJ, false>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
+    if (L.serial_legs) {            // two serial legs in lane order (DeviceModel::serial_legs): tree walks by DPP row shifts
+      if (materialise) hipLaunchKernelGGL((k_linearize_fast<NJ, true, true>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
+      else hipLaunchKernelGGL((k_linearize_fast<NJ, false, true>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
+    } else {                        // any tree: walks over LDS tables
+      if (materialise) hipLaunchKernelGGL((k_linearize_fast<NJ, true, false>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
+      else hipLaunchKernelGGL((k_linearize_fast<NJ, false, false>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
+    }
   });
 }
 void warm_shift(int nj, int slots, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_warm_shift<NJ>, dim3(slots), dim3(kWave), 0, st, L)); }

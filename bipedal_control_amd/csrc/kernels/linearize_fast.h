@@ -23,8 +23,15 @@ namespace bpmpc {
 // on the base position; their columns of df/dx are zero, of the contact Jacobians the identity), so lane l carries coordinate l + 3 and
 // the lanes 0..2 write those constant columns next to their other roles.  A node then fits 16 lanes and a wavefront serves four nodes
 // instead of two.  The roles that are numbered by LANE (momentum column l < 6, force column l < 12, contact l < 4) do not move.
-template <int NJ, bool PACK = false>
+// CHAIN: the robot is two serial legs of NJ / 2 joints whose joints sit in consecutive lanes in chain order (DeviceModel::serial_legs; every
+// robot of the reference is).  The tree walks of an evaluation - chain composition, joint twists, subtree sums of composites and momenta -
+// then run through DPP row shifts between neighbouring lanes (a joint's parent is the lane before it, its child the lane behind it): no LDS
+// table, no memory round trip per level (a wave of this kernel lived mostly in the ~40 dependent LDS round trips of those walks per
+// evaluation).  The arithmetic of the joint lanes is the table walk's operation for operation; the whole-robot sums associate differently.
+template <int NJ, bool PACK = false, bool CHAIN_ = false>
 struct LinFastCfg {
+  static constexpr bool CHAIN = CHAIN_;
+  static constexpr int LEG = NJ / 2;                 // joints per leg (CHAIN)
   static constexpr int NB = NJ + 1, G = 6 + NJ, NX = 12 + NJ, NU = 12 + NJ;
   static constexpr int G0 = (PACK && G > 16 && G - 3 <= 16) ? 3 : 0;   // coordinate of lane 0
   static constexpr int LPN = (G - G0 <= 16) ? 16 : 32;   // lanes per node
@@ -70,9 +77,10 @@ __device__ __forceinline__ void load_shared_model(const DeviceModel& md, LinFast
 //   joint origins og and velocities wv (twist walk of an evaluation) / cone terms (cost phase, after both evaluations)
 // Node-level results that every lane of the node computes identically (flow-map rows 0..5, base velocity, Euler sines / cosines) are
 // parked here by one lane and read back where they are used instead of occupying registers of all lanes across the derivative phases.
-template <int NJ, bool FULL = true>
+template <int NJ, bool FULL = true, bool CHAIN = false>
 struct LinFastNodeLds {
   using C = LinFastCfg<NJ>;
+  static constexpr int NT = CHAIN ? 1 : NJ, NBT = CHAIN ? 1 : C::NB, NW = CHAIN ? 3 : C::G - 3;   // CHAIN: no walk tables, only the Euler rates
   static constexpr bool kFull = FULL;
   // node inputs, staged once so that nothing is loaded from global memory after the first output store
   double x[C::NX], u[C::NU];
@@ -81,15 +89,15 @@ struct LinFastNodeLds {
     struct { double zref[FULL ? kNumContacts : 1], zdref[FULL ? kNumContacts : 1]; };   // value-only: swing references straight from HBM
   };
   union {
-    double T[NJ][9];             // joint-local rotation E of joint g-6 (its fixed offset is a model constant: LinFastShared::pfix)
+    double T[NT][9];             // joint-local rotation E of joint g-6 (its fixed offset is a model constant: LinFastShared::pfix)
     double a2[FULL ? 9 : 1][12]; // rows 3..11, x columns 0..11 of the stage-two Jacobian
-    double comp[C::NB][10];      // per body mass / first moment / inertia about o0
-    double hb[C::NB][6];         // per body momentum about o0
+    double comp[NBT][10];        // per body mass / first moment / inertia about o0
+    double hb[NBT][6];           // per body momentum about o0
     double cvel_full[FULL ? kNumContacts : 1][3];   // contact point velocities of the first stage (FULL)
     struct { double dx[C::NX], du[C::NU]; };   // cost vectors (both evaluations are done by then)
   };
   union {
-    struct { double og[C::G - 3][3], wv[C::G - 3][3]; };   // joint origins (coordinates 3..), a_g * v_g
+    struct { double og[NW][3], wv[NW][3]; };   // joint origins (coordinates 3..), a_g * v_g
     double cone[FULL ? kNumContacts : 1][FULL ? 13 : 1];   // value-only: the barrier value stays in the lane that computes it
   };
   double cpos_v[FULL ? 1 : kNumContacts][3], cvel_v[FULL ? 1 : kNumContacts][3];     // value-only: contact points and velocities of the current evaluation
@@ -118,6 +126,16 @@ __device__ __forceinline__ double node_allreduce_add(double x) {
   x = row16_allreduce_add(x);
   if (LPN == 32) x += __shfl_xor(x, 16);
   return x;
+}
+
+// x of the lane CTRL points at inside this lane's 16-lane DPP row (0.0 where that lane lies outside the row): row_shr:n = lane - n, row_shl:n = lane + n.
+// Must run with every lane of the row active (a disabled source lane does not deliver).
+constexpr int kDppRowShl = 0x100, kDppRowShr = 0x110;
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
 }
 
 // v[g] for g < 6 (0 otherwise) without dynamic register indexing (which would push the array into scratch memory)
@@ -173,6 +191,23 @@ struct LaneKin {    // what the contact part needs from the evaluation
   double sy, cy, sp, cp;   // Euler sines / cosines (world axes of the Euler joints)
 };
 
+// CHAIN: v[] holds this lane's own body entry (zeros in the lanes without a body) and becomes the sum over the subtree its coordinate
+// moves: joints add their child's finished sum level by level from the leaf up (the additions of the table loop, in its order); the
+// base body (coordinate 5) adds the two leg heads, the other base coordinates (whole robot) copy the base body's lane.
+template <class C, int N>
+__device__ __forceinline__ void chain_subtree_sum(double (&v)[N], int g, bool is_joint, int depth) {
+#pragma unroll
+  for (int d = C::LEG - 1; d >= 1; --d) {
+    const bool on = is_joint && depth == d;
+    for (int c = 0; c < N; ++c) { const double child = dpp_row_f64<kDppRowShl + 1>(v[c]); v[c] = on ? v[c] + child : v[c]; }
+  }
+  for (int c = 0; c < N; ++c) {
+    const double h1 = dpp_row_f64<kDppRowShl + 1>(v[c]), h2 = dpp_row_f64<kDppRowShl + 1 + C::LEG>(v[c]);
+    v[c] = g == 5 ? (v[c] + h1) + h2 : v[c];
+  }
+  for (int c = 0; c < N; ++c) { const double whole = __shfl(v[c], 5 - C::G0, C::LPN); v[c] = g < 5 ? whole : v[c]; }
+}
+
 // One evaluation of the centroidal dynamics for the node owned by this lane group.  `stage` selects where the node-level
 // results (A_b^{-1} blocks, contact points, com) are kept in LDS.
 #ifdef BPMPC_EVAL_PROFILE
@@ -201,22 +236,40 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
   kin.sy = sy; kin.cy = cy; kin.sp = sp; kin.cp = cp;
   if constexpr (NodeLds::kFull) { if (g == G0) { nl.trig[0] = sy; nl.trig[1] = cy; nl.trig[2] = sp; nl.trig[3] = cp; } }
   EVPROF(0);
-  // ---- joint-local transforms to LDS, chain walk
+  // ---- joint-local transforms (to LDS for the table walk), chain walk
+  double E[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
   if (is_joint) {
     const double* a = sh.axis[lb.body];
     const double v = 1.0 - cg;
     const double rot[9] = {cg + v * a[0] * a[0],        v * a[0] * a[1] - sg * a[2], v * a[0] * a[2] + sg * a[1],
                            v * a[1] * a[0] + sg * a[2], cg + v * a[1] * a[1],        v * a[1] * a[2] - sg * a[0],
                            v * a[2] * a[0] - sg * a[1], v * a[2] * a[1] + sg * a[0], cg + v * a[2] * a[2]};
-    double E[9];
     mat3_mul(sh.Rfix[lb.body], rot, E);
-    for (int i = 0; i < 9; ++i) nl.T[g - 6][i] = E[i];
+    if constexpr (!C::CHAIN) for (int i = 0; i < 9; ++i) nl.T[g - 6][i] = E[i];
   }
-  lds_wave_sync();
+  if constexpr (!C::CHAIN) lds_wave_sync();
   double R[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
                  -sp, cp * sr, cp * cr};
   double o[3] = {pb[0], pb[1], pb[2]};
   const int maxdepth = md.max_depth;
+  if constexpr (C::CHAIN) {
+    // level by level: a joint of depth d composes the frame of its parent - the base (d = 1) or the lane before it, which finished at
+    // level d - 1 - with its own local transform: the same two products as a step of the table walk, in the same order
+    const double* pfx = sh.pfix[lb.body];
+    const double pj[3] = {pfx[0], pfx[1], pfx[2]};
+#pragma unroll
+    for (int d = 1; d <= C::LEG; ++d) {
+      double Rp[9], op[3];
+      if (d == 1) { for (int i = 0; i < 9; ++i) Rp[i] = R[i]; for (int i = 0; i < 3; ++i) op[i] = o[i]; }
+      else { for (int i = 0; i < 9; ++i) Rp[i] = dpp_row_f64<kDppRowShr + 1>(R[i]); for (int i = 0; i < 3; ++i) op[i] = dpp_row_f64<kDppRowShr + 1>(o[i]); }
+      double t[3], Rn[9];
+      mat3_vec(Rp, pj, t);
+      mat3_mul(Rp, E, Rn);
+      const bool on = is_joint && lb.depth == d;
+      for (int i = 0; i < 3; ++i) o[i] = on ? op[i] + t[i] : o[i];
+      for (int i = 0; i < 9; ++i) R[i] = on ? Rn[i] : R[i];
+    }
+  } else
 #pragma nounroll
   for (int d = 0; d < maxdepth; ++d) {
     const bool on = is_joint && d < lb.depth;
@@ -239,6 +292,8 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
   for (int i = 0; i < 3; ++i) { kin.ah[i] = ah[i]; kin.og[i] = o[i]; }
   EVPROF(1);
   // ---- body quantities, contact positions
+  double s[10];                      // the lane's composite (CHAIN: starts as its own body's entry)
+  for (int c = 0; c < 10; ++c) s[c] = 0.0;
   double cw[3] = {0.0, 0.0, 0.0}, Iwb[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (is_body) {
     double cb[3], d[3];
@@ -256,7 +311,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
     Iwb[5] = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
     const double m = sh.mass[lb.body];
     const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    double* cm = nl.comp[lb.body];
+    double* cm = C::CHAIN ? s : nl.comp[lb.body];
     cm[0] = m;
     cm[1] = m * d[0]; cm[2] = m * d[1]; cm[3] = m * d[2];
     cm[4] = Iwb[0] + m * (dd - d[0] * d[0]);
@@ -275,12 +330,13 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
   lds_wave_sync();
   EVPROF(2);
   // ---- subtree sums -> composite mass, com, inertia about the composite com (lanes below 5 see the whole robot)
-  double s[10];
-  for (int c = 0; c < 10; ++c) s[c] = 0.0;
+  if constexpr (C::CHAIN) chain_subtree_sum<C, 10>(s, g, is_joint, lb.depth);
+  else {
 #pragma nounroll
-  for (int m = NB - 1; m >= 0; --m) {
-    const double sel = ((lb.subtree >> m) & 1u) ? 1.0 : 0.0;
-    for (int c = 0; c < 10; ++c) s[c] += sel * nl.comp[m][c];
+    for (int m = NB - 1; m >= 0; --m) {
+      const double sel = ((lb.subtree >> m) & 1u) ? 1.0 : 0.0;
+      for (int c = 0; c < 10; ++c) s[c] += sel * nl.comp[m][c];
+    }
   }
   const double Mc = s[0];
   const double invM = Mc > 0.0 ? 1.0 / Mc : 0.0;
@@ -361,8 +417,10 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
   if constexpr (TWIST) {
   EVPROF(4);
   // ---- twists: omega_g = sum over the revolute ancestors (self included) of a v, v_og = velocity of the joint origin
-  if (g >= 3 && g < G) {
-    for (int i = 0; i < 3; ++i) { nl.wv[g - 3][i] = ah[i] * vg; nl.og[g - 3][i] = o[i]; }
+  const double wvo[3] = {ah[0] * vg, ah[1] * vg, ah[2] * vg};
+  if constexpr (C::CHAIN) { if (g >= 3 && g < 6) for (int i = 0; i < 3; ++i) nl.wv[g - 3][i] = wvo[i]; }
+  else if (g >= 3 && g < G) {
+    for (int i = 0; i < 3; ++i) { nl.wv[g - 3][i] = wvo[i]; nl.og[g - 3][i] = o[i]; }
   }
   lds_wave_sync();
   {
@@ -372,6 +430,24 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
       for (int i = 0; i < 3; ++i) om[i] += sel * nl.wv[k - 3][i];
     }
     double prev[3] = {pb[0], pb[1], pb[2]};
+    if constexpr (C::CHAIN) {
+      // level by level as the composition: the parent's twist (angular velocity with its own joint rate, velocity of its origin) and origin
+      // come from the base (depth 1) or from the lane before
+#pragma unroll
+      for (int d = 1; d <= C::LEG; ++d) {
+        double omp[3], vop[3], orp[3];
+        if (d == 1) { for (int i = 0; i < 3; ++i) { omp[i] = om[i]; vop[i] = vo[i]; orp[i] = prev[i]; } }
+        else { for (int i = 0; i < 3; ++i) { omp[i] = dpp_row_f64<kDppRowShr + 1>(om[i]); vop[i] = dpp_row_f64<kDppRowShr + 1>(vo[i]); orp[i] = dpp_row_f64<kDppRowShr + 1>(o[i]); } }
+        const double r[3] = {o[0] - orp[0], o[1] - orp[1], o[2] - orp[2]};
+        double t[3];
+        cross3(omp, r, t);
+        const bool on = is_joint && lb.depth == d;
+        for (int i = 0; i < 3; ++i) {
+          vo[i] = on ? vop[i] + t[i] : vo[i];
+          om[i] = on ? omp[i] + wvo[i] : om[i];
+        }
+      }
+    } else
 #pragma nounroll
     for (int d = 0; d < maxdepth; ++d) {
       const bool on = is_joint && d < lb.depth;
@@ -393,6 +469,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
   if constexpr (DERIV) {
   EVPROF(5);
   // ---- body momenta about o0 (hb shares LDS with comp, which is dead now), subtree momenta
+  double hs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (is_body) {
     const double rc[3] = {cw[0] - o[0], cw[1] - o[1], cw[2] - o[2]};
     double t[3], l[3], Iw[3], L[3];
@@ -402,14 +479,17 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
     sym3_mul(Iwb, om, Iw);
     const double d0[3] = {cw[0] - pb[0], cw[1] - pb[1], cw[2] - pb[2]};
     cross3(d0, l, L);
-    for (int i = 0; i < 3; ++i) { nl.hb[lb.body][i] = l[i]; nl.hb[lb.body][3 + i] = Iw[i] + L[i]; }
+    if constexpr (C::CHAIN) for (int i = 0; i < 3; ++i) { hs[i] = l[i]; hs[3 + i] = Iw[i] + L[i]; }
+    else for (int i = 0; i < 3; ++i) { nl.hb[lb.body][i] = l[i]; nl.hb[lb.body][3 + i] = Iw[i] + L[i]; }
   }
-  lds_wave_sync();
-  double hs[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if constexpr (C::CHAIN) chain_subtree_sum<C, 6>(hs, g, is_joint, lb.depth);
+  else {
+    lds_wave_sync();
 #pragma nounroll
-  for (int m = NB - 1; m >= 0; --m) {
-    const double sel = ((lb.subtree >> m) & 1u) ? 1.0 : 0.0;
-    for (int c = 0; c < 6; ++c) hs[c] += sel * nl.hb[m][c];
+    for (int m = NB - 1; m >= 0; --m) {
+      const double sel = ((lb.subtree >> m) & 1u) ? 1.0 : 0.0;
+      for (int c = 0; c < 6; ++c) hs[c] += sel * nl.hb[m][c];
+    }
   }
   const double ltot[3] = {__shfl(hs[0], 5 - G0, LPN), __shfl(hs[1], 5 - G0, LPN), __shfl(hs[2], 5 - G0, LPN)};
   EVPROF(6);
@@ -556,8 +636,8 @@ struct RoleSlots {
 // of variables), b, q, r, the nc rows of C, D, e, the 320-byte record of the node-dependent part of Q and R; 9.6 instead of 21.8 KB per
 // node.  The numbers that are written are the same bits in both modes.
 // `ln`: lane inside the node's lane group; it carries coordinate g = ln + G0 (LinFastCfg) and the lane-numbered roles.
-template <int NJ, bool MAT = true, class Cfg = LinFastCfg<NJ, true>>
-__device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, LinFastNodeLds<NJ>& nl, bool valid,
+template <int NJ, bool MAT = true, class Cfg = LinFastCfg<NJ, true>, class NL = LinFastNodeLds<NJ, true, Cfg::CHAIN>>
+__device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, NL& nl, bool valid,
                                                const NodeInputs& in, const LinFastOut& o, int ln) {
 #ifdef BPMPC_LINFAST_PROFILE
   long long lf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -626,9 +706,9 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   LaneKin<NJ> kin;
 #ifdef BPMPC_EVAL_PROFILE
   long long evacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  eval_lane<NJ, true, true, LinFastNodeLds<NJ>, LinFastShared<NJ>, C>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin, evacc);
+  eval_lane<NJ, true, true, NL, LinFastShared<NJ>, C>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin, evacc);
 #else
-  eval_lane<NJ, true, true, LinFastNodeLds<NJ>, LinFastShared<NJ>, C>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
+  eval_lane<NJ, true, true, NL, LinFastShared<NJ>, C>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
 #endif
   LFPROF(1);
   // park the stage-one columns (HBM scratch) for the RK2 combination
@@ -752,7 +832,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     const double* xh2 = nl.xh2;      // published by the lds_wave_sync at the top of eval_lane
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
-    eval_lane<NJ, true, true, LinFastNodeLds<NJ>, LinFastShared<NJ>, C>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
+    eval_lane<NJ, true, true, NL, LinFastShared<NJ>, C>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
     BPMPC_LIN_ROW_FENCE();           // keeps the loads of the combination phase (parked columns, stage-one blocks) out of the evaluation's registers
     lds_wave_sync();
     v2t = tr ? nl.vlin[1][ln] : 0.0;

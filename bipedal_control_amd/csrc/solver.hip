@@ -100,6 +100,7 @@ struct bpmpc_solver {
   // BPMPC_RICCATI_WAVE: 0 never a wave per problem; 1 (default) as described; 2 riccati_wave.h at every batch size, 4 riccati_wave2.h at every
   // batch size (tests); 3 riccati_wave2.h whenever a wave per problem is used
   int riccati_wave = 1;
+  bool force_tables = false;                                // BPMPC_LIN_TABLES=1: the table walks also on a robot of two serial legs (tests)
   int trial_wide_from = 16;                                 // workgroups per CU from which the value-only kernel runs at one more wave per SIMD (BPMPC_TRIAL_WIDE_FROM)
   bool riccati_double_buffered() const { return riccati_wave != 2 && riccati_wave != 4 && batch <= num_cus; }
   bool has_solution = false;                               // a solve has completed on the current setup
@@ -145,6 +146,7 @@ struct bpmpc_solver {
     // workgroups onto batch x klen node slots and every slot beyond a problem's grid is a lane group that idles
     L.klen = n_nodes_max > 0 ? n_nodes_max : settings.max_nodes;
     L.cold = cold ? 1 : 0;
+    L.serial_legs = (dm.serial_legs && !force_tables) ? 1 : 0;
     L.ls = ls;
     L.reg_prim = settings.reg_prim;
     return L;
@@ -781,6 +783,7 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     HIP_CHECK(hipSetDevice(settings->device));
     { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, settings->device)); s->num_cus = prop.multiProcessorCount; }
     { const char* e = std::getenv("BPMPC_TRIAL_WIDE_FROM"); if (e) s->trial_wide_from = std::max(0, std::atoi(e)); }
+    { const char* e = std::getenv("BPMPC_LIN_TABLES"); s->force_tables = e && e[0] == '1'; }
     { const char* e = std::getenv("BPMPC_RICCATI_WAVE"); s->riccati_wave = e ? std::atoi(e) : 1; }
     {
       bool block_diagonal = true;
