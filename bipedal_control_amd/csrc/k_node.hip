@@ -57,7 +57,10 @@ template <int NJ, bool MAT, bool CHAIN>
 __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linearize_fast(Launch L) {
   using C = LinFastCfg<NJ, true, CHAIN>;
   constexpr int LPN = C::LPN, NPW = C::NPW, kLinWaves = lin_waves<NJ>();
-  __shared__ LinFastNodeLds<NJ, true, CHAIN> lds[kLinWaves * NPW];
+  // the stage-one columns wait in LDS when two workgroups per CU (eight waves: the registers allow no more) still fit, else in HBM scratch
+  constexpr bool PARK = sizeof(LinFastNodeLds<NJ, true, CHAIN, true>) * (kLinWaves * NPW) + sizeof(LinFastShared<NJ>) <= 80 * 1024;
+  using NL = LinFastNodeLds<NJ, true, CHAIN, PARK>;
+  __shared__ NL lds[kLinWaves * NPW];
   __shared__ LinFastShared<NJ> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
 #ifdef BPMPC_LIN_TIMELINE                  // per workgroup: start, model staged, end (10 ns ticks) and the hardware id -> tools/lin_timeline.py
   const long long tl0 = wall_clock64();
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linea
 #define BPMPC_LIN_PROF_PROBLEM 0     // the problem whose first 64 nodes report their phase cycles (-DBPMPC_LINFAST_PROFILE): 0 runs on an empty chip, batch / 2 in steady state
 #endif
   out.prof = (valid && b == BPMPC_LIN_PROF_PROBLEM && k < 64) ? L.buf.rprof + 8 * k : nullptr;
-  linearize_fast<NJ, MAT, C>(*L.model, shared, lds[sub], valid, in, out, g);      // g: lane inside the node's group
+  linearize_fast<NJ, MAT, C, NL>(*L.model, shared, lds[sub], valid, in, out, g);      // g: lane inside the node's group
 #ifdef BPMPC_LIN_TIMELINE
   if (threadIdx.x % kWave == 0 && blockIdx.x < 2048) {      // every wave: the workgroup's end is the latest of its waves
     double* t = L.buf.rprof + 16 * blockIdx.x + 4 * (threadIdx.x / kWave);

@@ -77,8 +77,9 @@ __device__ __forceinline__ void load_shared_model(const DeviceModel& md, LinFast
 //   joint origins og and velocities wv (twist walk of an evaluation) / cone terms (cost phase, after both evaluations)
 // Node-level results that every lane of the node computes identically (flow-map rows 0..5, base velocity, Euler sines / cosines) are
 // parked here by one lane and read back where they are used instead of occupying registers of all lanes across the derivative phases.
-template <int NJ, bool FULL = true, bool CHAIN = false>
+template <int NJ, bool FULL = true, bool CHAIN = false, bool PARK = false>
 struct LinFastNodeLds {
+  static constexpr bool kPark = PARK;   // the stage-one Jacobian columns wait in LDS (when two workgroups per CU still fit) instead of in HBM scratch
   using C = LinFastCfg<NJ>;
   static constexpr int NT = CHAIN ? 1 : NJ, NBT = CHAIN ? 1 : C::NB, NW = CHAIN ? 3 : C::G - 3;   // CHAIN: no walk tables, only the Euler rates
   static constexpr bool kFull = FULL;
@@ -104,6 +105,7 @@ struct LinFastNodeLds {
   // node-level results of the two stages: A_b^{-1} blocks, contact points, com, flow-map rows 0..5, base linear velocity, Euler sin / cos
   double X12[FULL ? 2 : 1][FULL ? 9 : 1], X22[FULL ? 2 : 1][FULL ? 9 : 1], cps[FULL ? 2 : 1][FULL ? kNumContacts : 1][3], com[FULL ? 2 : 1][3];
   double fh[FULL ? 2 : 1][FULL ? 6 : 1], vlin[FULL ? 2 : 1][FULL ? 3 : 1], trig[FULL ? 4 : 1];
+  double park[(FULL && PARK) ? 15 : 1][(FULL && PARK) ? 16 : 1];   // [row][lane]: rows 3..11 of x column 6+g, rows 6..11 of the joint-velocity column
   // contact points / velocities of an evaluation (FULL: the stage's own copy, kept for the RK2 combination)
   __device__ __forceinline__ double (*cpos(int stage))[3] { if constexpr (FULL) return cps[stage]; else return cpos_v; }
   __device__ __forceinline__ double (*cvel())[3] { if constexpr (FULL) return cvel_full; else return cvel_v; }
@@ -636,7 +638,7 @@ struct RoleSlots {
 // of variables), b, q, r, the nc rows of C, D, e, the 320-byte record of the node-dependent part of Q and R; 9.6 instead of 21.8 KB per
 // node.  The numbers that are written are the same bits in both modes.
 // `ln`: lane inside the node's lane group; it carries coordinate g = ln + G0 (LinFastCfg) and the lane-numbered roles.
-template <int NJ, bool MAT = true, class Cfg = LinFastCfg<NJ, true>, class NL = LinFastNodeLds<NJ, true, Cfg::CHAIN>>
+template <int NJ, bool MAT = true, class Cfg = LinFastCfg<NJ, true>, class NL = LinFastNodeLds<NJ, true, Cfg::CHAIN, false>>
 __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, NL& nl, bool valid,
                                                const NodeInputs& in, const LinFastOut& o, int ln) {
 #ifdef BPMPC_LINFAST_PROFILE
@@ -712,7 +714,10 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
 #endif
   LFPROF(1);
   // park the stage-one columns (HBM scratch) for the RK2 combination
-  {
+  if constexpr (NL::kPark) {
+    for (int rr = 0; rr < 9; ++rr) nl.park[rr][ln] = e1.ar_q[rr];
+    for (int rr = 0; rr < 6; ++rr) nl.park[9 + rr][ln] = e1.br_j[rr];
+  } else {
     double* pk = o.park + o.s * (15 * LPN);
     for (int rr = 0; rr < 9; ++rr) pk[rr * LPN + ln] = e1.ar_q[rr];
     for (int rr = 0; rr < 6; ++rr) pk[9 * LPN + rr * LPN + ln] = is_joint ? e1.br_j[rr] : 0.0;   // whole 128-byte lines
@@ -850,7 +855,11 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   lds_wave_sync();
   // rows of A and B;  A = I + dt/2 (A1 + A2 + dt A2 A1),  B = dt/2 (B1 + B2 + dt A2 B1)
   double c1q[9], c1h[9], c1f[9], c1j[9];
-  {
+  if constexpr (NL::kPark) {
+    for (int rr = 0; rr < 9; ++rr) c1q[rr] = nl.park[rr][ln];
+    for (int rr = 0; rr < 3; ++rr) c1j[rr] = 0.0;
+    for (int rr = 3; rr < 9; ++rr) c1j[rr] = is_joint ? nl.park[9 + rr - 3][ln] : 0.0;
+  } else {
     const double* pk = o.park + o.s * (15 * LPN);
     for (int rr = 0; rr < 9; ++rr) c1q[rr] = pk[rr * LPN + ln];
     for (int rr = 0; rr < 9; ++rr) c1j[rr] = 0.0;
