@@ -240,13 +240,18 @@ def main():
         if use_dist:
             report = [float(v) for v in bd.reduce_stats(report).tolist()]
             # every rank holds everybody's result: rank 0's copy of the last rank's block must be what that rank computed
+            # (checksum of the BIT PATTERNS, folded to 52 bits so that it travels exactly in a double: a floating-point sum of the same numbers
+            #  depends on the reduction order torch picks for the alignment of the view - 1 ulp apart between the local block and its gathered copy)
+            def bit_checksum(tv):
+                w = tv.contiguous().view(torch.int64)
+                return float(int(((w & 0xFFFFFFFF).sum() + (w >> 32).sum()).item()) % (1 << 52))
             probe = torch.zeros(2, dtype=torch.float64)
             if rank == world - 1:
-                probe = torch.tensor([float(gather.x_local.sum()), float(gather.u_local.sum())], dtype=torch.float64)
+                probe = torch.tensor([bit_checksum(gather.x_local), bit_checksum(gather.u_local)], dtype=torch.float64)
             probe = bd.reduce_stats(probe.tolist())
             if args.gather == "all" or rank == 0:       # (gather to root: only rank 0 holds the other ranks' blocks)
                 xb, ub = gather.block(world - 1)
-                gathered_ok = gathered_ok and float(xb.sum()) == float(probe[0]) and float(ub.sum()) == float(probe[1])
+                gathered_ok = gathered_ok and bit_checksum(xb) == float(probe[0]) and bit_checksum(ub) == float(probe[1])
         ktimes = {k: mpc.kernel_time(k, reset=False) for k in KERNEL_CLASSES}
         # ---- second timed region: the fused solve mode, same problems, same number of steps, no kernel carries an event pair
         fused = None
