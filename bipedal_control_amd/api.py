@@ -141,7 +141,8 @@ class BipedalRobotInterface:
 
     def sqpSettings(self):
         v = self.get("sqp")
-        return dict(dt=v[0], sqpIteration=int(v[1]), deltaTol=v[2], g_max=v[3], g_min=v[4])
+        return dict(dt=v[0], sqpIteration=int(v[1]), deltaTol=v[2], g_max=v[3], g_min=v[4], useFeedbackPolicy=bool(v[5]),
+                    projectStateInputEqualityConstraints=bool(v[6]), integratorType="RK2")
 
     _IPM_FIELDS = ("dt", "ipmIteration", "deltaTol", "g_max", "g_min", "computeLagrangeMultipliers", "useFeedbackPolicy", "initialBarrierParameter",
                    "targetBarrierParameter", "barrierLinearDecreaseFactor", "barrierSuperlinearDecreasePower", "barrierReductionCostTol",

@@ -33,6 +33,8 @@ int guarded(F&& body) {
     return fail(BPMPC_ERR_CAPACITY, e.what());
   } catch (const std::invalid_argument& e) {
     return fail(BPMPC_ERR_INVALID_ARGUMENT, e.what());
+  } catch (const UnsupportedSetting& e) {
+    return fail(BPMPC_ERR_UNSUPPORTED, e.what());
   } catch (const std::exception& e) {
     return fail(BPMPC_ERR_IO, e.what());
   }
@@ -106,7 +108,8 @@ int bpmpc_model_get(const bpmpc_model* m, const char* name, double* out, int cap
     if (n == "hard_cone") return list({r.hard_friction_cone ? 1.0 : 0.0, r.sqp_inequality_mu, r.sqp_inequality_delta});
     if (n == "swing") return list({r.swing.lift_off_velocity, r.swing.touch_down_velocity, r.swing.swing_height, r.swing.swing_time_scale});
     if (n == "rollout") return list({r.rollout.abs_tol, r.rollout.rel_tol, r.rollout.time_step, (double)r.rollout.max_steps_per_second, r.mrt_frequency, r.mpc_frequency});
-    if (n == "sqp") return list({r.sqp.dt, (double)r.sqp.sqp_iteration, r.sqp.delta_tol, r.sqp.g_max, r.sqp.g_min});
+    if (n == "sqp") return list({r.sqp.dt, (double)r.sqp.sqp_iteration, r.sqp.delta_tol, r.sqp.g_max, r.sqp.g_min, (double)r.sqp.use_feedback_policy,
+                                 1.0 /* projectStateInputEqualityConstraints */, 0.0 /* integratorType: 0 = RK2 */});
     // settings blocks the reference loads beside sqp (BipedalRobotInterface.cpp:98-100); field order documented in include/bpmpc.h
     if (n == "ipm") {
       const IpmConfig& p = r.ipm;

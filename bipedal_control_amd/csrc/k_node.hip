@@ -159,6 +159,10 @@ __global__ __launch_bounds__(kWave) void k_warm_shift(Launch L) {
   double a;
   time_segment(tp, np + 1, L.buf.g_start[(size_t)g * N + i], &j, &a);
   const int e0 = effective(j), e1 = effective(j + 1);
+  if (!L.feedback) {      // FeedforwardController (sqp.useFeedbackPolicy false): the interpolated input trajectory, no state feedback
+    if (l < NU) u[(size_t)i * NU + l] = a * up[(size_t)e0 * NU + l] + (1.0 - a) * up[(size_t)e1 * NU + l];
+    return;
+  }
   for (int idx = l; idx < NU * NX; idx += kWave) {
     Ks[0][idx] = Kp[(size_t)e0 * NU * NX + idx];
     Ks[1][idx] = Kp[(size_t)e1 * NU * NX + idx];
@@ -198,12 +202,12 @@ __global__ __launch_bounds__(kWave) void k_trial(Launch L) {
 // per CU since the node tables share one storage).  nx = 24: three (168 registers) - line search 0.492 -> 0.404 ms on G1 / 1024, 0.152 ->
 // 0.129 at batch 256.  nx = 22: four (128 registers) pays once the launch has several rounds of workgroups (1.18 -> 1.13 ms at batch 4096),
 // is neutral at batch 512 and loses at 256 (0.108 -> 0.112): chosen per launch, WIDE.
-template <int NJ, bool WIDE>
+template <int NJ, bool WIDE, bool CHAIN>
 __global__ __launch_bounds__(kTrialWaves * kWave) __attribute__((amdgpu_waves_per_eu(NJ <= 10 ? (WIDE ? 4 : 3) : 3, NJ <= 10 ? (WIDE ? 4 : 3) : 3)))
 void k_trial_fast(Launch L) {
-  using C = LinFastCfg<NJ, true>;
+  using C = LinFastCfg<NJ, true, CHAIN>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
-  __shared__ LinFastNodeLds<NJ, false> lds[kTrialWaves * NPW];
+  __shared__ LinFastNodeLds<NJ, false, CHAIN> lds[kTrialWaves * NPW];
   __shared__ LinFastShared<NJ, false> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
   load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
   __syncthreads();
@@ -223,11 +227,11 @@ void k_trial_fast(Launch L) {
 
 // Values of the active equality rows at the CURRENT iterate (after a solve: the solution), per node in registration order: the value-only
 // evaluation of the line search with a zero step and one more output (linearize_fast.h trial_fast<.., EQV>).
-template <int NJ>
+template <int NJ, bool CHAIN>
 __global__ __launch_bounds__(kTrialWaves * kWave) void k_constraint_values(Launch L, double* eqv) {
-  using C = LinFastCfg<NJ, true>;
+  using C = LinFastCfg<NJ, true, CHAIN>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
-  __shared__ LinFastNodeLds<NJ, false> lds[kTrialWaves * NPW];
+  __shared__ LinFastNodeLds<NJ, false, CHAIN> lds[kTrialWaves * NPW];
   __shared__ LinFastShared<NJ, false> shared;
   load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
   __syncthreads();
@@ -265,13 +269,13 @@ __global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L) {
 // are alone on their CUs and what they cost is the latency of their rounds: eight waves walk the horizon in half the chunks of four
 // (the sums are the ones of k_ls_decide term by term while the horizon has at most kDecideThreads nodes).
 constexpr int kTailThreads = 512;
-template <int NJ>
+template <int NJ, bool CHAIN>
 __global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int max_trials) {
-  using C = LinFastCfg<NJ, true>;
+  using C = LinFastCfg<NJ, true, CHAIN>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW, CHUNK = (kTailThreads / kWave) * NPW;
   const int b = blockIdx.x;
   if (L.buf.done[b]) return;
-  __shared__ LinFastNodeLds<NJ, false> lds[CHUNK];
+  __shared__ LinFastNodeLds<NJ, false, CHAIN> lds[CHUNK];
   __shared__ LinFastShared<NJ, false> shared;
   __shared__ double partial[3 * kTailThreads + 5];
   load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTailThreads);
@@ -350,17 +354,28 @@ int trial_fast_workgroups(int nj, int nodes) {
 void trial_fast(int nj, bool wide, int nodes, hipStream_t st, const Launch& L) {
   const int grid = trial_fast_workgroups(nj, nodes);
   KL_NJ(nj, {
-    if (wide && NJ <= 10) hipLaunchKernelGGL((k_trial_fast<NJ, true>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
-    else hipLaunchKernelGGL((k_trial_fast<NJ, false>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
+    if (L.serial_legs) {
+      if (wide && NJ <= 10) hipLaunchKernelGGL((k_trial_fast<NJ, true, true>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
+      else hipLaunchKernelGGL((k_trial_fast<NJ, false, true>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
+    } else {
+      if (wide && NJ <= 10) hipLaunchKernelGGL((k_trial_fast<NJ, true, false>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
+      else hipLaunchKernelGGL((k_trial_fast<NJ, false, false>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
+    }
   });
 }
 void ls_decide(int nj, int batch, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, st, L)); }
 void ls_tail(int nj, int batch, hipStream_t st, const Launch& L, int max_trials) {
-  KL_NJ(nj, hipLaunchKernelGGL(k_ls_tail<NJ>, dim3(batch), dim3(kTailThreads), 0, st, L, max_trials));
+  KL_NJ(nj, {
+    if (L.serial_legs) hipLaunchKernelGGL((k_ls_tail<NJ, true>), dim3(batch), dim3(kTailThreads), 0, st, L, max_trials);
+    else hipLaunchKernelGGL((k_ls_tail<NJ, false>), dim3(batch), dim3(kTailThreads), 0, st, L, max_trials);
+  });
 }
 void constraint_values(int nj, int nodes, hipStream_t st, const Launch& L, double* eqv) {
   const int grid = trial_fast_workgroups(nj, nodes);
-  KL_NJ(nj, hipLaunchKernelGGL(k_constraint_values<NJ>, dim3(grid), dim3(kTrialWaves * kWave), 0, st, L, eqv));
+  KL_NJ(nj, {
+    if (L.serial_legs) hipLaunchKernelGGL((k_constraint_values<NJ, true>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L, eqv);
+    else hipLaunchKernelGGL((k_constraint_values<NJ, false>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L, eqv);
+  });
 }
 void rollout(int nj, int batch, hipStream_t st, const DeviceModel* model, const RolloutArgs& a) {
   KL_NJ(nj, hipLaunchKernelGGL(k_rollout<NJ>, dim3((batch + LinFastCfg<NJ>::NPW - 1) / LinFastCfg<NJ>::NPW), dim3(kWave), 0, st, model, a));

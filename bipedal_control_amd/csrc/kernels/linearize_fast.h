@@ -1025,8 +1025,8 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
 // linearize_fast; reference version: trial_node in linesearch.h).
 // EQV: also store the values of the active equality rows (registration order zeroForce_i, zeroVelocity_i, normalVelocity_i per contact,
 // BipedalRobotInterface.cpp:187-191) to eqv[0..nc): the solution metrics of the solver observers (bpmpc_solver_constraint_values).
-template <int NJ, class Cfg = LinFastCfg<NJ, true>, bool EQV = false>
-__device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastShared<NJ, false>& sh, LinFastNodeLds<NJ, false>& nl, bool valid,
+template <int NJ, class Cfg = LinFastCfg<NJ, true>, bool EQV = false, class NL = LinFastNodeLds<NJ, false, Cfg::CHAIN>>
+__device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastShared<NJ, false>& sh, NL& nl, bool valid,
                                            const NodeInputs& in, double alpha, const double* dx, const double* du, const double* dxn,
                                            double* perf, int ln, double* eqv = nullptr) {
   using C = Cfg;
@@ -1069,7 +1069,7 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
   LaneEval e1;
   LaneKin<NJ> kin;
-  eval_lane<NJ, false, true, LinFastNodeLds<NJ, false>, LinFastShared<NJ, false>, C>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
+  eval_lane<NJ, false, true, NL, LinFastShared<NJ, false>, C>(md, sh, nl, 0, lb, path, g, xh, qg, ujg, e1, kin);
   const double v1t = ln == 0 ? kin.vb[0] : (ln == 1 ? kin.vb[1] : kin.vb[2]);
   if (g >= 5 && g < G)
     for (int i = 0; i < kNumContacts; ++i)
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
     const double* xh2 = nl.xh2;      // published by the lds_wave_sync at the top of eval_lane
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
-    eval_lane<NJ, false, false, LinFastNodeLds<NJ, false>, LinFastShared<NJ, false>, C>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
+    eval_lane<NJ, false, false, NL, LinFastShared<NJ, false>, C>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
     v2t = ln == 0 ? kin2.vb[0] : (ln == 1 ? kin2.vb[1] : kin2.vb[2]);
   }
   double dyn_sse = 0.0;

@@ -41,6 +41,7 @@ struct RolloutArgs {
   const double* x_start;              // [batch][NX]
   double duration, abs_tol, rel_tol, time_step;
   int max_steps;
+  int feedback;                       // sqp.useFeedbackPolicy: 1 LinearController u = uff(t) + K(t) x, 0 FeedforwardController u = u(t)
   double* x_end;                      // [batch][NX]
   double* u_end;                      // [batch][NU]: controller at the final time and state
   int* steps;                         // [batch][2]: accepted, rejected
@@ -141,11 +142,12 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
       const double* K0 = w.Kc[sub][0] + r * NX;
       const double* K1 = w.Kc[sub][1] + r * NX;
       double s0 = w.uc[sub][0][r], s1 = w.uc[sub][1][r];
-      for (int c = 0; c < NX; ++c) {
-        const double xc = nl.x[c];
-        s0 += K0[c] * (xc - w.xc[sub][0][c]);
-        s1 += K1[c] * (xc - w.xc[sub][1][c]);
-      }
+      if (a.feedback)
+        for (int c = 0; c < NX; ++c) {
+          const double xc = nl.x[c];
+          s0 += K0[c] * (xc - w.xc[sub][0][c]);
+          s1 += K1[c] * (xc - w.xc[sub][1][c]);
+        }
       nl.u[r] = al * s0 + (1.0 - al) * s1;
     }
     lds_wave_sync();

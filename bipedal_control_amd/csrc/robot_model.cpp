@@ -209,6 +209,16 @@ RobotModel load_robot_model(const std::string& urdf_path, const std::string& tas
   task->get("sqp.deltaTol", &m.sqp.delta_tol);
   task->get("sqp.g_max", &m.sqp.g_max);
   task->get("sqp.g_min", &m.sqp.g_min);
+  {
+    // what the reference hands to SqpMpc as sqp::Settings (BipedalController.cpp:303-306, BipedalRobotInterface.cpp:99) and this engine
+    // does not implement is refused, not ignored: a drop-in must not run a different optimiser silently
+    std::string v;
+    if (task->get("sqp.integratorType", &v) && v != "RK2")
+      throw UnsupportedSetting("task.info: sqp.integratorType " + v + " is not implemented (RK2 sensitivities only)");
+    if (task->get("sqp.projectStateInputEqualityConstraints", &v) && !(v == "true" || v == "1"))
+      throw UnsupportedSetting("task.info: sqp.projectStateInputEqualityConstraints " + v + " is not implemented (the equality constraints are always projected)");
+    if (task->get("sqp.useFeedbackPolicy", &v)) m.sqp.use_feedback_policy = (v == "true" || v == "1") ? 1 : 0;
+  }
   task->get("sqp.inequalityConstraintMu", &m.sqp_inequality_mu);
   task->get("sqp.inequalityConstraintDelta", &m.sqp_inequality_delta);
   task->get("mpc.timeHorizon", &m.time_horizon);

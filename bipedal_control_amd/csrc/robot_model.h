@@ -1,6 +1,7 @@
 // Host-side model constants of the MPC problem: what BipedalRobotInterface assembles at construction
 // (ocs2_bipedal_robot/src/BipedalRobotInterface.cpp:67-204) reduced to plain arrays the kernels consume.
 #pragma once
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -26,7 +27,14 @@ struct ModeTemplate {
 };
 
 struct SwingConfig { double lift_off_velocity = 0, touch_down_velocity = 0, swing_height = 0.1, swing_time_scale = 0.15; };
+// A task.info that asks for a variant of the reference's solver this engine does not implement (load_robot_model): BPMPC_ERR_UNSUPPORTED
+struct UnsupportedSetting : std::runtime_error { using std::runtime_error::runtime_error; };
+
 struct SqpConfig { double dt = 0.015; int sqp_iteration = 1; double delta_tol = 1e-4, g_max = 1e-2, g_min = 1e-6;
+                   // keys that select the ARITHMETIC of the solver (task.info:76,80,81): the engine implements integratorType RK2 and
+                   // projectStateInputEqualityConstraints true only and refuses anything else; both values of useFeedbackPolicy
+                   // (LinearController / FeedforwardController of the solution, of the warm start and of the policy rollout)
+                   int use_feedback_policy = 1;
                    // [OCS2-upstream] sqp::Settings defaults not present in task.info
                    double alpha_decay = 0.5, alpha_min = 1e-4, gamma_c = 1e-6, armijo_factor = 1e-4, cost_tol = 1e-4; };
 

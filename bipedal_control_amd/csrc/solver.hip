@@ -147,6 +147,7 @@ struct bpmpc_solver {
     L.klen = n_nodes_max > 0 ? n_nodes_max : settings.max_nodes;
     L.cold = cold ? 1 : 0;
     L.serial_legs = (dm.serial_legs && !force_tables) ? 1 : 0;
+    L.feedback = rm.sqp.use_feedback_policy;
     L.ls = ls;
     L.reg_prim = settings.reg_prim;
     return L;
@@ -700,6 +701,7 @@ void rollout(bpmpc_solver* s, const double* t_start, const double* x_start, doub
   a.x = bf.x; a.u = bf.u; a.K = bf.K; a.t_start = bf.roll_t; a.x_start = x_start ? bf.roll_x0 : bf.p_x0;
   a.duration = duration; a.abs_tol = s->rm.rollout.abs_tol; a.rel_tol = s->rm.rollout.rel_tol; a.time_step = s->rm.rollout.time_step;
   a.max_steps = (int)(s->rm.rollout.max_steps_per_second * std::max(1.0, duration));
+  a.feedback = s->rm.sqp.use_feedback_policy;
   a.x_end = bf.roll_x; a.u_end = bf.roll_u; a.steps = bf.roll_steps; a.status = bf.roll_status;
   kl::rollout(s->rm.nj, B, s->stream, s->d_model, a);
   HIP_CHECK(hipGetLastError());

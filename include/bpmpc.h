@@ -57,7 +57,9 @@ int bpmpc_model_dims(const bpmpc_model* model, int* nx, int* nu, int* n_contacts
  * Names: "initial_state" (BipedalRobotInterface::getInitialState), "default_joint_state", "Q", "R", "robot_mass",
  * "com_height", "body_mass", "body_com", "body_inertia", "joint_parent", "joint_rotation", "joint_offset", "joint_axis",
  * "contact_body", "contact_offset", "cone" (mu, regularization, gripper force, hessian shift, barrier mu, barrier delta),
- * "swing" (liftOffVelocity, touchDownVelocity, swingHeight, swingTimeScale), "sqp" (dt, sqpIteration, deltaTol, g_max, g_min),
+ * "swing" (liftOffVelocity, touchDownVelocity, swingHeight, swingTimeScale), "sqp" (dt, sqpIteration, deltaTol, g_max, g_min,
+ * useFeedbackPolicy, projectStateInputEqualityConstraints (always 1), integratorType (always 0 = RK2): bpmpc_model_create returns
+ * BPMPC_ERR_UNSUPPORTED with the key in bpmpc_last_error() for a task.info that sets the latter two otherwise),
  * "time_horizon", "position_error_gain", "phase_transition_stance_time", "hard_cone" (flag, sqp.inequalityConstraintMu, Delta),
  * "rollout" (AbsTolODE, RelTolODE, timeStep, maxNumStepsPerSecond, mrt frequency, mpc frequency).
  * The other two solver-settings blocks the reference loads beside `sqp` (src/BipedalRobotInterface.cpp:98-100; accessors ddpSettings(),

@@ -32,7 +32,8 @@ struct HipSqpSolverSettings {
   int device = 0;
   int maxNodes = 160;        // shooting intervals incl. event nodes: timeHorizon / sqp.dt + 2 per gait event inside the horizon
   int sqpIterations = 0;     // <= 0: sqp.sqpIteration of task.info
-  bool useFeedbackPolicy = true;   // sqp.useFeedbackPolicy (task.info:80): LinearController, otherwise FeedforwardController
+  int useFeedbackPolicy = -1;      // -1: sqp.useFeedbackPolicy of task.info (task.info:80), as the sqp::Settings the reference hands to SqpMpc
+                                   // (BipedalController.cpp:303-306); 1 / 0 override what getPrimalSolution() returns: LinearController / FeedforwardController
   bool computeSolutionMetrics = false;   // fill getSolutionMetrics() after every run (one more kernel and a read-back: for solver observers)
   bool useHardFrictionConeConstraint = false;   // the interface's fourth constructor argument (BipedalRobotInterface.h:66-69): cones as inequality constraints
 };
@@ -61,6 +62,11 @@ class HipSqpSolver final : public SolverBase {
       throw std::runtime_error("[HipSqpSolver] " + why);
     }
     check(bpmpc_model_dims(model_, &nx_, &nu_, nullptr, nullptr));
+    if (settings_.useFeedbackPolicy < 0) {       // the file's sqp block decides (integratorType / projectStateInputEqualityConstraints the engine
+      double sqp[8] = {0};                       // does not implement were refused by bpmpc_model_create above: BPMPC_ERR_UNSUPPORTED)
+      check(bpmpc_model_get(model_, "sqp", sqp, 8) >= 6 ? BPMPC_OK : BPMPC_ERR_IO);
+      settings_.useFeedbackPolicy = sqp[5] != 0.0 ? 1 : 0;
+    }
   }
   ~HipSqpSolver() override {
     bpmpc_solver_destroy(solver_);

@@ -4,7 +4,9 @@
 // TargetTrajectoriesPublisher would have left there.  Three MPC runs (cold start, then two receding-horizon runs); per run one line of
 // checksums of what getPrimalSolution returns.  tests/test_gpu_adaptor_mock_run.py compares with the same solves through the Python mirror.
 //   build: g++ -std=c++17 -I include -I integration -I integration/mock_ocs2 integration/mock_run.cpp -L bipedal_control_amd -lbpmpc -Wl,-rpath,... -o mock_run
-//   run:   ./mock_run assets/h1 h1_mpc.urdf
+//   run:   ./mock_run assets/h1 h1_mpc.urdf [task file instead of assets/h1/task.info]
+// With a task file whose sqp.useFeedbackPolicy is false the primal solution carries a FeedforwardController: the line then reports
+// "feedforward 1", sb = checksum of its uffArray_ (the input trajectory) and sk = 0.
 #include <cstdio>
 #include <string>
 
@@ -22,7 +24,7 @@ struct FixedReferences final : ocs2::ReferenceManagerInterface {
 int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: mock_run <asset dir> <urdf file name>\n"); return 2; }
   const std::string dir = argv[1];
-  const std::string urdf = dir + "/" + argv[2], task = dir + "/task.info", reference = dir + "/reference.info", gaitfile = dir + "/gait.info";
+  const std::string urdf = dir + "/" + argv[2], task = argc > 3 ? std::string(argv[3]) : dir + "/task.info", reference = dir + "/reference.info", gaitfile = dir + "/gait.info";
   try {
     bpmpc_model* model = nullptr;
     if (bpmpc_model_create(urdf.c_str(), task.c_str(), reference.c_str(), &model) != 0) throw std::runtime_error(bpmpc_last_error());
@@ -68,18 +70,21 @@ int main(int argc, char** argv) {
       ocs2::PrimalSolution primal;
       mpc.getSolverPtr()->getPrimalSolution(t + horizon, &primal);
       const auto* ctrl = dynamic_cast<const ocs2::LinearController*>(primal.controllerPtr_.get());
-      if (!ctrl) throw std::runtime_error("no LinearController in the primal solution");
+      const auto* ffwd = dynamic_cast<const ocs2::FeedforwardController*>(primal.controllerPtr_.get());
+      if (!ctrl && !ffwd) throw std::runtime_error("neither a LinearController nor a FeedforwardController in the primal solution");
       const size_t n = primal.timeTrajectory_.size();
-      if (primal.stateTrajectory_.size() != n || primal.inputTrajectory_.size() != n || ctrl->biasArray_.size() != n || ctrl->gainArray_.size() != n)
+      if (primal.stateTrajectory_.size() != n || primal.inputTrajectory_.size() != n ||
+          (ctrl && (ctrl->biasArray_.size() != n || ctrl->gainArray_.size() != n)) || (ffwd && (ffwd->uffArray_.size() != n || ffwd->timeStamp_.size() != n)))
         throw std::runtime_error("trajectory lengths differ");
       double st = 0, sx = 0, su = 0, sb = 0, sk = 0;
       for (size_t i = 0; i < n; ++i) {
         st += primal.timeTrajectory_[i] * (1 + i % 3);
         for (int j = 0; j < nx; ++j) sx += primal.stateTrajectory_[i].data()[j] * (1 + (i + j) % 7);
         for (int j = 0; j < nu; ++j) su += primal.inputTrajectory_[i].data()[j] * (1 + (i + j) % 5);
-        for (int j = 0; j < nu; ++j) sb += ctrl->biasArray_[i].data()[j] * (1 + (i + j) % 4);
-        for (int a = 0; a < nu; ++a)
-          for (int b = 0; b < nx; ++b) sk += ctrl->gainArray_[i](a, b) * (1 + (a + 2 * b) % 3);      // by (row, column): independent of the storage order
+        for (int j = 0; j < nu; ++j) sb += (ctrl ? ctrl->biasArray_[i] : ffwd->uffArray_[i]).data()[j] * (1 + (i + j) % 4);
+        if (ctrl)
+          for (int a = 0; a < nu; ++a)
+            for (int b = 0; b < nx; ++b) sk += ctrl->gainArray_[i](a, b) * (1 + (a + 2 * b) % 3);      // by (row, column): independent of the storage order
       }
       // what a ConstraintTermObserver on "<foot>_zeroVelocity" would see (BipedalRobotSqpMpcNode.cpp:74-86): term 3 i + 1 of every intermediate node
       const ocs2::ProblemMetrics& metrics = mpc.getSolverPtr()->getSolutionMetrics();
@@ -91,9 +96,9 @@ int main(int argc, char** argv) {
           for (long j = 0; j < v.size(); ++j) { szv += v.data()[j] * (1 + (i + c + j) % 3); ++nzv; }
         }
       const ocs2::PerformanceIndex& perf = mpc.getSolverPtr()->getPerformanceIndeces();
-      std::printf("run %d points %zu iterations %zu merit %.17g dyn %.17g st %.17g sx %.17g su %.17g sb %.17g sk %.17g final %.17g nzv %zu szv %.17g prejumps %zu\n", k, n,
+      std::printf("run %d points %zu iterations %zu merit %.17g dyn %.17g st %.17g sx %.17g su %.17g sb %.17g sk %.17g final %.17g nzv %zu szv %.17g prejumps %zu feedforward %d\n", k, n,
                   mpc.getSolverPtr()->getNumIterations(), perf.merit, perf.dynamicsViolationSSE, st, sx, su, sb, sk, mpc.getSolverPtr()->getFinalTime(), nzv, szv,
-                  metrics.preJumps.size());
+                  metrics.preJumps.size(), ffwd ? 1 : 0);
     }
     bpmpc_model_destroy(model);
   } catch (const std::exception& e) {

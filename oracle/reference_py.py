@@ -371,8 +371,10 @@ def time_segment(times, t):
     return i, (times[i + 1] - t) / (times[i + 1] - times[i])
 
 
-def warm_start_from_previous(model, nodes, x_measured, prev_nodes, prev_x, prev_u, prev_K):
-    """Initial iterate (x[N+1], u[N]) of a new solve on `nodes` given the previous solve's result."""
+def warm_start_from_previous(model, nodes, x_measured, prev_nodes, prev_x, prev_u, prev_K, feedback=True):
+    """Initial iterate (x[N+1], u[N]) of a new solve on `nodes` given the previous solve's result.  feedback = sqp.useFeedbackPolicy
+    (task.info:80): the previous solution is a LinearController (u = uff(t) + K(t) x) or, false, a FeedforwardController (u = u(t):
+    [OCS2-upstream, recalled] multiple_shooting::toPrimalSolution builds it from the same time / input arrays)."""
     N = int(nodes["N"])
     nx, nu = model["nx"], model["nu"]
     tp, xp, uff, KK = primal_solution_arrays(prev_nodes, prev_x, prev_u, prev_K)
@@ -392,7 +394,11 @@ def warm_start_from_previous(model, nodes, x_measured, prev_nodes, prev_x, prev_
             x[i + 1] = x[i]
         else:
             j, a = time_segment(tp, t)
-            u[i] = a * uff[j] + (1.0 - a) * uff[j + 1] + (a * KK[j] + (1.0 - a) * KK[j + 1]) @ x[i]
+            if feedback:
+                u[i] = a * uff[j] + (1.0 - a) * uff[j + 1] + (a * KK[j] + (1.0 - a) * KK[j + 1]) @ x[i]
+            else:
+                uin = uff + np.einsum("kij,kj->ki", KK, xp)      # the input trajectory of the primal solution (pre-event / terminal entries repeated)
+                u[i] = a * uin[j] + (1.0 - a) * uin[j + 1]
             j2, a2 = time_segment(tp, t_next)
             x[i + 1] = a2 * xp[j2] + (1.0 - a2) * xp[j2 + 1]
     return x, u

@@ -68,6 +68,7 @@ def test_adaptor_runs_and_matches_the_python_mirror(tmp_path, robot, urdf):
         a, b = np.meshgrid(np.arange(nu), np.arange(nx), indexing="ij")
         sk = float(np.sum(KK * (1 + (a + 2 * b) % 3)[None]))
         got = fields(out[k])
+        assert got["feedforward"] == 0
         assert got["run"] == k and got["points"] == n + 1 and got["iterations"] == iterations
         assert got["merit"] == st[0].merit_after and got["dyn"] == st[0].dynamics_sse_after and got["final"] == tt[-1]
         for name, ref in (("st", st_), ("sx", sx), ("su", su), ("sb", sb), ("sk", sk)):       # sums in another order: rounding only
@@ -93,3 +94,49 @@ def test_adaptor_runs_and_matches_the_python_mirror(tmp_path, robot, urdf):
             assert row == lq["nc"]
             i_inter += 1
         assert got["nzv"] == nzv and got["prejumps"] == int((kinds != 0).sum()) and abs(got["szv"] - szv) <= 1e-9 * max(1.0, abs(szv)), (got["szv"], szv)
+
+
+def test_adaptor_returns_a_feedforward_controller_when_the_task_file_says_so(tmp_path):
+    """sqp.useFeedbackPolicy false (task.info:80) reaches the adaptor through the model (HipSqpSolver::Settings::useFeedbackPolicy = -1:
+    the file decides): getPrimalSolution carries a FeedforwardController over the input trajectory (pre-event / terminal entries repeated),
+    and the receding-horizon warm start on the device evaluates the previous solution as such - the same solves through the Python mirror."""
+    import bipedal_control_amd as bp
+    from bipedal_control_amd import scenarios as sc
+    from oracle import reference_py as rp
+    from tests import oracle_bridge as ob
+    exe = str(tmp_path / "mock_run")
+    lib = os.path.join(ROOT, "bipedal_control_amd")
+    inc = [os.path.join(ROOT, d) for d in ("include", "integration", os.path.join("integration", "mock_ocs2"))]
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror"] + [a for i in inc for a in ("-I", i)] + [os.path.join(ROOT, "integration", "mock_run.cpp"),
+                   "-L", lib, "-lbpmpc", "-Wl,-rpath," + lib, "-o", exe], check=True)
+    text = open(sc.H1["task"]).read()
+    task = tmp_path / "task_feedforward.info"
+    task.write_text(text.replace("useFeedbackPolicy true", "useFeedbackPolicy false", 1))
+    out = subprocess.run([exe, os.path.join(ROOT, "assets", "h1"), "h1_mpc.urdf", str(task)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == 3
+    itf = bp.BipedalRobotInterface(str(task), sc.H1["urdf"], sc.H1["reference"])
+    itf.gaitFile = sc.H1["gait"]
+    nx = nu = itf.stateDim
+    horizon, period = 1.005, 0.02
+    gs = bp.GaitSchedule(itf)
+    gs.insertModeSequenceTemplate(bp.loadModeSequenceTemplate(sc.H1["gait"], "trot"), -1.225, 3 * horizon)
+    sched = gs.getModeSchedule(-horizon, 3 * horizon)
+    x0 = itf.getInitialState()
+    mpc = bp.BatchedSqpMpc(itf, max_batch=1, max_nodes=96, return_gains=True)
+    for k in range(3):
+        t0 = k * period
+        target = [itf.cmdVelToTargetTrajectories((0.3, 0.0, 0.0, 0.0), t0, x0, horizon)]
+        t, x, u, K, st = (mpc.run if k == 0 else mpc.advance)(t0, x0.reshape(1, nx), sched, target, horizon=horizon, gains=True)
+        n = st[0].n_nodes
+        nodes = ob.oracle_nodes({"schedule": sched, "targets": target, "t0": t0, "x0": x0.reshape(1, nx), "horizon": horizon}, 0)
+        tt, xx, bias, KK = rp.primal_solution_arrays(nodes, x[0, :n + 1], u[0, :n], K[0, :n])
+        uu = bias + np.einsum("kij,kj->ki", KK, xx)          # the input trajectory with the repeated entries
+        i = np.arange(n + 1)[:, None]
+        su = float(np.sum(uu * (1 + (i + np.arange(nu)[None, :]) % 5)))
+        sb = float(np.sum(uu * (1 + (i + np.arange(nu)[None, :]) % 4)))
+        w = out[k].split()
+        got = {w[j]: float(w[j + 1]) for j in range(0, len(w) - 1, 2)}
+        assert got["feedforward"] == 1 and got["sk"] == 0.0 and got["points"] == n + 1
+        assert got["merit"] == st[0].merit_after and got["dyn"] == st[0].dynamics_sse_after
+        for name, ref in (("su", su), ("sb", sb)):
+            assert abs(got[name] - ref) <= 1e-11 * max(1.0, abs(ref)), (k, name, got[name], ref)

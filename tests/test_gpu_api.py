@@ -99,14 +99,24 @@ def test_bench_contract():
     assert "workload" in d["config"] and d["value"] > 0
 
 
-def test_receding_horizon_loop_matches_oracle(ctx):
+@pytest.mark.parametrize("feedback", [True, False])
+def test_receding_horizon_loop_matches_oracle(ctx, feedback, tmp_path):
     """the MPC loop (BipedalController.cpp:332-350) with warm starts shifted on the device
     (bpmpc_solver_setup_from_previous) against the oracle's restatement of SqpSolver::initializeStateInputTrajectories
     (oracle/reference_py.py warm_start_from_previous).  The tick period (0.02 s) is not a multiple of dt (0.015 s) and the
-    horizon contains gait events, so inputs, gains and states are all interpolated."""
+    horizon contains gait events, so inputs, gains and states are all interpolated.  feedback False: a task.info with
+    sqp.useFeedbackPolicy false - the previous solution is evaluated as a FeedforwardController."""
     import numpy as np
     from oracle import reference_py as rp
     bp, sc, ob, itf = ctx
+    if not feedback:
+        text = open(sc.H1["task"]).read()
+        assert text.index("useFeedbackPolicy true") > text.index("\nsqp")
+        task = tmp_path / "task_feedforward.info"
+        task.write_text(text.replace("useFeedbackPolicy true", "useFeedbackPolicy false", 1))     # the sqp block is the first with this key
+        itf = bp.BipedalRobotInterface(str(task), sc.H1["urdf"], sc.H1["reference"])
+        itf.gaitFile = sc.H1["gait"]
+        assert itf.sqpSettings()["useFeedbackPolicy"] is False
     B, NI, tick = 3, 40, 0.02
     horizon = NI * sc.DT
     x_meas = sc.perturbed_initial_states(itf, B)
@@ -130,7 +140,7 @@ def test_receding_horizon_loop_matches_oracle(ctx):
             if prev[b] is None:
                 xi, ui = rp.cold_start(m, nodes, x_meas[b])
             else:
-                xi, ui = rp.warm_start_from_previous(m, nodes, x_meas[b], *prev[b])
+                xi, ui = rp.warm_start_from_previous(m, nodes, x_meas[b], *prev[b], feedback=feedback)
             xo, uo, Ko, st = om.solve(nodes, x_meas[b], xi, ui, iterations=1, g_max=sq["g_max"], g_min=sq["g_min"], delta_tol=sq["deltaTol"])
             n = stats[b].n_nodes
             assert n == nodes["N"]
