@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0 (contract in the task description) with `roofline
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -67,8 +68,10 @@ def parse_args():
     ap.add_argument("--gait-start", type=float, default=-1.225,
                     help="time at which the gait template of the trot workload is inserted (default: t0 = 0 falls mid-swing; 0 = SURVEY 8(d) config 2 to the letter)")
     ap.add_argument("--no-fused", action="store_true", help="skip the second timed region (fused solve mode)")
-    ap.add_argument("--gather", default="all", choices=["all", "root"],
-                    help="collective of the solved trajectories per step: all-gather (every rank holds every block) or gather to rank 0")
+    ap.add_argument("--gather", default="auto", choices=["auto", "all", "root"],
+                    help="collective of the solved trajectories per step: all-gather (every rank holds every block) or gather to rank 0; auto = "
+                         "root for --scaling strong and --workload gait-sweep (the north-star's \"final gather\": one job, one owner of the "
+                         "result), all for weak scaling (independent per-GPU batches, the contract's default line)")
     ap.add_argument("--chunks", type=int, default=0, help="horizon chunks of the linearise/project || Riccati pipeline (0 = library default, 1 = off)")
     return ap.parse_args()
 
@@ -87,8 +90,15 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def default_gather(scaling, workload):
+    """`--gather auto`: what the job needs at the least - see the option's help."""
+    return "root" if (scaling == "strong" or workload == "gait-sweep") else "all"
+
+
 def main():
     args = parse_args()
+    if args.gather == "auto":
+        args.gather = default_gather(args.scaling, args.workload)
     if "RANK" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
 
@@ -213,13 +223,29 @@ def main():
             step()
         fence(barrier=False)
         elapsed = time.perf_counter() - t0
+        rank_ms = elapsed / args.steps * 1e3                    # this rank's own clock: the line reports min / max over the ranks (stragglers)
         if use_dist:
             elapsed = float(bd.reduce_stats([elapsed], op="max")[0])
+            rank_ms_min = -float(bd.reduce_stats([-rank_ms], op="max")[0])
+        else:
+            rank_ms_min = rank_ms
         mpc.synchronize()
 
         t, x, u, _, stats = mpc.fetch()
         ok = sum(1 for st in stats if st.status == 0)
         lin_timed = mpc.kernel_time("linearize", reset=False)         # HIP events on the launch stream, over exactly the timed steps
+        # error bar of `value`: the same region of `steps` steps four more times (the line's value stays the FIRST region, the contract's)
+        spread = [elapsed / args.steps * 1e3]
+        if world == 1:
+            mpc.set_profile(0)
+            for _ in range(4):
+                fence()
+                ts0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                fence(barrier=False)
+                spread.append((time.perf_counter() - ts0) / args.steps * 1e3)
+            mpc.set_profile(0 if args.no_profile else (1 if args.profile_all else 2))
         kt_steps = args.steps
         if not args.no_profile and not args.profile_all:
             # per-kernel breakdown from a short extra pass with every kernel class timed (each event pair costs 1-2 us of stream time,
@@ -295,7 +321,7 @@ def main():
                 fused["hbm_bytes_per_step"] = prof.get("fused_hbm_bytes_per_step")
                 fused["materialised_hbm_bytes_per_step"] = prof.get("materialised_hbm_bytes_per_step")
                 fused["hbm_bytes_source"] = prof["source"]
-            roofline = {"kernel": "k_linearize_fast<%d, true>" % (nx - 12), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"kernel": "k_linearize_fast<%d, true, ..>" % (nx - 12), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": (prof["source"] if prof else None),
                         "avg_launch_us": round(1e6 * avg_s, 2),
                         "algorithmic_bytes_per_launch": round(alg_bytes), "launches_per_step": launches_per_step,
@@ -318,10 +344,16 @@ def main():
                           "parallelism": "problem-sharded x%d, one %s of trajectories per solve (%s), overlapped with the next solve" % (
                               world, "all-gather" if args.gather == "all" else "gather to rank 0", backend if use_dist else "none at N = 1"),
                           "accepted_steps_rank0": ok,
+                          "distributed": {"backend": (dist.get_backend() if use_dist else None), "world_size_seen": (dist.get_world_size() if use_dist else 1),
+                                          "gather": args.gather if use_dist else None, "devices": ("one shared device" if one_device and world > 1 else "one per rank"),
+                                          "rank_ms_per_step_min": round(rank_ms_min, 4), "rank_ms_per_step_max": round(elapsed / args.steps * 1e3, 4)},
                           "job_report": {"merit_sum": report[0], "dynamics_sse_sum": report[1], "equality_sse_sum": report[2], "failures": int(report[3]),
                                          "gather_consistent": bool(gathered_ok)}},
                "ms_per_solve": round(ms_per_step / max(1, total // world), 6),
                "kernel_ms_per_step": {k: round(v[0] / max(1, kt_steps), 4) for k, v in ktimes.items()},
+               "timing_spread": {"regions": len(spread), "steps_per_region": args.steps, "ms_per_step_min": round(min(spread), 4),
+                                 "ms_per_step_median": round(float(np.median(spread)), 4), "ms_per_step_max": round(max(spread), 4),
+                                 "note": "region 1 carries the event pair around the roofline kernel and is `ms_per_step`; regions 2.. run without it"},
                "roofline": roofline, "fused": fused}
         kms = out["kernel_ms_per_step"]
         n_all_nodes = int(sum(g_nodes[p_grid])) if world == 1 else None
@@ -343,19 +375,30 @@ def main():
             roofline["bound"] = top if fr[top] >= 0.5 else "latency"
             roofline["bound_fracs"] = fr
             roofline["bound_note"] = ("`frac` stays achieved / HBM peak (the roof the north-star names); fp64-issue / mfma fractions use executed-instruction "
-                                      "counts from profiles/r03_sq_counters.json (builder run) at this run's kernel time")
+                                      "counts from profiles/%s (builder run) at this run's kernel time" % sq_counters_file())
         if world == 1 and args.cpu_sample > 0:
             if sweep:
                 out["cpu_baseline"] = cpu_baseline_sweep(itf, cp, min(args.cpu_sample, 16), x, stats, args.robot)
             else:
                 out["cpu_baseline"] = cpu_baseline(prob, min(args.cpu_sample, B), x, u, stats, args.robot)
                 if ":" not in args.robot:       # (the lane-emulation build of the test tier loads the soft-cone model)
-                    out["cpu_baseline_analytic"] = cpu_baseline_analytic(prob, min(args.cpu_sample, B), x, stats, args.robot)
+                    try:                    # a context figure must never cost the measured line (stale test library, missing compiler, ...)
+                        out["cpu_baseline_analytic"] = cpu_baseline_analytic(prob, min(args.cpu_sample, B), x, stats, args.robot)
+                    except Exception as e:
+                        out["cpu_baseline_analytic"] = {"value": None, "why": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
     if use_dist:
         assert gathered_ok, "gathered trajectories differ from the local result"
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sq_counters_file():
+    """File name (under profiles/) of the committed SQ counter summary of the headline command: profiles/traffic_index.json["sq_counters"]."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic_index.json"))).get("sq_counters", "r03_sq_counters.json")
+    except Exception:
+        return "r03_sq_counters.json"
 
 
 def committed_traffic(robot, gait, sweep, batch, intervals):
@@ -380,7 +423,13 @@ def committed_traffic(robot, gait, sweep, batch, intervals):
     def pick_sum(prefix):          # the sweep is one launch (k_riccati_fast*) or two (k_riccati_wave*, k_riccati_rollout) per step
         vals = [v.get("hbm_bytes_per_launch") for k, v in ks.items() if k.startswith(prefix) and v.get("hbm_bytes_per_launch")]
         return sum(vals) if vals else None
-    kernels = {"linearize_materialised": pick("k_linearize_fast", "true>"), "linearize_fused": pick("k_linearize_fast", "false>"),
+    def pick_lin(mat):             # k_linearize_fast<NJ, MAT[, CHAIN]>: the second template argument says materialised / fused
+        for k, v in ks.items():
+            m = re.match(r"k_linearize_fast<\d+, (true|false)", k)
+            if m and (m.group(1) == "true") == mat:
+                return v.get("hbm_bytes_per_launch")
+        return None
+    kernels = {"linearize_materialised": pick_lin(True), "linearize_fused": pick_lin(False),
                "project_lu": pick("k_project_lu"), "project": pick("k_project_fast"), "riccati": pick_sum("k_riccati"), "linesearch": pick("k_trial_fast")}
     return {"source": "profiles/%s (builder run of the same command under rocprofv3 --pmc; not measured in this process)" % name, "kernels": kernels,
             "materialised_hbm_bytes_per_step": tj.get("materialised_hbm_bytes_per_step"), "fused_hbm_bytes_per_step": tj.get("fused_hbm_bytes_per_step")}
@@ -395,8 +444,13 @@ def roofline_all(nx, nu, nut_mean, kernel_ms, n_lin_nodes, n_nodes_total, fp64, 
         project     A, B, b, Q, R, q, r, Px, Pu, Pe in; projected At, Bt, bt, Qt, Rt, Pt, qt, rt out (Bt, Rt, Pt, rt at nut columns / rows)
         riccati     projected model + Px, Pu, Pe in; K, dx, du out
         linesearch  x, u, dx, du, x_next, dx_next, xref, swing references in; 3 sums out
-      frac = algorithmic bytes / kernel time / 8 TB/s;  traffic_ratio = PMC bytes of the committed pass / algorithmic bytes (> 1: re-reads,
-      padding, scratch).  bound: as for `roofline` (largest of hbm / fp64-issue / mfma if >= 0.5, else latency)."""
+      traffic_ratio = PMC bytes of the committed pass / algorithmic bytes (> 1: re-reads, padding, scratch; < 1: the kernel exchanges its
+      operands PACKED - joint rows of [Px | Pe | Pu] only, projected model in 16-column blocks up to nx + 1 + nut - and touches fewer bytes
+      than the dense reference unit).  hbm_util = counter bytes / kernel time / 8 TB/s: the share of the HBM roof the kernel really uses.
+      frac = algorithmic bytes / kernel time / 8 TB/s where the kernel moves at least its algorithmic bytes; where traffic_ratio < 1 the dense
+      unit would credit bytes the kernel never touches, so frac = hbm_util there and packed_bytes_per_unit (counter bytes / units) is the
+      unit it is computed on (frac_basis says which).  bound: largest of hbm_util (hbm frac without counters) / fp64-issue / mfma if
+      >= 0.5, else latency."""
     d = 8.0
     proj_model = nx * nx + nx * nut_mean + nx + nx * nx + nx + nut_mean * nut_mean + nut_mean * nx + nut_mean
     pxe = nu * nx + nu * nu + nu
@@ -414,14 +468,18 @@ def roofline_all(nx, nu, nut_mean, kernel_ms, n_lin_nodes, n_nodes_total, fp64, 
         if not ms or not n_units:
             continue
         alg = bytes_per_unit * n_units
-        ach = alg / (1e-3 * ms) / 1e9
-        fr = {"hbm": round(ach / HBM_PEAK_GBS, 4)}
+        tr = (prof or {}).get("kernels", {}).get(pkey)
+        util = (tr / (1e-3 * ms) / 1e9 / HBM_PEAK_GBS) if tr else None
+        packed = bool(tr) and tr < alg
+        ach = (tr if packed else alg) / (1e-3 * ms) / 1e9
+        fr = {"hbm": round(util if util is not None else ach / HBM_PEAK_GBS, 4)}
         e = (fp64 or {}).get(cls) or {}
         if "issue_frac" in e:
             fr["fp64-issue"], fr["mfma"] = e["issue_frac"], e["mfma_frac"]
         top = max(fr, key=fr.get)
-        tr = (prof or {}).get("kernels", {}).get(pkey)
-        out[cls] = {"ms": ms, "algorithmic_bytes_per_unit": round(bytes_per_unit), "units": int(n_units), "achieved": round(ach, 1), "frac": fr["hbm"],
+        out[cls] = {"ms": ms, "algorithmic_bytes_per_unit": round(bytes_per_unit), "units": int(n_units), "achieved": round(ach, 1),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "frac_basis": "counter traffic (packed operands)" if packed else "algorithmic bytes",
+                    "packed_bytes_per_unit": round(tr / n_units) if packed else None, "hbm_util": round(util, 4) if util is not None else None,
                     "bound": top if fr[top] >= 0.5 else "latency", "bound_fracs": fr, "traffic": tr,
                     "traffic_ratio": round(tr / alg, 3) if tr else None, "dominant": cls == dominant}
     return out
@@ -439,7 +497,7 @@ def roofline_fp64(robot, kernel_ms, n_lin_nodes, n_nodes_total, n_stages_total, 
                            VALU instruction is counted as one FP64 slot
       mfma_frac            MFMA flop / launch time / 78.6 TFLOP/s
     Durations are this run's HIP-event times; the counter file only applies to the headline workload."""
-    cpath, fpath = os.path.join(ROOT, "profiles", "r03_sq_counters.json"), os.path.join(ROOT, "profiles", "flop_counts.json")
+    cpath, fpath = os.path.join(ROOT, "profiles", sq_counters_file()), os.path.join(ROOT, "profiles", "flop_counts.json")
     if not (os.path.exists(cpath) and os.path.exists(fpath)):
         return None
     try:
@@ -452,13 +510,13 @@ def roofline_fp64(robot, kernel_ms, n_lin_nodes, n_nodes_total, n_stages_total, 
                "riccati": ("k_riccati_fast", flops["riccati_stage"] * n_stages_total),
                "linesearch": ("k_trial_fast", 2 * flops["flow_map"] * n_nodes_total + flops["ee_kinematics"] * n_nodes_total)}
     out = {"peak_tflops": FP64_PEAK_TFLOPS, "note": "restatement_flops = CPU restatement's operation count (forward-mode AD for the lineariser: not a bound); "
-                                                     "issue_frac = executed VALU lane-ops / time / FP64 issue rate; counters from profiles/r03_sq_counters.json"}
+                                                     "issue_frac = executed VALU lane-ops / time / FP64 issue rate; counters from profiles/" + sq_counters_file()}
     for cls, (prefix, rflops) in classes.items():
         ms = kernel_ms.get(cls)
         if not ms:
             continue
         e = {"ms": ms, "restatement_flops": int(rflops), "restatement_tflops": round(rflops / (1e-3 * ms) / 1e12, 2)}
-        names = sorted((k for k in counters if k.startswith(prefix)), key=lambda k: (not k.endswith("true>"), k))     # the timed lineariser is <NJ, true>
+        names = sorted((k for k in counters if k.startswith(prefix)), key=lambda k: (re.match(r"k_linearize_fast<\d+, false", k) is not None, k))     # the timed lineariser is <NJ, true, ..>
         ck = counters[names[0]] if (applicable and names) else None
         if ck:
             lane_ops = ck.get("SQ_INSTS_VALU", 0.0) * 64.0
@@ -532,7 +590,7 @@ def cpu_baseline_analytic(prob, sample, x_gpu, stats, robot="h1"):
     from tests.hostemu import build_hostemu
     from oracle import reference_py as rp
     try:
-        lib = C.CDLL(build_hostemu.build(optimised=True))
+        lib = C.CDLL(build_hostemu.build(optimised=True, outdir=os.environ.get("TMPDIR", "/tmp")))      # not into tests/hostemu: a concurrent pytest builds there
     except Exception as e:      # no compiler on this box
         return {"value": None, "why": "could not build tests/hostemu with -O3 -march=native: %s" % e}
     lib.emu_model_create.restype = C.c_void_p

@@ -133,19 +133,23 @@ BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags + 3 sums*/
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   if (p.done[0]) return;
   const double alpha = p.alpha[0];
+  // the node sums are formed by the first NSUM lanes whatever the size of the workgroup, so that the first round (k_ls_decide, 256 lanes) and
+  // the back-tracking rounds (k_ls_tail, 512 lanes) add the same terms in the same order at every horizon length
+  constexpr int NSUM = NL < 256 ? NL : 256;
   BP_LANES(tid, NL) {
     double a = 0.0, b = 0.0, c = 0.0;
-    for (int k = tid; k < p.n_nodes; k += NL) { a += p.trial_perf[3 * k]; b += p.trial_perf[3 * k + 1]; c += p.trial_perf[3 * k + 2]; }
+    if (tid < NSUM)
+      for (int k = tid; k < p.n_nodes; k += NSUM) { a += p.trial_perf[3 * k]; b += p.trial_perf[3 * k + 1]; c += p.trial_perf[3 * k + 2]; }
     if (tid < NX) { const double d = p.x0[tid] - (p.x[tid] + alpha * p.dx[tid]); b += d * d; }
     partial[tid] = a; partial[NL + tid] = b; partial[2 * NL + tid] = c;
   }
   BP_SYNC();
   // the three sums in lane order, one lane each; lanes beyond the nodes (and beyond the nx mismatch terms) hold exact zeros and are
-  // skipped - the numbers equal those of one lane adding all NL entries
+  // skipped - the numbers equal those of one lane adding all NSUM entries
   BP_LANES(tid, NL) {
     if (tid < 3) {
       int lim = p.n_nodes > NX ? p.n_nodes : NX;
-      if (lim > NL) lim = NL;
+      if (lim > NSUM) lim = NSUM;
       double s = 0.0;
       for (int i = 0; i < lim; ++i) s += partial[tid * NL + i];
       partial[3 * NL + 2 + tid] = s;

@@ -841,6 +841,7 @@ void bpmpc_solver_destroy(bpmpc_solver* s) {
     /* a call that threw between enqueueing copies from / to the pinned arenas and its own synchronisation: wait for them before the */ \
     /* next call recycles (or frees) that memory */                                               \
     if ((solver)->stream) (void)hipStreamSynchronize((solver)->stream);                           \
+    if ((solver)->producer_stream) (void)hipStreamSynchronize((solver)->producer_stream);         \
     return translate(e);                                                                          \
   }                                                                                               \
   return BPMPC_OK;

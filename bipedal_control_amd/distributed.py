@@ -67,7 +67,9 @@ class TrajectoryGather:
         else:
             blk = self.n_x + self.n_u
             parts = [self.gathered[r * blk:(r + 1) * blk] for r in range(self.world)] if self.rank == 0 else None
-            self.pending.append(dist.gather(self.local, parts, dst=0, group=self.group, async_op=True))
+            # dst is a GLOBAL rank: the first rank of the group (rank 0 of the default group)
+            dst = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            self.pending.append(dist.gather(self.local, parts, dst=dst, group=self.group, async_op=True))
 
     def drain(self):
         """Make the current stream (GPU) / the caller (CPU) wait for every collective in flight: afterwards the local block may be

@@ -244,6 +244,11 @@ int bpmpc_solver_stage(bpmpc_solver* solver, const char* stage);
  *                                    columns), "Mt" = [Pt | rt | Rt] (nu rows of WP columns), WP = 16 * ceil((nx + 1 + nu) / 16); block
  *                                    columns beyond nx + 1 + nut and rows >= nut of Mt are not written (kernels/project_node.h PackedLq);
  *                                    the plain names return "unknown buffer".
+ * The elimination outputs depend on the path as well: on the default fast path (structured elimination, input weight without force /
+ * joint-velocity cross terms) only "Vt" (the joint rows of [Px | Pe | Pu], nj rows of WP columns; columns at and beyond
+ * 16 * ceil((nx + 1 + nut) / 16) are not written and hold whatever an earlier, wider node left there), "Pe" and "nut" are written -
+ * "Px" and "Pu" are NOT (they read as zeros or as the leftovers of an earlier run on another path); they are written with
+ * BPMPC_DENSE_PROJECT=1 (environment, read when the solver is created) and by the reference kernels.
  * Integer buffers are converted to double.  Returns the element count or a negative status; out == NULL only queries the element
  * count. */
 int bpmpc_solver_read(bpmpc_solver* solver, const char* name, double* out, long capacity);

@@ -113,3 +113,23 @@ def test_bench_self_launch_command():
     cmd = call.call_args[0][0]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+
+
+def test_default_collective_of_the_bench_line():
+    """bench.py --gather auto: one job with one owner of the result (strong scaling, the gait-library sweep: the north-star's "RCCL ... only
+    for the final gather") gathers to rank 0; independent per-GPU batches (weak scaling, the contract's default line) keep the all-gather."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.default_gather("strong", "trot") == "root"
+    assert bench.default_gather("weak", "gait-sweep") == "root"
+    assert bench.default_gather("strong", "gait-sweep") == "root"
+    assert bench.default_gather("weak", "trot") == "all"
+    import sys
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        assert bench.parse_args().gather == "auto"
+    finally:
+        sys.argv = argv

@@ -93,6 +93,16 @@ def test_bench_contract():
     assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["scaling"] == "weak" and d["n_gpus"] == 1 and d["steps"] == 3
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["bound"] in ("hbm", "fp64-issue", "mfma", "latency")
     assert set(("linearize", "riccati")) <= set(d["roofline_all"]) and any(v.get("dominant") for v in d["roofline_all"].values() if isinstance(v, dict))
+    for cls, v in d["roofline_all"].items():
+        if not isinstance(v, dict):
+            continue
+        assert set(("frac", "frac_basis", "hbm_util", "packed_bytes_per_unit", "algorithmic_bytes_per_unit", "bound")) <= set(v), cls
+        if v["traffic_ratio"] is not None and v["traffic_ratio"] < 1.0:       # packed operands: the fraction is counted on the bytes the kernel moves
+            assert v["frac_basis"].startswith("counter") and abs(v["frac"] - v["hbm_util"]) < 1e-3 and v["packed_bytes_per_unit"] < v["algorithmic_bytes_per_unit"]
+        if v["hbm_util"] is not None and v["hbm_util"] < 0.5 and max(v["bound_fracs"].values()) < 0.5:
+            assert v["bound"] == "latency", cls
+    ts = d["timing_spread"]
+    assert ts["regions"] == 5 and ts["ms_per_step_min"] <= ts["ms_per_step_median"] <= ts["ms_per_step_max"] and ts["ms_per_step_min"] > 0
     assert d["cpu_baseline_analytic"]["max_abs_x_diff_vs_gpu"] < 1e-8 and d["cpu_baseline_analytic"]["failures"] == 0
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-4
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["max_abs_x_diff_vs_gpu"] < 1e-8

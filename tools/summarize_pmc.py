@@ -37,8 +37,9 @@ def main(fetch_dir, write_dir, out, extra=""):
                          "hbm_bytes_per_launch": int(1024 * (2.0 * f / max(nf, 1) + w / max(nw, 1)))}
     # the roofline kernel is the materialised lineariser (template argument `true`); per-step totals of both solve modes: every kernel
     # class runs once per step except the two linearisers, which split the steps between them
-    lin = next((k for k in kernels if k.startswith("k_linearize_fast") and k.endswith("true>")), None) or next((k for k in kernels if k.startswith("k_linearize_fast")), None)
-    lin_f = next((k for k in kernels if k.startswith("k_linearize_fast") and k.endswith("false>")), None)
+    import re
+    lin = next((k for k in kernels if re.match(r"k_linearize_fast<\d+, true", k)), None) or next((k for k in kernels if k.startswith("k_linearize_fast")), None)
+    lin_f = next((k for k in kernels if re.match(r"k_linearize_fast<\d+, false", k)), None)
     # the sweep: k_riccati_fast* (workgroup per problem) or k_riccati_wave (wavefront per problem; its roll-out k_riccati_rollout is a launch of its own)
     ric = next((k for k in kernels if k.startswith("k_riccati_fast") or k.startswith("k_riccati_wave")), None)
     steps = kernels[ric]["launches"] if ric else 0
