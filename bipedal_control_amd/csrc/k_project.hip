@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kWave) BPMPC_LUS_WPE void k_project_lu_s(Launch L) 
 #ifndef BPMPC_PROJECT_WPE
 #define BPMPC_PROJECT_WPE 3
 #endif
-template <int NJ, bool PK>
+template <int NJ, bool PK, bool WJ>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PK ? BPMPC_PROJECT_WPE : 2, 4))) void k_project_fast(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   __shared__ ProjectMfmaWorkspace<NJ, PK> ws;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PK ? BPMP
   out.Wt = L.buf.Wt + s * PackedLq<NJ>::W_SIZE; out.Qp = L.buf.Qp + s * PackedLq<NJ>::Q_SIZE; out.Mt = L.buf.Mt + s * PackedLq<NJ>::M_SIZE;
   if constexpr (PK) { in.zero = L.buf.zero_page; in.Vt = L.buf.Vt + s * NJ * PackedLq<NJ>::WP; in.mode = L.buf.g_mode[(size_t)g * L.N + k] & 3; }   // written by the structured elimination
   else out.Vt = L.buf.Vt + s * NJ * PackedLq<NJ>::WP;   // FullPivLU elimination (Px, Pu, Pe): this kernel packs the joint rows for the sweep's loaders
-  project_apply_mfma<NJ, PK>(ws, in, out, dt, dt * (1.0 / L.model->robot_mass), L.model->Q, L.model->R, L.reg_prim);   // as written by linearize_fast
+  project_apply_mfma<NJ, PK, WJ>(ws, in, out, dt, dt * (1.0 / L.model->robot_mass), L.model->Q, L.model->R, L.reg_prim);   // as written by linearize_fast
 }
 
 #define KL_NJ(nj, ...)                                                          \
@@ -128,10 +128,12 @@ void project_lu_s(int nj, int max_vel_rows, bool packed, int nodes, hipStream_t 
     }
   });
 }
-void project_fast(int nj, bool packed, int nodes, hipStream_t st, const Launch& L) {
+// joint_rows false: the joint rows of Wt are left to the sweep (packed operands and a sweep that completes them only: riccati_wave2.h)
+void project_fast(int nj, bool packed, bool joint_rows, int nodes, hipStream_t st, const Launch& L) {
   KL_NJ(nj, {
-    if (packed) hipLaunchKernelGGL((k_project_fast<NJ, true>), dim3(nodes), dim3(kWave), 0, st, L);
-    else hipLaunchKernelGGL((k_project_fast<NJ, false>), dim3(nodes), dim3(kWave), 0, st, L);
+    if (packed && !joint_rows) hipLaunchKernelGGL((k_project_fast<NJ, true, false>), dim3(nodes), dim3(kWave), 0, st, L);
+    else if (packed) hipLaunchKernelGGL((k_project_fast<NJ, true, true>), dim3(nodes), dim3(kWave), 0, st, L);
+    else hipLaunchKernelGGL((k_project_fast<NJ, false, true>), dim3(nodes), dim3(kWave), 0, st, L);
   });
 }
 

@@ -22,20 +22,20 @@ namespace bpmpc {
 #ifndef BPMPC_RICCATI_WAVE_DEFAULT
 #define BPMPC_RICCATI_WAVE_DEFAULT 1     // BPMPC_RICCATI_WAVE unset: 1 = batches larger than the chip use the wave-per-problem sweep
 #endif
-template <int NJ>
+template <int NJ, bool JW>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BPMPC_WAVE_WPE, 2))) void k_riccati_wave(Launch L) {
   __shared__ RiccatiWaveWorkspace<NJ> ws;
   RiccatiFastIO io;
   if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
-  riccati_wave<NJ>(ws, io);
+  riccati_wave<NJ, JW>(ws, io);
 }
 // the same sweep arranged for two waves per SIMD (riccati_wave2.h)
-template <int NJ>
+template <int NJ, bool JW>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_riccati_wave2(Launch L) {
   __shared__ RiccatiWave2Workspace<NJ> ws;
   RiccatiFastIO io;
   if (!riccati_fast_io<NJ>(L, io, ws.T)) return;
-  riccati_wave2<NJ>(ws, io);
+  riccati_wave2<NJ, JW>(ws, io);
 }
 
 template <int NJ>
@@ -55,10 +55,13 @@ __global__ __launch_bounds__(kRolloutPairThreads) __attribute__((amdgpu_waves_pe
 
 namespace kl {
 
-void riccati_wave(int nj, bool two_per_simd, int batch, hipStream_t st, const Launch& L) {
+// joint_rows false: Wt holds the rows 0..11 only, the sweep completes the joint rows from Vt (k_project_fast<.., false>)
+void riccati_wave(int nj, bool two_per_simd, bool joint_rows, int batch, hipStream_t st, const Launch& L) {
   KL_NJ(nj, {
-    if (two_per_simd) hipLaunchKernelGGL(k_riccati_wave2<NJ>, dim3(batch), dim3(kWave), 0, st, L);
-    else hipLaunchKernelGGL(k_riccati_wave<NJ>, dim3(batch), dim3(kWave), 0, st, L);
+    if (two_per_simd && !joint_rows) hipLaunchKernelGGL((k_riccati_wave2<NJ, false>), dim3(batch), dim3(kWave), 0, st, L);
+    else if (two_per_simd) hipLaunchKernelGGL((k_riccati_wave2<NJ, true>), dim3(batch), dim3(kWave), 0, st, L);
+    else if (!joint_rows) hipLaunchKernelGGL((k_riccati_wave<NJ, false>), dim3(batch), dim3(kWave), 0, st, L);
+    else hipLaunchKernelGGL((k_riccati_wave<NJ, true>), dim3(batch), dim3(kWave), 0, st, L);
   });
 }
 void riccati_rollout(int nj, int batch, hipStream_t st, const Launch& L) {

@@ -33,7 +33,7 @@ void copy_pairs(int grid, hipStream_t st, const double* a_src, double* a_dst, si
 // ---- k_project.hip: constraint elimination and change of variables
 void project_reference(int nj, int slots, hipStream_t st, const Launch& L);
 void project_lu_s(int nj, int max_vel_rows, bool packed, int nodes, hipStream_t st, const Launch& L);
-void project_fast(int nj, bool packed, int nodes, hipStream_t st, const Launch& L);
+void project_fast(int nj, bool packed, bool joint_rows, int nodes, hipStream_t st, const Launch& L);
 
 // ---- k_riccati.hip: workgroup-per-problem sweeps
 void riccati_reference(int nj, int batch, hipStream_t st, const Launch& L);
@@ -41,7 +41,7 @@ void riccati_fast(int nj, bool double_buffered, int batch, hipStream_t st, const
 void riccati_fast8(int nj, int batch, hipStream_t st, const Launch& L);
 
 // ---- k_riccati_wave.hip: wave-per-problem sweeps and their roll-out
-void riccati_wave(int nj, bool two_per_simd, int batch, hipStream_t st, const Launch& L);
+void riccati_wave(int nj, bool two_per_simd, bool joint_rows, int batch, hipStream_t st, const Launch& L);
 void riccati_rollout(int nj, int batch, hipStream_t st, const Launch& L);
 
 }  // namespace kl

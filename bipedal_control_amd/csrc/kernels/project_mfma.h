@@ -43,7 +43,11 @@ struct ProjectMfmaWorkspace {
 // The three products for a compile-time number of block columns NBC (packed width nx + 1 + nut <= 16 NBC).  Everything
 // that is read from HBM (operands, accumulator initial values) is loaded before the first output store: vmcnt retires in
 // order, a load issued behind a store would wait for that store to reach memory.
-template <int NJ, int NBC, bool PK, class IssueX, class WriteX>
+// WJ = false: the joint rows 12.. of Wt = [At | bt | Bt] are neither computed nor written - they are [I | b | 0] + dt x (joint rows of
+// [Px | Pe | Pu]) = Vt, which the wave-per-problem sweeps load anyway and complete themselves (riccati_wave2.h, JW): at the batch sizes where
+// this kernel streams (4.7 TB/s) that is 3.8 KB per node it does not write and the sweep does not read, and the whole second block row of
+// the first product (rows 16..) is not issued.
+template <int NJ, int NBC, bool PK, bool WJ, class IssueX, class WriteX>
 __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ, PK>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
                                                      double dt_over_mass, const double* Qc, const double* Rc, double reg, int nut,
                                                      IssueX&& issue_x, WriteX&& write_x, const double& pev) {
@@ -167,7 +171,7 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ, PK
   // Every HBM load of this node has been issued by now, so results may leave as soon as they exist.
   // ---- [At | bt | Bt] = [A | b | 0] + B X, stored at once (frees the B operands and these accumulators)
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
+  for (int bi = 0; bi < (WJ ? 2 : 1); ++bi)
 #pragma unroll
     for (int bj = 0; bj < NBC; ++bj) {
       double b[KS];
@@ -180,7 +184,7 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ, PK
       double* wrow = out.Wt + (16 * bi + lk) * WP + 16 * bj + li;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (16 * bi + lk + 4 * r < NX) wrow[4 * r * WP] = acc[r];
+        if (16 * bi + lk + 4 * r < (WJ ? NX : 12)) wrow[4 * r * WP] = acc[r];
     }
   // ---- the arithmetic on the operands of the other two products (their loads travelled under the first one)
 #pragma unroll
@@ -264,7 +268,7 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ, PK
 
 // PK: [Px | Pe | Pu] arrives as the packed joint rows of the structured elimination (in.Vt; the force rows are generated from in.mode)
 // instead of as Px, Pu, Pe - a compile-time choice: both paths in one kernel cost nx = 24 its third wave per SIMD.
-template <int NJ, bool PK = false>
+template <int NJ, bool PK = false, bool WJ = true>
 __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ, PK>& ws, const ProjectIn& in, const ProjectOut& out, double dt,
                                                    double dt_over_mass, const double* Qc, const double* Rc, double reg = 0.0) {
   using WS = ProjectMfmaWorkspace<NJ, PK>;
@@ -278,7 +282,7 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ, PK>&
     constexpr int WP = PackedLq<NJ>::WP, QP = PackedLq<NJ>::QP;
     for (int idx = l; idx < NX * 32; idx += kWave) {
       const int i = idx >> 5, j = idx & 31;
-      out.Wt[i * WP + j] = j < NX ? (i == j ? 1.0 : 0.0) : (j == NX ? in.b[i] : 0.0);
+      if (WJ || i < 12) out.Wt[i * WP + j] = j < NX ? (i == j ? 1.0 : 0.0) : (j == NX ? in.b[i] : 0.0);
       out.Qp[i * QP + j] = (i == j) ? reg : 0.0;
     }
     if (!PK && out.Vt)
@@ -315,8 +319,8 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ, PK>&
         if (idx < NV) ws.X[idx / 48][idx % 48] = vv[it];
       }
     };
-    if (nbc <= 2) project_apply_blocks<NJ, 2, true>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, pev);
-    else project_apply_blocks<NJ, WS::NBC_MAX, true>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, pev);
+    if (nbc <= 2) project_apply_blocks<NJ, 2, true, WJ>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, pev);
+    else project_apply_blocks<NJ, WS::NBC_MAX, true, WJ>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, pev);
   } else {
     auto issue_x = [&]() {                             // (test path, FullPivLU-format inputs: staged in one go)
       constexpr int IT = (NU * NX + kWave - 1) / kWave;
@@ -347,8 +351,8 @@ __device__ __forceinline__ void project_apply_mfma(ProjectMfmaWorkspace<NJ, PK>&
     };
     auto write_x = []() {};
     const double no_pe = 0.0;
-    if (nbc <= 2) project_apply_blocks<NJ, 2, false>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, no_pe);
-    else project_apply_blocks<NJ, WS::NBC_MAX, false>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, no_pe);
+    if (nbc <= 2) project_apply_blocks<NJ, 2, false, WJ>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, no_pe);
+    else project_apply_blocks<NJ, WS::NBC_MAX, false, WJ>(ws, in, out, dt, dt_over_mass, Qc, Rc, reg, nut, issue_x, write_x, no_pe);
   }
 }
 

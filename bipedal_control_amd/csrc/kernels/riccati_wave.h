@@ -55,7 +55,9 @@ struct RiccatiWaveWorkspace {
 __device__ __forceinline__ int wave_stance_first(int mode) { return mode == 2 ? 6 : 0; }
 __device__ __forceinline__ int wave_stance_count(int mode) { return mode == 3 ? 12 : ((mode == 1 || mode == 2) ? 6 : 0); }   // 0 and kModeEvent: none
 
-template <int NJ>
+// JW off: the joint rows 12.. of Wt = [A~ | b~ | B~] are not in HBM (k_project_fast<.., WJ = false>): they are [I | b | 0] + dt Vt, loaded from
+// Vt in the place of the rows of Wt and completed when the operands of the next stage become the current ones (riccati_wave2.h has the same).
+template <int NJ, bool JW = true>
 __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const RiccatiFastIO& io) {
   using WS = RiccatiWaveWorkspace<NJ>;
   using PL = PackedLq<NJ>;
@@ -145,7 +147,7 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi) {
     const int row = 16 * bi + li, j = row - 12;
-    oBt[bi] = row < NX ? 8u * (unsigned)(row * WP + BC + lk) : kOut;
+    oBt[bi] = row < (JW ? NX : 12) ? 8u * (unsigned)(row * WP + BC + lk) : kOut;      // (operand rows >= 12 only feed rows of Acl that are not kept)
     oPu[bi] = (j >= 0 && row < NX) ? 8u * (unsigned)(j * WP + BC + lk) : kOut;
   }
   // Qp[16 bi + lk + 4 r][li] and [16 + li] (columns <= nx): rows are 4 * 32 * 8 = 1024 bytes apart
@@ -180,14 +182,40 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
   double cPu[2][4];                           // Pu likewise (force rows generated)
   v4d cPI[2][2];                              // [Px | Pe] (force rows generated)
 
+  // JW off: offsets of the joint rows in Vt (row 4 (ks - 3) + lk; the last k-step masked beyond nj), b of the joint rows of the stage being
+  // loaded in the lanes of column nx, dt of that stage
+  auto offJ = [&](int ks) { return ks == 3 ? gV0 : (ks == 4 ? gV0 + RS : gV0l); };
+  double nbj[3] = {0.0, 0.0, 0.0};
   auto load_W = [&](double (&w)[KS][NB], int k, int nt) {
     const __amdgpu_buffer_rsrc_t rw = rsrc(io.Wt + (size_t)k * PL::W_SIZE, PL::W_SIZE);
+    const __amdgpu_buffer_rsrc_t rv = rsrc(io.Vt + (size_t)k * (NJ * WP), NJ * WP);
     const int nbc = (BC + nt + 15) >> 4;      // block columns >= nbc are not written by the change of variables: neither loaded nor used
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int bj = 0; bj < NB; ++bj)
-        if (bj < 2 || bj < nbc) w[ks][bj] = bload(rw, offW(ks) + 128u * bj);
+      for (int bj = 0; bj < NB; ++bj) {
+        if (JW || ks < 3) { if (bj < 2 || bj < nbc) w[ks][bj] = bload(rw, offW(ks) + 128u * bj); }
+        else w[ks][bj] = bload(rv, (bj < 2 || bj < nbc) ? offJ(ks) + 128u * bj : kOut);
+      }
+    if constexpr (!JW) {
+      const __amdgpu_buffer_rsrc_t rb = rsrc(io.lqb + (size_t)k * NX, NX);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) nbj[q] = bload(rb, li == XR ? 8u * (unsigned)(12 + 4 * q + lk) : kOut);
+    }
+  };
+  // completes the joint rows of a freshly loaded W, cB, cWT of stage k (JW off)
+  auto complete_joint_rows = [&](double (&w)[KS][NB], int k) {
+    const double dtk = io.gdt[k];
+#pragma unroll
+    for (int ks = 3; ks < KS; ++ks) {
+      const int row = 4 * ks + lk;
+      w[ks][0] = dtk * w[ks][0] + (li == row ? 1.0 : 0.0);
+      const double w1 = dtk * w[ks][1] + (16 + li == row ? 1.0 : 0.0);
+      cWT[ks] = li < XR ? w1 : 0.0;
+      w[ks][1] = w1 + nbj[ks - 3];
+      w[ks][2] = dtk * w[ks][2];
+      cB[ks] = dtk * cB[ks];
+    }
   };
   auto load_BM = [&](int k, int nt) {
     const __amdgpu_buffer_rsrc_t rw = rsrc(io.Wt + (size_t)k * PL::W_SIZE, PL::W_SIZE);
@@ -195,7 +223,10 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
     const int nbc = (BC + nt + 15) >> 4;
     const bool in = li < nt;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) cB[ks] = bload(rw, in ? offW(ks) + 8u * BC : kOut);
+    for (int ks = 0; ks < KS; ++ks) {
+      if (JW || ks < 3) cB[ks] = bload(rw, in ? offW(ks) + 8u * BC : kOut);
+      else cB[ks] = bload(rsrc(io.Vt + (size_t)k * (NJ * WP), NJ * WP), in ? offJ(ks) + 8u * BC : kOut);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const unsigned o = (lk + 4 * r < nt) ? gM[r >> 1] + RS * (unsigned)(r & 1) : kOut;
@@ -208,7 +239,7 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
     const __amdgpu_buffer_rsrc_t rq = rsrc(io.Qp + (size_t)k * PL::Q_SIZE, PL::Q_SIZE);
     const __amdgpu_buffer_rsrc_t rw = rsrc(io.Wt + (size_t)k * PL::W_SIZE, PL::W_SIZE);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) cWT[ks] = bload(rw, offWT(ks));
+    for (int ks = 0; ks < (JW ? KS : 3); ++ks) cWT[ks] = bload(rw, offWT(ks));      // (JW off: the joint rows come from nW when it is completed)
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
@@ -295,6 +326,7 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
   load_BM(k_top, nt_c);
   load_Q(k_top);
   load_late(k_top, nt_c, mode_c);
+  if constexpr (!JW) complete_joint_rows(cW, k_top);
 
 #ifdef BPMPC_RICCATI_PROFILE
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -525,6 +557,7 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int bj = 0; bj < NB; ++bj) cW[ks][bj] = nW[ks][bj];
+      if constexpr (!JW) complete_joint_rows(cW, k - 1);
     }
     nt_c = nt_n; mode_c = mode_n; nt_n = nt_nn; mode_n = mode_nn;
     RWPROF(6);

@@ -29,10 +29,11 @@ struct RiccatiWave2Workspace {
   alignas(16) double T[kTile];
   double ob[NX], ok[NU], om[NX + 2];
   double rv[16], qv[32];
+  double bq[12];                 // b of the joint rows of the current stage (JW off)
   unsigned char nut[kMaxRiccatiStages], mode[kMaxRiccatiStages];
 };
 
-template <int NJ>
+template <int NJ, bool JW = true>
 __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, const RiccatiFastIO& io) {
   using WS = RiccatiWave2Workspace<NJ>;
   using PL = PackedLq<NJ>;
@@ -110,7 +111,8 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi) {
     const int row = 16 * bi + li, j = row - 12;
-    oBt[bi] = row < NX ? 8u * (unsigned)(row * WP + BC + lk) : kOut;
+    // (B~ row-major feeds rows 3..11 of Acl only: operand rows >= 12 - the joint rows, which Wt does not hold when JW is off - read as zero)
+    oBt[bi] = row < (JW ? NX : 12) ? 8u * (unsigned)(row * WP + BC + lk) : kOut;
     oPu[bi] = (j >= 0 && row < NX) ? 8u * (unsigned)(j * WP + BC + lk) : kOut;
   }
   const unsigned gQ = 8u * (unsigned)(lk * QP + li);                   // Qp[lk + 4 r][li]: rows 1024 bytes apart
@@ -120,11 +122,21 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
   const unsigned gV = 8u * (unsigned)(lk * WP + li);
   const unsigned gVl = (8 + lk < NJ) ? gV + 2 * RS : kOut;
   const unsigned gPe = li == XR ? 8u * (unsigned)lk : kOut;
+  // JW off: the joint rows 12.. of W = [A~ | b~ | B~] are not in HBM (k_project_fast<.., false, ..> does not write them); they are
+  // [I | b | 0] + dt [Px | Pe | Pu](joint rows) and the joint rows of [Px | Pe | Pu] are Vt, which this sweep loads anyway:
+  // the k-steps 3.. of every column of W come from Vt (same row stride, same columns) and are completed at the top of the stage
+  auto offJ = [&](int ks) { return ks == 3 ? gV : (ks == 4 ? gV + RS : gVl); };
+  double bjl = 0.0;                            // b[12 + l] of the stage being loaded (lanes 0..11)
 
   // ---- operand registers (no double buffers)
   double cW[NB][KS];                          // column bj of W: W[4 ks + lk][16 bj + li]
   double cWT[KS];                             // column 1 restricted to the state columns (A-operand of the second block row of A' SW)
   double cB[KS];                              // W[4 ks + lk][BC + li], li < nt
+  // JW off: the k-steps 3.. (joint rows) of the columns live in arrays of their own - loaded from Vt, completed at the top of the stage
+  // (kept apart from cW / cB: with the in-place completion the compiler left parts of cW in scratch memory)
+  double jW[NB][KS - 3], jB[KS - 3];
+#define BP_W(bj, ks) ((JW || (ks) < 3) ? cW[bj][(ks) < KS ? (ks) : 0] : jW[bj][(ks) >= 3 ? (ks) - 3 : 0])
+#define BP_B(ks) ((JW || (ks) < 3) ? cB[(ks) < KS ? (ks) : 0] : jB[(ks) >= 3 ? (ks) - 3 : 0])
   v4d cM[NB];                                 // Mt, rows < nt
   v4d cQ00, cQ01, cQ11;                       // Qp blocks (0, 0), (0, 1), (1, 1)
   double cBt[2][4], cPu[2][4];
@@ -134,9 +146,17 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
     const __amdgpu_buffer_rsrc_t rw = rsrc(io.Wt + (size_t)k * PL::W_SIZE, PL::W_SIZE);
     const __amdgpu_buffer_rsrc_t rm = rsrc(io.Mt + (size_t)k * PL::M_SIZE, PL::M_SIZE);
     const __amdgpu_buffer_rsrc_t rq = rsrc(io.Qp + (size_t)k * PL::Q_SIZE, PL::Q_SIZE);
+    const __amdgpu_buffer_rsrc_t rv = rsrc(io.Vt + (size_t)k * (NJ * WP), NJ * WP);
     const bool in = li < nt;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) { cW[0][ks] = bload(rw, offW(ks)); cB[ks] = bload(rw, in ? offW(ks) + 8u * BC : kOut); }
+    for (int ks = 0; ks < KS; ++ks) {
+      if (JW || ks < 3) { cW[0][ks] = bload(rw, offW(ks)); cB[ks] = bload(rw, in ? offW(ks) + 8u * BC : kOut); }
+      else { jW[0][ks - 3] = bload(rv, offJ(ks)); jB[ks - 3] = bload(rv, in ? offJ(ks) + 8u * BC : kOut); }
+    }
+    if constexpr (!JW) {                      // b of the joint rows: one value per lane, through LDS to the lanes of column nx at the top of the stage
+      const __amdgpu_buffer_rsrc_t rb = rsrc(io.lqb + (size_t)k * NX, NX);
+      bjl = bload(rb, l < 12 ? 8u * (unsigned)(12 + l) : kOut);      // (beyond nx: zero)
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       cM[0][r] = bload(rm, (lk + 4 * r < nt) ? gM + RS * (unsigned)r : kOut);
@@ -147,12 +167,19 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
     const __amdgpu_buffer_rsrc_t rw = rsrc(io.Wt + (size_t)k * PL::W_SIZE, PL::W_SIZE);
     const __amdgpu_buffer_rsrc_t rm = rsrc(io.Mt + (size_t)k * PL::M_SIZE, PL::M_SIZE);
     const __amdgpu_buffer_rsrc_t rq = rsrc(io.Qp + (size_t)k * PL::Q_SIZE, PL::Q_SIZE);
+    const __amdgpu_buffer_rsrc_t rv = rsrc(io.Vt + (size_t)k * (NJ * WP), NJ * WP);
     const int nbc = (BC + nt + 15) >> 4;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      cW[1][ks] = bload(rw, offW(ks) + 128u);
-      cWT[ks] = bload(rw, lx ? offW(ks) + 128u : kOut);
-      if (nbc > 2) cW[2][ks] = bload(rw, offW(ks) + 256u);
+      if (JW || ks < 3) {
+        cW[1][ks] = bload(rw, offW(ks) + 128u);
+        if constexpr (JW) cWT[ks] = bload(rw, lx ? offW(ks) + 128u : kOut);       // (JW off: derived from cW[1] where it is used - twelve registers)
+        if constexpr (JW) { if (nbc > 2) cW[2][ks] = bload(rw, offW(ks) + 256u); }
+        else cW[2][ks] = bload(rw, nbc > 2 ? offW(ks) + 256u : kOut);
+      } else {
+        jW[1][ks - 3] = bload(rv, offJ(ks) + 128u);
+        jW[2][ks - 3] = bload(rv, nbc > 2 ? offJ(ks) + 256u : kOut);        // (unconditional: a conditionally defined value that is completed every stage ends up in scratch)
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -215,7 +242,7 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
   int nt_c = stage_nt(k_top), mode_c = stage_mode(k_top);
   int nt_n = stage_nt(k_top - 1), mode_n = stage_mode(k_top - 1);
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) cW[2][ks] = 0.0;
+  for (int ks = 0; ks < KS; ++ks) { cW[2][ks] = 0.0; if (ks >= 3) jW[2][ks - 3] = 0.0; }
   cM[2] = v4d{0.0, 0.0, 0.0, 0.0};
   load_g1(k_top, nt_c);
   load_g2(k_top, nt_c);
@@ -239,6 +266,20 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
     // load in flight).
     asm volatile("" : "+v"(l));
     li = l & 15; lk = l >> 4; lx = li < XR; lxe = li <= XR;
+    if constexpr (!JW) {              // the joint rows of W from what was loaded of Vt: [I | b | 0] + dt Vt
+      const double dtk = io.gdt[k];
+      if (l < 12) ws.bq[l] = bjl;
+      lds_wave_sync();
+#pragma unroll
+      for (int ks = 3; ks < KS; ++ks) {
+        const int row = 4 * ks + lk;
+        jW[0][ks - 3] = dtk * jW[0][ks - 3] + (li == row ? 1.0 : 0.0);
+        const double bcol = li == XR ? ws.bq[4 * (ks - 3) + lk] : 0.0;
+        jW[1][ks - 3] = (dtk * jW[1][ks - 3] + (16 + li == row ? 1.0 : 0.0)) + bcol;     // state columns 16..; the b column carries dt Pe + b
+        jW[2][ks - 3] = dtk * jW[2][ks - 3];
+        jB[ks - 3] = dtk * jB[ks - 3];
+      }
+    }
     RW2PROF(0);
     // ---- the products of the stage, one block column at a time
     double Sa1[KS];                                                     // S(4 ks + lk, 16 + li), state columns only
@@ -259,27 +300,27 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        sw0 = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ks >> 2][0][ks & 3], cW[bj][ks], sw0, 0, 0, 0);
-        sw1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Sa1[ks], cW[bj][ks], sw1, 0, 0, 0);
+        sw0 = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ks >> 2][0][ks & 3], BP_W(bj, ks), sw0, 0, 0, 0);
+        sw1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Sa1[ks], BP_W(bj, ks), sw1, 0, 0, 0);
       }
       v4d acc = cM[bj];
       if (nt > 0) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cB[ks], ks < 4 ? sw0[ks & 3] : sw1[ks & 3], acc, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(BP_B(ks), ks < 4 ? sw0[ks & 3] : sw1[ks & 3], acc, 0, 0, 0);
       }
       m[bj] = acc;
       if (bj == 0) {
         v4d a = cQ00;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f64_16x16x4f64(cW[0][ks], ks < 4 ? sw0[ks & 3] : sw1[ks & 3], a, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f64_16x16x4f64(BP_W(0, ks), ks < 4 ? sw0[ks & 3] : sw1[ks & 3], a, 0, 0, 0);
         sn00 = a;
       }
       if (bj == 1) {
         v4d a = cQ01, b = cQ11;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          a = __builtin_amdgcn_mfma_f64_16x16x4f64(cW[0][ks], ks < 4 ? sw0[ks & 3] : sw1[ks & 3], a, 0, 0, 0);
-          b = __builtin_amdgcn_mfma_f64_16x16x4f64(cWT[ks], ks < 4 ? sw0[ks & 3] : sw1[ks & 3], b, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f64_16x16x4f64(BP_W(0, ks), ks < 4 ? sw0[ks & 3] : sw1[ks & 3], a, 0, 0, 0);
+          b = __builtin_amdgcn_mfma_f64_16x16x4f64(JW ? cWT[ks] : (lx ? BP_W(1, ks) : 0.0), ks < 4 ? sw0[ks & 3] : sw1[ks & 3], b, 0, 0, 0);
         }
         sn01 = a; sn11 = b;
       }
@@ -293,7 +334,7 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acl[bj][r] = cW[bj][r];
+      for (int r = 0; r < 4; ++r) acl[bj][r] = BP_W(bj, r);
     // ---- elimination (riccati_wave.h): [G g H] through the tile, forward elimination + back substitution, Z / Yn for the update of S
     load_bt(k, nt);
     if (nt > 0) {
@@ -466,6 +507,8 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
         }
   }
   if (l == 0) io.carry[NXX + NX] = (double)status;
+#undef BP_W
+#undef BP_B
 }
 
 }  // namespace bpmpc

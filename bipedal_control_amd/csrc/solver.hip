@@ -102,6 +102,13 @@ struct bpmpc_solver {
   int riccati_wave = 1;
   bool force_tables = false;                                // BPMPC_LIN_TABLES=1: the table walks also on a robot of two serial legs (tests)
   int trial_wide_from = 16;                                 // workgroups per CU from which the value-only kernel runs at one more wave per SIMD (BPMPC_TRIAL_WIDE_FROM)
+  bool wt_joint_rows = false;                               // BPMPC_WT_JOINT_ROWS=1: the change of variables always writes the joint rows of Wt (A/B of the byte cut below)
+  // which sweep runs the current batch (see launch_riccati)
+  bool sweep_wave_regime() const { return riccati_wave == 2 || riccati_wave == 4 || ((riccati_wave == 1 || riccati_wave == 3) && batch > 2 * num_cus); }
+  bool sweep_two_per_simd() const { return sweep_wave_regime() && (riccati_wave >= 3 || (riccati_wave == 1 && batch > 4 * num_cus)); }
+  // the wave-per-problem sweeps (riccati_wave.h, riccati_wave2.h) complete the joint rows of Wt = [At | bt | Bt] itself from Vt ([I | b | 0] + dt Vt): the change of variables then
+  // neither computes nor writes them (3.8 KB per node less each way at the batch sizes where both kernels stream)
+  bool sweep_completes_joint_rows() const { return !wt_joint_rows && structured_project && !settings.reference_kernels && !riccati_double_buffered() && sweep_wave_regime(); }
   bool riccati_double_buffered() const { return riccati_wave != 2 && riccati_wave != 4 && batch <= num_cus; }
   bool has_solution = false;                               // a solve has completed on the current setup
   bool has_rollout = false;                                // roll_x holds the end states of a rollout
@@ -223,7 +230,7 @@ void bpmpc_solver::launch_project(hipStream_t on, const Launch& L, int nodes) {
   // packed joint rows of [Px | Pe | Pu] when the input weight allows the change of variables to generate the force rows; Px, Pu, Pe for the
   // general one (which packs the joint rows for the sweeps' loaders itself)
   TIMED_ON(on, "project_lu", kl::project_lu_s(nj(), max_vel_rows, structured_project, nodes, on, L));
-  TIMED_ON(on, "project", kl::project_fast(nj(), structured_project, nodes, on, L));
+  TIMED_ON(on, "project", kl::project_fast(nj(), structured_project, !sweep_completes_joint_rows(), nodes, on, L));
 }
 void bpmpc_solver::stage_project() {
   const Launch L = launch_params();
@@ -234,16 +241,14 @@ void bpmpc_solver::launch_riccati(const Launch& L) {
   if (riccati_double_buffered()) { TIMED("riccati", kl::riccati_fast8(nj(), batch, stream, L)); return; }
   // up to two problems per CU the four-wave workgroups finish in one round (0.61 against 0.91 ms at batch 512); beyond that a wave per
   // problem, four per CU, wins (G1 / 1024: 1.30 against 1.54 ms; 4096: 4.07 against 4.53 ms)
-  const bool wave_regime = batch > 2 * num_cus;
-  if (!(riccati_wave == 2 || riccati_wave == 4 || ((riccati_wave == 1 || riccati_wave == 3) && wave_regime))) {
+  if (!sweep_wave_regime()) {
     TIMED("riccati", kl::riccati_fast(nj(), false, batch, stream, L));
     return;
   }
   // two waves per SIMD (riccati_wave2.h) need eight problems per CU to fill the chip - the dispatcher packs a CU before it opens the next
   // one, 1024 problems would occupy half of the CUs - and win from the first batch that takes riccati_wave.h a second round: beyond four
   // problems per CU (batch 1024: 0.98 against 1.27 ms; 4096: 3.75 against 3.22 ms)
-  const bool two_per_simd = riccati_wave >= 3 || (riccati_wave == 1 && batch > 4 * num_cus);
-  TIMED("riccati", { kl::riccati_wave(nj(), two_per_simd, batch, stream, L); if (L.k0 == 0) kl::riccati_rollout(nj(), batch, stream, L); });
+  TIMED("riccati", { kl::riccati_wave(nj(), sweep_two_per_simd(), !sweep_completes_joint_rows(), batch, stream, L); if (L.k0 == 0) kl::riccati_rollout(nj(), batch, stream, L); });
 }
 void bpmpc_solver::stage_riccati() {
   const Launch L = launch_params();
@@ -785,6 +790,7 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     HIP_CHECK(hipSetDevice(settings->device));
     { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, settings->device)); s->num_cus = prop.multiProcessorCount; }
     { const char* e = std::getenv("BPMPC_TRIAL_WIDE_FROM"); if (e) s->trial_wide_from = std::max(0, std::atoi(e)); }
+    { const char* e = std::getenv("BPMPC_WT_JOINT_ROWS"); s->wt_joint_rows = e && e[0] == '1'; }
     { const char* e = std::getenv("BPMPC_LIN_TABLES"); s->force_tables = e && e[0] == '1'; }
     { const char* e = std::getenv("BPMPC_RICCATI_WAVE"); s->riccati_wave = e ? std::atoi(e) : 1; }
     {
