@@ -405,6 +405,24 @@ def warm_start_from_previous(model, nodes, x_measured, prev_nodes, prev_x, prev_
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# RK2 sensitivity discretisation of a flow map, generic ([OCS2-upstream] ocs2_oc SensitivityIntegrator rk2
+# as ocs2_sqp uses it, task.info:81 integratorType RK2): x+ = x + dt/2 (f(x, u) + f(x + dt f(x, u), u)) and its Jacobians by the chain rule.
+# The C++ oracle has the same composition built in for the robot's flow map; tests/test_third_party_pins.py pins THIS function to a
+# symbolic differentiation (sympy) on a toy system and the C++ oracle to this function.
+# ---------------------------------------------------------------------------------------------------------------
+def rk2_discretize(flow, x, u, dt):
+    """flow(x, u) -> (f, df/dx, df/du).  Returns x+, A = dx+/dx, B = dx+/du."""
+    f1, A1, B1 = flow(x, u)
+    x2 = x + dt * f1
+    f2, A2, B2 = flow(x2, u)
+    n = len(x)
+    xn = x + 0.5 * dt * f1 + 0.5 * dt * f2
+    A = np.eye(n) + 0.5 * dt * (A1 + A2 + dt * A2 @ A1)
+    B = 0.5 * dt * (B1 + B2 + dt * A2 @ B1)
+    return xn, A, B
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # MRT side (SURVEY.md section 8(f) rank 3): MRT_BASE::rolloutPolicy = TimeTriggeredRollout::run under the LinearController of
 # the last PrimalSolution, as used by MRT_ROS_Dummy_Loop (ocs2_bipedal_robot_ros/src/BipedalRobotDummyNode.cpp:61,72-86) and
 # BipedalController (bipedal_controllers/src/BipedalController.cpp:322).  rollout settings: task.info:158-167 (ODE45,

@@ -8,7 +8,7 @@ mpc.setup(prob["t0"],prob["x0"],prob["schedule"],prob["targets"],horizon=prob["h
 for st in ("linearize","project","riccati"): mpc.stage(st)
 mpc.synchronize()
 mpc.stage("riccati"); mpc.synchronize()
-r=mpc.read("rprof").reshape(256,8)
+r=mpc.read("rprof").reshape(-1,8)[:256]
 print("cycles per stage by phase (P0 regs->LDS+sync, -, P1+sync, P2+sync, P3+sync, P4, P3 own work of wave 0 (Sn), P3 own work of wave 3 (elimination)):")
 print((r.mean(axis=0)/107).round(0))
 print("total per stage", (r.mean(axis=0)/107)[:6].sum())
