@@ -74,7 +74,7 @@ __device__ __forceinline__ void load_shared_model(const DeviceModel& md, LinFast
 //          -> contact velocities (between the first evaluation and the constraint rows) -> ... second evaluation ... -> the stage-two
 //          block a2 -> after the rows of A and B the cost vectors dx, du
 //   swing references (read by the constraint rows, BEFORE the second evaluation) / stage-two momentum and base position xh2
-//   joint origins og and velocities wv (twist walk of an evaluation) / cone terms (cost phase, after both evaluations)
+//   (the cone terms of the cost phase lie beside dx, du in tab)
 // Node-level results that every lane of the node computes identically (flow-map rows 0..5, base velocity, Euler sines / cosines) are
 // parked here by one lane and read back where they are used instead of occupying registers of all lanes across the derivative phases.
 template <int NJ, bool FULL = true, bool CHAIN = false, bool PARK = false>
@@ -95,12 +95,11 @@ struct LinFastNodeLds {
     double comp[NBT][10];        // per body mass / first moment / inertia about o0
     double hb[NBT][6];           // per body momentum about o0
     double cvel_full[FULL ? kNumContacts : 1][3];   // contact point velocities of the first stage (FULL)
-    struct { double dx[C::NX], du[C::NU]; };   // cost vectors (both evaluations are done by then)
+    // cost phase (both evaluations and the combination are done by then): the cost vectors and, beside them, the cone terms
+    // (value-only: the barrier value stays in the lane that computes it)
+    struct { double dx[C::NX], du[C::NU], cone[FULL ? kNumContacts : 1][FULL ? 13 : 1]; };
   };
-  union {
-    struct { double og[NW][3], wv[NW][3]; };   // joint origins (coordinates 3..), a_g * v_g
-    double cone[FULL ? kNumContacts : 1][FULL ? 13 : 1];   // value-only: the barrier value stays in the lane that computes it
-  };
+  double og[NW][3], wv[NW][3];   // joint origins (coordinates 3..), a_g * v_g (twist walk of an evaluation; CHAIN: the Euler rates only)
   double cpos_v[FULL ? 1 : kNumContacts][3], cvel_v[FULL ? 1 : kNumContacts][3];     // value-only: contact points and velocities of the current evaluation
   // node-level results of the two stages: A_b^{-1} blocks, contact points, com, flow-map rows 0..5, base linear velocity, Euler sin / cos
   double X12[FULL ? 2 : 1][FULL ? 9 : 1], X22[FULL ? 2 : 1][FULL ? 9 : 1], cps[FULL ? 2 : 1][FULL ? kNumContacts : 1][3], com[FULL ? 2 : 1][3];
