@@ -65,19 +65,26 @@ __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linea
 #ifdef BPMPC_LIN_TIMELINE                  // per workgroup: start, model staged, end (10 ns ticks) and the hardware id -> tools/lin_timeline.py
   const long long tl0 = wall_clock64();
 #endif
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kLinWaves * kWave);
-  __syncthreads();
-#ifdef BPMPC_LIN_TIMELINE
-  const long long tl1 = wall_clock64();
-#endif
+  // The memory round trips of a workgroup's start overlap: (1) the problem's flags and grid, the node's word (valid | mode | kind, written
+  // by k_prepare) and the lane's entries of the iterate - addresses that only depend on the slot, loaded before anything is known about
+  // the node - are in flight while (2) the model block is staged; (3) what hangs on the grid (dt, swing references) follows.
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;       // sub: node slot of the workgroup
   const int widx = blockIdx.x * (kLinWaves * NPW) + sub;          // batch * max_nodes < 2^31 is checked at creation
   bool valid = widx < L.batch * L.klen;
   const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
-  const int act = L.buf.active[b], grid = L.buf.p_grid[b];           // unconditional loads: two round trips to the node's facts, not four
-  const int n_nodes = L.buf.g_nodes[grid];
-  const NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
-  valid = valid && act != 0 && k < n_nodes;
+  const int act = L.buf.active[b], grid = L.buf.p_grid[b];
+  const int info = L.buf.n_info[(size_t)b * L.N + k];
+  constexpr int NXc = 12 + NJ;
+  const double* xk = L.buf.x + ((size_t)b * (L.N + 1) + k) * NXc;
+  const LinFastPre pre = linearize_preload<C>(xk, xk + NXc, L.buf.u + ((size_t)b * L.N + k) * NXc, L.buf.xref + ((size_t)b * L.N + k) * NXc, g);
+  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kLinWaves * kWave);
+  NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
+  in.kind = info & 1; in.mode = (info >> 1) & 3;                  // (the same facts as the grid tables hold, one hop earlier)
+  __syncthreads();
+#ifdef BPMPC_LIN_TIMELINE
+  const long long tl1 = wall_clock64();
+#endif
+  valid = valid && act != 0 && info != 0;
   const size_t s = valid ? (size_t)b * L.N + k : 0;
   LinFastOut out;
   out.A = L.buf.A; out.B = L.buf.B; out.b = L.buf.b; out.Q = L.buf.Q; out.R = L.buf.R; out.q = L.buf.q; out.r = L.buf.r; out.c = L.buf.c;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linea
 #define BPMPC_LIN_PROF_PROBLEM 0     // the problem whose first 64 nodes report their phase cycles (-DBPMPC_LINFAST_PROFILE): 0 runs on an empty chip, batch / 2 in steady state
 #endif
   out.prof = (valid && b == BPMPC_LIN_PROF_PROBLEM && k < 64) ? L.buf.rprof + 8 * k : nullptr;
-  linearize_fast<NJ, MAT, C, NL>(*L.model, shared, lds[sub], valid, in, out, g);      // g: lane inside the node's group
+  linearize_fast<NJ, MAT, C, NL>(*L.model, shared, lds[sub], valid, in, pre, out, g);      // g: lane inside the node's group
 #ifdef BPMPC_LIN_TIMELINE
   if (threadIdx.x % kWave == 0 && blockIdx.x < 2048) {      // every wave: the workgroup's end is the latest of its waves
     double* t = L.buf.rprof + 16 * blockIdx.x + 4 * (threadIdx.x / kWave);

@@ -572,6 +572,25 @@ constexpr size_t kLinDumpDoubles = (size_t)kLinDumpNodes * 16 + kLinDumpSlack;
 // constant numbers per node.
 constexpr int kQrdStride = 40;
 
+// What a lane needs of the node's iterate, loaded by the kernel wrapper BEFORE the model block is staged (and before the node is known to
+// exist: the addresses only depend on the slot), so that the memory round trips of a workgroup's start overlap instead of following
+// each other: x / u elements ln and ln + 16, and the entries of x_next and x_ref of the lane's rows.
+struct LinFastPre {
+  double x0, x1, u0, u1, xn_q, xn_h, xn_t, xr_q, xr_h, xr_t;
+};
+template <class Cfg>
+__device__ __forceinline__ LinFastPre linearize_preload(const double* x, const double* xnext, const double* u, const double* xref, int ln) {
+  constexpr int G = Cfg::G, NX = Cfg::NX, G0 = Cfg::G0;
+  const int g = ln + G0;
+  const bool tr = G0 > 0 && ln < 3;
+  LinFastPre p;
+  p.x0 = x[ln]; p.u0 = u[ln];
+  p.x1 = ln + 16 < NX ? x[ln + 16] : 0.0; p.u1 = ln + 16 < NX ? u[ln + 16] : 0.0;
+  p.xn_q = g < G ? xnext[6 + g] : 0.0; p.xn_h = ln < 6 ? xnext[ln] : 0.0; p.xn_t = tr ? xnext[6 + ln] : 0.0;
+  p.xr_q = g < G ? xref[6 + g] : 0.0; p.xr_h = ln < 6 ? xref[ln] : 0.0; p.xr_t = tr ? xref[6 + ln] : 0.0;
+  return p;
+}
+
 struct LinFastOut {
   double *A, *B, *b, *Q, *R, *q, *r, *c, *C, *D, *e, *perf;
   int* nc;
@@ -639,7 +658,7 @@ struct RoleSlots {
 // `ln`: lane inside the node's lane group; it carries coordinate g = ln + G0 (LinFastCfg) and the lane-numbered roles.
 template <int NJ, bool MAT = true, class Cfg = LinFastCfg<NJ, true>, class NL = LinFastNodeLds<NJ, true, Cfg::CHAIN, false>>
 __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, NL& nl, bool valid,
-                                               const NodeInputs& in, const LinFastOut& o, int ln) {
+                                               const NodeInputs& in, const LinFastPre& pre, const LinFastOut& o, int ln) {
 #ifdef BPMPC_LINFAST_PROFILE
   long long lf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long lf_prev = clock64();
@@ -682,11 +701,11 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   constexpr int NS = Slots::NS;
   const Slots slots{ln, g, o.dump + ((o.s & (size_t)(kLinDumpNodes - 1)) * 16 + ln)};
   // ---- stage the node inputs in LDS: after this block nothing is read from global memory except model constants
-  for (int idx = ln; idx < NX; idx += LPN) { nl.x[idx] = in.x[idx]; nl.u[idx] = in.u[idx]; }
+  static_assert(LPN == 16 && NX <= 32 && NX == NU, "two elements of x and of u per lane");
+  nl.x[ln] = pre.x0; nl.u[ln] = pre.u0;
+  if (ln + 16 < NX) { nl.x[ln + 16] = pre.x1; nl.u[ln + 16] = pre.u1; }
   // the entries of x_next and x_ref this lane needs later (rows 6+g, ln and - packed lanes 0..2 - 6+ln)
-  const double xn_q = g < G ? in.xnext[6 + g] : 0.0, xn_h = ln < 6 ? in.xnext[ln] : 0.0;
-  const double xr_q = g < G ? in.xref[6 + g] : 0.0, xr_h = ln < 6 ? in.xref[ln] : 0.0;
-  const double xn_t = tr ? in.xnext[6 + ln] : 0.0, xr_t = tr ? in.xref[6 + ln] : 0.0;
+  const double xn_q = pre.xn_q, xn_h = pre.xn_h, xr_q = pre.xr_q, xr_h = pre.xr_h, xn_t = pre.xn_t, xr_t = pre.xr_t;
   if (ln < kNumContacts) { nl.zref[ln] = in.zref[ln]; nl.zdref[ln] = in.zdref[ln]; }
   LaneBody lb;
   {
