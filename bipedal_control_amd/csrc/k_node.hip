@@ -216,20 +216,38 @@ void k_trial_fast(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
   __shared__ LinFastNodeLds<NJ, false, CHAIN> lds[kTrialWaves * NPW];
   __shared__ LinFastShared<NJ, false> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
-  __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
   const int widx = blockIdx.x * (kTrialWaves * NPW) + sub;
   bool valid = widx < L.batch * L.klen;
   const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
-  const int fin = L.buf.done[b], grid = L.buf.p_grid[b];
-  const double alpha = L.buf.alpha[b];
-  const int n_nodes = L.buf.g_nodes[grid];
-  const NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
-  valid = valid && fin == 0 && k < n_nodes;
-  const size_t s = valid ? (size_t)b * L.N + k : 0;
   const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
-  trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, alpha, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
+  if constexpr (WIDE) {       // capped at 128 registers: values in flight across the model staging cost it scratch (1.07 -> 1.18 ms at batch 4096)
+    load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
+    __syncthreads();
+    const int fin = L.buf.done[b], grid = L.buf.p_grid[b];
+    const double alpha = L.buf.alpha[b];
+    const int n_nodes = L.buf.g_nodes[grid];
+    const NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
+    valid = valid && fin == 0 && k < n_nodes;
+    const size_t s = valid ? (size_t)b * L.N + k : 0;
+    trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, alpha, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
+  } else {
+    // the node's facts and the lane's entries of iterate and step are requested before the model block is staged, as in k_linearize_fast
+    // (line search 0.099 -> 0.096 ms at batch 256)
+    const int fin = L.buf.done[b], grid = L.buf.p_grid[b];
+    const double alpha = L.buf.alpha[b];
+    const int info = L.buf.n_info[(size_t)b * L.N + k];
+    const size_t s0 = (size_t)b * L.N + k;
+    const double* xk = L.buf.x + ((size_t)b * (L.N + 1) + k) * NX;
+    const TrialPre pre = trial_preload<C>(xk, xk + NX, L.buf.u + s0 * NU, L.buf.xref + s0 * NX, dx, dx + NX, L.buf.du + s0 * NU, g);
+    load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
+    NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
+    in.kind = info & 1; in.mode = (info >> 1) & 3;
+    __syncthreads();
+    valid = valid && fin == 0 && info != 0;
+    const size_t s = valid ? s0 : 0;
+    trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, alpha, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g, nullptr, &pre);
+  }
 }
 
 // Values of the active equality rows at the CURRENT iterate (after a solve: the solution), per node in registration order: the value-only

@@ -1043,10 +1043,22 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
 // linearize_fast; reference version: trial_node in linesearch.h).
 // EQV: also store the values of the active equality rows (registration order zeroForce_i, zeroVelocity_i, normalVelocity_i per contact,
 // BipedalRobotInterface.cpp:187-191) to eqv[0..nc): the solution metrics of the solver observers (bpmpc_solver_constraint_values).
+// The lane's entries of the iterate and of the step, loaded by the kernel wrapper before the model block is staged (as LinFastPre)
+struct TrialPre {
+  LinFastPre x, d;      // of (x, x_next, u, x_ref) and of (dx, dx_next, du, -)
+};
+template <class Cfg>
+__device__ __forceinline__ TrialPre trial_preload(const double* x, const double* xnext, const double* u, const double* xref, const double* dx,
+                                                  const double* dxn, const double* du, int ln) {
+  TrialPre p;
+  p.x = linearize_preload<Cfg>(x, xnext, u, xref, ln);
+  p.d = linearize_preload<Cfg>(dx, dxn, du, dx /* unused */, ln);
+  return p;
+}
 template <int NJ, class Cfg = LinFastCfg<NJ, true>, bool EQV = false, class NL = LinFastNodeLds<NJ, false, Cfg::CHAIN>>
 __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastShared<NJ, false>& sh, NL& nl, bool valid,
                                            const NodeInputs& in, double alpha, const double* dx, const double* du, const double* dxn,
-                                           double* perf, int ln, double* eqv = nullptr) {
+                                           double* perf, int ln, double* eqv = nullptr, const TrialPre* pre = nullptr) {
   using C = Cfg;
   constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN, G0 = C::G0;
   const int g = ln + G0;
@@ -1065,13 +1077,23 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   const bool is_joint = g >= 6 && g < G;
   const double dt = in.dt, hdt = 0.5 * in.dt;
   const int mode = in.mode;
-  for (int idx = ln; idx < NX; idx += LPN) {
-    nl.x[idx] = in.x[idx] + alpha * dx[idx];
-    nl.u[idx] = in.u[idx] + alpha * du[idx];
+  double xn_q, xn_h, xr_q, xr_h, xn_t, xr_t;
+  if (pre) {                            // (compile-time after inlining) the same expressions on values that arrived before the model block
+    static_assert(LPN == 16 && NX <= 32, "two elements of x and of u per lane");
+    nl.x[ln] = pre->x.x0 + alpha * pre->d.x0; nl.u[ln] = pre->x.u0 + alpha * pre->d.u0;
+    if (ln + 16 < NX) { nl.x[ln + 16] = pre->x.x1 + alpha * pre->d.x1; nl.u[ln + 16] = pre->x.u1 + alpha * pre->d.u1; }
+    xn_q = g < G ? pre->x.xn_q + alpha * pre->d.xn_q : 0.0; xn_h = ln < 6 ? pre->x.xn_h + alpha * pre->d.xn_h : 0.0;
+    xn_t = tr ? pre->x.xn_t + alpha * pre->d.xn_t : 0.0;
+    xr_q = pre->x.xr_q; xr_h = pre->x.xr_h; xr_t = pre->x.xr_t;
+  } else {
+    for (int idx = ln; idx < NX; idx += LPN) {
+      nl.x[idx] = in.x[idx] + alpha * dx[idx];
+      nl.u[idx] = in.u[idx] + alpha * du[idx];
+    }
+    xn_q = g < G ? in.xnext[6 + g] + alpha * dxn[6 + g] : 0.0; xn_h = ln < 6 ? in.xnext[ln] + alpha * dxn[ln] : 0.0;
+    xr_q = g < G ? in.xref[6 + g] : 0.0; xr_h = ln < 6 ? in.xref[ln] : 0.0;
+    xn_t = tr ? in.xnext[6 + ln] + alpha * dxn[6 + ln] : 0.0; xr_t = tr ? in.xref[6 + ln] : 0.0;
   }
-  const double xn_q = g < G ? in.xnext[6 + g] + alpha * dxn[6 + g] : 0.0, xn_h = ln < 6 ? in.xnext[ln] + alpha * dxn[ln] : 0.0;
-  const double xr_q = g < G ? in.xref[6 + g] : 0.0, xr_h = ln < 6 ? in.xref[ln] : 0.0;
-  const double xn_t = tr ? in.xnext[6 + ln] + alpha * dxn[6 + ln] : 0.0, xr_t = tr ? in.xref[6 + ln] : 0.0;
   LaneBody lb;
   {
     const int body = (g >= 5 && g < G) ? g - 5 : 0;
