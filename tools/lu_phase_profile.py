@@ -12,6 +12,6 @@ mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=pro
 for st in ("linearize", "project"): mpc.stage(st)
 mpc.synchronize()
 mpc.stage("project"); mpc.synchronize()
-r = mpc.read("rprof").reshape(B, 8)
+r = mpc.read("rprof").reshape(-1, 8)[:B]
 print("project_lu_s.h, cycles: loads, elimination, U + rank, back substitution, outputs")
 print(r.mean(axis=0).round(0)[:5], "total", r.mean(axis=0)[:5].sum().round(0), " min", r.min(axis=0).round(0)[:5], " max", r.max(axis=0).round(0)[:5])

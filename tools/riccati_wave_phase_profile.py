@@ -14,7 +14,7 @@ lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horiz
 for st in ("linearize", "project", "riccati"): mpc.stage(st)
 mpc.synchronize()
 mpc.stage("riccati"); mpc.synchronize()
-r = mpc.read("rprof").reshape(B, 8)
+r = mpc.read("rprof").reshape(-1, 8)[:B]
 n = lay["n_nodes_max"]
 if variant == "5":
     print("riccati_pair.h, wave 0, cycles per stage (products + tile + loads, wait B1, elimination, wait B2, updates + LDS writes, wait B3, S read):")
