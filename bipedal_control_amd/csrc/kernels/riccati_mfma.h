@@ -308,6 +308,9 @@ __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 
     __syncthreads();
   }
   // the history stays for the step norms when the horizon fitted one pass; their tiles of K follow it in LDS
+#ifdef BPMPC_RICCATI_PROFILE
+  if (BPMPC_RICCATI_PROFILE == 1 && io.prof && tid == 0) io.prof[6] = (double)clock64();     // start of the step norms (the caller turns it into a duration)
+#endif
   riccati_step_norms<NJ, NT>(status, io, N <= cap ? hist : nullptr, hist + (size_t)(cap + 4) * NX);
 }
 

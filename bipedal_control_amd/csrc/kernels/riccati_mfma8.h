@@ -39,16 +39,25 @@ struct RiccatiMfma8Workspace {
   static constexpr int WC = NX + 1 + NU;
   static constexpr int LDW = ((WC + 15) / 16) * 16 + 2;
   static_assert(NX + 1 <= 32 && NU <= 32, "two block rows / columns");
+  // Sets of stage data in LDS.  Two: stage k - 1 can only be staged once the outputs of stage k + 1 are finished (B3 of stage k), and the
+  // staging - 26 KB through the LDS store path, ~1.1 k cycles of own work on three waves - ends ~0.7 k cycles after the S update.
+  // Three (-DBPMPC_RICCATI8_SETS=3, where 160 KB hold them: nx = 22, 163 040 B): it is staged beside S W (or beside G:
+  // BPMPC_RICCATI8_STAGE_PHASE=2) of stage k, a whole stage before it is used.  Measured, round 4: 0.360 (beside S W) / 0.368 ms (beside G)
+  // against 0.337 with two sets - the store path and the waves' issue slots are what the chain's phases need too; not the default.
+#ifndef BPMPC_RICCATI8_SETS
+#define BPMPC_RICCATI8_SETS 2
+#endif
+  static constexpr int NS = (NJ <= 10 && BPMPC_RICCATI8_SETS == 3) ? 3 : 2;
   alignas(16) double S[RB][LDN];        // [S | s], not symmetrised
-  alignas(16) double Qq[2][RB][LDN];    // [Q~ | q~]
+  alignas(16) double Qq[NS][RB][LDN];   // [Q~ | q~]
   alignas(16) double Sn[RB][LDN];       // [Sn | sn]
   alignas(16) double Zt[RE][LDN];       // pivot rows of the forward elimination of [G | g]
   alignas(16) double Yn[RE][LDN];       // the same rows divided by their pivots
-  alignas(16) double W[2][RB][LDW];     // [A~ | b~ | B~]
-  alignas(16) double PW[2][RB][LDW];    // [Px | Pe | Pu]
+  alignas(16) double W[NS][RB][LDW];    // [A~ | b~ | B~]
+  alignas(16) double PW[NS][RB][LDW];   // [Px | Pe | Pu]
   alignas(16) double SW[RB][LDW];       // sym(S) W
-  alignas(16) double M[2][RE][LDW];     // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
-  double r[2][NU];
+  alignas(16) double M[NS][RE][LDW];    // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
+  double r[NS][NU];
   int status;
   unsigned char nut[kMaxRiccatiStages];
   unsigned char mode[kMaxRiccatiStages];
@@ -93,7 +102,8 @@ __device__ __forceinline__ void back_substitute_wave(double (&v)[ROWS], int nt) 
 template <int NJ>
 __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, const RiccatiFastIO& io) {
   using WS = RiccatiMfma8Workspace<NJ>;
-  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccati8Threads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, RE = WS::RE;
+  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccati8Threads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, RE = WS::RE, NS = WS::NS;
+  static_assert(sizeof(WS) <= 160 * 1024, "LDS of a CU");
   constexpr int NXX = NX * NX, NXU = NX * NU;
   constexpr int KS = (NX + 3) / 4;          // k-steps over the state dimension
   constexpr int BC = NX + 1;                // first column of B~ / Pu / R~ in the packed layouts
@@ -156,6 +166,11 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     ld.prefetch(n0, n0 > 0 ? (io.mode[kt] & 3) : kModeEvent);
   }
   __syncthreads();
+  int cur = 0, nxt = NS - 1;             // sets of stage k and of stage k - 1 (three sets: ... -> 0 -> 2 -> 1 -> 0; two: 0 <-> 1); stage k + 1 lies in the third / in nxt
+  if (NS == 3 && role_l && k_top >= io.k_lo) {      // three sets: the first stage is staged here, every later one during S W of its predecessor
+    ld.stage(ws.W[cur], ws.PW[cur], ws.Qq[cur], ws.M[cur], ws.r[cur], ws.nut[k_top]);
+    if (k_top > io.k_lo) ld.prefetch(ws.nut[k_top - 1], ws.mode[k_top - 1]);
+  }
 #ifdef BPMPC_RICCATI_PROFILE
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = clock64();
@@ -220,10 +235,10 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     }
   };
 
-  int pend_k = -1, pend_nt = 0;          // stage whose outputs are still to be finished (uniform)
+  int pend_k = -1, pend_nt = 0, pend_set = 0;     // stage whose outputs are still to be finished (uniform)
+  int nt_next = ws.nut[k_top > 0 ? k_top : 0];    // max_nodes <= kMaxRiccatiStages is checked when the solver is created
   for (int k = k_top; k >= io.k_lo; --k) {
-    const int nt = ws.nut[k];            // max_nodes <= kMaxRiccatiStages is checked when the solver is created
-    const int cur = k & 1;
+    const int nt = nt_next;              // read a stage ahead (behind B0): an LDS round trip less at the top of every stage
     double (*const W)[LDW] = ws.W[cur];
     double (*const PW)[LDW] = ws.PW[cur];
     double (*const Qq)[LDN] = ws.Qq[cur];
@@ -248,12 +263,22 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       blk_store<LDN, 32>(&ws.Sn[0][0], r0, c0, l, acc);
     };
     // ---- P0 (L): registers -> packed LDS layouts; what the projection kernel does not write (block columns >= nbc, rows >= nt) is staged as zero
-    if (role_l) ld.stage(W, PW, Qq, M, rvec, nt);
+#if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 20      // how long the loader waves wait for their prefetch (and for whatever they stored since)
+    if (role_l) { const long long tw0 = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tacc[7] += clock64() - tw0; }
+#endif
+#if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 21      // the staging writes alone
+    const long long ts0 = clock64();
+#endif
+    if (NS == 2 && role_l) ld.stage(W, PW, Qq, M, rvec, nt);
+#if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 21
+    tacc[7] += clock64() - ts0;
+#endif
     RM8OWN(0);
     lds_barrier();                     // B0
     RM8PROF(0);
+    if (k > io.k_lo) nt_next = ws.nut[k - 1];
     // ---- P1: SW = sym(S) W, s added to the b column: up to six blocks on C0..C3, F, E (L: the loads of the next stage)
-    if (role_l && k > io.k_lo) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
+    if (NS == 2 && role_l && k > io.k_lo) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
     if (w != 4 && w != 5) {
       const int id = w < 4 ? w : w - 2;
       if (id < 2 * nbc) {
@@ -278,6 +303,14 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         blk_store<LDW, 32>(&ws.SW[0][0], r0, c0, l, acc);
       }
     }
+#ifndef BPMPC_RICCATI8_STAGE_PHASE
+#define BPMPC_RICCATI8_STAGE_PHASE 1       // three sets: the phase whose barrier the staging of stage k - 1 precedes (1: S W, 2: G)
+#endif
+    auto stage_ahead = [&]() {      // stage k - 1 (requested a stage ago) into the set nobody reads any more, then the request for stage k - 2
+      ld.stage(ws.W[nxt], ws.PW[nxt], ws.Qq[nxt], ws.M[nxt], ws.r[nxt], ws.nut[k - 1]);
+      if (k - 1 > io.k_lo) ld.prefetch(ws.nut[k - 2], ws.mode[k - 2]);
+    };
+    if (NS == 3 && BPMPC_RICCATI8_STAGE_PHASE == 1 && role_l && k > io.k_lo) stage_ahead();
     RM8OWN(1);
     lds_barrier();                     // B1
     RM8PROF(1);
@@ -301,6 +334,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         sn_block(3);
       }
     }
+    if (NS == 3 && BPMPC_RICCATI8_STAGE_PHASE == 2 && role_l && k > io.k_lo) stage_ahead();
     RM8OWN(2);
     lds_barrier();                     // B2
     RM8PROF(2);
@@ -353,8 +387,8 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     } else {
       if (w == 4 || w == 5) sn_block(w - 4);
       if (w == 4) sn_block(2);         // (not C3: a block of Sn beside E on SIMD 3 slowed the elimination from 2290 to 2720 cycles)
-      if (w == 5 && pend_k >= 0) finish_m(pend_k, cur ^ 1);      // (not E after its back substitution: the staging barrier waited for it)
-      if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, cur ^ 1, pend_nt, w < 3 ? w : 3);
+      if (w == 5 && pend_k >= 0) finish_m(pend_k, pend_set);      // (not E after its back substitution: the staging barrier waited for it)
+      if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, pend_set, pend_nt, w < 3 ? w : 3);
       RM8PROF(6);
       lds_barrier();                   // B3
       RM8PROF(3);
@@ -376,7 +410,8 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         blk_store<LDN, 32>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, two barriers ago
       }
     }
-    pend_k = k; pend_nt = nt;
+    pend_k = k; pend_nt = nt; pend_set = cur;
+    if (NS == 3) { const int t = cur; cur = nxt; nxt = 3 - t - nxt; } else { nxt = cur; cur ^= 1; }
     RM8OWN(4);
     RM8PROF(4);
     // no barrier: the next staging writes the other buffer set, and its barrier orders S, Y and the status
@@ -393,8 +428,8 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #endif
 #endif
   __syncthreads();
-  if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, pend_k & 1, pend_nt, w < 3 ? w : 3);
-  if (w == 5 && pend_k >= 0) finish_m(pend_k, pend_k & 1);
+  if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, pend_set, pend_nt, w < 3 ? w : 3);
+  if (w == 5 && pend_k >= 0) finish_m(pend_k, pend_set);
   __syncthreads();
   if (io.k_lo > 0) {                                   // hand over to the launch that sweeps the earlier stages
     for (int idx = tid; idx < NXX; idx += NT) io.carry[idx] = ws.S[idx / NX][idx % NX];
@@ -418,7 +453,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     riccati_rollout_deep<NJ, NT>(reinterpret_cast<double*>(&ws), kHistCap, st, io);
 #endif
 #ifdef BPMPC_RICCATI_PROFILE
-    if (BPMPC_RICCATI_PROFILE == 1 && io.prof && tid == 0) io.prof[5] = (double)(clock64() - tr0);     // roll-out + step norms, whole horizon
+    if (BPMPC_RICCATI_PROFILE == 1 && io.prof && tid == 0) { const long long te = clock64(); io.prof[5] = (double)(te - tr0); io.prof[6] = (double)te - io.prof[6]; }     // roll-out + step norms, whole horizon; [6]: the step norms alone
 #endif
   }
 }
