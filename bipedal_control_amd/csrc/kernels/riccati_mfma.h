@@ -226,16 +226,18 @@ struct PackedStageLoader {
   }
   // registers -> LDS: W = [A~ | b~ | B~], Qq = [Q~ | q~], M = [P~ | r~ | R~] (MR rows), PW = [Px | Pe | Pu], r~ also to rvec
   __device__ __forceinline__ void stage(double (*W)[LDW], double (*PW)[LDW], double (*Qq)[LDN], double (*M)[LDW], double* rvec, int nt) const {
+    stage_wm(W, M, rvec, nt);
+    stage_pq(PW, Qq);
+  }
+  // the two halves of stage(): what the first products of a stage read (W, M) and what is read a phase later or by the outputs only (PW, Qq)
+  __device__ __forceinline__ void stage_wm(double (*W)[LDW], double (*M)[LDW], double* rvec, int nt) const {
     const int cend = 16 * ((BC + nt + 15) >> 4);
-    double* Wf = &W[0][0]; double* Qf = &Qq[0][0]; double* Mf = &M[0][0];
+    double* Wf = &W[0][0]; double* Mf = &M[0][0];
 #pragma unroll
     for (int e = 0; e < SW; ++e)
       if ((e + 1) * NLD <= NPW || wo[e] >= 0) {     // only the last slot of a stream is partial; (a select between two double2 goes through scratch memory: component-wise)
         const bool in = wc[e] < cend; double2 v; v.x = in ? wx[e] : 0.0; v.y = in ? wy[e] : 0.0; *reinterpret_cast<double2*>(Wf + wo[e]) = v;
       }
-#pragma unroll
-    for (int e = 0; e < SQ; ++e)
-      if ((e + 1) * NLD <= NPQ || qo[e] >= 0) { double2 v; v.x = qx[e]; v.y = qy[e]; *reinterpret_cast<double2*>(Qf + qo[e]) = v; }
 #pragma unroll
     for (int e = 0; e < SM; ++e)
       if ((e + 1) * NLD <= NPM || mo[e] >= 0) {
@@ -244,6 +246,12 @@ struct PackedStageLoader {
         *reinterpret_cast<double2*>(Mf + mo[e]) = v;
         if (mc[e] == NX) rvec[mr[e]] = v.x;                          // r~ (nx is even: the first element of its pair)
       }
+  }
+  __device__ __forceinline__ void stage_pq(double (*PW)[LDW], double (*Qq)[LDN]) const {
+    double* Qf = &Qq[0][0];
+#pragma unroll
+    for (int e = 0; e < SQ; ++e)
+      if ((e + 1) * NLD <= NPQ || qo[e] >= 0) { double2 v; v.x = qx[e]; v.y = qy[e]; *reinterpret_cast<double2*>(Qf + qo[e]) = v; }
     pw.stage(PW);
   }
 };

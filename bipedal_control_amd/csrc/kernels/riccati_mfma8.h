@@ -9,7 +9,7 @@
 // The gain Y = H^-1 [G g] (back substitution), [Acl | bcl] = [A | b] - B Y, [K | kff] = [Px | Pe] - Pu Y and m are outputs,
 // not inputs of the next stage: they are finished one stage later, beside the chain, from the other half of the double
 // buffered stage data.  Roles of the eight waves (w = wave index; waves w and w + 4 share a SIMD and its matrix core):
-//     C  w = 0..3   one per SIMD: blocks of SW, G, the S update; C0..C2 finish Acl, K of the previous stage while E eliminates
+//     C  w = 0..3   one per SIMD: blocks of SW and their parts of G, the S update (C0, C1, C3); C0..C2 finish Acl, K of the previous stage while E eliminates
 //     L  w = 4, 5   prefetch (global -> registers, a whole stage ahead), staging (registers -> LDS); Sn blocks beside the elimination;
 //                   L5 also m of the previous stage (its store is younger than the loads it waits for next, so it delays nothing)
 //     F  w = 6      third loader; a block of SW; finishes the fourth block of Acl, K
@@ -18,9 +18,15 @@
 //                   then back substitution (beside the chain); a block of SW
 // vmcnt retires in order, so a wave's wait for a load also waits for every store it issued BEFORE that load (riccati_mfma.h
 // holds results in registers for a stage to get around that).  Here C and F only store, L4 only loads, and L5 stores (in P3) long before it
-// prefetches again (in P1 of the next stage) and waits for that (a stage later still).  Per stage: staging | B0 | SW | B1 | G (C3: a block of Sn) | B2 | forward elimination (others: Sn,
-// outputs of stage k + 1) | B3 | S update (E: back substitution) - four barriers, the S update needs none before the next
-// staging barrier.
+// prefetches again (in P1 of the next stage) and waits for that (a stage later still).
+// Per stage: staging | B0 | SW and, from the accumulators, G | B2 | forward elimination (others: Sn, outputs of stage k + 1) | B3 |
+// S update (E: back substitution) - three barriers, the S update needs none before the next staging barrier.
+// Round 4 (0.339 -> 0.316 ms at batch 256): (1) G = [P | r | R] + B' SW had a phase of its own - a barrier, SW back from LDS, six matrix
+// instructions on three waves.  The accumulator layout of v_mfma_f64_16x16x4_f64 IS its B-operand layout (lane (li, lk), register r <->
+// row lk + 4 r, column li), so the wave that holds a block of SW multiplies it from the registers: block row 0 gives the state rows 0..15 of
+// B' SW (added to M), block row 1 the rows 16.. (to Mb), the elimination wave adds the two parts when it loads its columns.  (2) Block (1, 0)
+// of S is the mirror of (0, 1) and is neither updated nor formed in Sn (one block of Sn less beside the elimination, whose side work had
+// become the longer part of its phase); sym(S) reads it from (0, 1), as the wave-per-problem sweeps do.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -39,25 +45,17 @@ struct RiccatiMfma8Workspace {
   static constexpr int WC = NX + 1 + NU;
   static constexpr int LDW = ((WC + 15) / 16) * 16 + 2;
   static_assert(NX + 1 <= 32 && NU <= 32, "two block rows / columns");
-  // Sets of stage data in LDS.  Two: stage k - 1 can only be staged once the outputs of stage k + 1 are finished (B3 of stage k), and the
-  // staging - 26 KB through the LDS store path, ~1.1 k cycles of own work on three waves - ends ~0.7 k cycles after the S update.
-  // Three (-DBPMPC_RICCATI8_SETS=3, where 160 KB hold them: nx = 22, 163 040 B): it is staged beside S W (or beside G:
-  // BPMPC_RICCATI8_STAGE_PHASE=2) of stage k, a whole stage before it is used.  Measured, round 4: 0.360 (beside S W) / 0.368 ms (beside G)
-  // against 0.337 with two sets - the store path and the waves' issue slots are what the chain's phases need too; not the default.
-#ifndef BPMPC_RICCATI8_SETS
-#define BPMPC_RICCATI8_SETS 2
-#endif
-  static constexpr int NS = (NJ <= 10 && BPMPC_RICCATI8_SETS == 3) ? 3 : 2;
   alignas(16) double S[RB][LDN];        // [S | s], not symmetrised
-  alignas(16) double Qq[NS][RB][LDN];   // [Q~ | q~]
+  alignas(16) double Qq[2][RB][LDN];    // [Q~ | q~]
   alignas(16) double Sn[RB][LDN];       // [Sn | sn]
   alignas(16) double Zt[RE][LDN];       // pivot rows of the forward elimination of [G | g]
   alignas(16) double Yn[RE][LDN];       // the same rows divided by their pivots
-  alignas(16) double W[NS][RB][LDW];    // [A~ | b~ | B~]
-  alignas(16) double PW[NS][RB][LDW];   // [Px | Pe | Pu]
+  alignas(16) double W[2][RB][LDW];     // [A~ | b~ | B~]
+  alignas(16) double PW[2][RB][LDW];    // [Px | Pe | Pu]
   alignas(16) double SW[RB][LDW];       // sym(S) W
-  alignas(16) double M[NS][RE][LDW];    // [P~ | r~ | R~] -> [G | g | H] -> Y in the first nx + 1 columns
-  double r[NS][NU];
+  alignas(16) double M[2][RE][LDW];     // [P~ | r~ | R~] -> its sum with the first part of B' SW -> Y in the first nx + 1 columns
+  alignas(16) double Mb[RE][LDW];       // the second part of B' SW (state rows 16 ..): [G | g | H] = M + Mb
+  double r[2][NU];
   int status;
   unsigned char nut[kMaxRiccatiStages];
   unsigned char mode[kMaxRiccatiStages];
@@ -102,8 +100,7 @@ __device__ __forceinline__ void back_substitute_wave(double (&v)[ROWS], int nt) 
 template <int NJ>
 __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, const RiccatiFastIO& io) {
   using WS = RiccatiMfma8Workspace<NJ>;
-  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccati8Threads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, RE = WS::RE, NS = WS::NS;
-  static_assert(sizeof(WS) <= 160 * 1024, "LDS of a CU");
+  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccati8Threads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, RE = WS::RE;
   constexpr int NXX = NX * NX, NXU = NX * NU;
   constexpr int KS = (NX + 3) / 4;          // k-steps over the state dimension
   constexpr int BC = NX + 1;                // first column of B~ / Pu / R~ in the packed layouts
@@ -113,9 +110,10 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   const int li = l & 15, lk = l >> 4;       // operand row/column index and k index of this lane
   const int N = io.base.N;
   #ifndef BPMPC_RICCATI8_LOADERS
-#define BPMPC_RICCATI8_LOADERS 3     // loader waves 4 .. : L4, L5 and F (with the packed stage loader three are 1 % faster than two)
+#define BPMPC_RICCATI8_LOADERS 3     // loader waves: L4, L5, F (3) and C3 (4), which has no part in the S update then (C2 takes block (1, 1)): two loaders on either SIMD pair
 #endif
-  const bool role_c = w < 4, role_l = w >= 4 && w < 4 + BPMPC_RICCATI8_LOADERS, role_f = w == 6, role_e = w == 7;
+  constexpr bool kC3Loads = BPMPC_RICCATI8_LOADERS == 4;
+  const bool role_c = w < 4, role_l = (w >= 4 && w < 4 + (kC3Loads ? 3 : BPMPC_RICCATI8_LOADERS)) || (kC3Loads && w == 3), role_f = w == 6, role_e = w == 7;
 #ifndef BPMPC_RICCATI8_PRIO_CHAIN
 #define BPMPC_RICCATI8_PRIO_CHAIN 0    // s_setprio of the chain waves C0..C3 / of the elimination wave E over the loader waves that share their SIMDs
 #endif
@@ -160,17 +158,12 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   // Prefetch registers and staging of the loader waves (PackedStageLoader, riccati_mfma.h): 128 threads, pairs t, t + 128, ..
   constexpr int NLD = BPMPC_RICCATI8_LOADERS * kWave;
   PackedStageLoader<NJ, NLD, RE, LDW, LDN> ld;
-  ld.init(io, tid - 4 * kWave, role_l, (size_t)(k_top > 0 ? k_top : 0));
+  ld.init(io, (w == 3 ? 3 : w - 4) * kWave + l, role_l, (size_t)(k_top > 0 ? k_top : 0));
   if (role_l && k_top >= io.k_lo) {     // the stage the loader's pointers stand on (the LDS copies of nut and mode may not be visible yet)
     const int kt = k_top > 0 ? k_top : 0, n0 = io.base.nut[kt];
     ld.prefetch(n0, n0 > 0 ? (io.mode[kt] & 3) : kModeEvent);
   }
   __syncthreads();
-  int cur = 0, nxt = NS - 1;             // sets of stage k and of stage k - 1 (three sets: ... -> 0 -> 2 -> 1 -> 0; two: 0 <-> 1); stage k + 1 lies in the third / in nxt
-  if (NS == 3 && role_l && k_top >= io.k_lo) {      // three sets: the first stage is staged here, every later one during S W of its predecessor
-    ld.stage(ws.W[cur], ws.PW[cur], ws.Qq[cur], ws.M[cur], ws.r[cur], ws.nut[k_top]);
-    if (k_top > io.k_lo) ld.prefetch(ws.nut[k_top - 1], ws.mode[k_top - 1]);
-  }
 #ifdef BPMPC_RICCATI_PROFILE
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = clock64();
@@ -235,10 +228,10 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     }
   };
 
-  int pend_k = -1, pend_nt = 0, pend_set = 0;     // stage whose outputs are still to be finished (uniform)
-  int nt_next = ws.nut[k_top > 0 ? k_top : 0];    // max_nodes <= kMaxRiccatiStages is checked when the solver is created
+  int pend_k = -1, pend_nt = 0;          // stage whose outputs are still to be finished (uniform)
   for (int k = k_top; k >= io.k_lo; --k) {
-    const int nt = nt_next;              // read a stage ahead (behind B0): an LDS round trip less at the top of every stage
+    const int nt = ws.nut[k];            // max_nodes <= kMaxRiccatiStages is checked when the solver is created
+    const int cur = k & 1;
     double (*const W)[LDW] = ws.W[cur];
     double (*const PW)[LDW] = ws.PW[cur];
     double (*const Qq)[LDN] = ws.Qq[cur];
@@ -269,16 +262,22 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 21      // the staging writes alone
     const long long ts0 = clock64();
 #endif
-    if (NS == 2 && role_l) ld.stage(W, PW, Qq, M, rvec, nt);
+#ifndef BPMPC_RICCATI8_SPLIT_STAGE
+#define BPMPC_RICCATI8_SPLIT_STAGE 0     // 1: only W and M are staged before B0; PW (read by the outputs a stage later) and Qq (read by the Sn blocks behind B2) follow behind it
+#endif
+    if (role_l) { if (BPMPC_RICCATI8_SPLIT_STAGE) ld.stage_wm(W, M, rvec, nt); else ld.stage(W, PW, Qq, M, rvec, nt); }
 #if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 21
     tacc[7] += clock64() - ts0;
 #endif
     RM8OWN(0);
     lds_barrier();                     // B0
     RM8PROF(0);
-    if (k > io.k_lo) nt_next = ws.nut[k - 1];
-    // ---- P1: SW = sym(S) W, s added to the b column: up to six blocks on C0..C3, F, E (L: the loads of the next stage)
-    if (NS == 2 && role_l && k > io.k_lo) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
+    // ---- P1: SW = sym(S) W, s added to the b column: up to six blocks on C0..C3, F, E (L: the loads of the next stage); and from each block,
+    //      while it is still in the accumulators (their layout is the B-operand layout: lane (li, lk), register r <-> SW[r0 + lk + 4 r][c0 + li]),
+    //      its part of [G | g | H](:, bj) = [P | r | R] + B' SW(:, bj): state rows 0..15 (block row 0, added to M) or 16.. (block row 1, to Mb).
+    //      Round 3 had a phase of its own for G (a barrier, SW back from LDS, six matrix instructions on three waves); the elimination adds the two parts.
+    if (BPMPC_RICCATI8_SPLIT_STAGE && role_l) ld.stage_pq(PW, Qq);
+    if (role_l && w != 3 && k > io.k_lo) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
     if (w != 4 && w != 5) {
       const int id = w < 4 ? w : w - 2;
       if (id < 2 * nbc) {
@@ -286,57 +285,39 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         const int r0 = 16 * bi, c0 = 16 * (id - bi * nbc);
         const int row = r0 + li;
         const double half = row < NX ? 0.5 : 0.0;
-        double a[KS], b[KS], sv[4];
+        constexpr int KG1 = KS - 4;                                      // k-steps of the second block row (state rows 16 .. nx - 1)
+        double a[KS], b[KS], sv[4], ga[4];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int kk = 4 * ks + lk;
-          a[ks] = half * (ws.S[row][kk] + ws.S[kk][row]);
+          // sym(S): the mean of the two triangles inside the diagonal blocks; block (1, 0) of S is never computed (the S update leaves it out, as
+          // the wave-per-problem sweeps do) - its elements are read from block (0, 1): both terms of the mean are then the same element
+          const bool up = (bi == 0 && ks >= 4), lo = (bi != 0 && ks < 4);
+          a[ks] = half * (ws.S[lo ? kk : row][lo ? row : kk] + ws.S[up ? row : kk][up ? kk : row]);
           b[ks] = W[kk][c0 + li];
         }
         const double smask = (c0 + li == NX) ? 1.0 : 0.0;              // s rides in the b column; rows >= nx of S are zero
 #pragma unroll
         for (int r = 0; r < 4; ++r) sv[r] = smask * ws.S[r0 + lk + 4 * r][NX];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ga[ks] = (bi == 0 || ks < KG1) ? W[r0 + 4 * ks + lk][BC + li] : 0.0;     // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
+        v4d g = blk_load<LDW, 32, 0>(&M[0][0], 0, c0, l);
+        if (bi != 0) g = v4d{0.0, 0.0, 0.0, 0.0};
         __builtin_amdgcn_sched_barrier(0);
         v4d acc = {sv[0], sv[1], sv[2], sv[3]};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
         blk_store<LDW, 32>(&ws.SW[0][0], r0, c0, l, acc);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          if (bi == 0 || ks < KG1) g = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[ks], acc[ks], g, 0, 0, 0);
+        blk_store<LDW, 32>(bi == 0 ? &M[0][0] : &ws.Mb[0][0], 0, c0, l, g);
       }
     }
-#ifndef BPMPC_RICCATI8_STAGE_PHASE
-#define BPMPC_RICCATI8_STAGE_PHASE 1       // three sets: the phase whose barrier the staging of stage k - 1 precedes (1: S W, 2: G)
-#endif
-    auto stage_ahead = [&]() {      // stage k - 1 (requested a stage ago) into the set nobody reads any more, then the request for stage k - 2
-      ld.stage(ws.W[nxt], ws.PW[nxt], ws.Qq[nxt], ws.M[nxt], ws.r[nxt], ws.nut[k - 1]);
-      if (k - 1 > io.k_lo) ld.prefetch(ws.nut[k - 2], ws.mode[k - 2]);
-    };
-    if (NS == 3 && BPMPC_RICCATI8_STAGE_PHASE == 1 && role_l && k > io.k_lo) stage_ahead();
+    if (role_l && w == 3 && k > io.k_lo) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);      // C3 as a loader: its requests follow its block
     RM8OWN(1);
-    lds_barrier();                     // B1
+    lds_barrier();                     // B2 (there is no B1 any more)
     RM8PROF(1);
-    // ---- P2: [G | g | H] = [P | r | R] + B' SW: nbc <= 3 blocks on C0..C2 (the elimination waits for them); C3: block 3 of Sn
-    if (role_c) {
-      if (w < nbc) {
-        const int c0 = 16 * w;
-        v4d acc = blk_load<LDW, 32, 0>(&M[0][0], 0, c0, l);
-        double a[KS], b[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int kk = 4 * ks + lk;
-          a[ks] = W[kk][BC + li];                                    // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
-          b[ks] = ws.SW[kk][c0 + li];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-        blk_store<LDW, 32>(&M[0][0], 0, c0, l, acc);
-      } else if (w == 3) {
-        sn_block(3);
-      }
-    }
-    if (NS == 3 && BPMPC_RICCATI8_STAGE_PHASE == 2 && role_l && k > io.k_lo) stage_ahead();
-    RM8OWN(2);
-    lds_barrier();                     // B2
     RM8PROF(2);
     // ---- P3 (E): forward elimination of [H | G g] -> Z, Yn;  B3;  back substitution -> Y (beside the chain)
     //      C0..C2, F: outputs of stage k + 1;  L4: blocks 0, 2 of Sn, L5: block 1;  C3: nothing (shares its SIMD with E);  B3;
@@ -365,7 +346,12 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #define BP_GJ_CASE(ROWS, FWD, BWD)                                                            \
       {                                                                                       \
         double v[ROWS];                                                                       \
-        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) { const double t = M[i][col]; v[i] = (used && i < nt) ? t : 0.0; } \
+        {   /* both parts of [H | G g]; every load is issued before the first sum (pinned: conditional sums had become ten load - wait - add branches) */ \
+          double ta[ROWS], tb[ROWS];                                                          \
+          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) { ta[i] = M[i][col]; tb[i] = ws.Mb[i][col]; } \
+          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) asm volatile("" : "+v"(ta[i]), "+v"(tb[i])); \
+          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) { const double t = ta[i] + tb[i]; v[i] = (used && i < nt) ? t : 0.0; } \
+        }                                                                                     \
         ok = FWD<ROWS>(v, nt, emit);                                                          \
         if (l == 0 && !ok) ws.status = 1;                                                     \
         RM8PROF(6);                                                                           \
@@ -386,14 +372,15 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #undef BP_GJ_CASE
     } else {
       if (w == 4 || w == 5) sn_block(w - 4);
-      if (w == 4) sn_block(2);         // (not C3: a block of Sn beside E on SIMD 3 slowed the elimination from 2290 to 2720 cycles)
-      if (w == 5 && pend_k >= 0) finish_m(pend_k, pend_set);      // (not E after its back substitution: the staging barrier waited for it)
-      if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, pend_set, pend_nt, w < 3 ? w : 3);
+      if (w == 4) sn_block(3);         // (not C3: a block of Sn beside E on SIMD 3 slowed the elimination from 2290 to 2720 cycles; block 2 = (1, 0) is not needed)
+      if (w == 5 && pend_k >= 0) finish_m(pend_k, cur ^ 1);      // (not E after its back substitution: the staging barrier waited for it)
+      if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, cur ^ 1, pend_nt, w < 3 ? w : 3);
       RM8PROF(6);
       lds_barrier();                   // B3
       RM8PROF(3);
-      if (role_c) {
-        const int r0 = 16 * (w >> 1), c0 = 16 * (w & 1);
+      if (kC3Loads ? w < 3 : (role_c && w != 2)) {          // block (1, 0) of S is the mirror of (0, 1): nobody reads it
+        const int blk = kC3Loads && w == 2 ? 3 : w;
+        const int r0 = 16 * (blk >> 1), c0 = 16 * (blk & 1);
         v4d acc = blk_load<LDN, 32, 0>(&ws.Sn[0][0], r0, c0, l);
         const int gcol = r0 + li < NX ? r0 + li : LDN - 1;              // the last padding column of Z is always zero
         double ag[4], yb[4];
@@ -410,8 +397,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         blk_store<LDN, 32>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, two barriers ago
       }
     }
-    pend_k = k; pend_nt = nt; pend_set = cur;
-    if (NS == 3) { const int t = cur; cur = nxt; nxt = 3 - t - nxt; } else { nxt = cur; cur ^= 1; }
+    pend_k = k; pend_nt = nt;
     RM8OWN(4);
     RM8PROF(4);
     // no barrier: the next staging writes the other buffer set, and its barrier orders S, Y and the status
@@ -428,11 +414,11 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #endif
 #endif
   __syncthreads();
-  if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, pend_set, pend_nt, w < 3 ? w : 3);
-  if (w == 5 && pend_k >= 0) finish_m(pend_k, pend_set);
+  if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, pend_k & 1, pend_nt, w < 3 ? w : 3);
+  if (w == 5 && pend_k >= 0) finish_m(pend_k, pend_k & 1);
   __syncthreads();
   if (io.k_lo > 0) {                                   // hand over to the launch that sweeps the earlier stages
-    for (int idx = tid; idx < NXX; idx += NT) io.carry[idx] = ws.S[idx / NX][idx % NX];
+    for (int idx = tid; idx < NXX; idx += NT) { const int r = idx / NX, c = idx % NX; io.carry[idx] = (r >= 16 && c < 16) ? ws.S[c][r] : ws.S[r][c]; }
     if (tid < NX) io.carry[NXX + tid] = ws.S[tid][NX];
     if (tid == 0) io.carry[NXX + NX] = (double)ws.status;
     return;
