@@ -179,7 +179,9 @@ struct PwVtLoader {
 // ds_write_b128 each.  Loader thread t owns the pairs t, t + NLD, .. of every stream.  The writer leaves the block columns
 // >= nbc and the rows >= nut of Mt untouched; they are neither loaded nor trusted here, zeros are staged instead.
 //   NLD: loader threads; MR: rows of Mt that are kept (reduced inputs the sweep can hold); LDW / LDN: LDS leading dimensions.
-template <int NJ, int NLD, int MR, int LDW, int LDN>
+//   AM: pairs that are not written by the projection kernel are masked by the ADDRESS of their load (a pair of zeros) instead of by selects at
+//   staging time - the staging sits between the S update and S W of the sweep, the requests do not (riccati_mfma8.h, round 4).
+template <int NJ, int NLD, int MR, int LDW, int LDN, bool AM = false>
 struct PackedStageLoader {
   using PL = PackedLq<NJ>;
   static constexpr int NX = PL::NX, NU = PL::NU, WP = PL::WP, QP = PL::QP, BC = NX + 1, NXX = NX * NX;
@@ -216,11 +218,17 @@ struct PackedStageLoader {
   __device__ __forceinline__ void prefetch(int nt, int mode) {
     const int cend = 16 * ((BC + nt + 15) >> 4);                     // first column that is not written / not needed
 #pragma unroll
-    for (int e = 0; e < SW; ++e) if (((e + 1) * NLD <= NPW || wo[e] >= 0) && wc[e] < cend) { const double2 v = gW[e * NLD]; wx[e] = v.x; wy[e] = v.y; }
+    for (int e = 0; e < SW; ++e) {
+      if constexpr (AM) { if ((e + 1) * NLD <= NPW || wo[e] >= 0) { const double2 v = *(wc[e] < cend ? gW + e * NLD : reinterpret_cast<const double2*>(pw.zero_one + 2)); wx[e] = v.x; wy[e] = v.y; } }
+      else if (((e + 1) * NLD <= NPW || wo[e] >= 0) && wc[e] < cend) { const double2 v = gW[e * NLD]; wx[e] = v.x; wy[e] = v.y; }
+    }
 #pragma unroll
     for (int e = 0; e < SQ; ++e) if ((e + 1) * NLD <= NPQ || qo[e] >= 0) { const int p = tl + e * NLD; const double2 v = gQ[(p / HQU) * HQ + p % HQU]; qx[e] = v.x; qy[e] = v.y; }
 #pragma unroll
-    for (int e = 0; e < SM; ++e) if (((e + 1) * NLD <= NPM || mo[e] >= 0) && mr[e] < nt && mc[e] < cend) { const double2 v = gM[e * NLD]; mx[e] = v.x; my[e] = v.y; }
+    for (int e = 0; e < SM; ++e) {
+      if constexpr (AM) { if ((e + 1) * NLD <= NPM || mo[e] >= 0) { const double2 v = *((mr[e] < nt && mc[e] < cend) ? gM + e * NLD : reinterpret_cast<const double2*>(pw.zero_one + 2)); mx[e] = v.x; my[e] = v.y; } }
+      else if (((e + 1) * NLD <= NPM || mo[e] >= 0) && mr[e] < nt && mc[e] < cend) { const double2 v = gM[e * NLD]; mx[e] = v.x; my[e] = v.y; }
+    }
     pw.prefetch(nt, mode);
     gW -= PL::W_SIZE / 2; gQ -= PL::Q_SIZE / 2; gM -= PL::M_SIZE / 2;
   }
@@ -236,12 +244,12 @@ struct PackedStageLoader {
 #pragma unroll
     for (int e = 0; e < SW; ++e)
       if ((e + 1) * NLD <= NPW || wo[e] >= 0) {     // only the last slot of a stream is partial; (a select between two double2 goes through scratch memory: component-wise)
-        const bool in = wc[e] < cend; double2 v; v.x = in ? wx[e] : 0.0; v.y = in ? wy[e] : 0.0; *reinterpret_cast<double2*>(Wf + wo[e]) = v;
+        const bool in = AM || wc[e] < cend; double2 v; v.x = in ? wx[e] : 0.0; v.y = in ? wy[e] : 0.0; *reinterpret_cast<double2*>(Wf + wo[e]) = v;
       }
 #pragma unroll
     for (int e = 0; e < SM; ++e)
       if ((e + 1) * NLD <= NPM || mo[e] >= 0) {
-        const bool in = mr[e] < nt && mc[e] < cend;
+        const bool in = AM || (mr[e] < nt && mc[e] < cend);
         double2 v; v.x = in ? mx[e] : 0.0; v.y = in ? my[e] : 0.0;
         *reinterpret_cast<double2*>(Mf + mo[e]) = v;
         if (mc[e] == NX) rvec[mr[e]] = v.x;                          // r~ (nx is even: the first element of its pair)

@@ -157,7 +157,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 
   // Prefetch registers and staging of the loader waves (PackedStageLoader, riccati_mfma.h): 128 threads, pairs t, t + 128, ..
   constexpr int NLD = BPMPC_RICCATI8_LOADERS * kWave;
-  PackedStageLoader<NJ, NLD, RE, LDW, LDN> ld;
+  PackedStageLoader<NJ, NLD, RE, LDW, LDN, true> ld;
   ld.init(io, (w == 3 ? 3 : w - 4) * kWave + l, role_l, (size_t)(k_top > 0 ? k_top : 0));
   if (role_l && k_top >= io.k_lo) {     // the stage the loader's pointers stand on (the LDS copies of nut and mode may not be visible yet)
     const int kt = k_top > 0 ? k_top : 0, n0 = io.base.nut[kt];
@@ -346,11 +346,20 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #define BP_GJ_CASE(ROWS, FWD, BWD)                                                            \
       {                                                                                       \
         double v[ROWS];                                                                       \
-        {   /* both parts of [H | G g]; every load is issued before the first sum (pinned: conditional sums had become ten load - wait - add branches) */ \
-          double ta[ROWS], tb[ROWS];                                                          \
-          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) { ta[i] = M[i][col]; tb[i] = ws.Mb[i][col]; } \
-          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) asm volatile("" : "+v"(ta[i]), "+v"(tb[i])); \
-          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) { const double t = ta[i] + tb[i]; v[i] = (used && i < nt) ? t : 0.0; } \
+        {   /* both parts of [H | G g].  The loads are pinned (as conditional sums they had become ten load - wait - add branches).  nx = 24: the second \
+               part arrives in two groups - 15 instead of 20 values in flight, or the kernel needs scratch -, which starts the elimination an LDS round trip later */ \
+          constexpr int H1 = NJ <= 10 ? ROWS : (ROWS + 1) / 2;                                \
+          double ta[ROWS], tb[H1];                                                            \
+          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) ta[i] = M[i][col];                 \
+          _Pragma("unroll") for (int i = 0; i < H1; ++i) tb[i] = ws.Mb[i][col];               \
+          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) asm volatile("" : "+v"(ta[i]));    \
+          _Pragma("unroll") for (int i = 0; i < H1; ++i) asm volatile("" : "+v"(tb[i]));      \
+          _Pragma("unroll") for (int i = 0; i < H1; ++i) { const double t = ta[i] + tb[i]; v[i] = (used && i < nt) ? t : 0.0; } \
+          if constexpr (H1 < ROWS) {                                                          \
+            _Pragma("unroll") for (int i = H1; i < ROWS; ++i) tb[i - H1] = ws.Mb[i][col];     \
+            _Pragma("unroll") for (int i = H1; i < ROWS; ++i) asm volatile("" : "+v"(tb[i - H1])); \
+            _Pragma("unroll") for (int i = H1; i < ROWS; ++i) { const double t = ta[i] + tb[i - H1]; v[i] = (used && i < nt) ? t : 0.0; } \
+          }                                                                                   \
         }                                                                                     \
         ok = FWD<ROWS>(v, nt, emit);                                                          \
         if (l == 0 && !ok) ws.status = 1;                                                     \

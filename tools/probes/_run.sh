@@ -1,3 +1,9 @@
-bash tools/probes/prof_ric2.sh "1" 2>&1 | grep ricp
-bash tools/probes/ab_step.sh "ricm3 ricm5" abr8 "--batch 256" 2>&1 | tail -4
-bash tools/probes/test_ab.sh "ricm5" "tests/test_gpu_parity.py tests/test_gpu_api.py tests/test_gpu_hard_cone.py -m gpu" 2>&1 | tail -3
+export TMPDIR=/tmp PYTHONPATH=.
+bash tools/probes/ab_step.sh "ricm3 ricm9" abr12 "--batch 256|--robot g1 --batch 256" 2>&1 | tail -8
+cp bipedal_control_amd/libbpmpc.so /tmp/keep2.so
+cp tools/probes/lib_ricm9.bin bipedal_control_amd/libbpmpc.so
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+cp tools/probes/lib_wavep.bin bipedal_control_amd/libbpmpc.so
+python tools/riccati_wave_phase_profile.py 4096 h1 4 2>&1 | tail -2
+python tools/riccati_wave_phase_profile.py 1024 g1 2 2>&1 | tail -2
+cp /tmp/keep2.so bipedal_control_amd/libbpmpc.so
