@@ -233,7 +233,7 @@ def main():
 
         t, x, u, _, stats = mpc.fetch()
         ok = sum(1 for st in stats if st.status == 0)
-        lin_timed = mpc.kernel_time("linearize", reset=False)         # HIP events on the launch stream, over exactly the timed steps
+        lin_timed = mpc.kernel_time("linearize", reset=False)         # HIP events attached to the kernel's dispatches on the launch stream, over exactly the timed steps
         # error bar of `value`: the same region of `steps` steps four more times (the line's value stays the FIRST region, the contract's)
         spread = [elapsed / args.steps * 1e3]
         if world == 1:
@@ -324,6 +324,8 @@ def main():
             roofline = {"kernel": "k_linearize_fast<%d, true, ..>" % (nx - 12), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": (prof["source"] if prof else None),
                         "avg_launch_us": round(1e6 * avg_s, 2),
+                        "timing": "HIP events attached to the kernel's dispatch on its launch stream (hipExtLaunchKernelGGL start / stop events), every "
+                                  "launch of the timed region: the kernel's duration, the figure the rocprofv3 kernel trace reports",
                         "algorithmic_bytes_per_launch": round(alg_bytes), "launches_per_step": launches_per_step,
                         "node_linearizations_per_s": round(n_intermediate_total / launches_per_step / avg_s, 1), "measured_on": "rank 0"}
         headline = (args.robot, gait, sweep, NI) == ("h1", "trot", False, 100)
@@ -353,7 +355,7 @@ def main():
                "kernel_ms_per_step": {k: round(v[0] / max(1, kt_steps), 4) for k, v in ktimes.items()},
                "timing_spread": {"regions": len(spread), "steps_per_region": args.steps, "ms_per_step_min": round(min(spread), 4),
                                  "ms_per_step_median": round(float(np.median(spread)), 4), "ms_per_step_max": round(max(spread), 4),
-                                 "note": "region 1 carries the event pair around the roofline kernel and is `ms_per_step`; regions 2.. run without it"},
+                                 "note": "region 1 carries the events of the roofline kernel and is `ms_per_step`; regions 2.. run without them"},
                "roofline": roofline, "fused": fused}
         kms = out["kernel_ms_per_step"]
         n_all_nodes = int(sum(g_nodes[p_grid])) if world == 1 else None

@@ -1,5 +1,6 @@
 // Per-node kernels in the lane-per-coordinate mapping (kernels/linearize_fast.h), line search, warm start, policy rollout.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <stdexcept>
 
@@ -356,16 +357,23 @@ namespace kl {
 
 void prepare(int nj, int slots, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_prepare<NJ>, dim3(slots), dim3(kWave), 0, st, L)); }
 void linearize_reference(int nj, int slots, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_linearize<NJ>, dim3(slots), dim3(kWave), 0, st, L)); }
-void linearize_fast(int nj, bool materialise, int nodes, hipStream_t st, const Launch& L) {
+// ev_start / ev_stop (both or neither): HIP events attached to the kernel's own dispatch (hipExtLaunchKernelGGL) - their elapsed time is the
+// kernel's duration, what the roofline of bench.py is defined on; a pair of hipEventRecord calls around the launch also brackets two barrier
+// packets and the dispatch latency (6 .. 12 us of a 175 us kernel, depending on the box)
+void linearize_fast(int nj, bool materialise, int nodes, hipStream_t st, const Launch& L, hipEvent_t ev_start, hipEvent_t ev_stop) {
   KL_NJ(nj, {
     constexpr int per_wg = lin_waves<NJ>() * LinFastCfg<NJ, true>::NPW;
-    const int grid = (nodes + per_wg - 1) / per_wg;
+    const dim3 grid((nodes + per_wg - 1) / per_wg), block(lin_waves<NJ>() * kWave);
+    auto launch = [&](auto kernel) {
+      if (ev_start && ev_stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev_start, ev_stop, 0, L);
+      else hipLaunchKernelGGL(kernel, grid, block, 0, st, L);
+    };
     if (L.serial_legs) {            // two serial legs in lane order (DeviceModel::serial_legs): tree walks by DPP row shifts
-      if (materialise) hipLaunchKernelGGL((k_linearize_fast<NJ, true, true>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
-      else hipLaunchKernelGGL((k_linearize_fast<NJ, false, true>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
+      if (materialise) launch(k_linearize_fast<NJ, true, true>);
+      else launch(k_linearize_fast<NJ, false, true>);
     } else {                        // any tree: walks over LDS tables
-      if (materialise) hipLaunchKernelGGL((k_linearize_fast<NJ, true, false>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
-      else hipLaunchKernelGGL((k_linearize_fast<NJ, false, false>), dim3(grid), dim3(lin_waves<NJ>() * kWave), 0, st, L);
+      if (materialise) launch(k_linearize_fast<NJ, true, false>);
+      else launch(k_linearize_fast<NJ, false, false>);
     }
   });
 }

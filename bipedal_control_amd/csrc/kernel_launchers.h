@@ -17,7 +17,7 @@ namespace kl {
 // ---- k_node.hip: per-node kernels in the lane-per-coordinate mapping, line search, warm start, policy rollout
 void prepare(int nj, int slots, hipStream_t st, const Launch& L);
 void linearize_reference(int nj, int slots, hipStream_t st, const Launch& L);
-void linearize_fast(int nj, bool materialise, int nodes, hipStream_t st, const Launch& L);
+void linearize_fast(int nj, bool materialise, int nodes, hipStream_t st, const Launch& L, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void warm_shift(int nj, int slots, hipStream_t st, const Launch& L);
 void ls_begin(int nj, int batch, hipStream_t st, const Launch& L);
 void trial_reference(int nj, int slots, hipStream_t st, const Launch& L);

@@ -176,6 +176,18 @@ struct bpmpc_solver {
     t.pending.emplace_back(a, b);
     if (t.pending.size() > 4096) collect_timers();   // a profiled loop that never asks for the times must not grow without bound
   }
+  // The lineariser's events are attached to its dispatch (kl::linearize_fast): their elapsed time is the kernel's duration, without the barrier
+  // packets and the dispatch latency a pair of hipEventRecord calls brackets as well
+  void launch_linearize_fast(hipStream_t on, const Launch& L, int nodes) {
+    if (!timed("linearize")) { kl::linearize_fast(nj(), settings.materialize_lq != 0, nodes, on, L); return; }
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); throw DeviceError("hipEventCreate failed"); }
+    kl::linearize_fast(nj(), settings.materialize_lq != 0, nodes, on, L, a, b);
+    KernelTimer& t = timers["linearize"];
+    t.pending.emplace_back(a, b);
+    if (t.pending.size() > 4096) collect_timers();
+  }
   void collect_timers() {
     for (auto& kv : timers) {
       hipError_t first_error = hipSuccess;                 // the events are destroyed whatever happens; the first failure is reported afterwards
@@ -223,7 +235,7 @@ void bpmpc_solver::stage_prepare() {
 void bpmpc_solver::stage_linearize() {
   const Launch L = launch_params();
   if (settings.reference_kernels) TIMED("linearize", kl::linearize_reference(nj(), batch * settings.max_nodes, stream, L));
-  else TIMED("linearize", kl::linearize_fast(nj(), settings.materialize_lq != 0, batch * L.klen, stream, L));
+  else { launch_linearize_fast(stream, L, batch * L.klen); HIP_CHECK(hipGetLastError()); }
 }
 // constraint elimination + change of variables of `nodes` node slots (the fast kernels)
 void bpmpc_solver::launch_project(hipStream_t on, const Launch& L, int nodes) {
@@ -302,7 +314,8 @@ void bpmpc_solver::pipelined_backward() {
     L.k0 = lo;
     L.klen = hi - lo;
     const int nodes = batch * L.klen;
-    TIMED_ON(producer_stream, "linearize", kl::linearize_fast(nj(), settings.materialize_lq != 0, nodes, producer_stream, L));
+    launch_linearize_fast(producer_stream, L, nodes);
+    HIP_CHECK(hipGetLastError());
     launch_project(producer_stream, L, nodes);
     HIP_CHECK(hipEventRecord(ev_chunk[c], producer_stream));
     HIP_CHECK(hipStreamWaitEvent(stream, ev_chunk[c], 0));
