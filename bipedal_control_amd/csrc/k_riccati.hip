@@ -47,12 +47,12 @@ __global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu
 }
 
 // Eight waves per problem with fixed roles (riccati_mfma8.h): one workgroup per CU.
-template <int NJ>
+template <int NJ, bool JW>
 __global__ __launch_bounds__(kRiccati8Threads) void k_riccati_fast8(Launch L) {
   __shared__ RiccatiMfma8Workspace<NJ> ws;
   RiccatiFastIO io;
   if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
-  riccati_mfma8<NJ>(ws, io);
+  riccati_mfma8<NJ, JW>(ws, io);
 }
 
 #define KL_NJ(nj, ...)                                                          \
@@ -71,7 +71,12 @@ void riccati_fast(int nj, bool double_buffered, int batch, hipStream_t st, const
     else hipLaunchKernelGGL((k_riccati_fast<NJ, false>), dim3(batch), dim3(kRiccatiThreads), 0, st, L);
   });
 }
-void riccati_fast8(int nj, int batch, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_riccati_fast8<NJ>, dim3(batch), dim3(kRiccati8Threads), 0, st, L)); }
+void riccati_fast8(int nj, bool joint_rows, int batch, hipStream_t st, const Launch& L) {
+  KL_NJ(nj, {
+    if (joint_rows) hipLaunchKernelGGL((k_riccati_fast8<NJ, true>), dim3(batch), dim3(kRiccati8Threads), 0, st, L);
+    else hipLaunchKernelGGL((k_riccati_fast8<NJ, false>), dim3(batch), dim3(kRiccati8Threads), 0, st, L);
+  });
+}
 
 }  // namespace kl
 }  // namespace bpmpc

@@ -181,13 +181,15 @@ struct PwVtLoader {
 //   NLD: loader threads; MR: rows of Mt that are kept (reduced inputs the sweep can hold); LDW / LDN: LDS leading dimensions.
 //   AM: pairs that are not written by the projection kernel are masked by the ADDRESS of their load (a pair of zeros) instead of by selects at
 //   staging time - the staging sits between the S update and S W of the sweep, the requests do not (riccati_mfma8.h, round 4).
-template <int NJ, int NLD, int MR, int LDW, int LDN, bool AM = false>
+//   JR: Wt holds no joint rows (k_project_fast<.., WJ = false>): they are [I | b | 0] + dt x (joint rows of [Px | Pe | Pu]) and are completed at
+//   staging time from the pairs of Vt this thread holds anyway - the same pair index, the same LDS offset, in W instead of PW (round 4).
+template <int NJ, int NLD, int MR, int LDW, int LDN, bool AM = false, bool JR = false>
 struct PackedStageLoader {
   using PL = PackedLq<NJ>;
   static constexpr int NX = PL::NX, NU = PL::NU, WP = PL::WP, QP = PL::QP, BC = NX + 1, NXX = NX * NX;
   static constexpr int HW = WP / 2, HQ = QP / 2;                    // pairs per row in HBM
   static constexpr int HQU = (NX + 2) / 2;                          // pairs per row of Qp that carry anything ([Q~ | q~]: nx + 1 columns)
-  static constexpr int NPW = NX * HW, NPQ = NX * HQU, NPM = MR * HW;
+  static constexpr int NPW = (JR ? 12 : NX) * HW, NPQ = NX * HQU, NPM = MR * HW;
   static constexpr int SW = (NPW + NLD - 1) / NLD, SQ = (NPQ + NLD - 1) / NLD, SM = (NPM + NLD - 1) / NLD;
   static_assert(LDW % 2 == 0 && LDN % 2 == 0 && NX % 2 == 0 && WP <= LDW && QP <= LDN && MR <= NU, "pairs stay aligned and inside the rows");
   // (x / y halves in separate arrays of doubles: arrays of double2 that live across the stage loop end up in scratch memory)
@@ -197,6 +199,11 @@ struct PackedStageLoader {
   // per slot, fixed for the whole sweep: LDS element offset of the pair, its column (and row, for Mt) for the masks; -1: no pair
   int wo[SW], wc[SW], qo[SQ], mo[SM], mc[SM], mr[SM];
   int tl;
+  // JR: per pair of Vt: the identity entries of the joint row inside the pair, the row whose b the pair carries (the pair that opens at column nx; -1: none)
+  static constexpr int SVJ = PwVtLoader<NJ, NLD, LDW>::SV;
+  double jix[SVJ], jiy[SVJ], jb[SVJ], dtk;
+  int jbo[SVJ];
+  const double *gB, *gDt;
 
   __device__ __forceinline__ void init(const RiccatiFastIO& io, int tl_, bool loader, size_t k) {
     tl = tl_;
@@ -207,6 +214,16 @@ struct PackedStageLoader {
     // Qp: the thread's pairs are not t + e NLD of the HBM rows (the last pairs of a row carry nothing), so the pointer stands on
     // the node and the pair offset is part of the slot
     gQ = reinterpret_cast<const double2*>(io.Qp + k * PL::Q_SIZE);
+    if constexpr (JR) {
+      gB = io.lqb + k * NX; gDt = io.gdt + k; dtk = 0.0;
+#pragma unroll
+      for (int e = 0; e < SVJ; ++e) {
+        const int p = tp + e * NLD, row = 12 + p / HW, col = 2 * (p % HW);
+        const bool ok = p < NJ * HW;
+        jix[e] = (ok && col == row) ? 1.0 : 0.0; jiy[e] = (ok && col + 1 == row) ? 1.0 : 0.0;
+        jbo[e] = (ok && col == NX) ? row : -1; jb[e] = 0.0;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < SW; ++e) { const int p = tp + e * NLD; const bool ok = p < NPW; wo[e] = ok ? (p / HW) * LDW + 2 * (p % HW) : -1; wc[e] = 2 * (p % HW); }
 #pragma unroll
@@ -230,6 +247,12 @@ struct PackedStageLoader {
       else if (((e + 1) * NLD <= NPM || mo[e] >= 0) && mr[e] < nt && mc[e] < cend) { const double2 v = gM[e * NLD]; mx[e] = v.x; my[e] = v.y; }
     }
     pw.prefetch(nt, mode);
+    if constexpr (JR) {
+      dtk = *gDt;
+#pragma unroll
+      for (int e = 0; e < SVJ; ++e) jb[e] = *(jbo[e] >= 0 ? gB + jbo[e] : pw.zero_one);
+      gB -= NX; gDt -= 1;
+    }
     gW -= PL::W_SIZE / 2; gQ -= PL::Q_SIZE / 2; gM -= PL::M_SIZE / 2;
   }
   // registers -> LDS: W = [A~ | b~ | B~], Qq = [Q~ | q~], M = [P~ | r~ | R~] (MR rows), PW = [Px | Pe | Pu], r~ also to rvec
@@ -254,6 +277,14 @@ struct PackedStageLoader {
         *reinterpret_cast<double2*>(Mf + mo[e]) = v;
         if (mc[e] == NX) rvec[mr[e]] = v.x;                          // r~ (nx is even: the first element of its pair)
       }
+    if constexpr (JR) {
+#pragma unroll
+      for (int e = 0; e < SVJ; ++e)
+        if ((e + 1) * NLD <= NJ * HW || pw.vo[e] >= 0) {
+          double2 v; v.x = __builtin_fma(dtk, pw.vx[e], jix[e] + jb[e]); v.y = __builtin_fma(dtk, pw.vy[e], jiy[e]);
+          *reinterpret_cast<double2*>(Wf + pw.vo[e]) = v;
+        }
+    }
   }
   __device__ __forceinline__ void stage_pq(double (*PW)[LDW], double (*Qq)[LDN]) const {
     double* Qf = &Qq[0][0];

@@ -97,7 +97,7 @@ __device__ __forceinline__ void back_substitute_wave(double (&v)[ROWS], int nt) 
   }
 }
 
-template <int NJ>
+template <int NJ, bool JW = true>     // JW: Wt holds its joint rows (off: the loaders complete them from Vt, PackedStageLoader JR)
 __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, const RiccatiFastIO& io) {
   using WS = RiccatiMfma8Workspace<NJ>;
   constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccati8Threads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, RE = WS::RE;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 
   // Prefetch registers and staging of the loader waves (PackedStageLoader, riccati_mfma.h): 128 threads, pairs t, t + 128, ..
   constexpr int NLD = BPMPC_RICCATI8_LOADERS * kWave;
-  PackedStageLoader<NJ, NLD, RE, LDW, LDN, true> ld;
+  PackedStageLoader<NJ, NLD, RE, LDW, LDN, true, !JW> ld;
   ld.init(io, (w == 3 ? 3 : w - 4) * kWave + l, role_l, (size_t)(k_top > 0 ? k_top : 0));
   if (role_l && k_top >= io.k_lo) {     // the stage the loader's pointers stand on (the LDS copies of nut and mode may not be visible yet)
     const int kt = k_top > 0 ? k_top : 0, n0 = io.base.nut[kt];

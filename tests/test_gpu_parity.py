@@ -413,7 +413,7 @@ def test_structured_and_dense_change_of_variables_agree(ctx, robot, gait, monkey
         lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
         mpc.enqueue(); mpc.synchronize()                                  # away from the cold start
         mpc.stage("linearize"); mpc.stage("project"); mpc.synchronize()
-        got[dense] = {k: mpc.read(k) for k in ("Wt", "Qp", "Mt", "nut", "g_kind", "g_mode")}
+        got[dense] = {k: mpc.read(k) for k in ("Wt", "Qp", "Mt", "nut", "g_kind", "g_mode", "Vt", "b", "g_dt")}
         n = lay["n_nodes_max"]
     nut = got["0"]["nut"].reshape(B, N)[:, :n].astype(int)
     assert np.array_equal(nut, got["1"]["nut"].reshape(B, N)[:, :n])
@@ -423,13 +423,20 @@ def test_structured_and_dense_change_of_variables_agree(ctx, robot, gait, monkey
     W = {d: got[d]["Wt"].reshape(B, N, nx, wp)[:, :n] for d in got}
     Q = {d: got[d]["Qp"].reshape(B, N, nx, 32)[:, :n] for d in got}
     M = {d: got[d]["Mt"].reshape(B, N, nx, wp)[:, :n] for d in got}
+    Vt = got["0"]["Vt"].reshape(B, N, nx - 12, wp)[:, :n]
+    bb = got["0"]["b"].reshape(B, N, nx)[:, :n]
+    dt = got["0"]["g_dt"][:n]
     worst = 0.0
     for other in ("0",):
         for b in range(B):
             for k in range(n):
                 nt = nut[b, k]
                 cend = 16 * ((nx + 1 + nt + 15) // 16) if kind[k] == 0 else 32
-                pairs = [(W[other][b, k, :, :cend], W["1"][b, k, :, :cend]), (Q[other][b, k, :, :nx + 1], Q["1"][b, k, :, :nx + 1])]
+                # the structured path leaves the joint rows of Wt to the sweep (round 4, every regime but the four-wave kernel): rows 0..11 are compared
+                # as written, the joint rows of the dense path against what the sweep's loaders complete: [I | b | 0] + dt x (joint rows of [Px | Pe | Pu]) = Vt
+                done = dt[k] * Vt[b, k, :, :cend]
+                done[:, 12:nx] += np.eye(nx - 12); done[:, nx] += bb[b, k, 12:]
+                pairs = [(W[other][b, k, :12, :cend], W["1"][b, k, :12, :cend]), (done, W["1"][b, k, 12:, :cend]), (Q[other][b, k, :, :nx + 1], Q["1"][b, k, :, :nx + 1])]
                 if kind[k] == 0:
                     pairs.append((M[other][b, k, :nt, :cend], M["1"][b, k, :nt, :cend]))
                 for a, d in pairs:
