@@ -38,12 +38,12 @@ __global__ __launch_bounds__(kRiccatiThreads) void k_riccati(Launch L) {
 }
 
 // The single-buffered variant is meant to run two workgroups per CU: cap its registers at 256 (VGPR + AGPR).
-template <int NJ, bool DB>
+template <int NJ, bool DB, bool JW>
 __global__ __launch_bounds__(kRiccatiThreads) __attribute__((amdgpu_waves_per_eu(DB ? 1 : 2, DB ? 8 : 2))) void k_riccati_fast(Launch L) {
   __shared__ RiccatiMfmaWorkspace<NJ, DB> ws;
   RiccatiFastIO io;
   if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
-  riccati_mfma<NJ, DB>(ws, io);
+  riccati_mfma<NJ, DB, JW>(ws, io);
 }
 
 // Eight waves per problem with fixed roles (riccati_mfma8.h): one workgroup per CU.
@@ -65,10 +65,13 @@ __global__ __launch_bounds__(kRiccati8Threads) void k_riccati_fast8(Launch L) {
 namespace kl {
 
 void riccati_reference(int nj, int batch, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_riccati<NJ>, dim3(batch), dim3(kRiccatiThreads), 0, st, L)); }
-void riccati_fast(int nj, bool double_buffered, int batch, hipStream_t st, const Launch& L) {
+void riccati_fast(int nj, bool double_buffered, bool joint_rows, int batch, hipStream_t st, const Launch& L) {
   KL_NJ(nj, {
-    if (double_buffered) hipLaunchKernelGGL((k_riccati_fast<NJ, true>), dim3(batch), dim3(kRiccatiThreads), 0, st, L);
-    else hipLaunchKernelGGL((k_riccati_fast<NJ, false>), dim3(batch), dim3(kRiccatiThreads), 0, st, L);
+    if (double_buffered) {
+      if (!joint_rows) throw std::runtime_error("riccati_fast: the double-buffered four-wave kernel reads the joint rows of Wt");
+      hipLaunchKernelGGL((k_riccati_fast<NJ, true, true>), dim3(batch), dim3(kRiccatiThreads), 0, st, L);
+    } else if (joint_rows) hipLaunchKernelGGL((k_riccati_fast<NJ, false, true>), dim3(batch), dim3(kRiccatiThreads), 0, st, L);
+    else hipLaunchKernelGGL((k_riccati_fast<NJ, false, false>), dim3(batch), dim3(kRiccatiThreads), 0, st, L);
   });
 }
 void riccati_fast8(int nj, bool joint_rows, int batch, hipStream_t st, const Launch& L) {

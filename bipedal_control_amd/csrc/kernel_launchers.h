@@ -37,7 +37,7 @@ void project_fast(int nj, bool packed, bool joint_rows, int nodes, hipStream_t s
 
 // ---- k_riccati.hip: workgroup-per-problem sweeps
 void riccati_reference(int nj, int batch, hipStream_t st, const Launch& L);
-void riccati_fast(int nj, bool double_buffered, int batch, hipStream_t st, const Launch& L);
+void riccati_fast(int nj, bool double_buffered, bool joint_rows, int batch, hipStream_t st, const Launch& L);
 void riccati_fast8(int nj, bool joint_rows, int batch, hipStream_t st, const Launch& L);     // joint_rows: Wt holds them (off: completed from Vt by the loaders)
 
 // ---- k_riccati_wave.hip: wave-per-problem sweeps and their roll-out

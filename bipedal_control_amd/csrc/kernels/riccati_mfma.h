@@ -476,7 +476,7 @@ __device__ __forceinline__ void riccati_rollout_sparse(double* lds /* (cap + 4) 
   }
 }
 
-template <int NJ, bool DB>
+template <int NJ, bool DB, bool JW = true>     // JW: Wt holds its joint rows (off: the loaders complete them from Vt, PackedStageLoader JR)
 __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, const RiccatiFastIO& io) {
   using WS = RiccatiMfmaWorkspace<NJ, DB>;
   constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccatiThreads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, ZR = WS::ZR, RCL = WS::RCL, RBM = WS::RBM;
@@ -524,7 +524,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
   // Prefetch registers and staging of the loader waves (0..2): PackedStageLoader, pairs t, t + 192, ..
   constexpr int NLD = 3 * kWave;                       // loader threads
   const bool loader = w < 3;
-  PackedStageLoader<NJ, NLD, (RBM < NU ? RBM : NU), LDW, LDN> ld;
+  PackedStageLoader<NJ, NLD, (RBM < NU ? RBM : NU), LDW, LDN, false, !JW> ld;
   ld.init(io, tid, loader, (size_t)(k_top > 0 ? k_top : 0));
   if (loader && k_top >= io.k_lo) {     // the stage the loader's pointers stand on (the LDS copies of nut and mode may not be visible yet)
     const int kt = k_top > 0 ? k_top : 0, n0 = io.base.nut[kt];

@@ -108,7 +108,7 @@ struct bpmpc_solver {
   bool sweep_two_per_simd() const { return sweep_wave_regime() && (riccati_wave >= 3 || (riccati_wave == 1 && batch > 4 * num_cus)); }
   // the wave-per-problem sweeps (riccati_wave.h, riccati_wave2.h) and the loaders of the eight-wave sweep (riccati_mfma8.h, PackedStageLoader JR) complete the joint rows of Wt = [At | bt | Bt] from Vt ([I | b | 0] + dt Vt): the change of variables then
   // neither computes nor writes them (3.8 KB per node less each way at the batch sizes where both kernels stream)
-  bool sweep_completes_joint_rows() const { return !wt_joint_rows && structured_project && !settings.reference_kernels && (riccati_double_buffered() || sweep_wave_regime()); }
+  bool sweep_completes_joint_rows() const { return !wt_joint_rows && structured_project && !settings.reference_kernels; }     // every fast sweep does
   bool riccati_double_buffered() const { return riccati_wave != 2 && riccati_wave != 4 && batch <= num_cus; }
   bool has_solution = false;                               // a solve has completed on the current setup
   bool has_rollout = false;                                // roll_x holds the end states of a rollout
@@ -254,7 +254,7 @@ void bpmpc_solver::launch_riccati(const Launch& L) {
   // up to two problems per CU the four-wave workgroups finish in one round (0.61 against 0.91 ms at batch 512); beyond that a wave per
   // problem, four per CU, wins (G1 / 1024: 1.30 against 1.54 ms; 4096: 4.07 against 4.53 ms)
   if (!sweep_wave_regime()) {
-    TIMED("riccati", kl::riccati_fast(nj(), false, batch, stream, L));
+    TIMED("riccati", kl::riccati_fast(nj(), false, !sweep_completes_joint_rows(), batch, stream, L));
     return;
   }
   // two waves per SIMD (riccati_wave2.h) need eight problems per CU to fill the chip - the dispatcher packs a CU before it opens the next
