@@ -160,13 +160,17 @@ struct bpmpc_solver {
     return L;
   }
 
+  // Events that only measure time: no system-scope fence when they complete (hipEventDisableSystemFence: "avoiding the cost of cache writeback and
+  // invalidation, and the performance impact of those actions on the execution of following work") - with the default flags the step that carries
+  // the roofline kernel's events ran 3 % slower than the steps without them (the kernel behind the lineariser found its inputs flushed from L2)
+  static constexpr unsigned kTimingEventFlags = hipEventDisableSystemFence;
   // settings.profile: 0 off, 1 every kernel class, 2 the linearisation kernel only (the roofline measurement of bench.py: every
   // event pair costs one to two microseconds of stream time, ten pairs per solve are 2 % of a step)
   bool timed(const char* cls) const { return settings.profile == 1 || (settings.profile == 2 && std::strcmp(cls, "linearize") == 0); }
   void time_begin(const char* cls, hipEvent_t* a, hipEvent_t* b, hipStream_t on = nullptr) {
     if (!timed(cls)) return;
-    HIP_CHECK(hipEventCreate(a));
-    if (hipEventCreate(b) != hipSuccess) { (void)hipEventDestroy(*a); throw DeviceError("hipEventCreate failed"); }
+    HIP_CHECK(hipEventCreateWithFlags(a, kTimingEventFlags));
+    if (hipEventCreateWithFlags(b, kTimingEventFlags) != hipSuccess) { (void)hipEventDestroy(*a); throw DeviceError("hipEventCreate failed"); }
     if (hipEventRecord(*a, on ? on : stream) != hipSuccess) { (void)hipEventDestroy(*a); (void)hipEventDestroy(*b); throw DeviceError("hipEventRecord failed"); }
   }
   void time_end(const char* cls, hipEvent_t a, hipEvent_t b, hipStream_t on = nullptr) {
@@ -181,8 +185,8 @@ struct bpmpc_solver {
   void launch_linearize_fast(hipStream_t on, const Launch& L, int nodes) {
     if (!timed("linearize")) { kl::linearize_fast(nj(), settings.materialize_lq != 0, nodes, on, L); return; }
     hipEvent_t a, b;
-    HIP_CHECK(hipEventCreate(&a));
-    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); throw DeviceError("hipEventCreate failed"); }
+    HIP_CHECK(hipEventCreateWithFlags(&a, kTimingEventFlags));
+    if (hipEventCreateWithFlags(&b, kTimingEventFlags) != hipSuccess) { (void)hipEventDestroy(a); throw DeviceError("hipEventCreate failed"); }
     kl::linearize_fast(nj(), settings.materialize_lq != 0, nodes, on, L, a, b);
     KernelTimer& t = timers["linearize"];
     t.pending.emplace_back(a, b);
