@@ -131,6 +131,20 @@ BP_DEVICE void linesearch_begin(double* partial /*kWave*3 + 5 LDS*/, const Probl
 template <int NJ, int NL = kWave>
 BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags + 3 sums*/, const ProblemLS& p, const LineSearchSettings& st) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
+#if !defined(BPMPC_HOST_EMULATION)
+  // Device: the entries of the iterate and of the step this lane updates if the trial is accepted are requested HERE, before the sums - their
+  // addresses depend on the lane only.  As a loop of x[idx] += alpha dx[idx] behind the decision (x and dx may alias as far as the compiler
+  // knows) the update was ten dependent memory round trips on four waves per CU: 16 us of a 20 us kernel at batch 256.
+  constexpr int UPD = (2400 + NL - 1) / NL;                       // covers (n + 1) nx of the reference's horizon; longer horizons finish in the loop below
+  const int nxe = (p.n_nodes + 1) * NX, nue = p.n_nodes * NU;
+  double xv[UPD], dxv[UPD], uv[UPD], duv[UPD];
+#pragma unroll
+  for (int j = 0; j < UPD; ++j) {
+    const int idx = (int)threadIdx.x + j * NL;
+    const int ix = idx < nxe ? idx : 0, iu = idx < nue ? idx : 0;
+    xv[j] = p.x[ix]; dxv[j] = p.dx[ix]; uv[j] = p.u[iu]; duv[j] = p.du[iu];
+  }
+#endif
   if (p.done[0]) return;
   const double alpha = p.alpha[0];
   // the node sums are formed by the first NSUM lanes whatever the size of the workgroup, so that the first round (k_ls_decide, 256 lanes) and
@@ -213,10 +227,21 @@ BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags + 3 sums*/
   BP_SYNC();
   const bool accepted = partial[3 * NL] != 0.0;
   if (accepted) {
+#if !defined(BPMPC_HOST_EMULATION)
+#pragma unroll
+    for (int j = 0; j < UPD; ++j) {
+      const int idx = (int)threadIdx.x + j * NL;
+      if (idx < nxe) p.x[idx] = xv[j] + alpha * dxv[j];
+      if (idx < nue) p.u[idx] = uv[j] + alpha * duv[j];
+    }
+    for (int idx = (int)threadIdx.x + UPD * NL; idx < nxe; idx += NL) p.x[idx] += alpha * p.dx[idx];
+    for (int idx = (int)threadIdx.x + UPD * NL; idx < nue; idx += NL) p.u[idx] += alpha * p.du[idx];
+#else
     BP_LANES(tid, NL) {
       for (int idx = tid; idx < (p.n_nodes + 1) * NX; idx += NL) p.x[idx] += alpha * p.dx[idx];
       for (int idx = tid; idx < p.n_nodes * NU; idx += NL) p.u[idx] += alpha * p.du[idx];
     }
+#endif
   }
 }
 
