@@ -10,7 +10,7 @@ shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --cpu-sample 0 $*"
+ARGS="--steps 3 --warmup 1 --settle 0 --cpu-sample 0 $*"
 A="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU"
 B="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM"
 rocprofv3 --kernel-trace --pmc $A --output-format csv -d $OUT/${TAG}_pmc_sqA -o run -- python bench.py $ARGS > /dev/null 2> $OUT/${TAG}_pmc_sqA.log || tail -5 $OUT/${TAG}_pmc_sqA.log

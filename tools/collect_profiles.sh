@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o run -- $BENCH > $OUT/${
 DB=$(find $OUT/${TAG}_stats -name "*.db" | head -1)
 python tools/summarize_rocpd.py "$DB" $OUT/${TAG}_kernel_stats.csv > /dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -o run -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 $EXTRA > /dev/null 2> $OUT/${TAG}_pmc_$C.log
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -o run -- python bench.py --steps 3 --warmup 1 --settle 0 --cpu-sample 0 $EXTRA > /dev/null 2> $OUT/${TAG}_pmc_$C.log
 done
 python tools/summarize_pmc.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_traffic.json "$EXTRA"
 tail -1 $OUT/${TAG}_bench_under_rocprof.json
