@@ -34,12 +34,12 @@ __global__ __launch_bounds__(kWave) void k_project(Launch L) {
 }
 
 #ifndef BPMPC_LUS_WPE
-#define BPMPC_LUS_WPE __attribute__((amdgpu_waves_per_eu(4, 4)))     // 68 registers, 9 KB of LDS per wave: four waves per SIMD, 0.107 -> 0.095 ms (five: the same)
+#define BPMPC_LUS_WPE __attribute__((amdgpu_waves_per_eu(4, 6)))     // 68 registers; 9 KB of LDS per wave: four waves per SIMD (0.107 -> 0.095 ms), 5.9 KB with the compact tile of the packed outputs: six
 #endif
 template <int NJ, int RM, bool PK>
 __global__ __launch_bounds__(kWave) BPMPC_LUS_WPE void k_project_lu_s(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ, WP = PackedLq<NJ>::WP;
-  __shared__ ProjectLuSLds<NJ> lds[kLuNodes];
+  __shared__ ProjectLuSLds<NJ, PK> lds[kLuNodes];
   const int sub = threadIdx.x / kLuLanes, j = threadIdx.x % kLuLanes;
   const int widx = blockIdx.x * kLuNodes + sub;
   bool valid = widx < L.batch * L.klen;

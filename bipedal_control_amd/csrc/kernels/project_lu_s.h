@@ -59,11 +59,17 @@ __device__ __forceinline__ unsigned long long lus_force_rows(int mode) {
   return mode == 0 ? p0 : (mode == 1 ? p1 : (mode == 2 ? p2 : p3));
 }
 
-template <int NJ>
+#ifndef BPMPC_LUS_COMPACT
+#define BPMPC_LUS_COMPACT 1                  // packed outputs: tile of nj rows x 16 columns, three passes (5.9 KB of LDS per wave instead of 9.0: six waves per SIMD)
+#endif
+template <int NJ, bool PK = false>
 struct ProjectLuSLds {                       // per node
+  static constexpr bool kCompact = PK && BPMPC_LUS_COMPACT;
+  static constexpr int UC = kCompact ? NJ : kMaxJoints;
+  static constexpr int TR = kCompact ? NJ : (12 + NJ) / 2, TC = kCompact ? 16 : 12 + NJ + 2;
   union {
-    alignas(16) double U[12][kMaxJoints];    // upper factor by position
-    double tile[(12 + NJ) / 2][12 + NJ + 2]; // output staging, half of the rows at a time (as project_lu4.h)
+    alignas(16) double U[12][UC];            // upper factor by position
+    double tile[TR][TC];                     // output staging: half of the rows at a time (as project_lu4.h); packed outputs: a block column at a time
   };
   double idiag[kMaxJoints];
   int colat[kMaxJoints];                     // joint column of D_v at position p
@@ -136,7 +142,7 @@ __device__ __forceinline__ void lu_s_step(LuSLane& s, int j) {
 // column 16 ceil((nx + 1 + nut) / 16)) and Px / Pu are not written at all: their force rows are zeros and single ones that every
 // reader generates from the contact mode (project_struct.h, riccati_mfma.h), 2.6 KB per node instead of 7.9.
 template <int NJ, int RM, bool PK = false>
-__device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, int mode, const double* D, const double* C, const double* e, double* Px,
+__device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ, PK>& nl, bool valid, int mode, const double* D, const double* C, const double* e, double* Px,
                                              double* Pu, double* Pe, int* nut_out, int sub, int j, double* Vt = nullptr, double* prof = nullptr) {
 #ifdef BPMPC_LUS_PROFILE
   long long tprev = clock64();
@@ -224,18 +230,20 @@ __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, 
   constexpr int HR = NU / 2;
   if constexpr (PK) {
     // packed joint rows: two passes of 24 columns through the tile (rows = joints)
-    constexpr int WP = PackedLq<NJ>::WP, BC = NX + 1, PW = 24;
-    static_assert(NJ <= (12 + NJ) / 2 && PW <= 12 + NJ + 2 && 2 * PW <= WP, "the tile holds nj rows of 24 columns");
+    constexpr int WP = PackedLq<NJ>::WP, BC = NX + 1;
+    constexpr bool CP = ProjectLuSLds<NJ, PK>::kCompact;
+    constexpr int PW = CP ? 16 : 24, NPASS = 48 / PW;
+    static_assert(NJ <= ProjectLuSLds<NJ, PK>::TR && PW <= ProjectLuSLds<NJ, PK>::TC && NPASS * PW <= WP, "the tile holds nj rows of PW columns");
     // columns below the first unwritten block column (whole 128-byte lines; zeros between the reduced inputs and the block boundary); the
     // readers mask the rest where it costs nothing: the sweeps' loaders by the address they load from, a stage ahead (PwVtLoader)
     const int cend_ = 16 * ((BC + nut + 15) >> 4);
-    const int cend = cend_ < 2 * PW ? cend_ : 2 * PW;      // the change of variables keeps three block columns (project_mfma.h NBC_MAX)
+    const int cend = cend_ < NPASS * PW ? cend_ : NPASS * PW;      // the change of variables keeps three block columns (project_mfma.h NBC_MAX)
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
       const int c0 = pass * PW;
       lds_wave_sync();
 #pragma unroll
-      for (int row = 0; row < NJ; ++row) { nl.tile[row][j] = 0.0; if (j < PW - 16) nl.tile[row][16 + j] = 0.0; }
+      for (int row = 0; row < NJ; ++row) { nl.tile[row][j] = 0.0; if (!CP && j < PW - 16) nl.tile[row][16 + j] = 0.0; }
       lds_wave_sync();
 #pragma unroll
       for (int p = 0; p < R; ++p) {
@@ -257,7 +265,7 @@ __device__ __forceinline__ void project_lu_s(ProjectLuSLds<NJ>& nl, bool valid, 
 #pragma unroll
           for (int row = 0; row < NJ; ++row) Vt[row * WP + c0 + j] = nl.tile[row][j];
         }
-        if (j < PW - 16 && c0 + 16 + j < cend) {
+        if (!CP && j < PW - 16 && c0 + 16 + j < cend) {
 #pragma unroll
           for (int row = 0; row < NJ; ++row) Vt[row * WP + c0 + 16 + j] = nl.tile[row][16 + j];
         }
