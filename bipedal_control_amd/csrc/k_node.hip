@@ -206,12 +206,12 @@ __global__ __launch_bounds__(kWave) void k_trial(Launch L) {
   trial_node<NJ>(*L.model, ws, in, L.buf.alpha[b], dx, L.buf.du + (size_t)sidx * NU, dx + NX, L.buf.trial_perf + (size_t)sidx * 3);
 }
 
-// Waves per SIMD of the value-only kernel (144 registers at nx = 22, 170 at nx = 24 when left alone; the LDS fits four / three workgroups
-// per CU since the node tables share one storage).  nx = 24: three (168 registers) - line search 0.492 -> 0.404 ms on G1 / 1024, 0.152 ->
-// 0.129 at batch 256.  nx = 22: four (128 registers) pays once the launch has several rounds of workgroups (1.18 -> 1.13 ms at batch 4096),
-// is neutral at batch 512 and loses at 256 (0.108 -> 0.112): chosen per launch, WIDE.
-template <int NJ, bool WIDE, bool CHAIN>
-__global__ __launch_bounds__(kTrialWaves * kWave) __attribute__((amdgpu_waves_per_eu(NJ <= 10 ? (WIDE ? 4 : 3) : 3, NJ <= 10 ? (WIDE ? 4 : 3) : 3)))
+// Waves per SIMD of the value-only kernel: three (168 registers; the LDS fits three workgroups per CU since the node tables share one storage) -
+// nx = 24: line search 0.492 -> 0.404 ms on G1 / 1024, 0.152 -> 0.129 at batch 256.  nx = 22 had a second variant at four waves per SIMD (128
+// registers, 64 B of scratch) for launches of many rounds (round 3: 1.18 -> 1.13 ms at batch 4096); since the inputs are requested before
+// the model block is staged (round 4) three waves win everywhere (line search 1.049 -> 0.975 ms at 4096, 0.290 -> 0.263 at 1024): removed.
+template <int NJ, bool CHAIN>
+__global__ __launch_bounds__(kTrialWaves * kWave) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_trial_fast(Launch L) {
   using C = LinFastCfg<NJ, true, CHAIN>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
@@ -222,19 +222,9 @@ void k_trial_fast(Launch L) {
   bool valid = widx < L.batch * L.klen;
   const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
   const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
-  if constexpr (WIDE) {       // capped at 128 registers: values in flight across the model staging cost it scratch (1.07 -> 1.18 ms at batch 4096)
-    load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
-    __syncthreads();
-    const int fin = L.buf.done[b], grid = L.buf.p_grid[b];
-    const double alpha = L.buf.alpha[b];
-    const int n_nodes = L.buf.g_nodes[grid];
-    const NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
-    valid = valid && fin == 0 && k < n_nodes;
-    const size_t s = valid ? (size_t)b * L.N + k : 0;
-    trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, alpha, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
-  } else {
+  {
     // the node's facts and the lane's entries of iterate and step are requested before the model block is staged, as in k_linearize_fast
-    // (line search 0.099 -> 0.096 ms at batch 256)
+    // (line search 0.099 -> 0.096 ms at batch 256, 1.049 -> 0.975 at 4096)
     const int fin = L.buf.done[b], grid = L.buf.p_grid[b];
     const double alpha = L.buf.alpha[b];
     const int info = L.buf.n_info[(size_t)b * L.N + k];
@@ -384,16 +374,11 @@ int trial_fast_workgroups(int nj, int nodes) {
   const int per_wg = kTrialWaves * (nj == 10 ? LinFastCfg<10, true>::NPW : LinFastCfg<12, true>::NPW);
   return (nodes + per_wg - 1) / per_wg;
 }
-void trial_fast(int nj, bool wide, int nodes, hipStream_t st, const Launch& L) {
+void trial_fast(int nj, int nodes, hipStream_t st, const Launch& L) {
   const int grid = trial_fast_workgroups(nj, nodes);
   KL_NJ(nj, {
-    if (L.serial_legs) {
-      if (wide && NJ <= 10) hipLaunchKernelGGL((k_trial_fast<NJ, true, true>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
-      else hipLaunchKernelGGL((k_trial_fast<NJ, false, true>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
-    } else {
-      if (wide && NJ <= 10) hipLaunchKernelGGL((k_trial_fast<NJ, true, false>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
-      else hipLaunchKernelGGL((k_trial_fast<NJ, false, false>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
-    }
+    if (L.serial_legs) hipLaunchKernelGGL((k_trial_fast<NJ, true>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
+    else hipLaunchKernelGGL((k_trial_fast<NJ, false>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
   });
 }
 void ls_decide(int nj, int batch, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, st, L)); }

@@ -22,7 +22,7 @@ void warm_shift(int nj, int slots, hipStream_t st, const Launch& L);
 void ls_begin(int nj, int batch, hipStream_t st, const Launch& L);
 void trial_reference(int nj, int slots, hipStream_t st, const Launch& L);
 int trial_fast_workgroups(int nj, int nodes);
-void trial_fast(int nj, bool wide, int nodes, hipStream_t st, const Launch& L);
+void trial_fast(int nj, int nodes, hipStream_t st, const Launch& L);
 void ls_decide(int nj, int batch, hipStream_t st, const Launch& L);
 void ls_tail(int nj, int batch, hipStream_t st, const Launch& L, int max_trials);
 void constraint_values(int nj, int nodes, hipStream_t st, const Launch& L, double* eqv);

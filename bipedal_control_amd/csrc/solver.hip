@@ -101,7 +101,6 @@ struct bpmpc_solver {
   // batch size (tests); 3 riccati_wave2.h whenever a wave per problem is used
   int riccati_wave = 1;
   bool force_tables = false;                                // BPMPC_LIN_TABLES=1: the table walks also on a robot of two serial legs (tests)
-  int trial_wide_from = 16;                                 // workgroups per CU from which the value-only kernel runs at one more wave per SIMD (BPMPC_TRIAL_WIDE_FROM)
   bool wt_joint_rows = false;                               // BPMPC_WT_JOINT_ROWS=1: the change of variables always writes the joint rows of Wt (A/B of the byte cut below)
   // which sweep runs the current batch (see launch_riccati)
   bool sweep_wave_regime() const { return riccati_wave == 2 || riccati_wave == 4 || ((riccati_wave == 1 || riccati_wave == 3) && batch > 2 * num_cus); }
@@ -283,8 +282,7 @@ void bpmpc_solver::stage_linesearch() {
   if (!settings.reference_kernels) {
     // first round for everybody, later rounds per problem on the device (k_ls_tail): no read-back inside a solve
     const int nodes = batch * L.klen;
-    const bool wide = (long long)kl::trial_fast_workgroups(nj(), nodes) > (long long)trial_wide_from * num_cus;   // > 4 rounds of 4 per CU (nx = 22 only)
-    kl::trial_fast(nj(), wide, nodes, stream, L);
+    kl::trial_fast(nj(), nodes, stream, L);
     kl::ls_decide(nj(), batch, stream, L);
     kl::ls_tail(nj(), batch, stream, L, max_trials);
     HIP_CHECK(hipGetLastError());
@@ -806,7 +804,6 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     s->nx = s->rm.nx; s->nu = s->rm.nu;
     HIP_CHECK(hipSetDevice(settings->device));
     { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, settings->device)); s->num_cus = prop.multiProcessorCount; }
-    { const char* e = std::getenv("BPMPC_TRIAL_WIDE_FROM"); if (e) s->trial_wide_from = std::max(0, std::atoi(e)); }
     { const char* e = std::getenv("BPMPC_WT_JOINT_ROWS"); s->wt_joint_rows = e && e[0] == '1'; }
     { const char* e = std::getenv("BPMPC_LIN_TABLES"); s->force_tables = e && e[0] == '1'; }
     { const char* e = std::getenv("BPMPC_RICCATI_WAVE"); s->riccati_wave = e ? std::atoi(e) : 1; }
