@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int max_tria
     }
     __threadfence();
     __syncthreads();
-    linesearch_decide<NJ, kTailThreads>(partial, p, L.ls);
+    linesearch_decide<NJ, kTailThreads, false>(partial, p, L.ls);
     __threadfence();
     __syncthreads();
     if (*done) break;

@@ -128,16 +128,16 @@ BP_DEVICE void linesearch_begin(double* partial /*kWave*3 + 5 LDS*/, const Probl
 }
 
 // NL lanes work on one problem (64 in the lane emulation, 256 on the GPU: the accepted step touches (2N+1) nx doubles)
-template <int NJ, int NL = kWave>
+template <int NJ, int NL = kWave, bool PRE = true>     // PRE (device): the update's operands are requested before the sums (k_ls_decide; the back-tracking kernel has no registers for them)
 BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags + 3 sums*/, const ProblemLS& p, const LineSearchSettings& st) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
 #if !defined(BPMPC_HOST_EMULATION)
   // Device: the entries of the iterate and of the step this lane updates if the trial is accepted are requested HERE, before the sums - their
   // addresses depend on the lane only.  As a loop of x[idx] += alpha dx[idx] behind the decision (x and dx may alias as far as the compiler
   // knows) the update was ten dependent memory round trips on four waves per CU: 16 us of a 20 us kernel at batch 256.
-  constexpr int UPD = (2400 + NL - 1) / NL;                       // covers (n + 1) nx of the reference's horizon; longer horizons finish in the loop below
+  constexpr int UPD = PRE ? (2400 + NL - 1) / NL : 0;             // covers (n + 1) nx of the reference's horizon; longer horizons finish in the loop below
   const int nxe = (p.n_nodes + 1) * NX, nue = p.n_nodes * NU;
-  double xv[UPD], dxv[UPD], uv[UPD], duv[UPD];
+  double xv[UPD + 1], dxv[UPD + 1], uv[UPD + 1], duv[UPD + 1];
 #pragma unroll
   for (int j = 0; j < UPD; ++j) {
     const int idx = (int)threadIdx.x + j * NL;
