@@ -265,7 +265,10 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #ifndef BPMPC_RICCATI8_SPLIT_STAGE
 #define BPMPC_RICCATI8_SPLIT_STAGE 0     // 1: only W and M are staged before B0; PW (read by the outputs a stage later) and Qq (read by the Sn blocks behind B2) follow behind it
 #endif
-    if (role_l) { if (BPMPC_RICCATI8_SPLIT_STAGE) ld.stage_wm(W, M, rvec, nt); else ld.stage(W, PW, Qq, M, rvec, nt); }
+#ifndef BPMPC_RICCATI8_ABLATE
+#define BPMPC_RICCATI8_ABLATE 0      // timing experiments (wrong results): bit 0: stage / prefetch only once; bit 1: no outputs beside the elimination; bit 2: no elimination
+#endif
+    if (role_l && (!(BPMPC_RICCATI8_ABLATE & 1) || k == k_top)) { if (BPMPC_RICCATI8_SPLIT_STAGE) ld.stage_wm(W, M, rvec, nt); else ld.stage(W, PW, Qq, M, rvec, nt); }
 #if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 21
     tacc[7] += clock64() - ts0;
 #endif
@@ -277,7 +280,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     //      its part of [G | g | H](:, bj) = [P | r | R] + B' SW(:, bj): state rows 0..15 (block row 0, added to M) or 16.. (block row 1, to Mb).
     //      Round 3 had a phase of its own for G (a barrier, SW back from LDS, six matrix instructions on three waves); the elimination adds the two parts.
     if (BPMPC_RICCATI8_SPLIT_STAGE && role_l) ld.stage_pq(PW, Qq);
-    if (role_l && w != 3 && k > io.k_lo) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
+    if (role_l && w != 3 && k > io.k_lo && !(BPMPC_RICCATI8_ABLATE & 1)) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
     if (w != 4 && w != 5) {
       const int id = w < 4 ? w : w - 2;
       if (id < 2 * nbc) {
@@ -361,6 +364,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
             _Pragma("unroll") for (int i = H1; i < ROWS; ++i) { const double t = ta[i] + tb[i - H1]; v[i] = (used && i < nt) ? t : 0.0; } \
           }                                                                                   \
         }                                                                                     \
+        if (BPMPC_RICCATI8_ABLATE & 4) ok = true; else                                        \
         ok = FWD<ROWS>(v, nt, emit);                                                          \
         if (l == 0 && !ok) ws.status = 1;                                                     \
         RM8PROF(6);                                                                           \
@@ -382,8 +386,8 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     } else {
       if (w == 4 || w == 5) sn_block(w - 4);
       if (w == 4) sn_block(3);         // (not C3: a block of Sn beside E on SIMD 3 slowed the elimination from 2290 to 2720 cycles; block 2 = (1, 0) is not needed)
-      if (w == 5 && pend_k >= 0) finish_m(pend_k, cur ^ 1);      // (not E after its back substitution: the staging barrier waited for it)
-      if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, cur ^ 1, pend_nt, w < 3 ? w : 3);
+      if (w == 5 && pend_k >= 0 && !(BPMPC_RICCATI8_ABLATE & 2)) finish_m(pend_k, cur ^ 1);      // (not E after its back substitution: the staging barrier waited for it)
+      if ((w < 3 || role_f) && pend_k >= 0 && !(BPMPC_RICCATI8_ABLATE & 2)) finish_outputs(pend_k, cur ^ 1, pend_nt, w < 3 ? w : 3);
       RM8PROF(6);
       lds_barrier();                   // B3
       RM8PROF(3);

@@ -1,0 +1,20 @@
+#!/bin/bash
+# riccati_mfma8s.h phase profile: libraries tools/probes/lib_<name>.bin built with -DBPMPC_RICCATI_PROFILE=1
+export TMPDIR=/tmp PYTHONPATH=.
+cp bipedal_control_amd/libbpmpc.so /tmp/keep.so
+for v in $1; do cp tools/probes/lib_$v.bin bipedal_control_amd/libbpmpc.so; python - <<PY
+import numpy as np
+import bipedal_control_amd as bp
+from bipedal_control_amd import scenarios
+itf=scenarios.h1_interface()
+prob=scenarios.trot_problem(itf,batch=256,n_intervals=100)
+mpc=bp.BatchedSqpMpc(itf,256,116)
+mpc.setup(prob["t0"],prob["x0"],prob["schedule"],prob["targets"],horizon=prob["horizon"])
+for st in ("linearize","project","riccati"): mpc.stage(st)
+mpc.synchronize(); mpc.stage("riccati"); mpc.synchronize()
+r=mpc.read("rprof").reshape(-1,8)[:256]
+np.set_printoptions(linewidth=200, suppress=True)
+print("$v per stage: C own, Bb wait, E-phase own (C0), Ba wait, L4 C-phase own, -, -, E elimination own:", (r.mean(axis=0)/107).round(0), " rollout+norms, norms:", r[:,5].mean().round(0), r[:,6].mean().round(0))
+PY
+done
+cp /tmp/keep.so bipedal_control_amd/libbpmpc.so
