@@ -34,6 +34,7 @@
 
 namespace bpmpc {
 
+typedef unsigned int bp8_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kRiccati8Threads = 512;
 
 template <int NJ>
@@ -175,7 +176,20 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #endif
 
   // Outputs of a stage that are not on the chain (block bw of each): [Acl | bcl] = [A | b] - B Y, [K | kff] = [Px | Pe] - Pu Y,
-  // from the buffer set `buf` that stage was staged into.
+  // from the buffer set `buf` that stage was staged into.  A wave always forms the same block: C0..C2 the blocks 0..2, F block 3.
+  constexpr unsigned kOob = 0x80000000u;                       // beyond num_records of the resources below
+  auto out_rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000); };
+  const __amdgpu_buffer_rsrc_t rAcl = out_rsrc(io.Acl), rKf = out_rsrc(io.Kfull), rbcl = out_rsrc(io.bcl), rkff = out_rsrc(io.kff);
+  unsigned oom[4], oov[4];
+  {
+    const int bw = w < 3 ? w : 3, r0 = 16 * (bw >> 1), col = 16 * (bw & 1) + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = r0 + lk + 4 * r;
+      oom[r] = (rr < NX && col < NX) ? (unsigned)(rr * NX + col) * 8u : kOob;
+      oov[r] = (rr < NX && col == NX) ? (unsigned)rr * 8u : kOob;
+    }
+  }
   auto finish_outputs = [&](int k, int buf, int nt, int bw) {
     double (*const W)[LDW] = ws.W[buf];
     double (*const PW)[LDW] = ws.PW[buf];
@@ -201,15 +215,21 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         kf = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[ks], yb[ks], kf, 0, 0, 0);
       }
     }
-    double* Acl = io.Acl + (size_t)k * NXX;
-    double* Kf = io.Kfull + (size_t)k * NXU;
-    const int col = c0 + li;
+    // buffer stores: where a register of the block goes is a byte offset that is fixed for the whole sweep (Acl and K share it; column nx goes to
+    // bcl / kff), an element that goes nowhere has an offset beyond the resource, the stage is the scalar offset of the instruction.  (As predicated
+    // plain stores with 64-bit addresses the eight stores of a block were most of the 2.2 k cycles a block took beside the elimination.)
+    const unsigned ku = (unsigned)__builtin_amdgcn_readfirstlane(k);
+    const unsigned sm = ku * (unsigned)(NXX * 8), sv = ku * (unsigned)(NX * 8);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int rr = r0 + lk + 4 * r;
-      if (rr < NX) {
-        if (col < NX) { Acl[rr * NX + col] = acl[r]; Kf[rr * NX + col] = kf[r]; }
-        else if (col == NX) { io.bcl[(size_t)k * NX + rr] = acl[r]; io.kff[(size_t)k * NU + rr] = kf[r]; }
+      bp8_u32x2 va, vk;
+      va.x = (unsigned)__double2loint(acl[r]); va.y = (unsigned)__double2hiint(acl[r]);
+      vk.x = (unsigned)__double2loint(kf[r]); vk.y = (unsigned)__double2hiint(kf[r]);
+      __builtin_amdgcn_raw_buffer_store_b64(va, rAcl, oom[r], sm, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(vk, rKf, oom[r], sm, 0);
+      if (c0 != 0) {                                             // wave-uniform: the block column that holds column nx
+        __builtin_amdgcn_raw_buffer_store_b64(va, rbcl, oov[r], sv, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(vk, rkff, oov[r], sv, 0);
       }
     }
   };
@@ -357,11 +377,12 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
           _Pragma("unroll") for (int i = 0; i < H1; ++i) tb[i] = ws.Mb[i][col];               \
           _Pragma("unroll") for (int i = 0; i < ROWS; ++i) asm volatile("" : "+v"(ta[i]));    \
           _Pragma("unroll") for (int i = 0; i < H1; ++i) asm volatile("" : "+v"(tb[i]));      \
-          _Pragma("unroll") for (int i = 0; i < H1; ++i) { const double t = ta[i] + tb[i]; v[i] = (used && i < nt) ? t : 0.0; } \
+          /* (no masks: rows >= nt of M and Mb are zero - they are staged as zeros and B~ has no columns there -, and a lane without a column eliminates column 0 into a spare column) */ \
+          _Pragma("unroll") for (int i = 0; i < H1; ++i) v[i] = ta[i] + tb[i];              \
           if constexpr (H1 < ROWS) {                                                          \
             _Pragma("unroll") for (int i = H1; i < ROWS; ++i) tb[i - H1] = ws.Mb[i][col];     \
             _Pragma("unroll") for (int i = H1; i < ROWS; ++i) asm volatile("" : "+v"(tb[i - H1])); \
-            _Pragma("unroll") for (int i = H1; i < ROWS; ++i) { const double t = ta[i] + tb[i - H1]; v[i] = (used && i < nt) ? t : 0.0; } \
+            _Pragma("unroll") for (int i = H1; i < ROWS; ++i) v[i] = ta[i] + tb[i - H1];     \
           }                                                                                   \
         }                                                                                     \
         if (BPMPC_RICCATI8_ABLATE & 4) ok = true; else                                        \

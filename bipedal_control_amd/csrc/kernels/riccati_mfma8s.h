@@ -615,9 +615,12 @@ __device__ __forceinline__ void riccati_mfma8s(RiccatiMfma8sWorkspace<NJ>& ws, c
       if (w < 2 && k > io.k_lo) { g_request(k - 1, ws.nut[k - 1], 16 * w, accn); if (w == 0) g_request(k - 1, ws.nut[k - 1], 32, acc2); }
       if (role_l) sn_block(sn_sid, accn);
       if (w == 5 && pend_k >= 0) finish_m(pend_k, prv, acc2[0], acc2[1]);
-      if (w < 3 && pend_k >= 0) {
+#ifndef BPMPC_RS8_OUT3
+#define BPMPC_RS8_OUT3 0      // who forms output block 3 beside the elimination: 0: C0 (behind its block 0), 1: C3 (on the SIMD of the elimination wave)
+#endif
+      if (w < (BPMPC_RS8_OUT3 == 1 ? 4 : 3) && pend_k >= 0) {
         finish_outputs(pend_k, prv, pend_nt, w, ro, ro + 4);
-        if (w == 0) { unsigned ob[8]; out_offsets(3, ob, ob + 4); finish_outputs(pend_k, prv, pend_nt, 3, ob, ob + 4); }
+        if (BPMPC_RS8_OUT3 == 0 && w == 0) { unsigned ob[8]; out_offsets(3, ob, ob + 4); finish_outputs(pend_k, prv, pend_nt, 3, ob, ob + 4); }
       }
 #ifdef BPMPC_RICCATI_PROFILE
       if (BPMPC_RICCATI_PROFILE == 3 && role_l) { RS8PROF(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RS8PROF(5); }

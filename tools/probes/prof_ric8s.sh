@@ -1,6 +1,6 @@
 #!/bin/bash
 # riccati_mfma8s.h phase profile: libraries tools/probes/lib_<name>.bin built with -DBPMPC_RICCATI_PROFILE=1
-export TMPDIR=/tmp PYTHONPATH=.
+export TMPDIR=/tmp PYTHONPATH=. BPMPC_RICCATI8_S=${BPMPC_RICCATI8_S:-1}
 cp bipedal_control_amd/libbpmpc.so /tmp/keep.so
 for v in $1; do cp tools/probes/lib_$v.bin bipedal_control_amd/libbpmpc.so; python - <<PY
 import numpy as np
