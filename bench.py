@@ -67,8 +67,9 @@ def parse_args():
                     help="h1 = the headline workload (nx = nu = 22); g1 = BASELINE.json configs[3] (nx = nu = 24, self-defined configuration); "
                          "openloong = the reference's own 12-joint robot")
     ap.add_argument("--gait", default=None, help="gait template of the trot workload (default: trot; g1: standing_trot = \"walk\")")
-    ap.add_argument("--gait-start", type=float, default=-1.225,
-                    help="time at which the gait template of the trot workload is inserted (default: t0 = 0 falls mid-swing; 0 = SURVEY 8(d) config 2 to the letter)")
+    ap.add_argument("--gait-start", type=float, default=0.0,
+                    help="time at which the gait template of the trot workload is inserted (default 0 = SURVEY 8(d) config 2 to the letter: the template tiled "
+                         "from t = 0, the solve starts on a mode switch; -1.225 = the rounds 1-4 scenario, t0 = 0 falls mid-swing)")
     ap.add_argument("--no-fused", action="store_true", help="skip the second timed region (fused solve mode)")
     ap.add_argument("--gather", default="auto", choices=["auto", "all", "root"],
                     help="collective of the solved trajectories per step: all-gather (every rank holds every block) or gather to rank 0; auto = "
@@ -326,7 +327,7 @@ def main():
                 fused["materialised_hbm_bytes_per_step"] = prof.get("materialised_hbm_bytes_per_step")
                 fused["hbm_bytes_source"] = prof["source"]
             roofline = {"kernel": "k_linearize_fast<%d, true, ..>" % (nx - 12), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": (prof["source"] if prof else None),
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_stale": bool(prof and prof.get("stale")), "traffic_source": (prof["source"] if prof else None),
                         "avg_launch_us": round(1e6 * avg_s, 2),
                         "timing": "HIP events attached to the kernel's dispatch on its launch stream (hipExtLaunchKernelGGL start / stop events), every "
                                   "launch of the timed region: the kernel's duration, the figure the rocprofv3 kernel trace reports",
@@ -337,8 +338,8 @@ def main():
             wl = "%s gait-library sweep: %d gaits (%s) x %d velocity commands, horizon=%d intervals (dt 0.015), generated on the device, " \
                  "gaits split over the ranks, cold start, 1 SQP iteration (BASELINE.json configs[4])" % (ROBOT_LABEL[args.robot], len(lib), ", ".join(names), per_gait, NI)
         else:
-            wl = "%s %s, horizon=%d intervals (dt 0.015), %s perturbed initial states, cold start, 1 SQP iteration (%s)" % (
-                ROBOT_LABEL[args.robot], gait, NI, ("batch=%d per GPU" % args.batch) if scaling == "weak" else ("global batch %d in contiguous slices" % total),
+            wl = "%s %s (template tiled from t = %g), horizon=%d intervals (dt 0.015), %s perturbed initial states, cold start, 1 SQP iteration (%s)" % (
+                ROBOT_LABEL[args.robot], gait, args.gait_start, NI, ("batch=%d per GPU" % args.batch) if scaling == "weak" else ("global batch %d in contiguous slices" % total),
                 "BASELINE.json configs[1]" if headline and scaling == "weak" and args.batch == 256 else
                 "BASELINE.json configs[2]" if headline and scaling == "strong" and total == 4096 else
                 "BASELINE.json configs[3]" if (args.robot, gait, NI) == ("g1", "standing_trot", 100) else "not the headline workload")
@@ -419,6 +420,15 @@ def committed_traffic(robot, gait, sweep, batch, intervals):
         tj = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
+    # the counters were collected on some build of the kernels: they describe THIS library only if the sources are still the same
+    try:
+        from bipedal_control_amd.build import csrc_hash
+        now = csrc_hash()
+    except Exception:
+        now = None
+    if tj.get("csrc_hash") != now:
+        return {"stale": True, "source": "profiles/%s was collected on other kernel sources (csrc_hash %s, now %s): not reported" % (name, str(tj.get("csrc_hash"))[:12], str(now)[:12]),
+                "kernels": {}, "materialised_hbm_bytes_per_step": None, "fused_hbm_bytes_per_step": None}
     ks = tj.get("all_kernels", {})
 
     def pick(prefix, suffix=""):
@@ -437,7 +447,7 @@ def committed_traffic(robot, gait, sweep, batch, intervals):
         return None
     kernels = {"linearize_materialised": pick_lin(True), "linearize_fused": pick_lin(False),
                "project_lu": pick("k_project_lu"), "project": pick("k_project_fast"), "riccati": pick_sum("k_riccati"), "linesearch": pick("k_trial_fast")}
-    return {"source": "profiles/%s (builder run of the same command under rocprofv3 --pmc; not measured in this process)" % name, "kernels": kernels,
+    return {"stale": False, "source": "profiles/%s (builder run of the same command under rocprofv3 --pmc; not measured in this process)" % name, "kernels": kernels,
             "materialised_hbm_bytes_per_step": tj.get("materialised_hbm_bytes_per_step"), "fused_hbm_bytes_per_step": tj.get("fused_hbm_bytes_per_step")}
 
 
@@ -453,9 +463,9 @@ def roofline_all(nx, nu, nut_mean, kernel_ms, n_lin_nodes, n_nodes_total, fp64, 
       traffic_ratio = PMC bytes of the committed pass / algorithmic bytes (> 1: re-reads, padding, scratch; < 1: the kernel exchanges its
       operands PACKED - joint rows of [Px | Pe | Pu] only, projected model in 16-column blocks up to nx + 1 + nut - and touches fewer bytes
       than the dense reference unit).  hbm_util = counter bytes / kernel time / 8 TB/s: the share of the HBM roof the kernel really uses.
-      frac = algorithmic bytes / kernel time / 8 TB/s where the kernel moves at least its algorithmic bytes; where traffic_ratio < 1 the dense
-      unit would credit bytes the kernel never touches, so frac = hbm_util there and packed_bytes_per_unit (counter bytes / units) is the
-      unit it is computed on (frac_basis says which).  bound: largest of hbm_util (hbm frac without counters) / fp64-issue / mfma if
+      frac = algorithmic bytes / kernel time / 8 TB/s for every kernel (one definition, comparable across kernels and rounds); where
+      traffic_ratio < 1 the dense unit credits bytes the kernel never touches: hbm_util and packed_bytes_per_unit (counter bytes / units,
+      from the committed counter pass - not measured in this process) say what it really moves.  bound: largest of hbm_util (hbm frac without counters) / fp64-issue / mfma if
       >= 0.5, else latency."""
     d = 8.0
     proj_model = nx * nx + nx * nut_mean + nx + nx * nx + nx + nut_mean * nut_mean + nut_mean * nx + nut_mean
@@ -477,14 +487,15 @@ def roofline_all(nx, nu, nut_mean, kernel_ms, n_lin_nodes, n_nodes_total, fp64, 
         tr = (prof or {}).get("kernels", {}).get(pkey)
         util = (tr / (1e-3 * ms) / 1e9 / HBM_PEAK_GBS) if tr else None
         packed = bool(tr) and tr < alg
-        ach = (tr if packed else alg) / (1e-3 * ms) / 1e9
+        ach = alg / (1e-3 * ms) / 1e9          # ONE definition of frac for every kernel and round: algorithmic bytes / time
         fr = {"hbm": round(util if util is not None else ach / HBM_PEAK_GBS, 4)}
         e = (fp64 or {}).get(cls) or {}
         if "issue_frac" in e:
             fr["fp64-issue"], fr["mfma"] = e["issue_frac"], e["mfma_frac"]
         top = max(fr, key=fr.get)
         out[cls] = {"ms": ms, "algorithmic_bytes_per_unit": round(bytes_per_unit), "units": int(n_units), "achieved": round(ach, 1),
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "frac_basis": "counter traffic (packed operands)" if packed else "algorithmic bytes",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "frac_basis": "algorithmic bytes",
+                    "bound_note": "hbm_util / traffic / packed_bytes_per_unit come from the committed counter pass (builder run, not measured in this process)" if tr else None,
                     "packed_bytes_per_unit": round(tr / n_units) if packed else None, "hbm_util": round(util, 4) if util is not None else None,
                     "bound": top if fr[top] >= 0.5 else "latency", "bound_fracs": fr, "traffic": tr,
                     "traffic_ratio": round(tr / alg, 3) if tr else None, "dominant": cls == dominant}

@@ -18,6 +18,22 @@ SOURCES = ["k_node.hip", "k_project.hip", "k_riccati.hip", "k_riccati_wave.hip",
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
+def csrc_hash(csrc=CSRC):
+    """sha1 over the names and contents of every source under csrc/ (objects excluded): what the library is built from.  tools/summarize_pmc.py
+    stores it beside the counter traffic of a profiled run; bench.py reports that traffic only while the hash still matches (a kernel
+    change without a re-collected profile would otherwise carry stale bytes into the bench line)."""
+    h = hashlib.sha1()
+    for root, dirs, files in sorted(os.walk(csrc)):
+        dirs[:] = sorted(d for d in dirs if d != "build")
+        for f in sorted(files):
+            if f.endswith((".h", ".hip", ".cpp")):
+                path = os.path.join(root, f)
+                h.update(os.path.relpath(path, csrc).encode())
+                with open(path, "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()
+
+
 def _newest_header():
     newest = os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "bpmpc.h"))
     for root, dirs, files in os.walk(CSRC):
@@ -34,11 +50,14 @@ def _newest_source():
 
 
 def build(force=False, verbose=False):
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("BPMPC_EXTRA_FLAGS", "").split()      # e.g. -DBPMPC_LINFAST_PROFILE for tools/*_phase_profile.py
     tag = hashlib.sha1(" ".join(extra).encode()).hexdigest()[:8] if extra else "default"
+    # the library is up to date only if it was linked from THIS tag's objects (objects are cached per flag set; the stamp names the last link)
+    stamp = os.path.join(OBJ, "linked_tag")
+    last_tag = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source() and last_tag == tag:
+        return LIB
     objdir = os.path.join(OBJ, tag)
     os.makedirs(objdir, exist_ok=True)
     headers = _newest_header()
@@ -60,6 +79,11 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    for stale in os.listdir(objdir):            # objects of units that are no longer in SOURCES
+        if stale.endswith(".o") and stale not in {os.path.splitext(x)[0] + ".o" for x in SOURCES}:
+            os.remove(os.path.join(objdir, stale))
+    with open(stamp, "w") as f:
+        f.write(tag)
     return LIB
 
 

@@ -209,10 +209,11 @@ __device__ __forceinline__ void riccati_wave(RiccatiWaveWorkspace<NJ>& ws, const
 #pragma unroll
     for (int ks = 3; ks < KS; ++ks) {
       const int row = 4 * ks + lk;
-      w[ks][0] = dtk * w[ks][0] + (li == row ? 1.0 : 0.0);
-      const double w1 = dtk * w[ks][1] + (16 + li == row ? 1.0 : 0.0);
+      // (identity and b only in rows of the state: a padding row >= nx would put a 1 into the b column - harmless only while every operand of the padding rows is masked)
+      w[ks][0] = dtk * w[ks][0] + ((row < NX && li == row) ? 1.0 : 0.0);
+      const double w1 = dtk * w[ks][1] + ((row < NX && 16 + li == row) ? 1.0 : 0.0);
       cWT[ks] = li < XR ? w1 : 0.0;
-      w[ks][1] = w1 + nbj[ks - 3];
+      w[ks][1] = w1 + (row < NX ? nbj[ks - 3] : 0.0);
       w[ks][2] = dtk * w[ks][2];
       cB[ks] = dtk * cB[ks];
     }

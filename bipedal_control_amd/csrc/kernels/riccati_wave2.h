@@ -273,9 +273,10 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
 #pragma unroll
       for (int ks = 3; ks < KS; ++ks) {
         const int row = 4 * ks + lk;
-        jW[0][ks - 3] = dtk * jW[0][ks - 3] + (li == row ? 1.0 : 0.0);
-        const double bcol = li == XR ? ws.bq[4 * (ks - 3) + lk] : 0.0;
-        jW[1][ks - 3] = (dtk * jW[1][ks - 3] + (16 + li == row ? 1.0 : 0.0)) + bcol;     // state columns 16..; the b column carries dt Pe + b
+        // (identity and b only in rows of the state: see riccati_wave.h)
+        jW[0][ks - 3] = dtk * jW[0][ks - 3] + ((row < NX && li == row) ? 1.0 : 0.0);
+        const double bcol = (row < NX && li == XR) ? ws.bq[4 * (ks - 3) + lk] : 0.0;
+        jW[1][ks - 3] = (dtk * jW[1][ks - 3] + ((row < NX && 16 + li == row) ? 1.0 : 0.0)) + bcol;     // state columns 16..; the b column carries dt Pe + b
         jW[2][ks - 3] = dtk * jW[2][ks - 3];
         jB[ks - 3] = dtk * jB[ks - 3];
       }

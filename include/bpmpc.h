@@ -240,7 +240,11 @@ int bpmpc_solver_stage(bpmpc_solver* solver, const char* stage);
  * "Px","Pu","Pe","nut","dx","du","K","Acl","summary","stats","g_kind","g_mode","g_nodes","g_dt","g_start","g_zref","g_zdref","g_time",
  * "p_grid","x0".  The projected LQ model depends on the kernel set:
  *   settings.reference_kernels = 1:  plain matrices "At","Bt","bt","Qt","Rt","Pt","qt","rt" and the gain scratch "Kt","kt";
- *   fast kernels (default):          the packed layout "Wt" = [At | bt | Bt] (nx rows of WP columns), "Qp" = [Qt | qt] (nx rows of 32
+ *   fast kernels (default):          the packed layout "Wt" = [At | bt | Bt] (nx rows of WP columns; on the default structured path only
+ *                                    its rows 0..11 are written: the JOINT rows 12..nx-1 read as zeros or as the leftovers of an earlier
+ *                                    run - they are [I | b | 0] + dt * "Vt" (row j of Vt = joint row 12 + j of [Px | Pe | Pu], dt = g_dt of
+ *                                    the node) and every sweep completes them itself; they are written with BPMPC_WT_JOINT_ROWS=1,
+ *                                    BPMPC_DENSE_PROJECT=1 or reference_kernels), "Qp" = [Qt | qt] (nx rows of 32
  *                                    columns), "Mt" = [Pt | rt | Rt] (nu rows of WP columns), WP = 16 * ceil((nx + 1 + nu) / 16); block
  *                                    columns beyond nx + 1 + nut and rows >= nut of Mt are not written (kernels/project_node.h PackedLq);
  *                                    the plain names return "unknown buffer".

@@ -46,7 +46,9 @@ def main(fetch_dir, write_dir, out, extra=""):
     per_step_common = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in kernels.items() if not k.startswith("k_linearize_fast") and not k.startswith("k_prepare")) / max(1, steps)
     import re
     mb, mi = re.search(r"--batch (\d+)", extra), re.search(r"--intervals (\d+)", extra)
-    res = {"batch": int(mb.group(1)) if mb else 256, "intervals": int(mi.group(1)) if mi else (150 if "gait-sweep" in extra else 100), "bench_arguments": extra, "kernel": lin,
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bipedal_control_amd.build import csrc_hash
+    res = {"csrc_hash": csrc_hash(), "batch": int(mb.group(1)) if mb else 256, "intervals": int(mi.group(1)) if mi else (150 if "gait-sweep" in extra else 100), "bench_arguments": extra, "kernel": lin,
            "materialised_hbm_bytes_per_step": int(per_step_common + kernels[lin]["hbm_bytes_per_launch"]) if lin and steps else None,
            "fused_hbm_bytes_per_step": int(per_step_common + kernels[lin_f]["hbm_bytes_per_launch"]) if lin_f and steps else None,
            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 " + extra,
