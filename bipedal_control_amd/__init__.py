@@ -4,8 +4,8 @@ Python is only the host-side mirror of the reference's operator interface (ctype
 include/bpmpc.h); all arithmetic of the hot path runs in hand-written HIP kernels (bipedal_control_amd/csrc/kernels).
 There is no CPU fallback: constructing a solver without the HIP library or without a GPU raises.
 """
-from .api import (BatchedSqpMpc, BipedalRobotInterface, BpmpcError, GaitSchedule, ModeSchedule, ModeSequenceTemplate,  # noqa: F401
+from .api import (BatchedDdpMpc, BatchedSqpMpc, BipedalRobotInterface, BpmpcError, GaitSchedule, ModeSchedule, ModeSequenceTemplate,  # noqa: F401
                   TargetTrajectories, WeightedWbc, load_library, loadModeSequenceTemplate, swing_reference, time_discretization_with_events)
 
-__all__ = ["BatchedSqpMpc", "BipedalRobotInterface", "BpmpcError", "GaitSchedule", "ModeSchedule", "ModeSequenceTemplate",
+__all__ = ["BatchedDdpMpc", "BatchedSqpMpc", "BipedalRobotInterface", "BpmpcError", "GaitSchedule", "ModeSchedule", "ModeSequenceTemplate",
            "TargetTrajectories", "WeightedWbc", "load_library", "loadModeSequenceTemplate", "swing_reference", "time_discretization_with_events"]

@@ -37,7 +37,7 @@ class BpmpcError(RuntimeError):
 class _Settings(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch", C.c_int), ("max_nodes", C.c_int), ("sqp_iterations", C.c_int), ("dt", C.c_double),
                 ("return_gains", C.c_int), ("profile", C.c_int), ("stream", C.c_void_p), ("reference_kernels", C.c_int),
-                ("pipeline_chunks", C.c_int), ("materialize_lq", C.c_int), ("reg_prim", C.c_double)]
+                ("pipeline_chunks", C.c_int), ("materialize_lq", C.c_int), ("reg_prim", C.c_double), ("solver", C.c_int), ("feedback_policy", C.c_int)]
 
 
 class _Schedule(C.Structure):
@@ -255,11 +255,15 @@ def time_discretization_with_events(initTime, finalTime, dt, eventTimes, capacit
 
 
 class BatchedSqpMpc:
+    # (the DDP variant is the same handle with solver="ddp": BatchedDdpMpc below)
     """A batch of independent SqpMpc instances on one MI355X.  `run` plays the role of MPC_BASE::run(t, x) /
     MPC_MRT_Interface::advanceMpc() (BipedalController.cpp:339) for every problem of the batch at once."""
 
     def __init__(self, interface, max_batch, max_nodes, sqp_iterations=0, dt=0.0, return_gains=False, profile=False, device=0, stream=None,
-                 reference_kernels=False, pipeline_chunks=0, materialize_lq=False, reg_prim=0.0):
+                 reference_kernels=False, pipeline_chunks=0, materialize_lq=False, reg_prim=0.0, solver="sqp", feedback_policy=None):
+        """solver: "sqp" (SqpMpc, default) or "ddp" (GaussNewtonDDP_MPC of BipedalRobotDdpMpcNode.cpp:70-71: one ILQR iteration per run, see
+        bpmpc_settings.solver in include/bpmpc.h).  feedback_policy: None = sqp.useFeedbackPolicy of task.info, True / False overrides it for the warm
+        start, the policy rollout and the controller built from the solution alike."""
         lib = load_library()
         self.interface = interface
         self.max_batch, self.max_nodes = int(max_batch), int(max_nodes)
@@ -270,7 +274,9 @@ class BatchedSqpMpc:
             # ordered against torch has to run on an explicit stream (torch.cuda.Stream().cuda_stream), see bench.py.
             raise ValueError("stream=0 (the default stream) cannot be handed over; pass an explicit stream handle or None for a solver-owned stream")
         st = _Settings(int(device), self.max_batch, self.max_nodes, int(sqp_iterations), float(dt), int(bool(return_gains)), int(profile),
-                       C.c_void_p(int(stream)) if stream is not None else None, int(bool(reference_kernels)), int(pipeline_chunks), int(bool(materialize_lq)), float(reg_prim))
+                       C.c_void_p(int(stream)) if stream is not None else None, int(bool(reference_kernels)), int(pipeline_chunks), int(bool(materialize_lq)), float(reg_prim),
+                       {"sqp": 0, "ddp": 1}[solver], 0 if feedback_policy is None else (1 if feedback_policy else 2))
+        self.solver = solver
         self._h = C.c_void_p()
         _check(lib.bpmpc_solver_create(interface.handle, C.byref(st), C.byref(self._h)))
         self._keep = None
@@ -505,3 +511,13 @@ class WeightedWbc:
 
     def reset(self):
         _check(load_library().bpmpc_wbc_reset(self._h))
+
+
+class BatchedDdpMpc(BatchedSqpMpc):
+    """A batch of GaussNewtonDDP_MPC instances (ocs2_bipedal_robot_ros/src/BipedalRobotDdpMpcNode.cpp:70-71; ddp block of task.info): the same
+    handle as BatchedSqpMpc with bpmpc_settings.solver = BPMPC_SOLVER_DDP.  `run` returns the accepted roll-out on its own time points:
+    t[b, :stats[b].n_nodes + 1], x likewise, u[b, :stats[b].n_nodes]; stats[b].step_size is the accepted step length."""
+
+    def __init__(self, interface, max_batch, max_nodes, **kw):
+        kw.pop("solver", None)
+        super().__init__(interface, max_batch, max_nodes, solver="ddp", return_gains=True, **kw)

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libbpmpc.so")
-SOURCES = ["k_node.hip", "k_project.hip", "k_riccati.hip", "k_riccati_wave.hip", "solver.hip", "wbc.hip", "capi.cpp", "info_tree.cpp", "urdf_tree.cpp",
+SOURCES = ["k_node.hip", "k_project.hip", "k_riccati.hip", "k_riccati_wave.hip", "k_ddp.hip", "solver.hip", "wbc.hip", "capi.cpp", "info_tree.cpp", "urdf_tree.cpp",
            "robot_model.cpp", "reference_gen.cpp", "device_model.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 

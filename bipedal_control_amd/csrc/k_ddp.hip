@@ -1,0 +1,214 @@
+// Kernels of the DDP slice (GaussNewtonDDP_MPC of ocs2_bipedal_robot_ros/src/BipedalRobotDdpMpcNode.cpp:70-71 with
+// `algorithm ILQR`, settings task.info:115-156): what one ILQR iteration needs beside the kernels the SQP path already has.
+//   backward pass   k_linearize with Launch::ilqr (Euler discretisation of the continuous-time model, Hessian shift; kernels/node_lq.h),
+//                   then the constraint elimination and the Riccati sweep of the reference kernel set - any exact solution of the
+//                   equality-constrained stage problems is THE ILQR policy; k_ddp_policy reads it back as du = lff + K dx
+//   line search     per step length: k_ddp_controller (u_nom + alpha lff), the policy roll-out of kernels/rollout.h with its observer
+//                   (TimeTriggeredRollout, ODE45; every accepted step is a time point), k_ddp_cost (intermediate cost at every time point),
+//                   k_ddp_select (trapezoidal performance index, Armijo test against the step-length-0 baseline, the largest accepted step)
+//   result          k_ddp_finish: the accepted roll-out ON ITS OWN TIME POINTS becomes the solution (x, u, times, stats)
+// [OCS2-upstream, recalled] throughout (oracle/ddp_py.py states what is and what is not restated; tests/test_recalled_behaviours.py names it).
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+
+#include "kernel_launchers.h"
+#include "launch.h"
+#include "kernels/node_lq.h"
+#include "kernels/linesearch.h"
+
+namespace bpmpc {
+
+namespace {
+
+// [OCS2-upstream] LinearInterpolation::timeSegment on the node times of a grid: the interval (t_j, t_{j+1}] that holds t (clamped)
+__device__ inline int ddp_interval(const double* t, int n_nodes, double q) {
+  if (q <= t[0]) return 0;
+  if (q >= t[n_nodes]) return n_nodes - 1;
+  int lo = 0, hi = n_nodes + 1;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (t[mid] < q) lo = mid + 1; else hi = mid; }
+  int i = lo - 1;
+  return i < 0 ? 0 : (i > n_nodes - 1 ? n_nodes - 1 : i);
+}
+
+}  // namespace
+
+// lff_k = du_k - K_k dx_k of the sweep's linear roll-out (zero at event nodes), int |lff|^2 dt, and the flags of the search
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_ddp_policy(Launch L, DdpBuffers d) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int grid = L.buf.p_grid[b], n = L.buf.g_nodes[grid];
+  __shared__ double part[kWave];
+  double acc = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const size_t s = (size_t)b * L.N + k;
+    const int kind = L.buf.g_kind[(size_t)grid * L.N + k];
+    double l = 0.0;
+    if (tid < NU && kind == 0) {
+      const double* Kr = L.buf.K + s * NU * NX + (size_t)tid * NX;
+      const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
+      double t = L.buf.du[s * NU + tid];
+      for (int c = 0; c < NX; ++c) t -= Kr[c] * dx[c];
+      l = t;
+    }
+    if (tid < NU) d.lff[s * NU + tid] = l;
+    acc += L.buf.g_dt[(size_t)grid * L.N + k] * l * l;
+  }
+  part[tid] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int i = 0; i < NU; ++i) s += part[i];
+    d.update_is[b] = s;
+    d.accepted[b] = 0;
+    d.alpha[b] = 0.0;
+    d.failed[b] = L.buf.summary[(size_t)b * 4 + 3] != 0.0 ? 1 : 0;      // the sweep met a non-positive pivot: no policy
+  }
+}
+
+// planned inputs of a step length: u_nom + alpha lff
+__global__ void k_ddp_controller(const double* u_nom, const double* lff, double alpha, double* u_out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) u_out[i] = u_nom[i] + alpha * lff[i];
+}
+
+// intermediate cost at every time point of a recorded roll-out: the node metric of the transcription with dt = 1 (tracking + soft cones)
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_ddp_cost(Launch L, DdpBuffers d) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  __shared__ NodeWorkspace<NJ> ws;
+  __shared__ double xref[NX], zero4[4], perf[3];
+  const int b = blockIdx.x / d.cap, i = blockIdx.x % d.cap, tid = threadIdx.x;
+  if (i >= d.rec_n[b]) return;
+  const int grid = L.buf.p_grid[b], n = L.buf.g_nodes[grid];
+  const size_t at = (size_t)b * d.cap + i;
+  const double t = d.rec_t[at];
+  const int j = ddp_interval(L.buf.g_time + (size_t)grid * (L.N + 1), n, t);
+  // x_ref(t): TargetTrajectories::getDesiredState (clamped linear interpolation), as prepare_node
+  {
+    const int n_pts = L.buf.p_tgt_n[b];
+    const double* tt = L.buf.p_tgt_t + (size_t)b * kMaxTargetPoints;
+    const double* tx = L.buf.p_tgt_x + (size_t)b * kMaxTargetPoints * NX;
+    if (tid < NX) {
+      double val;
+      if (n_pts == 1 || t <= tt[0]) val = tx[tid];
+      else if (t >= tt[n_pts - 1]) val = tx[(n_pts - 1) * NX + tid];
+      else {
+        int q = 0;
+        while (q + 1 < n_pts - 1 && tt[q + 1] < t) ++q;
+        const double al = (tt[q + 1] - t) / (tt[q + 1] - tt[q]);
+        val = al * tx[q * NX + tid] + (1.0 - al) * tx[(q + 1) * NX + tid];
+      }
+      xref[tid] = val;
+    }
+    if (tid < 4) zero4[tid] = 0.0;
+  }
+  __syncthreads();
+  NodeInputs in;
+  in.kind = 0; in.mode = L.buf.g_mode[(size_t)grid * L.N + j]; in.dt = 1.0;
+  in.x = d.rec_x + at * NX; in.xnext = in.x; in.u = d.rec_u + at * NU; in.xref = xref; in.zref = zero4; in.zdref = zero4;
+  node_performance<NJ>(*L.model, ws, in, perf);
+  __syncthreads();
+  if (tid == 0) d.cost[at] = perf[0];
+}
+
+// performance index of the recorded roll-out (trapezoidalIntegration over its time points), Armijo test, the record becomes the solution when
+// it is the baseline (alpha == 0) or the first - largest - accepted step
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_ddp_select(Launch L, DdpBuffers d, double alpha, double armijo, const int* roll_status) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ int take;
+  if (tid == 0) {
+    const int n = d.rec_n[b];
+    const double* t = d.rec_t + (size_t)b * d.cap;
+    const double* c = d.cost + (size_t)b * d.cap;
+    double merit = 0.0;
+    for (int i = 0; i + 1 < n; ++i) merit += 0.5 * (c[i + 1] + c[i]) * (t[i + 1] - t[i]);
+    const bool ok = roll_status[b] == 0 && n >= 2 && !d.failed[b];
+    int tk = 0;
+    if (alpha == 0.0) {
+      d.merit0[b] = ok ? merit : 0.0;
+      d.merit[b] = merit;
+      if (!ok) d.failed[b] = 1;                         // no baseline: nothing to compare with, the nominal trajectories stay
+      tk = ok ? 1 : 0;
+    } else if (ok && !d.accepted[b] && merit < d.merit0[b] - armijo * alpha * d.update_is[b]) {
+      d.accepted[b] = 1; d.alpha[b] = alpha; d.merit[b] = merit;
+      tk = 1;
+    }
+    take = tk;
+  }
+  __syncthreads();
+  if (!take) return;
+  const int n = d.rec_n[b];
+  if (tid == 0) d.sol_n[b] = n;
+  for (int i = tid; i < n; i += kWave) d.sol_t[(size_t)b * d.cap + i] = d.rec_t[(size_t)b * d.cap + i];
+  for (int i = tid; i < n * NX; i += kWave) d.sol_x[(size_t)b * d.cap * NX + i] = d.rec_x[(size_t)b * d.cap * NX + i];
+  for (int i = tid; i < n * NU; i += kWave) d.sol_u[(size_t)b * d.cap * NU + i] = d.rec_u[(size_t)b * d.cap * NU + i];
+}
+
+// the solution in the solver's own arrays: x[b][i], u[b][i] at the roll-out's time points (the input at the last point is dropped: the
+// arrays hold one input per interval), statistics
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_ddp_finish(Launch L, DdpBuffers d) {
+  constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const bool failed = d.failed[b] != 0;
+  const int n = failed ? 0 : d.sol_n[b];
+  double* x = L.buf.x + (size_t)b * (L.N + 1) * NX;
+  double* u = L.buf.u + (size_t)b * L.N * NU;
+  for (int i = tid; i < n * NX; i += kWave) x[i] = d.sol_x[(size_t)b * d.cap * NX + i];
+  for (int i = tid; i < (n - 1) * NU; i += kWave) u[i] = d.sol_u[(size_t)b * d.cap * NU + i];
+  if (tid == 0) {
+    double* s = L.buf.stats + (size_t)b * kStatsStride;
+    const int it = L.buf.iterations[b] + 1;
+    L.buf.iterations[b] = it;
+    s[0] = (double)(failed ? L.buf.g_nodes[L.buf.p_grid[b]] : n - 1);
+    s[1] = (double)it;
+    s[2] = failed ? 2.0 : (d.accepted[b] ? 0.0 : 1.0);          // 0: a step was accepted, 1: none (the baseline roll-out is the solution), 2: numerical failure (nominal kept)
+    s[3] = d.merit0[b]; s[4] = 0.0; s[5] = 0.0;
+    s[6] = d.merit[b]; s[7] = 0.0; s[8] = 0.0;
+    s[9] = d.alpha[b];
+    s[10] = -d.update_is[b];
+    s[11] = 0.0; s[12] = 0.0;
+    L.buf.active[b] = 0;
+    d.n_points[b] = failed ? 0 : n;
+  }
+}
+
+// receding-horizon warm start of the next run: the previous solution is a FeedforwardController on the roll-out's own time points, one time
+// trajectory per problem (k_warm_shift reads tp_* per grid: problem b becomes its own "grid"), no pre-event entries
+__global__ void k_ddp_keep_times(DdpBuffers d, int batch, int N, double* tp_time, int* tp_kind, int* tp_nodes, int* tp_grid) {
+  const int b = blockIdx.x;
+  if (b >= batch) return;
+  const int n = d.n_points[b];
+  for (int i = threadIdx.x; i < N + 1; i += blockDim.x) tp_time[(size_t)b * (N + 1) + i] = i < n ? d.sol_t[(size_t)b * d.cap + i] : 0.0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) tp_kind[(size_t)b * N + i] = 0;
+  if (threadIdx.x == 0) { tp_nodes[b] = n - 1; tp_grid[b] = b; }
+}
+
+#define KL_NJ(nj, ...)                                                          \
+  do {                                                                          \
+    if ((nj) == 10) { constexpr int NJ = 10; __VA_ARGS__; }                     \
+    else if ((nj) == 12) { constexpr int NJ = 12; __VA_ARGS__; }                \
+    else throw std::runtime_error("unsupported joint count");                   \
+  } while (0)
+
+namespace kl {
+
+void ddp_policy(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d) { KL_NJ(nj, hipLaunchKernelGGL(k_ddp_policy<NJ>, dim3(batch), dim3(kWave), 0, st, L, d)); }
+void ddp_controller(hipStream_t st, const double* u_nom, const double* lff, double alpha, double* u_out, size_t n) {
+  hipLaunchKernelGGL(k_ddp_controller, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, u_nom, lff, alpha, u_out, n);
+}
+void ddp_cost(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d) { KL_NJ(nj, hipLaunchKernelGGL(k_ddp_cost<NJ>, dim3(batch * d.cap), dim3(kWave), 0, st, L, d)); }
+void ddp_select(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d, double alpha, double armijo, const int* roll_status) {
+  KL_NJ(nj, hipLaunchKernelGGL(k_ddp_select<NJ>, dim3(batch), dim3(kWave), 0, st, L, d, alpha, armijo, roll_status));
+}
+void ddp_keep_times(int batch, int N, hipStream_t st, const DdpBuffers& d, double* tp_time, int* tp_kind, int* tp_nodes, int* tp_grid) {
+  hipLaunchKernelGGL(k_ddp_keep_times, dim3(batch), dim3(kWave), 0, st, d, batch, N, tp_time, tp_kind, tp_nodes, tp_grid);
+}
+void ddp_finish(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d) { KL_NJ(nj, hipLaunchKernelGGL(k_ddp_finish<NJ>, dim3(batch), dim3(kWave), 0, st, L, d)); }
+
+}  // namespace kl
+}  // namespace bpmpc

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
   out.C = L.buf.C + s * kMaxEqRows * NX; out.D = L.buf.D + s * kMaxEqRows * NU; out.e = L.buf.e + s * kMaxEqRows;
   out.nc = L.buf.nc + s; out.perf = L.buf.perf + s * 3;
   out.prof = (b == 0 && k < 64) ? L.buf.rprof + 8 * k : nullptr;
-  linearize_node<NJ>(*L.model, ws, in, out);
+  linearize_node<NJ>(*L.model, ws, in, out, L.ilqr != 0, L.ilqr_shift);
 }
 
 constexpr int kTrialWaves = 4; // same for the value-only trial kernel (smaller per-node LDS: four waves, 8 waves per CU)

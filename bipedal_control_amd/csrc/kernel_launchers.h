@@ -11,6 +11,7 @@ namespace bpmpc {
 struct Launch;
 struct DeviceModel;
 struct RolloutArgs;
+struct DdpBuffers;
 
 namespace kl {
 
@@ -43,6 +44,14 @@ void riccati_fast8(int nj, bool joint_rows, int batch, hipStream_t st, const Lau
 // ---- k_riccati_wave.hip: wave-per-problem sweeps and their roll-out
 void riccati_wave(int nj, bool two_per_simd, bool joint_rows, int batch, hipStream_t st, const Launch& L);
 void riccati_rollout(int nj, int batch, hipStream_t st, const Launch& L);
+
+// ---- k_ddp.hip: the DDP slice (one ILQR iteration; backward pass on the reference kernel set, line search over policy roll-outs)
+void ddp_policy(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
+void ddp_controller(hipStream_t st, const double* u_nom, const double* lff, double alpha, double* u_out, size_t n);
+void ddp_cost(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
+void ddp_select(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d, double alpha, double armijo, const int* roll_status);
+void ddp_finish(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
+void ddp_keep_times(int batch, int N, hipStream_t st, const DdpBuffers& d, double* tp_time, int* tp_kind, int* tp_nodes, int* tp_grid);
 
 }  // namespace kl
 }  // namespace bpmpc

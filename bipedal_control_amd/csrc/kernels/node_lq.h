@@ -123,8 +123,12 @@ BP_DEVICE double eq_row_value(const DeviceModel& md, const NodeWorkspace<NJ>& ws
   return g;
 }
 
+// ilqr (the DDP slice, solver.hip run_ddp; [OCS2-upstream, recalled] ILQR::discreteLQWorker): the continuous-time model at the node is
+// discretised by ONE Euler step - A = I + dt A_c, B = dt B_c, no dynamics bias (the nominal trajectory of a DDP is a roll-out) - and
+// input_shift (hessian_correction::shiftHessian, DIAGONAL_SHIFT: added to every diagonal entry of Hm = R + B' S B, i.e. of R) is added to
+// the dt-scaled R.  Cost and constraints as in the multiple-shooting transcription.
 template <int NJ>
-BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, const NodeInputs& in, const NodeLQOut& out) {
+BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, const NodeInputs& in, const NodeLQOut& out, bool ilqr = false, double input_shift = 0.0) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ, G = 6 + NJ;
   CentroidalWorkspace<NJ>& k = ws.k;
 
@@ -138,7 +142,7 @@ BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, cons
       if (tid < kMaxEqRows) out.e[tid] = 0.0;
       double d = 0.0;
       if (tid < NX) {
-        d = in.x[tid] - in.xnext[tid];
+        d = ilqr ? 0.0 : in.x[tid] - in.xnext[tid];
         out.b[tid] = d;
         out.q[tid] = 0.0;
       }
@@ -243,7 +247,7 @@ BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, cons
   }
   BP_SYNC();
   LQPROF(2);
-  eval_centroidal<NJ, true, false>(md, k);
+  if (!ilqr) eval_centroidal<NJ, true, false>(md, k);      // (ilqr: the stage-one derivatives are the model; k.Ar / k.Br keep them)
   LQPROF(3);
 
   // ---- RK2 sensitivities ([OCS2-upstream] SensitivityIntegrator rk2):
@@ -271,13 +275,13 @@ BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, cons
           double prod = 0.0;
           for (int l = 0; l < 9; ++l) prod += k.Ar[rr][3 + l] * c1[l];
           if (!is_x) prod += (c < 12) ? k.Ar[rr][c % 3] * imt : k.Ar[rr][c];   // A2[:,0:3] (I/m) and A2[:,12+j] identity blocks of B1
-          val = (is_x && r == c ? 1.0 : 0.0) + hdt * (c1[rr] + c2[rr] + dt * prod);
+          val = (is_x && r == c ? 1.0 : 0.0) + (ilqr ? dt * c1[rr] : hdt * (c1[rr] + c2[rr] + dt * prod));
         }
         dst[r * ld] = val;
       }
     }
     if (tid < NX) {
-      const double bb = ws.x0[tid] + hdt * ws.f1[tid] + hdt * k.f[tid] - ws.xn[tid];
+      const double bb = ilqr ? 0.0 : ws.x0[tid] + hdt * ws.f1[tid] + hdt * k.f[tid] - ws.xn[tid];
       out.b[tid] = bb;
       ws.bvec[tid] = bb;
       ws.dx[tid] = ws.x0[tid] - ws.xref[tid];
@@ -318,7 +322,7 @@ BP_DEVICE void linearize_node(const DeviceModel& md, NodeWorkspace<NJ>& ws, cons
           const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);  // xx xy xz yy yz zz
           val += cn[3] * cn[4 + a] * cn[4 + b] + cn[2] * cn[7 + sidx];
         }
-        out.R[r * NU + c] = dt * val;
+        out.R[r * NU + c] = dt * val + ((ilqr && r == c) ? input_shift : 0.0);
       }
     } else {
       for (int idx = tid - NX - NU; idx < NU * NX; idx += kWave - NX - NU) out.P[idx] = 0.0;

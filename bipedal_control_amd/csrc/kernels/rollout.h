@@ -45,7 +45,12 @@ struct RolloutArgs {
   double* x_end;                      // [batch][NX]
   double* u_end;                      // [batch][NU]: controller at the final time and state
   int* steps;                         // [batch][2]: accepted, rejected
-  int* status;                        // [batch]: 0 ok, 1 max steps, 2 no step size found, 3 too many events in the window
+  int* status;                        // [batch]: 0 ok, 1 max steps, 2 no step size found, 3 too many events in the window, 4 more time points than rec_cap
+  // optional record of the roll-out's own time points ([OCS2-upstream] the observer of integrate_adaptive: the begin of every segment, every
+  // accepted step): rec_t [batch][rec_cap], rec_x [batch][rec_cap][NX], rec_u [batch][rec_cap][NU] (the controller at the point), rec_n [batch]
+  double *rec_t, *rec_x, *rec_u;
+  int* rec_n;
+  int rec_cap;
 };
 
 template <int NJ>
@@ -164,12 +169,30 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
     kq = e.vg;
   };
 
+  // the observer: one time point (t, x, u(t, x)).  Every lane of the WAVE calls it (publish / controller synchronise the wave's LDS traffic);
+  // only the problems with `mine` write
+  int n_rec = 0;
+  auto record = [&](double ts, double vh, double vq, bool mine) {
+    publish(vh, vq);
+    controller(ts);
+    if (mine) {
+      if (valid && n_rec < a.rec_cap) {
+        const size_t at = (size_t)b * a.rec_cap + n_rec;
+        if (g == 0) a.rec_t[at] = ts;
+        if (g < 6) a.rec_x[at * NX + g] = vh;
+        if (g < G) a.rec_x[at * NX + 6 + g] = vq;
+        for (int r = g; r < NU; r += LPN) a.rec_u[at * NU + r] = nl.u[r];
+      }
+      ++n_rec;
+    }
+  };
   double xh = g < 6 ? a.x_start[(size_t)b * NX + g] : 0.0, xq = g < G ? a.x_start[(size_t)b * NX + 6 + g] : 0.0;
   double k1h = 0.0, k1q = 0.0;
   double t = t0, dt = a.time_step, seg_end = t0;
   int seg = -1;                        // index of the current interval; -1: none opened yet
-  bool done = !valid || status != 0, have_k1 = false, fresh = true;
+  bool done = !valid || status != 0, have_k1 = false, fresh = true, opened = false;
   int accepted = 0, rejected = 0, failed_in_a_row = 0;
+  bool stepped = false;
   constexpr double kEps = 2.220446049250313e-16, kWeakEps = 1e-6;
   for (;;) {
     // ---- integrate_adaptive bookkeeping: open the next interval when the current one is exhausted
@@ -183,7 +206,9 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
       dt = a.time_step;
       have_k1 = false;                                          // a new controlled stepper: m_first_call
       fresh = true;
+      opened = true;
     }
+    if (a.rec_t && __any(opened)) { record(t, xh, xq, opened && !done); opened = false; }
     if (!__any(!done)) break;
     if (fresh && !done && (t + dt) - seg_end > kEps) dt = seg_end - t;
     fresh = false;
@@ -225,9 +250,11 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
         ++accepted;
         failed_in_a_row = 0;
         fresh = true;
+        stepped = true;
         if (accepted > a.max_steps) { status = 1; done = true; }
       }
     }
+    if (a.rec_t && __any(stepped)) { record(t, xh, xq, stepped); stepped = false; }
   }
   // inputTrajectory.back() = computeInput(final time, final state)
   publish(xh, xq);
@@ -236,7 +263,11 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
     if (g < 6) a.x_end[(size_t)b * NX + g] = xh;
     if (g < G) a.x_end[(size_t)b * NX + 6 + g] = xq;
     for (int r = g; r < NU; r += LPN) a.u_end[(size_t)b * NU + r] = nl.u[r];
-    if (g == 0) { a.steps[2 * b] = accepted; a.steps[2 * b + 1] = rejected; a.status[b] = status; }
+    if (g == 0) {
+      a.steps[2 * b] = accepted; a.steps[2 * b + 1] = rejected;
+      if (a.rec_t) { a.rec_n[b] = n_rec < a.rec_cap ? n_rec : a.rec_cap; if (status == 0 && n_rec > a.rec_cap) status = 4; }
+      a.status[b] = status;
+    }
   }
 }
 

@@ -153,9 +153,10 @@ struct bpmpc_solver {
     L.klen = n_nodes_max > 0 ? n_nodes_max : settings.max_nodes;
     L.cold = cold ? 1 : 0;
     L.serial_legs = (dm.serial_legs && !force_tables) ? 1 : 0;
-    L.feedback = rm.sqp.use_feedback_policy;
+    L.feedback = feedback();
     L.ls = ls;
     L.reg_prim = settings.reg_prim;
+    L.ilqr = 0; L.ilqr_shift = 0.0;
     return L;
   }
 
@@ -217,6 +218,11 @@ struct bpmpc_solver {
   void stage_linesearch();
   void pipelined_backward();
   void run_iterations();
+  void run_ddp();
+  DdpBuffers ddp{};                                       // the DDP slice (settings.solver = BPMPC_SOLVER_DDP)
+  bool is_ddp() const { return settings.solver == BPMPC_SOLVER_DDP; }
+  // one value for the warm start, the policy rollout and the controller a caller builds (sqp.useFeedbackPolicy / ddp.useFeedbackPolicy of task.info, or the override)
+  int feedback() const { return settings.feedback_policy == 1 ? 1 : (settings.feedback_policy == 2 ? 0 : (is_ddp() ? rm.ddp.use_feedback_policy : rm.sqp.use_feedback_policy)); }
   int nj() const { return rm.nj; }
 };
 
@@ -328,6 +334,7 @@ void bpmpc_solver::pipelined_backward() {
 
 void bpmpc_solver::run_iterations() {
   if (rm.nj != 10 && rm.nj != 12) throw std::runtime_error("unsupported joint count");
+  if (is_ddp()) { run_ddp(); has_solution = true; return; }
   const int iters = ls.max_iterations;
   for (int it = 0; it < iters; ++it) {
     if (!settings.reference_kernels && settings.pipeline_chunks > 1) {
@@ -340,6 +347,58 @@ void bpmpc_solver::run_iterations() {
     stage_linesearch();
   }
   has_solution = true;
+}
+
+// One ILQR iteration of the DDP slice (k_ddp.hip; oracle/ddp_py.py is its restatement, step for step).  Everything is enqueued on the solver's
+// stream; the host only walks the step lengths.
+void bpmpc_solver::run_ddp() {
+  const DdpConfig& dc = rm.ddp;
+  Launch L = launch_params();
+  L.ilqr = 1; L.ilqr_shift = dc.ls_hessian_correction_multiple;
+  const int slots = batch * settings.max_nodes;
+  // backward pass: Euler-discretised LQ model, constraint elimination, Riccati recursion (its linear roll-out gives du = lff + K dx)
+  TIMED("linearize", kl::linearize_reference(nj(), slots, stream, L));
+  TIMED("project", kl::project_reference(nj(), slots, stream, L));
+  TIMED("riccati", kl::riccati_reference(nj(), batch, stream, L));
+  kl::ddp_policy(nj(), batch, stream, L, ddp);
+  HIP_CHECK(hipGetLastError());
+  // line search: the baseline (step length 0: the new gains, no feedforward increment), then maxStepLength, x contractionRate, .. >= minStepLength
+  std::vector<double> alphas{0.0};
+  constexpr double kContractionRate = 0.5, kArmijoCoefficient = 1e-4;       // [OCS2-upstream] line_search::Settings defaults (not in task.info)
+  for (double a = dc.ls_max_step_length; a >= dc.ls_min_step_length && alphas.size() < 64; a *= kContractionRate) alphas.push_back(a);
+  const int N = settings.max_nodes, NX = nx, NU = nu;
+  RolloutArgs a{};
+  a.batch = batch; a.N = N; a.p_grid = buf.p_grid; a.g_nodes = buf.g_nodes; a.g_kind = buf.g_kind; a.g_time = buf.g_time;
+  a.x = buf.x; a.u = ddp.u_alpha; a.K = buf.K; a.t_start = buf.roll_t; a.x_start = buf.p_x0;
+  a.abs_tol = rm.rollout.abs_tol; a.rel_tol = rm.rollout.rel_tol; a.time_step = rm.rollout.time_step;
+  a.feedback = 1;                                                            // the search rolls out the FEEDBACK policy whatever controller is handed out
+  a.x_end = buf.roll_x; a.u_end = buf.roll_u; a.steps = buf.roll_steps; a.status = buf.roll_status;
+  a.rec_t = ddp.rec_t; a.rec_x = ddp.rec_x; a.rec_u = ddp.rec_u; a.rec_n = ddp.rec_n; a.rec_cap = ddp.cap;
+  {   // every problem rolls out over its own horizon [t_0, t_N]: the kernel takes ONE duration, so the horizons must agree (they do: one `horizon` per setup)
+    std::vector<double> ts(batch);
+    double dur = -1.0;
+    for (int b = 0; b < batch; ++b) {
+      const int g = grid_of_problem[b];
+      ts[b] = node_times[(size_t)g * (N + 1)];
+      const double d = node_times[(size_t)g * (N + 1) + grid_nodes[g]] - ts[b];
+      if (dur >= 0.0 && std::fabs(d - dur) > 1e-9) throw std::invalid_argument("DDP: the problems of a batch must share the horizon length");
+      dur = d;
+    }
+    HIP_CHECK(hipMemcpyAsync(buf.roll_t, ts.data(), ts.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));      // (ts is a local: the copy must have left it)
+    a.duration = dur;
+    a.max_steps = (int)(rm.rollout.max_steps_per_second * std::max(1.0, dur));
+  }
+  for (double alpha : alphas) {
+    kl::ddp_controller(stream, buf.u, ddp.lff, alpha, ddp.u_alpha, (size_t)batch * N * NU);
+    kl::rollout(rm.nj, batch, stream, d_model, a);
+    kl::ddp_cost(nj(), batch, stream, L, ddp);
+    kl::ddp_select(nj(), batch, stream, L, ddp, alpha, kArmijoCoefficient, buf.roll_status);
+    HIP_CHECK(hipGetLastError());
+  }
+  kl::ddp_finish(nj(), batch, stream, L, ddp);
+  HIP_CHECK(hipGetLastError());
+  (void)NX;
 }
 
 namespace {
@@ -409,6 +468,17 @@ void allocate(bpmpc_solver* s) {
   b.stats = s->alloc<double>("stats", B * kStatsStride);
   b.done = s->alloc<int>("done", B, true); b.active = s->alloc<int>("active", B, true); b.iterations = s->alloc<int>("iterations", B, true);
   b.remaining = s->alloc<int>(nullptr, 1);
+  if (s->is_ddp()) {
+    DdpBuffers& d = s->ddp;
+    d.cap = (int)N + 1;
+    const size_t P = B * (size_t)d.cap;
+    d.lff = s->alloc<double>("ddp_lff", S * NU); d.u_alpha = s->alloc<double>(nullptr, S * NU);
+    d.rec_t = s->alloc<double>(nullptr, P); d.rec_x = s->alloc<double>(nullptr, P * NX); d.rec_u = s->alloc<double>(nullptr, P * NU); d.rec_n = s->alloc<int>(nullptr, B);
+    d.sol_t = s->alloc<double>("ddp_t", P); d.sol_x = s->alloc<double>(nullptr, P * NX); d.sol_u = s->alloc<double>("ddp_u", P * NU); d.sol_n = s->alloc<int>(nullptr, B);
+    d.cost = s->alloc<double>(nullptr, P); d.merit0 = s->alloc<double>(nullptr, B); d.merit = s->alloc<double>(nullptr, B); d.alpha = s->alloc<double>(nullptr, B);
+    d.update_is = s->alloc<double>("ddp_update_is", B);
+    d.accepted = s->alloc<int>(nullptr, B); d.failed = s->alloc<int>(nullptr, B); d.n_points = s->alloc<int>("ddp_points", B, true);
+  }
 }
 
 template <typename T>
@@ -448,6 +518,10 @@ void preserve_previous(bpmpc_solver* s, int batch, bool warm_arrays) {
   HIP_CHECK(hipMemcpyAsync(bp.tp_kind, bp.g_kind, B * N * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
   HIP_CHECK(hipMemcpyAsync(bp.tp_nodes, bp.g_nodes, B * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
   HIP_CHECK(hipMemcpyAsync(bp.tp_grid, bp.p_grid, B * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
+  if (s->is_ddp()) {      // the previous DDP solution lives on the time points of its roll-out, not on the grid it was computed on
+    kl::ddp_keep_times(batch, (int)N, s->stream, s->ddp, bp.tp_time, bp.tp_kind, bp.tp_nodes, bp.tp_grid);
+    HIP_CHECK(hipGetLastError());
+  }
 }
 
 // common tail of every setup flavour: initial iterate (initializer, warm arrays or shifted previous solution), activation
@@ -721,7 +795,7 @@ void rollout(bpmpc_solver* s, const double* t_start, const double* x_start, doub
   a.x = bf.x; a.u = bf.u; a.K = bf.K; a.t_start = bf.roll_t; a.x_start = x_start ? bf.roll_x0 : bf.p_x0;
   a.duration = duration; a.abs_tol = s->rm.rollout.abs_tol; a.rel_tol = s->rm.rollout.rel_tol; a.time_step = s->rm.rollout.time_step;
   a.max_steps = (int)(s->rm.rollout.max_steps_per_second * std::max(1.0, duration));
-  a.feedback = s->rm.sqp.use_feedback_policy;
+  a.feedback = s->feedback();
   a.x_end = bf.roll_x; a.u_end = bf.roll_u; a.steps = bf.roll_steps; a.status = bf.roll_status;
   kl::rollout(s->rm.nj, B, s->stream, s->d_model, a);
   HIP_CHECK(hipGetLastError());
@@ -759,16 +833,25 @@ void fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double*
     for (Down& d : down)
       if (d.host && d.pin) std::memcpy(d.host, d.pin, d.bytes);
   }
-  if (out_t)
+  std::vector<int> ddp_points;
+  if (s->is_ddp() && s->has_solution) {       // the solution lives on the time points of the accepted roll-out (k_ddp_finish); a failed problem keeps its grid
+    ddp_points.resize(B);
+    HIP_CHECK(hipMemcpy(ddp_points.data(), s->ddp.n_points, B * sizeof(int), hipMemcpyDeviceToHost));
+  }
+  if (out_t) {
+    std::vector<double> tp;
+    if (!ddp_points.empty()) { tp.resize(B * (size_t)s->ddp.cap); HIP_CHECK(hipMemcpy(tp.data(), s->ddp.sol_t, tp.size() * sizeof(double), hipMemcpyDeviceToHost)); }
     for (size_t b = 0; b < B; ++b) {
+      if (!ddp_points.empty() && ddp_points[b] > 0) { std::copy(tp.begin() + b * s->ddp.cap, tp.begin() + b * s->ddp.cap + ddp_points[b], out_t + b * (N + 1)); continue; }
       const int g = s->grid_of_problem[b];
       std::copy(s->node_times.begin() + (size_t)g * (N + 1), s->node_times.begin() + (size_t)g * (N + 1) + s->grid_nodes[g] + 1, out_t + b * (N + 1));
     }
+  }
   if (stats) {
     for (size_t b = 0; b < B; ++b) {
       const double* r = &raw[b * kStatsStride];
       bpmpc_stats& st = stats[b];
-      st.n_nodes = s->grid_nodes[s->grid_of_problem[b]];
+      st.n_nodes = (!ddp_points.empty() && ddp_points[b] > 0) ? ddp_points[b] - 1 : s->grid_nodes[s->grid_of_problem[b]];
       st.iterations = (int)r[1]; st.status = (int)r[2]; st.reserved = 0;
       st.merit_before = r[3]; st.dynamics_sse_before = r[4]; st.equality_sse_before = r[5];
       st.merit_after = r[6]; st.dynamics_sse_after = r[7]; st.equality_sse_after = r[8];
@@ -801,6 +884,22 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     if (!(settings->reg_prim >= 0.0)) { set_last_error("reg_prim must be >= 0"); return BPMPC_ERR_INVALID_ARGUMENT; }
     s->dm = make_device_model(s->rm);
     s->settings = *settings;
+    if (settings->solver != BPMPC_SOLVER_SQP && settings->solver != BPMPC_SOLVER_DDP) { set_last_error("bpmpc_solver_create: unknown solver"); return BPMPC_ERR_INVALID_ARGUMENT; }
+    if (settings->feedback_policy < 0 || settings->feedback_policy > 2) { set_last_error("bpmpc_solver_create: feedback_policy must be 0, 1 or 2"); return BPMPC_ERR_INVALID_ARGUMENT; }
+    if (settings->solver == BPMPC_SOLVER_DDP) {
+      // what the slice implements is what the reference configures (task.info:115-156); every other value of the ddp block is refused, not ignored
+      const DdpConfig& d = s->rm.ddp;
+      if (d.algorithm != 1) { set_last_error("DDP: only ddp.algorithm ILQR is implemented (SLQ integrates continuous-time Riccati equations)"); return BPMPC_ERR_UNSUPPORTED; }
+      if (d.strategy != 0) { set_last_error("DDP: only ddp.strategy LINE_SEARCH is implemented"); return BPMPC_ERR_UNSUPPORTED; }
+      if (d.ls_hessian_correction_strategy != 0) { set_last_error("DDP: only lineSearch.hessianCorrectionStrategy DIAGONAL_SHIFT is implemented"); return BPMPC_ERR_UNSUPPORTED; }
+      if (d.max_num_iterations != 1 || settings->sqp_iterations > 1) { set_last_error("DDP: one ILQR iteration per run (ddp.maxNumIterations 1): later iterations live on the roll-out's adaptive time grid"); return BPMPC_ERR_UNSUPPORTED; }
+      if (!(d.ls_min_step_length > 0.0) || !(d.ls_max_step_length >= d.ls_min_step_length)) { set_last_error("DDP: lineSearch.minStepLength / maxStepLength"); return BPMPC_ERR_INVALID_ARGUMENT; }
+      if (d.use_feedback_policy && settings->feedback_policy != 2) { set_last_error("DDP: ddp.useFeedbackPolicy true is not implemented (the gains live on the nominal grid, the solution on the roll-out's time points)"); return BPMPC_ERR_UNSUPPORTED; }
+      if (settings->feedback_policy == 1) { set_last_error("DDP: feedback_policy 1 (LinearController) is not implemented for the DDP solution"); return BPMPC_ERR_UNSUPPORTED; }
+      s->settings.reference_kernels = 1;
+      s->settings.return_gains = 1;
+      s->settings.pipeline_chunks = 1;
+    }
     s->nx = s->rm.nx; s->nu = s->rm.nu;
     HIP_CHECK(hipSetDevice(settings->device));
     { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, settings->device)); s->num_cus = prop.multiProcessorCount; }

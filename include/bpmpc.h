@@ -63,8 +63,9 @@ int bpmpc_model_dims(const bpmpc_model* model, int* nx, int* nu, int* n_contacts
  * "time_horizon", "position_error_gain", "phase_transition_stance_time", "hard_cone" (flag, sqp.inequalityConstraintMu, Delta),
  * "rollout" (AbsTolODE, RelTolODE, timeStep, maxNumStepsPerSecond, mrt frequency, mpc frequency).
  * The other two solver-settings blocks the reference loads beside `sqp` (src/BipedalRobotInterface.cpp:98-100; accessors ddpSettings(),
- * ipmSettings(), include/ocs2_bipedal_robot/BipedalRobotInterface.h:78-80) are loaded and exposed; NO solver of this library consumes
- * them (the reference constructs no IPM solver either; its DDP solver lives in one stand-alone node, BipedalRobotDdpMpcNode.cpp:70-74):
+ * ipmSettings(), include/ocs2_bipedal_robot/BipedalRobotInterface.h:78-80) are loaded and exposed.  The ipm block has no consumer (the
+ * reference constructs no IPM solver either); the ddp block is what bpmpc_settings.solver = BPMPC_SOLVER_DDP runs on (the reference's DDP
+ * solver lives in one stand-alone node, BipedalRobotDdpMpcNode.cpp:70-74):
  *   "ipm": dt, ipmIteration, deltaTol, g_max, g_min, computeLagrangeMultipliers, useFeedbackPolicy, initialBarrierParameter,
  *          targetBarrierParameter, barrierLinearDecreaseFactor, barrierSuperlinearDecreasePower, barrierReductionCostTol,
  *          barrierReductionConstraintTol, fractionToBoundaryMargin, usePrimalStepSizeForDual, initialSlackLowerBound,
@@ -144,7 +145,23 @@ typedef struct {
   double reg_prim;      /* [OCS2-upstream] HPIPM's reg_prim (hpipm_catkin sets 1e-12): added to the diagonal of every stage Hessian
                            [R~ P~'; P~ Q~] of the projected QP, terminal stage included, before the Riccati factorisation.  0 (default) =
                            exact recursion; 1e-12 moves the H1 input step by ~5e-9 relative (tests/test_recalled_behaviours.py). */
+  int solver;           /* BPMPC_SOLVER_SQP (0, default): SqpMpc, the solver of BipedalController.cpp:303-306 / BipedalRobotSqpMpcNode.cpp:70.
+                           BPMPC_SOLVER_DDP (1): GaussNewtonDDP_MPC of ocs2_bipedal_robot_ros/src/BipedalRobotDdpMpcNode.cpp:70-71 with the ddp block of
+                           task.info:115-156 - ONE ILQR iteration per run (ddp.algorithm ILQR, maxNumIterations 1, strategy LINE_SEARCH, hessian
+                           correction DIAGONAL_SHIFT; anything else: BPMPC_ERR_UNSUPPORTED): Euler-discretised LQ model on the time grid of the
+                           nominal trajectories, equality-constrained Riccati recursion, line search over TimeTriggeredRollout roll-outs of the
+                           policy (rollout block of task.info).  The solution is the accepted roll-out ON ITS OWN TIME POINTS: bpmpc_solver_fetch
+                           returns them in out_t, stats.n_nodes = points - 1 (at most max_nodes), stats.step_size = the accepted step length,
+                           merit_before / merit_after = performance index of the baseline / accepted roll-out; the controller is a
+                           FeedforwardController (ddp.useFeedbackPolicy false) - out_K of a DDP solve holds the gains of the policy on the
+                           nominal grid, for inspection.  Runs on the reference kernel set (reference_kernels is implied).  SLQ, later
+                           iterations on the roll-out's grid and the continuous-time backward pass are not implemented. */
+  int feedback_policy;  /* 0 (default): sqp.useFeedbackPolicy of task.info decides for the warm start, the policy rollout AND the controller a caller
+                           builds from the solution; 1: LinearController, 2: FeedforwardController - one value for all three, as the single
+                           sqp::Settings of the reference */
 } bpmpc_settings;
+#define BPMPC_SOLVER_SQP 0
+#define BPMPC_SOLVER_DDP 1
 
 typedef struct {
   int n_events;

@@ -32,8 +32,10 @@ struct HipSqpSolverSettings {
   int device = 0;
   int maxNodes = 160;        // shooting intervals incl. event nodes: timeHorizon / sqp.dt + 2 per gait event inside the horizon
   int sqpIterations = 0;     // <= 0: sqp.sqpIteration of task.info
-  int useFeedbackPolicy = -1;      // -1: sqp.useFeedbackPolicy of task.info (task.info:80), as the sqp::Settings the reference hands to SqpMpc
-                                   // (BipedalController.cpp:303-306); 1 / 0 override what getPrimalSolution() returns: LinearController / FeedforwardController
+  int solver = BPMPC_SOLVER_SQP;   // BPMPC_SOLVER_DDP: the engine's GaussNewtonDDP slice (HipDdpMpc.h; one ILQR iteration per run, ddp block of task.info)
+  int useFeedbackPolicy = -1;      // -1: sqp.useFeedbackPolicy (ddp.useFeedbackPolicy for the DDP solver) of task.info, as the single settings object the
+                                   // reference hands to its solver (BipedalController.cpp:303-306); 1 / 0 override it - for the engine's warm start and
+                                   // policy rollout AND for the controller getPrimalSolution() returns alike (bpmpc_settings.feedback_policy)
   bool computeSolutionMetrics = false;   // fill getSolutionMetrics() after every run (one more kernel and a read-back: for solver observers)
   bool useHardFrictionConeConstraint = false;   // the interface's fourth constructor argument (BipedalRobotInterface.h:66-69): cones as inequality constraints
 };
@@ -47,6 +49,8 @@ class HipSqpSolver final : public SolverBase {
   HipSqpSolver(const std::string& taskFile, const std::string& urdfFile, const std::string& referenceFile, const OptimalControlProblem& ocp,
                Settings settings = Settings())
       : settings_(settings), ocp_(ocp) {
+    if (settings_.solver == BPMPC_SOLVER_DDP && settings_.computeSolutionMetrics)
+      throw std::runtime_error("[HipSqpSolver] solution metrics are evaluated on the shooting grid: not available for the DDP solver");
     check(bpmpc_model_create_ex(urdfFile.c_str(), taskFile.c_str(), referenceFile.c_str(), settings_.useHardFrictionConeConstraint ? 1 : 0, &model_));
     bpmpc_settings s{};
     s.device = settings_.device;
@@ -54,6 +58,8 @@ class HipSqpSolver final : public SolverBase {
     s.max_nodes = settings_.maxNodes;
     s.sqp_iterations = settings_.sqpIterations;
     s.return_gains = 1;
+    s.solver = settings_.solver;
+    s.feedback_policy = settings_.useFeedbackPolicy < 0 ? 0 : (settings_.useFeedbackPolicy ? 1 : 2);
     const int rc = bpmpc_solver_create(model_, &s, &solver_);
     if (rc != BPMPC_OK) {
       const std::string why = bpmpc_last_error();
@@ -63,9 +69,10 @@ class HipSqpSolver final : public SolverBase {
     }
     check(bpmpc_model_dims(model_, &nx_, &nu_, nullptr, nullptr));
     if (settings_.useFeedbackPolicy < 0) {       // the file's sqp block decides (integratorType / projectStateInputEqualityConstraints the engine
-      double sqp[8] = {0};                       // does not implement were refused by bpmpc_model_create above: BPMPC_ERR_UNSUPPORTED)
+      double sqp[8] = {0}, ddp[20] = {0};        // does not implement were refused by bpmpc_model_create above: BPMPC_ERR_UNSUPPORTED)
       check(bpmpc_model_get(model_, "sqp", sqp, 8) >= 6 ? BPMPC_OK : BPMPC_ERR_IO);
-      settings_.useFeedbackPolicy = sqp[5] != 0.0 ? 1 : 0;
+      check(bpmpc_model_get(model_, "ddp", ddp, 20) >= 13 ? BPMPC_OK : BPMPC_ERR_IO);
+      settings_.useFeedbackPolicy = (settings_.solver == BPMPC_SOLVER_DDP ? ddp[12] : sqp[5]) != 0.0 ? 1 : 0;
     }
   }
   ~HipSqpSolver() override {

@@ -4,12 +4,13 @@
 // TargetTrajectoriesPublisher would have left there.  Three MPC runs (cold start, then two receding-horizon runs); per run one line of
 // checksums of what getPrimalSolution returns.  tests/test_gpu_adaptor_mock_run.py compares with the same solves through the Python mirror.
 //   build: g++ -std=c++17 -I include -I integration -I integration/mock_ocs2 integration/mock_run.cpp -L bipedal_control_amd -lbpmpc -Wl,-rpath,... -o mock_run
-//   run:   ./mock_run assets/h1 h1_mpc.urdf [task file instead of assets/h1/task.info]
+//   run:   ./mock_run assets/h1 h1_mpc.urdf [task file instead of assets/h1/task.info | -] [ddp]
 // With a task file whose sqp.useFeedbackPolicy is false the primal solution carries a FeedforwardController: the line then reports
 // "feedforward 1", sb = checksum of its uffArray_ (the input trajectory) and sk = 0.
 #include <cstdio>
 #include <string>
 
+#include "HipDdpMpc.h"
 #include "HipSqpMpc.h"
 
 namespace {
@@ -24,7 +25,8 @@ struct FixedReferences final : ocs2::ReferenceManagerInterface {
 int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: mock_run <asset dir> <urdf file name>\n"); return 2; }
   const std::string dir = argv[1];
-  const std::string urdf = dir + "/" + argv[2], task = argc > 3 ? std::string(argv[3]) : dir + "/task.info", reference = dir + "/reference.info", gaitfile = dir + "/gait.info";
+  const bool ddp = argc > 4 && std::string(argv[4]) == "ddp";      // the DDP counterpart (HipDdpMpc); "-" as the task file = the asset's own
+  const std::string urdf = dir + "/" + argv[2], task = (argc > 3 && std::string(argv[3]) != "-") ? std::string(argv[3]) : dir + "/task.info", reference = dir + "/reference.info", gaitfile = dir + "/gait.info";
   try {
     bpmpc_model* model = nullptr;
     if (bpmpc_model_create(urdf.c_str(), task.c_str(), reference.c_str(), &model) != 0) throw std::runtime_error(bpmpc_last_error());
@@ -53,8 +55,11 @@ int main(int argc, char** argv) {
     mpcSettings.coldStart_ = false;
     ocs2::bipedal_robot::HipSqpSolver::Settings ss;
     ss.maxNodes = 96;
-    ss.computeSolutionMetrics = true;
-    ocs2::bipedal_robot::HipSqpMpc mpc(mpcSettings, task, urdf, reference, ocp, ss);
+    ss.computeSolutionMetrics = !ddp;         // (the observers read the constraint rows on the shooting grid: not defined on a DDP roll-out)
+    std::unique_ptr<ocs2::MPC_BASE> mpc_owner;
+    if (ddp) mpc_owner.reset(new ocs2::bipedal_robot::HipDdpMpc(mpcSettings, task, urdf, reference, ocp, ss));      // BipedalRobotDdpMpcNode.cpp:70-71
+    else mpc_owner.reset(new ocs2::bipedal_robot::HipSqpMpc(mpcSettings, task, urdf, reference, ocp, ss));
+    ocs2::MPC_BASE& mpc = *mpc_owner;
     mpc.getSolverPtr()->setReferenceManager(refs);
     mpc.getSolverPtr()->addSynchronizedModule(std::make_shared<ocs2::SolverSynchronizedModule>());
     const double cmd[4] = {0.3, 0.0, 0.0, 0.0};
@@ -90,7 +95,7 @@ int main(int argc, char** argv) {
       const ocs2::ProblemMetrics& metrics = mpc.getSolverPtr()->getSolutionMetrics();
       double szv = 0;
       size_t nzv = 0;
-      for (size_t i = 0; i < metrics.intermediates.size(); ++i)
+      for (size_t i = 0; !ddp && i < metrics.intermediates.size(); ++i)
         for (int c = 0; c < 4; ++c) {
           const ocs2::vector_t& v = metrics.intermediates[i].stateInputEqConstraint[3 * c + 1];
           for (long j = 0; j < v.size(); ++j) { szv += v.data()[j] * (1 + (i + c + j) % 3); ++nzv; }

@@ -1,6 +1,7 @@
 // Compile-only translation unit (tests/test_integration_headers.py): instantiates the adaptor against integration/mock_ocs2 so that
 // a missing override of a SolverBase / MPC_BASE pure virtual, a typo or a signature mismatch with include/bpmpc.h fails the build.
 // Syntax check only - it pins nothing about OCS2 and is never linked or run.
+#include "HipDdpMpc.h"
 #include "HipSqpMpc.h"
 
 namespace {
@@ -21,5 +22,9 @@ int syntax_check_only() {
   mpc.run(0.0, x);
   ocs2::PrimalSolution primal;
   mpc.getSolverPtr()->getPrimalSolution(1.0, &primal);
-  return static_cast<int>(mpc.getSolverPtr()->getNumIterations()) + static_cast<int>(mpc.getSolverPtr()->getPerformanceIndeces().merit);
+  ocs2::bipedal_robot::HipDdpMpc ddp(ocs2::mpc::Settings(), "task.info", "robot.urdf", "reference.info", ocp);       // the DDP counterpart (BipedalRobotDdpMpcNode.cpp:70-71)
+  ddp.getSolverPtr()->setReferenceManager(std::make_shared<FixedReferences>());
+  ddp.run(0.0, x);
+  return static_cast<int>(mpc.getSolverPtr()->getNumIterations()) + static_cast<int>(mpc.getSolverPtr()->getPerformanceIndeces().merit) +
+         static_cast<int>(ddp.getSolverPtr()->getNumIterations());
 }

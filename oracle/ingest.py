@@ -378,6 +378,13 @@ def build_model(urdf_path, task_path, reference_path, use_hard_friction_cone=Fal
     m["phase_transition_stance_time"] = float(info_get(task, "model_settings.phaseTransitionStanceTime"))
     m["swing"] = {k: float(info_get(task, "swing_trajectory_config." + k))
                   for k in ("liftOffVelocity", "touchDownVelocity", "swingHeight", "swingTimeScale")}
+    # ddp block (task.info:115-156): what the ILQR restatement of oracle/ddp_py.py reads
+    m["ddp"] = dict(algorithm=str(info_get(task, "ddp.algorithm", "SLQ")), maxNumIterations=int(info_get(task, "ddp.maxNumIterations", 15)),
+                    timeStep=float(info_get(task, "ddp.timeStep", 0.01)), useFeedbackPolicy=str(info_get(task, "ddp.useFeedbackPolicy", "true")).lower() in ("true", "1"),
+                    strategy=str(info_get(task, "ddp.strategy", "LINE_SEARCH")),
+                    minStepLength=float(info_get(task, "ddp.lineSearch.minStepLength", 0.05)), maxStepLength=float(info_get(task, "ddp.lineSearch.maxStepLength", 1.0)),
+                    hessianCorrectionStrategy=str(info_get(task, "ddp.lineSearch.hessianCorrectionStrategy", "DIAGONAL_SHIFT")),
+                    hessianCorrectionMultiple=float(info_get(task, "ddp.lineSearch.hessianCorrectionMultiple", 1e-6)))
     m["rollout"] = dict(AbsTolODE=float(info_get(task, "rollout.AbsTolODE", 1e-5)), RelTolODE=float(info_get(task, "rollout.RelTolODE", 1e-3)),
                         timeStep=float(info_get(task, "rollout.timeStep", 0.015)), maxNumStepsPerSecond=int(info_get(task, "rollout.maxNumStepsPerSecond", 10000)))
     m["sqp"] = dict(dt=float(info_get(task, "sqp.dt")), sqpIteration=int(info_get(task, "sqp.sqpIteration")),

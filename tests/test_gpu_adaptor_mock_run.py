@@ -140,3 +140,44 @@ def test_adaptor_returns_a_feedforward_controller_when_the_task_file_says_so(tmp
         assert got["merit"] == st[0].merit_after and got["dyn"] == st[0].dynamics_sse_after
         for name, ref in (("su", su), ("sb", sb)):
             assert abs(got[name] - ref) <= 1e-11 * max(1.0, abs(ref)), (k, name, got[name], ref)
+
+
+def test_ddp_adaptor_runs_and_matches_the_python_mirror(tmp_path):
+    """integration/HipDdpMpc.h (the counterpart of GaussNewtonDDP_MPC at BipedalRobotDdpMpcNode.cpp:70-71) executed: three MPC runs - a cold
+    start and two receding-horizon runs - hand back the accepted roll-out on its own time points with a FeedforwardController
+    (ddp.useFeedbackPolicy false, task.info:146); the same runs through the Python mirror (BatchedDdpMpc)."""
+    import bipedal_control_amd as bp
+    from bipedal_control_amd import scenarios as sc
+    exe = str(tmp_path / "mock_run")
+    lib = os.path.join(ROOT, "bipedal_control_amd")
+    inc = [os.path.join(ROOT, d) for d in ("include", "integration", os.path.join("integration", "mock_ocs2"))]
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror"] + [a for i in inc for a in ("-I", i)] + [os.path.join(ROOT, "integration", "mock_run.cpp"),
+                   "-L", lib, "-lbpmpc", "-Wl,-rpath," + lib, "-o", exe], check=True)
+    out = subprocess.run([exe, os.path.join(ROOT, "assets", "h1"), "h1_mpc.urdf", "-", "ddp"], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == 3
+    itf = sc.interface("h1")
+    nx = nu = itf.stateDim
+    horizon, period = 1.005, 0.02
+    gs = bp.GaitSchedule(itf)
+    gs.insertModeSequenceTemplate(bp.loadModeSequenceTemplate(sc.H1["gait"], "trot"), -1.225, 3 * horizon)
+    sched = gs.getModeSchedule(-horizon, 3 * horizon)
+    x0 = itf.getInitialState()
+    mpc = bp.BatchedDdpMpc(itf, max_batch=1, max_nodes=96)
+    iterations = 0
+    for k in range(3):
+        t0 = k * period
+        target = [itf.cmdVelToTargetTrajectories((0.3, 0.0, 0.0, 0.0), t0, x0, horizon)]
+        t, x, u, K, st = (mpc.run if k == 0 else mpc.advance)(t0, x0.reshape(1, nx), sched, target, horizon=horizon)
+        n = st[0].n_nodes
+        iterations += st[0].iterations
+        tt, xx = t[0, :n + 1], x[0, :n + 1]
+        uu = np.vstack([u[0, :n], u[0, n - 1:n]])                      # the input of the terminal point repeats the previous one
+        i = np.arange(n + 1)[:, None]
+        ref = dict(st=float(np.sum(tt * (1 + np.arange(n + 1) % 3))), sx=float(np.sum(xx * (1 + (i + np.arange(nx)[None, :]) % 7))),
+                   su=float(np.sum(uu * (1 + (i + np.arange(nu)[None, :]) % 5))), sb=float(np.sum(uu * (1 + (i + np.arange(nu)[None, :]) % 4))))
+        w = out[k].split()
+        got = {w[j]: float(w[j + 1]) for j in range(0, len(w) - 1, 2)}
+        assert got["feedforward"] == 1 and got["sk"] == 0.0 and got["points"] == n + 1 and got["iterations"] == iterations
+        assert got["merit"] == st[0].merit_after and got["final"] == tt[-1] and st[0].step_size > 0
+        for name in ("st", "sx", "su", "sb"):
+            assert abs(got[name] - ref[name]) <= 1e-11 * max(1.0, abs(ref[name])), (k, name, got[name], ref[name])
