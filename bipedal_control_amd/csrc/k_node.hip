@@ -49,7 +49,7 @@ constexpr int kTrialWaves = 4; // same for the value-only trial kernel (smaller 
 // at nx = 24 (a wave serves four nodes of 4.2 KB each, packed lanes, LinFastCfg) - two workgroups, eight waves per CU
 #ifndef BPMPC_LIN_WAVES
 #define BPMPC_LIN_WAVES 4      // five (two workgroups = ten waves per CU fit since the node tables share one storage): 0.302 against 0.223 ms at batch
-#endif                        // 256, 4.22 against 3.20 at 4096 - the kernel is not short of waves
+#endif                        // 256, 4.22 against 3.20 at 4096 - the kernel is not short of waves (experiments/LOG.md)
 template <int NJ> constexpr int lin_waves() { return BPMPC_LIN_WAVES; }
 #ifndef BPMPC_LIN_WPE
 #define BPMPC_LIN_WPE __attribute__((amdgpu_waves_per_eu(2, BPMPC_LIN_WAVES > 4 ? 3 : 2)))
@@ -219,6 +219,12 @@ void k_trial_fast(Launch L) {
   __shared__ LinFastShared<NJ, false> shared;     // model constants indexed per lane, shared by the nodes of the workgroup
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
   const int widx = blockIdx.x * (kTrialWaves * NPW) + sub;
+  {   // a workgroup whose problems have all finished their line search has nothing to evaluate (the second round: all but a few workgroups)
+    const int total = L.batch * L.klen, w0 = blockIdx.x * (kTrialWaves * NPW), w1 = (w0 + kTrialWaves * NPW < total ? w0 + kTrialWaves * NPW : total) - 1;
+    bool any = false;
+    for (int pb = w0 / L.klen; pb <= w1 / L.klen; ++pb) any = any || L.buf.done[pb] == 0;
+    if (!any) return;
+  }
   bool valid = widx < L.batch * L.klen;
   const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
   const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + k) * NX;
@@ -274,9 +280,9 @@ __global__ __launch_bounds__(kWave) void k_rollout(const DeviceModel* model, Rol
 
 constexpr int kDecideThreads = 256;
 template <int NJ>
-__global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L) {
+__global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L, int look_first) {
   __shared__ double partial[3 * kDecideThreads + 5];
-  linesearch_decide<NJ, kDecideThreads>(partial, problem_ls<NJ>(L, blockIdx.x), L.ls);
+  linesearch_decide<NJ, kDecideThreads>(partial, problem_ls<NJ>(L, blockIdx.x), L.ls, look_first != 0);
 }
 
 // Back-tracking rounds after the first one, entirely on the device: a workgroup per problem that has not accepted yet (normally
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L) {
 // (the sums are the ones of k_ls_decide term by term while the horizon has at most kDecideThreads nodes).
 constexpr int kTailThreads = 512;
 template <int NJ, bool CHAIN>
-__global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int max_trials) {
+__global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int first_round, int max_trials) {
   using C = LinFastCfg<NJ, true, CHAIN>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW, CHUNK = (kTailThreads / kWave) * NPW;
   const int b = blockIdx.x;
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int max_tria
   const ProblemLS p = problem_ls<NJ>(L, b);
   volatile const int* done = L.buf.done + b;
   volatile const double* alpha = L.buf.alpha + b;
-  for (int round = 1; round < max_trials; ++round) {
+  for (int round = first_round; round < max_trials; ++round) {
     const double al = *alpha;
     for (int k0 = 0; k0 < n; k0 += CHUNK) {
       const int k = k0 + sub;
@@ -381,11 +387,11 @@ void trial_fast(int nj, int nodes, hipStream_t st, const Launch& L) {
     else hipLaunchKernelGGL((k_trial_fast<NJ, false>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L);
   });
 }
-void ls_decide(int nj, int batch, hipStream_t st, const Launch& L) { KL_NJ(nj, hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, st, L)); }
-void ls_tail(int nj, int batch, hipStream_t st, const Launch& L, int max_trials) {
+void ls_decide(int nj, int batch, hipStream_t st, const Launch& L, bool look_first) { KL_NJ(nj, hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, st, L, look_first ? 1 : 0)); }
+void ls_tail(int nj, int batch, hipStream_t st, const Launch& L, int first_round, int max_trials) {
   KL_NJ(nj, {
-    if (L.serial_legs) hipLaunchKernelGGL((k_ls_tail<NJ, true>), dim3(batch), dim3(kTailThreads), 0, st, L, max_trials);
-    else hipLaunchKernelGGL((k_ls_tail<NJ, false>), dim3(batch), dim3(kTailThreads), 0, st, L, max_trials);
+    if (L.serial_legs) hipLaunchKernelGGL((k_ls_tail<NJ, true>), dim3(batch), dim3(kTailThreads), 0, st, L, first_round, max_trials);
+    else hipLaunchKernelGGL((k_ls_tail<NJ, false>), dim3(batch), dim3(kTailThreads), 0, st, L, first_round, max_trials);
   });
 }
 void constraint_values(int nj, int nodes, hipStream_t st, const Launch& L, double* eqv) {

@@ -129,8 +129,9 @@ BP_DEVICE void linesearch_begin(double* partial /*kWave*3 + 5 LDS*/, const Probl
 
 // NL lanes work on one problem (64 in the lane emulation, 256 on the GPU: the accepted step touches (2N+1) nx doubles)
 template <int NJ, int NL = kWave, bool PRE = true>     // PRE (device): the update's operands are requested before the sums (k_ls_decide; the back-tracking kernel has no registers for them)
-BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags + 3 sums*/, const ProblemLS& p, const LineSearchSettings& st) {
+BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags + 3 sums*/, const ProblemLS& p, const LineSearchSettings& st, bool look_first = false) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
+  if (look_first && p.done[0]) return;       // a launch in which nearly every problem is finished already (the second round): no requests for those
 #if !defined(BPMPC_HOST_EMULATION)
   // Device: the entries of the iterate and of the step this lane updates if the trial is accepted are requested HERE, before the sums - their
   // addresses depend on the lane only.  As a loop of x[idx] += alpha dx[idx] behind the decision (x and dx may alias as far as the compiler

@@ -286,11 +286,18 @@ void bpmpc_solver::stage_linesearch() {
   int max_trials = 0;
   for (double a = 1.0; a >= ls.alpha_min; a *= ls.alpha_decay) ++max_trials;
   if (!settings.reference_kernels) {
-    // first round for everybody, later rounds per problem on the device (k_ls_tail): no read-back inside a solve
+    // first round for everybody.  Second round again as a launch over all nodes: a problem that back-tracks once (config 2 tiled from t = 0: one
+    // of 256, six of 4096) has its ~107 trial nodes evaluated by seven workgroups at once instead of four passes of ONE workgroup in k_ls_tail
+    // (95 -> ~35 us for the whole batch); workgroups of finished problems leave after reading two flags.  Later rounds per problem on the
+    // device (k_ls_tail).  No read-back inside a solve.  BPMPC_LS_WIDE_ROUNDS (default 2) = rounds that run as launches over all nodes.
     const int nodes = batch * L.klen;
-    kl::trial_fast(nj(), nodes, stream, L);
-    kl::ls_decide(nj(), batch, stream, L);
-    kl::ls_tail(nj(), batch, stream, L, max_trials);
+    static const int wide_rounds = [] { const char* e = std::getenv("BPMPC_LS_WIDE_ROUNDS"); const int v = e ? std::atoi(e) : 2; return v < 1 ? 1 : v; }();
+    int round = 0;
+    for (; round < wide_rounds && round < max_trials; ++round) {
+      kl::trial_fast(nj(), nodes, stream, L);
+      kl::ls_decide(nj(), batch, stream, L, round > 0);
+    }
+    kl::ls_tail(nj(), batch, stream, L, round, max_trials);
     HIP_CHECK(hipGetLastError());
     time_end("linesearch", ev_a, ev_b);
     return;
