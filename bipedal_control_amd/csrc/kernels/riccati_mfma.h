@@ -79,8 +79,8 @@ __device__ __forceinline__ v4d blk_load(const double* Mx, int r0, int c0, int l)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = r0 + (l >> 4) + 4 * r;
-    if constexpr (NXR >= 32) c[r] = Mx[row * LD + c0 + (l & 15)];
-    else c[r] = Mx[(row < NXR ? row : ZR) * LD + c0 + (l & 15)];
+    if constexpr (NXR >= 32) c[r] = lds1(Mx[row * LD + c0 + (l & 15)]);
+    else c[r] = lds1(Mx[(row < NXR ? row : ZR) * LD + c0 + (l & 15)]);
   }
   return c;
 }
@@ -597,12 +597,12 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
-        a[ks] = half * (ws.S[rowc][kk] + ws.S[kk][rowc]);
-        b[ks] = W[kk][c0 + li];
+        a[ks] = half * (lds1(ws.S[rowc][kk]) + lds1(ws.S[kk][rowc]));
+        b[ks] = lds1(W[kk][c0 + li]);
       }
       const double smask = (c0 + li == NX) ? 1.0 : 0.0;              // s rides in the b column; rows >= nx of S are zero
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int rr = r0 + lk + 4 * r; sv[r] = smask * ws.S[RCL >= 32 ? rr : (rr < RCL ? rr : ZR)][NX]; }
+      for (int r = 0; r < 4; ++r) { const int rr = r0 + lk + 4 * r; sv[r] = smask * lds1(ws.S[RCL >= 32 ? rr : (rr < RCL ? rr : ZR)][NX]); }
       __builtin_amdgcn_sched_barrier(0);
       v4d acc = {sv[0], sv[1], sv[2], sv[3]};
 #pragma unroll
@@ -622,8 +622,8 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
-        a[ks] = W[kk][bcol];                                       // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
-        b[ks] = ws.SW[kk][c0 + li];
+        a[ks] = lds1(W[kk][bcol]);                                 // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
+        b[ks] = lds1(ws.SW[kk][c0 + li]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -712,8 +712,8 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int kk = 4 * ks + lk;
-          a[ks] = W[kk][acol];                                      // A'(i, kk)
-          b[ks] = ws.SW[kk][c0 + li];
+          a[ks] = lds1(W[kk][acol]);                                // A'(i, kk)
+          b[ks] = lds1(ws.SW[kk][c0 + li]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -742,10 +742,10 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
           const int kk = 4 * ks + lk;
-          yb[ks] = M[kk][c0 + li];
-          ag[ks] = -ws.G0[kk][gcol];                                   // -G'(i, kk)
-          ab[ks] = -W[rowc][BC + kk];                               // -B(i, kk); rows >= nx of W and PW are zero
-          ap[ks] = -PW[rowc][BC + kk];                              // -Pu(i, kk)
+          yb[ks] = lds1(M[kk][c0 + li]);
+          ag[ks] = -lds1(ws.G0[kk][gcol]);                                  // -G'(i, kk)
+          ab[ks] = -lds1(W[rowc][BC + kk]);                             // -B(i, kk); rows >= nx of W and PW are zero
+          ap[ks] = -lds1(PW[rowc][BC + kk]);                             // -Pu(i, kk)
         }
         __builtin_amdgcn_sched_barrier(0);
         const int nks = ksn == 3 ? 3 : 2;

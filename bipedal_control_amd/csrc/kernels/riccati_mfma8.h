@@ -203,9 +203,9 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kk = 4 * ks + lk;
-      yb[ks] = M[kk][c0 + li];                                   // -Y (E stores the gain negated); rows >= nt are zero
-      ab[ks] = W[row][BC + kk];                                  // B(i, kk); rows >= nx of W and PW are zero
-      ap[ks] = PW[row][BC + kk];                                 // Pu(i, kk)
+      yb[ks] = lds1(M[kk][c0 + li]);                             // -Y (E stores the gain negated); rows >= nt are zero
+      ab[ks] = lds1(W[row][BC + kk]);                                // B(i, kk); rows >= nx of W and PW are zero
+      ap[ks] = lds1(PW[row][BC + kk]);                               // Pu(i, kk)
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -267,8 +267,8 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int kk = 4 * ks + lk;
-        a[ks] = W[kk][acol];                                        // A'(i, kk)
-        b[ks] = ws.SW[kk][c0 + li];
+        a[ks] = lds1(W[kk][acol]);                                  // A'(i, kk)
+        b[ks] = lds1(ws.SW[kk][c0 + li]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -316,14 +316,14 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
           // sym(S): the mean of the two triangles inside the diagonal blocks; block (1, 0) of S is never computed (the S update leaves it out, as
           // the wave-per-problem sweeps do) - its elements are read from block (0, 1): both terms of the mean are then the same element
           const bool up = (bi == 0 && ks >= 4), lo = (bi != 0 && ks < 4);
-          a[ks] = half * (ws.S[lo ? kk : row][lo ? row : kk] + ws.S[up ? row : kk][up ? kk : row]);
-          b[ks] = W[kk][c0 + li];
+          a[ks] = half * (lds1(ws.S[lo ? kk : row][lo ? row : kk]) + lds1(ws.S[up ? row : kk][up ? kk : row]));
+          b[ks] = lds1(W[kk][c0 + li]);
         }
         const double smask = (c0 + li == NX) ? 1.0 : 0.0;              // s rides in the b column; rows >= nx of S are zero
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sv[r] = smask * ws.S[r0 + lk + 4 * r][NX];
+        for (int r = 0; r < 4; ++r) sv[r] = smask * lds1(ws.S[r0 + lk + 4 * r][NX]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ga[ks] = (bi == 0 || ks < KG1) ? W[r0 + 4 * ks + lk][BC + li] : 0.0;     // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
+        for (int ks = 0; ks < 4; ++ks) ga[ks] = (bi == 0 || ks < KG1) ? lds1(W[r0 + 4 * ks + lk][BC + li]) : 0.0;     // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
         v4d g = blk_load<LDW, 32, 0>(&M[0][0], 0, c0, l);
         if (bi != 0) g = v4d{0.0, 0.0, 0.0, 0.0};
         __builtin_amdgcn_sched_barrier(0);
@@ -373,8 +373,8 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
                part arrives in two groups - 15 instead of 20 values in flight, or the kernel needs scratch -, which starts the elimination an LDS round trip later */ \
           constexpr int H1 = NJ <= 10 ? ROWS : (ROWS + 1) / 2;                                \
           double ta[ROWS], tb[H1];                                                            \
-          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) ta[i] = M[i][col];                 \
-          _Pragma("unroll") for (int i = 0; i < H1; ++i) tb[i] = ws.Mb[i][col];               \
+          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) ta[i] = lds1(M[i][col]);           \
+          _Pragma("unroll") for (int i = 0; i < H1; ++i) tb[i] = lds1(ws.Mb[i][col]);         \
           _Pragma("unroll") for (int i = 0; i < ROWS; ++i) asm volatile("" : "+v"(ta[i]));    \
           _Pragma("unroll") for (int i = 0; i < H1; ++i) asm volatile("" : "+v"(tb[i]));      \
           /* (no masks: rows >= nt of M and Mb are zero - they are staged as zeros and B~ has no columns there -, and a lane without a column eliminates column 0 into a spare column) */ \
@@ -421,8 +421,8 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const int kk = 4 * ks + lk;
-          ag[ks] = -ws.Zt[kk][gcol];                                    // -Z'(i, kk)
-          yb[ks] = ws.Yn[kk][c0 + li];
+          ag[ks] = -lds1(ws.Zt[kk][gcol]);                                    // -Z'(i, kk)
+          yb[ks] = lds1(ws.Yn[kk][c0 + li]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
