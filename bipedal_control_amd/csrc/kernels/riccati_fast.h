@@ -150,6 +150,10 @@ __device__ __forceinline__ void fnmac_row_bcast(double& acc, double m) {
   if constexpr (FIRST) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(P));
   else asm volatile("v_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(P));
 }
+#ifndef BPMPC_ELIM_V2
+#define BPMPC_ELIM_V2 1
+#endif
+#if !BPMPC_ELIM_V2
 // One pivot step; `row` = pivot row P already normalised.  The reciprocal chain of pivot P + 1 (broadcast, v_rcp_f64, two
 // Newton steps, product: seven dependent instructions) is issued one instruction at a time between the independent updates of
 // this step - row P + 1 is updated first - so that it costs issue slots, not latency.
@@ -190,7 +194,7 @@ __device__ __forceinline__ void gauss_jordan_rows_step(double (&v)[ROWS], int nt
     }
   }
 }
-template <int ROWS>
+template <int ROWS, bool EXACT = false>
 __device__ __forceinline__ bool gauss_jordan_rows(double (&v)[ROWS], int nt) {
   if (nt <= 0) return true;
   const double piv = row_bcast<0>(v[0]);
@@ -199,6 +203,72 @@ __device__ __forceinline__ bool gauss_jordan_rows(double (&v)[ROWS], int nt) {
   return ok;
 }
 
+#else
+// Round 5: one pivot step of the Gauss-Jordan elimination as ONE assembly statement (see forward_eliminate_rows below for the why: a lone wave
+// pays ~8 cycles per instruction whatever it is, and the compiler puts wait states around every assembly statement that touches a register another
+// one defined).  %0: the next pivot row, %1 ..: the ROWS - 2 other rows; the reciprocal chain of the next pivot (broadcast, v_rcp_f64, two Newton
+// steps, product - the operations of fast_reciprocal) stands between the updates.  Same operations on the same values: bit-identical results.
+#define BP_GJ_U(i) "v_fmac_f64_dpp %" #i ", %" #i ", -%[row] row_newbcast:%[p] row_mask:0xf bank_mask:0xf\n\t"
+#define BP_GJ_HEAD "s_nop 1\n\t" BP_GJ_U(0) BP_GJ_U(1) BP_GJ_U(2) "v_mov_b64_dpp %[piv], %0 row_newbcast:%[pn] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_rcp_f64 %[r], %[piv]\n\t" BP_GJ_U(3) "v_fma_f64 %[e], -%[piv], %[r], 1.0\n\t" BP_GJ_U(4) "v_fmac_f64 %[r], %[r], %[e]\n\t" BP_GJ_U(5) \
+  "v_fma_f64 %[e], -%[piv], %[r], 1.0\n\t" BP_GJ_U(6) "v_fmac_f64 %[r], %[r], %[e]\n\t"
+#define BP_GJ_MUL "v_mul_f64 %[nr], %0, %[r]\n\t"
+#define BP_GJ_OUT [piv] "=&v"(piv), [r] "=&v"(r), [e] "=&v"(e), [nr] "=&v"(next_row)
+#define BP_GJ_IN [row] "v"(row), [p] "n"(P), [pn] "n"(PN)
+#define BP_GJ_O(j) "+v"(v[(j) < P ? (j) : ((j) + 2 < ROWS ? (j) + 2 : 0)])      /* j-th row that is neither P nor P + 1 */
+template <int ROWS, int P, bool EXACT>
+__device__ __forceinline__ void gauss_jordan_rows_step(double (&v)[ROWS], int nt, bool& ok, int& minhi, double& lastp, double row) {
+  constexpr bool has_next = P + 1 < ROWS;
+  constexpr int PN = has_next ? P + 1 : P;
+  double piv = 1.0, next_row = 0.0;
+  if constexpr (has_next) {
+    double r, e;
+    static_assert(ROWS == 8 || ROWS == 9 || ROWS == 10 || ROWS == 12, "gauss_jordan_rows: row counts with a statement");
+    if constexpr (ROWS == 8)
+      asm volatile(BP_GJ_HEAD BP_GJ_MUL : "+v"(v[PN]), BP_GJ_O(0), BP_GJ_O(1), BP_GJ_O(2), BP_GJ_O(3), BP_GJ_O(4), BP_GJ_O(5), BP_GJ_OUT : BP_GJ_IN);
+    else if constexpr (ROWS == 9)
+      asm volatile(BP_GJ_HEAD BP_GJ_U(7) BP_GJ_MUL : "+v"(v[PN]), BP_GJ_O(0), BP_GJ_O(1), BP_GJ_O(2), BP_GJ_O(3), BP_GJ_O(4), BP_GJ_O(5), BP_GJ_O(6), BP_GJ_OUT : BP_GJ_IN);
+    else if constexpr (ROWS == 10)
+      asm volatile(BP_GJ_HEAD BP_GJ_U(7) BP_GJ_MUL BP_GJ_U(8)
+                   : "+v"(v[PN]), BP_GJ_O(0), BP_GJ_O(1), BP_GJ_O(2), BP_GJ_O(3), BP_GJ_O(4), BP_GJ_O(5), BP_GJ_O(6), BP_GJ_O(7), BP_GJ_OUT : BP_GJ_IN);
+    else
+      asm volatile(BP_GJ_HEAD BP_GJ_U(7) BP_GJ_MUL BP_GJ_U(8) BP_GJ_U(9) BP_GJ_U(10)
+                   : "+v"(v[PN]), BP_GJ_O(0), BP_GJ_O(1), BP_GJ_O(2), BP_GJ_O(3), BP_GJ_O(4), BP_GJ_O(5), BP_GJ_O(6), BP_GJ_O(7), BP_GJ_O(8), BP_GJ_O(9), BP_GJ_OUT : BP_GJ_IN);
+  } else {
+    fnmac_row_bcast<P, true>(v[0], row);
+#pragma unroll
+    for (int i = 1; i < ROWS - 1; ++i) fnmac_row_bcast<P, false>(v[i], row);
+  }
+  v[P] = row;
+  if constexpr (has_next) {
+    if constexpr (EXACT) {
+      if constexpr (P + 2 == ROWS) lastp = piv; else minhi = min(minhi, __double2hiint(piv));     // (see forward_eliminate_rows_step)
+      gauss_jordan_rows_step<ROWS, P + 1, EXACT>(v, nt, ok, minhi, lastp, next_row);
+    } else if (P + 1 < nt) {  // wave-uniform
+      ok = ok && (piv > 0.0);
+      gauss_jordan_rows_step<ROWS, P + 1, EXACT>(v, nt, ok, minhi, lastp, next_row);
+    }
+  }
+}
+#undef BP_GJ_U
+#undef BP_GJ_HEAD
+#undef BP_GJ_MUL
+#undef BP_GJ_OUT
+#undef BP_GJ_IN
+#undef BP_GJ_O
+template <int ROWS, bool EXACT = false>
+__device__ __forceinline__ bool gauss_jordan_rows(double (&v)[ROWS], int nt) {
+  if (nt <= 0) return true;
+  const double piv = row_bcast<0>(v[0]);
+  bool ok = piv > 0.0;
+  int minhi = 0x7fffffff;
+  double lastp = piv;
+  gauss_jordan_rows_step<ROWS, 0, EXACT>(v, nt, ok, minhi, lastp, v[0] * fast_reciprocal(piv));
+  if constexpr (EXACT) ok = ok && minhi > 0 && lastp > 0.0;
+  return ok;
+}
+#endif
+
 // Forward elimination only, same row layout and pivot pipeline as gauss_jordan_rows: row P is divided by its pivot and
 // eliminated from the rows below it; emit(P, z, y) sees pivot row P before (z) and after (y) the division.  The rows end
 // up unit upper triangular in the H lanes; back_substitute_rows finishes H^-1 [G g].
@@ -206,6 +276,10 @@ __device__ __forceinline__ bool gauss_jordan_rows(double (&v)[ROWS], int nt) {
 // the wave is alone on its SIMD and waits for every link), so it takes ONE Newton step here: v_rcp_f64 is good to 4.6e-8,
 // one step to 2.2e-15 relative, two are correctly rounded (tools/probes/rcp_probe.hip) - a perturbation of the pivot by ten
 // ulp, the size of the rounding errors of the elimination itself.
+#ifndef BPMPC_ELIM_V2
+#define BPMPC_ELIM_V2 1
+#endif
+#if !BPMPC_ELIM_V2
 template <int ROWS, int P, class Emit>
 __device__ __forceinline__ void forward_eliminate_rows_step(double (&v)[ROWS], int nt, bool& ok, double row, Emit& emit) {
   constexpr bool has_next = P + 1 < ROWS;
@@ -238,7 +312,7 @@ __device__ __forceinline__ void forward_eliminate_rows_step(double (&v)[ROWS], i
     }
   }
 }
-template <int ROWS, class Emit>
+template <int ROWS, bool EXACT = false, class Emit>
 __device__ __forceinline__ bool forward_eliminate_rows(double (&v)[ROWS], int nt, Emit&& emit) {
   if (nt <= 0) return true;
   const double piv = row_bcast<0>(v[0]);
@@ -246,6 +320,106 @@ __device__ __forceinline__ bool forward_eliminate_rows(double (&v)[ROWS], int nt
   forward_eliminate_rows_step<ROWS, 0>(v, nt, ok, v[0] * fast_reciprocal(piv), emit);
   return ok;
 }
+#else
+// Round 5.  A lone wave issues one FP64 instruction in ~8 cycles whether it depends on the one before or not (tools/probes/dep_probe.hip: dependent
+// v_fma_f64 8.0, two independent chains 6.2 each), so a pivot step costs its INSTRUCTIONS, and a third of the 150 of the version above computed
+// nothing: wait states the compiler puts in front of every DPP / transcendental consumer whose producer sits in inline assembly (it does not count
+// the assembly statements in between), a compare + scalar AND + uniform branch per pivot.  Here the whole step is assembly in a fixed order - the
+// update of the next pivot row, two more updates (the two wait states a DPP read needs behind the VALU write of its register), broadcast,
+// v_rcp_f64, an update (the wait state of a transcendental result), Newton step, product, the other updates; s_nop only in the last steps, which
+// have no updates left to fill with - and with EXACT (nt == ROWS: the instantiations for 9 and 10 reduced inputs) the positivity of the pivots is
+// one v_min_f64 per step, no branch.  Same operations on the same values: bit-identical results.
+// One pivot step as ONE assembly statement (the compiler puts a wait state in front of every statement that reads a register an earlier assembly
+// statement defined - five per pivot with a statement per instruction): update of the next pivot row %0, NO more updates (%1 ..), and between
+// them the reciprocal chain of the next pivot in the order described above.
+// (every statement opens with two wait states: the compiler may copy an operand into its register right in front of the statement, and a DPP read
+//  needs them behind a VALU write - seen: a v_mov_b64 in front of the update of the last step, wrong results)
+#define BP_PIV_U(i) "v_fmac_f64_dpp %" #i ", %" #i ", -%[row] row_newbcast:%[p] row_mask:0xf bank_mask:0xf\n\t"
+#define BP_PIV_MOV "v_mov_b64_dpp %[piv], %0 row_newbcast:%[pn] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define BP_PIV_RCP "v_rcp_f64 %[r], %[piv]\n\t"
+#define BP_PIV_FMA "v_fma_f64 %[e], -%[piv], %[r], 1.0\n\t"
+#define BP_PIV_FMAC "v_fmac_f64 %[r], %[r], %[e]\n\t"
+#define BP_PIV_MUL "v_mul_f64 %[nr], %0, %[r]\n\t"
+#define BP_PIV_OUT [piv] "=&v"(piv), [r] "=&v"(r), [e] "=&v"(e), [nr] "=&v"(next_row)
+#define BP_PIV_IN [row] "v"(row), [p] "n"(P), [pn] "n"(PN)
+template <int ROWS, int P, int PN>
+__device__ __forceinline__ void pivot_step_asm(double (&v)[ROWS], double row, double& piv, double& next_row) {
+  constexpr int NO = ROWS - P - 2;
+  double r, e;
+  auto& a = v;
+  constexpr int B = P + 2;                        // first of the other rows
+  if constexpr (NO == 0)
+    asm volatile("s_nop 1\n\t" BP_PIV_U(0) "s_nop 1\n\t" BP_PIV_MOV BP_PIV_RCP "s_nop 0\n\t" BP_PIV_FMA BP_PIV_FMAC BP_PIV_MUL : "+v"(a[PN]), BP_PIV_OUT : BP_PIV_IN);
+  else if constexpr (NO == 1)
+    asm volatile("s_nop 1\n\t" BP_PIV_U(0) BP_PIV_U(1) "s_nop 0\n\t" BP_PIV_MOV BP_PIV_RCP "s_nop 0\n\t" BP_PIV_FMA BP_PIV_FMAC BP_PIV_MUL : "+v"(a[PN]), "+v"(a[B < ROWS ? B : 0]), BP_PIV_OUT : BP_PIV_IN);
+  else if constexpr (NO == 2)
+    asm volatile("s_nop 1\n\t" BP_PIV_U(0) BP_PIV_U(1) BP_PIV_U(2) BP_PIV_MOV BP_PIV_RCP "s_nop 0\n\t" BP_PIV_FMA BP_PIV_FMAC BP_PIV_MUL
+                 : "+v"(a[PN]), "+v"(a[B < ROWS ? B : 0]), "+v"(a[B + 1 < ROWS ? B + 1 : 0]), BP_PIV_OUT : BP_PIV_IN);
+  else if constexpr (NO == 3)
+    asm volatile("s_nop 1\n\t" BP_PIV_U(0) BP_PIV_U(1) BP_PIV_U(2) BP_PIV_MOV BP_PIV_RCP BP_PIV_U(3) BP_PIV_FMA BP_PIV_FMAC BP_PIV_MUL
+                 : "+v"(a[PN]), "+v"(a[B < ROWS ? B : 0]), "+v"(a[B + 1 < ROWS ? B + 1 : 0]), "+v"(a[B + 2 < ROWS ? B + 2 : 0]), BP_PIV_OUT : BP_PIV_IN);
+  else if constexpr (NO == 4)
+    asm volatile("s_nop 1\n\t" BP_PIV_U(0) BP_PIV_U(1) BP_PIV_U(2) BP_PIV_MOV BP_PIV_RCP BP_PIV_U(3) BP_PIV_FMA BP_PIV_U(4) BP_PIV_FMAC BP_PIV_MUL
+                 : "+v"(a[PN]), "+v"(a[B < ROWS ? B : 0]), "+v"(a[B + 1 < ROWS ? B + 1 : 0]), "+v"(a[B + 2 < ROWS ? B + 2 : 0]), "+v"(a[B + 3 < ROWS ? B + 3 : 0]), BP_PIV_OUT : BP_PIV_IN);
+  else if constexpr (NO == 5)
+    asm volatile("s_nop 1\n\t" BP_PIV_U(0) BP_PIV_U(1) BP_PIV_U(2) BP_PIV_MOV BP_PIV_RCP BP_PIV_U(3) BP_PIV_FMA BP_PIV_U(4) BP_PIV_FMAC BP_PIV_U(5) BP_PIV_MUL
+                 : "+v"(a[PN]), "+v"(a[B < ROWS ? B : 0]), "+v"(a[B + 1 < ROWS ? B + 1 : 0]), "+v"(a[B + 2 < ROWS ? B + 2 : 0]), "+v"(a[B + 3 < ROWS ? B + 3 : 0]),
+                   "+v"(a[B + 4 < ROWS ? B + 4 : 0]), BP_PIV_OUT : BP_PIV_IN);
+  else if constexpr (NO == 6)
+    asm volatile("s_nop 1\n\t" BP_PIV_U(0) BP_PIV_U(1) BP_PIV_U(2) BP_PIV_MOV BP_PIV_RCP BP_PIV_U(3) BP_PIV_FMA BP_PIV_U(4) BP_PIV_FMAC BP_PIV_U(5) BP_PIV_MUL BP_PIV_U(6)
+                 : "+v"(a[PN]), "+v"(a[B < ROWS ? B : 0]), "+v"(a[B + 1 < ROWS ? B + 1 : 0]), "+v"(a[B + 2 < ROWS ? B + 2 : 0]), "+v"(a[B + 3 < ROWS ? B + 3 : 0]),
+                   "+v"(a[B + 4 < ROWS ? B + 4 : 0]), "+v"(a[B + 5 < ROWS ? B + 5 : 0]), BP_PIV_OUT : BP_PIV_IN);
+  else if constexpr (NO == 7)
+    asm volatile("s_nop 1\n\t" BP_PIV_U(0) BP_PIV_U(1) BP_PIV_U(2) BP_PIV_MOV BP_PIV_RCP BP_PIV_U(3) BP_PIV_FMA BP_PIV_U(4) BP_PIV_FMAC BP_PIV_U(5) BP_PIV_MUL BP_PIV_U(6) BP_PIV_U(7)
+                 : "+v"(a[PN]), "+v"(a[B < ROWS ? B : 0]), "+v"(a[B + 1 < ROWS ? B + 1 : 0]), "+v"(a[B + 2 < ROWS ? B + 2 : 0]), "+v"(a[B + 3 < ROWS ? B + 3 : 0]),
+                   "+v"(a[B + 4 < ROWS ? B + 4 : 0]), "+v"(a[B + 5 < ROWS ? B + 5 : 0]), "+v"(a[B + 6 < ROWS ? B + 6 : 0]), BP_PIV_OUT : BP_PIV_IN);
+  else {
+    static_assert(NO == 8, "forward_eliminate_rows: at most ten rows");
+    asm volatile("s_nop 1\n\t" BP_PIV_U(0) BP_PIV_U(1) BP_PIV_U(2) BP_PIV_MOV BP_PIV_RCP BP_PIV_U(3) BP_PIV_FMA BP_PIV_U(4) BP_PIV_FMAC BP_PIV_U(5) BP_PIV_MUL BP_PIV_U(6) BP_PIV_U(7) BP_PIV_U(8)
+                 : "+v"(a[PN]), "+v"(a[B < ROWS ? B : 0]), "+v"(a[B + 1 < ROWS ? B + 1 : 0]), "+v"(a[B + 2 < ROWS ? B + 2 : 0]), "+v"(a[B + 3 < ROWS ? B + 3 : 0]),
+                   "+v"(a[B + 4 < ROWS ? B + 4 : 0]), "+v"(a[B + 5 < ROWS ? B + 5 : 0]), "+v"(a[B + 6 < ROWS ? B + 6 : 0]), "+v"(a[B + 7 < ROWS ? B + 7 : 0]), BP_PIV_OUT : BP_PIV_IN);
+  }
+}
+#undef BP_PIV_U
+#undef BP_PIV_MOV
+#undef BP_PIV_RCP
+#undef BP_PIV_FMA
+#undef BP_PIV_FMAC
+#undef BP_PIV_MUL
+#undef BP_PIV_OUT
+#undef BP_PIV_IN
+template <int ROWS, int P, bool EXACT, class Emit>
+__device__ __forceinline__ void forward_eliminate_rows_step(double (&v)[ROWS], int nt, bool& ok, int& minhi, double& lastp, double row, Emit& emit) {
+  constexpr bool has_next = P + 1 < ROWS;
+  constexpr int PN = has_next ? P + 1 : P;
+  double piv = 1.0, next_row = 0.0;
+  if constexpr (has_next) pivot_step_asm<ROWS, P, PN>(v, row, piv, next_row);
+  emit(P, v[P], row);
+  v[P] = row;
+  if constexpr (has_next) {
+    if constexpr (EXACT) {
+      // positive pivots, one integer instruction per step: the high word of a double > 0 is a positive integer (zero, denormals and negative numbers are
+      // not; a NaN may be, but it makes every later pivot NaN and the last one is compared as a double)
+      if constexpr (P + 2 == ROWS) lastp = piv; else minhi = min(minhi, __double2hiint(piv));
+      forward_eliminate_rows_step<ROWS, P + 1, EXACT>(v, nt, ok, minhi, lastp, next_row, emit);
+    } else if (P + 1 < nt) {  // wave-uniform
+      ok = ok && (piv > 0.0);
+      forward_eliminate_rows_step<ROWS, P + 1, EXACT>(v, nt, ok, minhi, lastp, next_row, emit);
+    }
+  }
+}
+template <int ROWS, bool EXACT = false, class Emit>
+__device__ __forceinline__ bool forward_eliminate_rows(double (&v)[ROWS], int nt, Emit&& emit) {
+  if (nt <= 0) return true;
+  const double piv = row_bcast<0>(v[0]);
+  bool ok = piv > 0.0;
+  int minhi = 0x7fffffff;
+  double lastp = piv;
+  forward_eliminate_rows_step<ROWS, 0, EXACT>(v, nt, ok, minhi, lastp, v[0] * fast_reciprocal(piv), emit);
+  if constexpr (EXACT) ok = ok && minhi > 0 && lastp > 0.0;
+  return ok;
+}
+#endif
 template <int ROWS, int P>
 __device__ __forceinline__ void back_substitute_rows_step(double (&v)[ROWS], int nt) {
   if constexpr (P >= 1) {

@@ -683,18 +683,21 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
       const bool is_h = c16 < nt, is_rhs = !is_h && rhs < NX + 1;
       const int col = is_h ? BC + c16 : (is_rhs ? rhs : 0);
       bool ok;
-#define BP_GJ_CASE(ROWS)                                                                      \
+      // (no masks on the loads - as conditional expressions they are a branch and a full wait each -: a lane without a column eliminates column 0 and
+      //  stores nothing, rows >= nt only ever change themselves)
+#define BP_GJ_CASE(ROWS, EXACT)                                                               \
       {                                                                                       \
         double v[ROWS];                                                                       \
-        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) v[i] = ((is_h || is_rhs) && i < nt) ? M[i][col] : 0.0; \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) v[i] = lds1(M[i][col]);              \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) asm volatile("" : "+v"(v[i]));       \
         lds_wave_sync();             /* every lane has its column before any right-hand side is overwritten (two waves: disjoint ones) */ \
-        ok = gauss_jordan_rows<ROWS>(v, nt);                                                  \
+        ok = gauss_jordan_rows<ROWS, EXACT>(v, nt);                                           \
         _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (is_rhs && i < nt) M[i][col] = v[i]; \
       }
-      if (nt <= 8) BP_GJ_CASE(8)
-      else if (nt == 9) BP_GJ_CASE(9)          // single support of this robot class: 14 rows of rank 13
-      else if (nt <= 10) BP_GJ_CASE(10)
-      else BP_GJ_CASE(12)
+      if (nt <= 8) BP_GJ_CASE(8, false)
+      else if (nt == 9) BP_GJ_CASE(9, true)    // single support of this robot class: 14 rows of rank 13
+      else if (nt <= 10) BP_GJ_CASE(10, true)
+      else BP_GJ_CASE(12, false)
 #undef BP_GJ_CASE
       if (l == 0 && !ok) ws.status = 1;
     } else {

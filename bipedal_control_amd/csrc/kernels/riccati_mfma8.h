@@ -168,9 +168,12 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #ifdef BPMPC_RICCATI_PROFILE
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = clock64();
-#define RM8PROF(slot) do { const long long tn_ = clock64(); tacc[slot] += tn_ - tprev; tprev = tn_; } while (0)
+#define RM8PROF(slot) do { if (BPMPC_RICCATI_PROFILE != 20) { const long long tn_ = clock64(); tacc[slot] += tn_ - tprev; tprev = tn_; } } while (0)
 #define RM8OWN(phase) do { if (BPMPC_RICCATI_PROFILE == 10 + (phase)) tacc[7] += clock64() - tprev; } while (0)   /* own work of a phase, before its barrier */
+  long long tsub = 0;                   /* BPMPC_RICCATI_PROFILE == 20: steps of an output block (entry, loads issued, loads here, products, stores issued) */
+#define RM8SUB(i) do { if (BPMPC_RICCATI_PROFILE == 20) { const long long tn_ = clock64(); if ((i) > 0) tacc[i] += tn_ - tsub; tsub = tn_; } } while (0)
 #else
+#define RM8SUB(i) ((void)0)
 #define RM8PROF(slot) ((void)0)
 #define RM8OWN(phase) ((void)0)
 #endif
@@ -191,6 +194,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     }
   }
   auto finish_outputs = [&](int k, int buf, int nt, int bw) {
+    RM8SUB(0);
     double (*const W)[LDW] = ws.W[buf];
     double (*const PW)[LDW] = ws.PW[buf];
     double (*const M)[LDW] = ws.M[buf];
@@ -208,6 +212,11 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       ap[ks] = lds1(PW[row][BC + kk]);                               // Pu(i, kk)
     }
     __builtin_amdgcn_sched_barrier(0);
+    RM8SUB(1);
+#if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 20
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RM8SUB(2);
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks < ksn) {                                            // wave-uniform
@@ -215,6 +224,11 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         kf = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[ks], yb[ks], kf, 0, 0, 0);
       }
     }
+#if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 20
+    asm volatile("v_mov_b64 %0, %0\n\ts_nop 4" : "+v"(acl[3]));
+    asm volatile("v_mov_b64 %0, %0\n\ts_nop 4" : "+v"(kf[3]));
+    RM8SUB(3);
+#endif
     // buffer stores: where a register of the block goes is a byte offset that is fixed for the whole sweep (Acl and K share it; column nx goes to
     // bcl / kff), an element that goes nowhere has an offset beyond the resource, the stage is the scalar offset of the instruction.  (As predicated
     // plain stores with 64-bit addresses the eight stores of a block were most of the 2.2 k cycles a block took beside the elimination.)
@@ -232,6 +246,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         __builtin_amdgcn_raw_buffer_store_b64(vk, rkff, oov[r], sv, 0);
       }
     }
+    RM8SUB(4);
   };
 
   // m = q~ - Y' r~, m0 = -r~' H^-1 g of a finished stage (one wave).  Rows >= nt of Y and of r~ are zero (the projection kernel pads
@@ -386,7 +401,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
           }                                                                                   \
         }                                                                                     \
         if (BPMPC_RICCATI8_ABLATE & 4) ok = true; else                                        \
-        ok = FWD<ROWS>(v, nt, emit);                                                          \
+        ok = FWD(v, nt, emit);                                                          \
         if (l == 0 && !ok) ws.status = 1;                                                     \
         RM8PROF(6);                                                                           \
         lds_barrier();                 /* B3 */                                               \
@@ -396,12 +411,12 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       }
       // the elimination is the longest dependent chain of a stage: instantiate it for the actual number of rows
       if (rows_layout) {
-        if (nt <= 8) BP_GJ_CASE(8, forward_eliminate_rows, back_substitute_rows)
-        else if (nt == 9) BP_GJ_CASE(9, forward_eliminate_rows, back_substitute_rows)          // single support of this robot class: 14 rows of rank 13
-        else BP_GJ_CASE(10, forward_eliminate_rows, back_substitute_rows)
+        if (nt <= 8) BP_GJ_CASE(8, forward_eliminate_rows<8>, back_substitute_rows)
+        else if (nt == 9) BP_GJ_CASE(9, (forward_eliminate_rows<9, true>), back_substitute_rows)          // single support of this robot class: 14 rows of rank 13
+        else BP_GJ_CASE(10, (forward_eliminate_rows<10, true>), back_substitute_rows)
       } else {
-        if (nt <= 12) BP_GJ_CASE(12, forward_eliminate_wave, back_substitute_wave)
-        else BP_GJ_CASE(RE, forward_eliminate_wave, back_substitute_wave)
+        if (nt <= 12) BP_GJ_CASE(12, forward_eliminate_wave<12>, back_substitute_wave)
+        else BP_GJ_CASE(RE, forward_eliminate_wave<RE>, back_substitute_wave)
       }
 #undef BP_GJ_CASE
     } else {
@@ -439,6 +454,9 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #ifdef BPMPC_RICCATI_PROFILE
 #if BPMPC_RICCATI_PROFILE == 2      // own work of every wave between B2 and B3
   if (io.prof && l == 0) io.prof[w] = (double)tacc[6];
+#elif BPMPC_RICCATI_PROFILE == 20   // steps of an output block, per wave: slots 1..4 of waves 0 (C0) and 6 (F)
+  if (io.prof && l == 0 && w == 0) for (int i = 1; i < 5; ++i) io.prof[i - 1] = (double)tacc[i];
+  if (io.prof && l == 0 && w == 6) for (int i = 1; i < 5; ++i) io.prof[3 + i] = (double)tacc[i];
 #elif BPMPC_RICCATI_PROFILE >= 10   // own work of every wave in phase BPMPC_RICCATI_PROFILE - 10 (0: staging, 1: SW, 2: G, 4: S update incl. E's back substitution)
   if (io.prof && l == 0) io.prof[w] = (double)tacc[7];
 #else

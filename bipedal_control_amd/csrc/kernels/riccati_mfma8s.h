@@ -589,7 +589,7 @@ __device__ __forceinline__ void riccati_mfma8s(RiccatiMfma8sWorkspace<NJ>& ws, c
           /* (no masks: rows >= nt of M and Mb are zero - B~ has no columns there -, and a lane without a column eliminates column 0 into a spare column) */ \
           _Pragma("unroll") for (int i = 0; i < ROWS; ++i) v[i] = ta[i] + tb[i];             \
         }                                                                                     \
-        ok = FWD<ROWS>(v, nt, emit);                                                          \
+        ok = FWD(v, nt, emit);                                                          \
         if (l == 0 && !ok) ws.status = 1;                                                     \
         RS8PROF(2);                                                                           \
         lds_barrier();                 /* Ba */                                               \
@@ -598,12 +598,12 @@ __device__ __forceinline__ void riccati_mfma8s(RiccatiMfma8sWorkspace<NJ>& ws, c
         _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (rhs && i < nt) M[i][col] = -v[i];    /* -Y */ \
       }
       if (rows_layout) {
-        if (nt <= 8) BP_GJS_CASE(8, forward_eliminate_rows, back_substitute_rows)
-        else if (nt == 9) BP_GJS_CASE(9, forward_eliminate_rows, back_substitute_rows)
-        else BP_GJS_CASE(10, forward_eliminate_rows, back_substitute_rows)
+        if (nt <= 8) BP_GJS_CASE(8, forward_eliminate_rows<8>, back_substitute_rows)
+        else if (nt == 9) BP_GJS_CASE(9, (forward_eliminate_rows<9, true>), back_substitute_rows)
+        else BP_GJS_CASE(10, (forward_eliminate_rows<10, true>), back_substitute_rows)
       } else {
-        if (nt <= 12) BP_GJS_CASE(12, forward_eliminate_wave, back_substitute_wave)
-        else BP_GJS_CASE(RE, forward_eliminate_wave, back_substitute_wave)
+        if (nt <= 12) BP_GJS_CASE(12, forward_eliminate_wave<12>, back_substitute_wave)
+        else BP_GJS_CASE(RE, forward_eliminate_wave<RE>, back_substitute_wave)
       }
 #undef BP_GJS_CASE
     } else {

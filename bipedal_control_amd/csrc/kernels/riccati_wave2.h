@@ -375,8 +375,8 @@ __device__ __forceinline__ void riccati_wave2(RiccatiWave2Workspace<NJ>& ws, con
       }
       if (rows_layout) {
         if (nt <= 8) BP_GJ_CASE(8, forward_eliminate_rows<8>(v, nt, emit), back_substitute_rows)
-        else if (nt == 9) BP_GJ_CASE(9, forward_eliminate_rows<9>(v, nt, emit), back_substitute_rows)
-        else BP_GJ_CASE(10, forward_eliminate_rows<10>(v, nt, emit), back_substitute_rows)
+        else if (nt == 9) BP_GJ_CASE(9, (forward_eliminate_rows<9, true>(v, nt, emit)), back_substitute_rows)
+        else BP_GJ_CASE(10, (forward_eliminate_rows<10, true>(v, nt, emit)), back_substitute_rows)
       } else {
         if (nt <= 12) BP_GJ_CASE(12, forward_eliminate_wave<12>(v, nt, emit), back_substitute_wave)
         else BP_GJ_CASE(16, forward_eliminate_wave<16>(v, nt, emit), back_substitute_wave)

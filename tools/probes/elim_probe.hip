@@ -10,6 +10,7 @@ template <int MODE, int ROWS>
 __global__ void k(const double* Hin, double* out, long long* cyc, int nt, int reps) {
   __shared__ double M[16][50];
   __shared__ double Zt[16][34], Yn[16][34];
+  __shared__ double ZY[16][2][34];
   const int l = threadIdx.x;
   for (int i = l; i < 16 * 50; i += 64) (&M[0][0])[i] = Hin[i];
   __syncthreads();
@@ -21,6 +22,7 @@ __global__ void k(const double* Hin, double* out, long long* cyc, int nt, int re
   const bool rhs = !is_h && rid < NX + 1;
   const bool used = is_h || rhs;
   const int col = is_h ? BC + (rows_layout ? c16 : l) : (rhs ? rid : 0);
+  const int ecol = rhs ? col : NX + 2 + (l & 3);
   double acc = 0.0;
   long long t0 = clock64();
   for (int rep = 0; rep < reps; ++rep) {
@@ -32,6 +34,9 @@ __global__ void k(const double* Hin, double* out, long long* cyc, int nt, int re
     if (MODE == 0) ok = gauss_jordan_wave<ROWS>(v, nt);
     if (MODE == 1) { ok = forward_eliminate_wave<ROWS>(v, nt, emit); }
     if (MODE == 2) { ok = forward_eliminate_rows<ROWS>(v, nt, emit); }
+    if (MODE == 6) { ok = forward_eliminate_rows<ROWS, true>(v, nt, emit); }
+    if (MODE == 7) { auto emit2 = [&](int p, double z, double y) { ZY[p][0][ecol] = z; ZY[p][1][ecol] = y; }; ok = forward_eliminate_rows<ROWS, true>(v, nt, emit2); }
+    if (MODE == 8) { auto emit3 = [&](int p, double z, double y) { Zt[p][ecol] = z; Yn[p][ecol] = y; }; ok = forward_eliminate_rows<ROWS, true>(v, nt, emit3); }
     if (MODE == 3) { ok = gauss_jordan_rows<ROWS>(v, nt); }
     if (MODE == 4) { ok = forward_eliminate_rows<ROWS>(v, nt, emit); back_substitute_rows<ROWS>(v, nt); }
     if (MODE == 5) { ok = forward_eliminate_wave<ROWS>(v, nt, emit); back_substitute_wave<ROWS>(v, nt); }
@@ -41,7 +46,7 @@ __global__ void k(const double* Hin, double* out, long long* cyc, int nt, int re
     __syncthreads();
   }
   long long t1 = clock64();
-  out[l] = acc + Zt[0][l & 15] + Yn[1][l & 15];
+  out[l] = acc + Zt[0][l & 15] + Yn[1][l & 15] + ZY[2][1][l & 15];
   if (l == 0) cyc[0] = (t1 - t0) / reps;
 }
 
@@ -56,18 +61,20 @@ int main() {
   hipMalloc(&dH, H.size() * 8); hipMalloc(&out, 64 * 8); hipMalloc(&cyc, 8);
   hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice);
   const char* names[] = {"Gauss-Jordan, v_readlane", "forward elimination + emit, v_readlane", "forward elimination + emit, DPP rows", "Gauss-Jordan, DPP rows",
-                         "forward + backward, DPP rows", "forward + backward, v_readlane"};
-  for (int mode = 0; mode < 6; ++mode) {
+                         "forward + backward, DPP rows", "forward + backward, v_readlane", "forward elimination + emit, DPP rows, exact", "... emit into interleaved Z / Yn, every lane", "... emit into Z, Yn, every lane"};
+  for (int mode = 0; mode < 9; ++mode) {
     for (int r = 0; r < 2; ++r) {
       switch (mode) {
         case 0: k<0, 9><<<1, 64>>>(dH, out, cyc, nt, 200); break; case 1: k<1, 9><<<1, 64>>>(dH, out, cyc, nt, 200); break;
         case 2: k<2, 9><<<1, 64>>>(dH, out, cyc, nt, 200); break; case 3: k<3, 9><<<1, 64>>>(dH, out, cyc, nt, 200); break;
         case 4: k<4, 9><<<1, 64>>>(dH, out, cyc, nt, 200); break; case 5: k<5, 9><<<1, 64>>>(dH, out, cyc, nt, 200); break;
+        case 6: k<6, 9><<<1, 64>>>(dH, out, cyc, nt, 200); break; case 7: k<7, 9><<<1, 64>>>(dH, out, cyc, nt, 200); break; case 8: k<8, 9><<<1, 64>>>(dH, out, cyc, nt, 200); break;
       }
       hipDeviceSynchronize();
     }
     long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-    printf("%-45s %lld cycles (nt = %d, incl. the LDS loads of the columns)\n", names[mode], c, nt);
+    double ho[64]; hipMemcpy(ho, out, sizeof(ho), hipMemcpyDeviceToHost); double cs = 0; for (int i = 0; i < 64; ++i) cs += ho[i] * (i + 1);
+    printf("%-60s %lld cycles (nt = %d, incl. the LDS loads of the columns)  checksum %.17g\n", names[mode], c, nt, cs);
   }
   return 0;
 }
