@@ -12,7 +12,7 @@ for s in b4096 g1 sweep; do
   cp $G/${RUN}_${s}_traffic.json $P/${PUB}_${s}_traffic.json
   last $G/${RUN}_${s}_bench_under_rocprof.json > $P/${PUB}_${s}_bench_line_under_rocprof.json
 done
-for b in h1 g1 sweep 4096 512 hunter h1_hard; do last $G/$RUN/bench_$b.json > $P/${PUB}_bench_line_$b.json; done
+for b in h1 g1 sweep 4096 512 hunter h1_hard h1_midswing; do last $G/$RUN/bench_$b.json > $P/${PUB}_bench_line_$b.json; done
 cp $G/$RUN/pytest.log $P/${PUB}_gpu_pytest.txt
 tail -n 2 $G/$RUN/latency.log > $P/${PUB}_latency.txt
 tail -n 1 $G/$RUN/wbc.log > $P/${PUB}_wbc.txt
