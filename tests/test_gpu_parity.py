@@ -522,6 +522,31 @@ def test_batch_4096_full_size_matches_small_batches_and_oracle(ctx):
         assert rel_x(x[i, :n + 1], x2[j, :n + 1]) < 1e-10 and rel_u(u[i, :n], u2[j, :n]) < 1e-10
     xo, uo, _, _ = ob.oracle_solve_like(prob2, 2, iterations=2)
     assert rel_x(x[4095, :n + 1], xo) < 1e-11 and rel_u(u[4095, :n], uo) < 1e-11
+    # (round 5) sixteen more problems spread over the batch - every CU position of the sixteen-per-CU sweep is hit - against the oracle
+    for i in np.linspace(1, B - 2, 16).astype(int):
+        xo, uo, _, _ = ob.oracle_solve_like(prob, int(i), iterations=2)
+        assert rel_x(x[i, :n + 1], xo) < 1e-11 and rel_u(u[i, :n], uo) < 1e-11, i
+
+
+def test_batch_4096_tiled_from_zero_back_tracking_problems_match_oracle(ctx):
+    """configs[2] as bench.py times it since round 5 (template tiled from t = 0: the solve starts on a mode switch): a handful of the 4096 problems
+    reject the full step and take alpha = 0.5 in the second, batch-wide line-search round.  Every one of them, and as many that accept at once,
+    against the oracle: iterate, step size and merit; the others are untouched by the second round (their step size is 1)."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    B, N, NN = 4096, 100, 116
+    prob = sc.trot_problem(itf, batch=B, n_intervals=N, gait_start=0.0)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=NN)
+    t, x, u, _, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    assert all(s.status == 0 for s in st)
+    steps = np.array([s.step_size for s in st])
+    back = np.flatnonzero(steps < 1.0)
+    assert 1 <= len(back) <= 64 and np.all(steps[back] == 0.5), (len(back), np.unique(steps))
+    n = st[0].n_nodes
+    others = [int(i) for i in np.linspace(0, B - 1, len(back) + 2).astype(int) if steps[i] == 1.0][:len(back)]
+    for i in list(back) + others:
+        xo, uo, _, so = ob.oracle_solve_like(prob, int(i), iterations=1)
+        assert rel_x(x[i, :n + 1], xo) < 1e-11 and rel_u(u[i, :n], uo) < 1e-11, i
+        assert so[0][3] == steps[i], (i, so[0][3], steps[i])              # column 3 of the oracle's per-iteration record: the accepted step size
 
 
 @pytest.mark.parametrize("variant", ["2", "4"])
