@@ -304,7 +304,6 @@ __global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int first_ro
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
   const int n = L.buf.g_nodes[L.buf.p_grid[b]];
-  const ProblemLS p = problem_ls<NJ>(L, b);
   volatile const int* done = L.buf.done + b;
   volatile const double* alpha = L.buf.alpha + b;
   for (int round = first_round; round < max_trials; ++round) {
@@ -320,6 +319,11 @@ __global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int first_ro
     }
     __threadfence();
     __syncthreads();
+    // the problem's pointers are formed HERE, from an index the compiler cannot see through: hoisted out of the round loop they lived across the trial
+    // evaluation, and at nx = 24 (256 registers) three of them went to scratch memory
+    int bb = b;
+    asm volatile("" : "+s"(bb));
+    const ProblemLS p = problem_ls<NJ>(L, bb);
     linesearch_decide<NJ, kTailThreads, false>(partial, p, L.ls);
     __threadfence();
     __syncthreads();

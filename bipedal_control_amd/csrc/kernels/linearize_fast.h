@@ -105,6 +105,10 @@ struct LinFastNodeLds {
   double X12[FULL ? 2 : 1][FULL ? 9 : 1], X22[FULL ? 2 : 1][FULL ? 9 : 1], cps[FULL ? 2 : 1][FULL ? kNumContacts : 1][3], com[FULL ? 2 : 1][3];
   double fh[FULL ? 2 : 1][FULL ? 6 : 1], vlin[FULL ? 2 : 1][FULL ? 3 : 1], trig[FULL ? 4 : 1];
   double park[(FULL && PARK) ? 15 : 1][(FULL && PARK) ? 16 : 1];   // [row][lane]: rows 3..11 of x column 6+g, rows 6..11 of the joint-velocity column
+  // value-only evaluation at nx = 24: the lane's entries of x_next and x_ref, known at the top and used at the bottom, wait here - at three waves per SIMD
+  // (168 registers) the allocator put exactly these six values into scratch memory
+  static constexpr bool kLate = !FULL && NJ > 10;
+  double late[kLate ? 6 : 1][kLate ? 16 : 1];
   // contact points / velocities of an evaluation (FULL: the stage's own copy, kept for the RK2 combination)
   __device__ __forceinline__ double (*cpos(int stage))[3] { if constexpr (FULL) return cps[stage]; else return cpos_v; }
   __device__ __forceinline__ double (*cvel())[3] { if constexpr (FULL) return cvel_full; else return cvel_v; }
@@ -1094,6 +1098,10 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
     xr_q = g < G ? in.xref[6 + g] : 0.0; xr_h = ln < 6 ? in.xref[ln] : 0.0;
     xn_t = tr ? in.xnext[6 + ln] + alpha * dxn[6 + ln] : 0.0; xr_t = tr ? in.xref[6 + ln] : 0.0;
   }
+  if constexpr (NL::kLate) {
+    static_assert(LPN == 16, "one slot per lane of the node");
+    nl.late[0][ln] = xn_q; nl.late[1][ln] = xn_h; nl.late[2][ln] = xn_t; nl.late[3][ln] = xr_q; nl.late[4][ln] = xr_h; nl.late[5][ln] = xr_t;
+  }
   LaneBody lb;
   {
     const int body = (g >= 5 && g < G) ? g - 5 : 0;
@@ -1146,8 +1154,9 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   if (ln < kNumContacts && stance_flag(mode, ln)) cone_pen = cone_own[1];
   LaneEval e2;
   double v2t;
+  const double f1 = lane_pick6(e1.fh, ln);          // the lane's own row of the first stage: the other five need not live through the second evaluation
   {
-    if (ln < 6) nl.xh2[ln] = xh[ln] + dt * lane_pick6(e1.fh, ln);
+    if (ln < 6) nl.xh2[ln] = xh[ln] + dt * f1;
     if (ln < 3) nl.xh2[6 + ln] = pb[ln] + dt * v1t;
     const double* xh2 = nl.xh2;      // published by the lds_wave_sync at the top of eval_lane
     const double qg2 = qg + dt * e1.vg;
@@ -1155,13 +1164,18 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
     eval_lane<NJ, false, false, NL, LinFastShared<NJ, false>, C>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
     v2t = ln == 0 ? kin2.vb[0] : (ln == 1 ? kin2.vb[1] : kin2.vb[2]);
   }
+  if constexpr (NL::kLate) {           // (the lane's own slots: no barrier)
+    typedef const volatile __attribute__((address_space(3))) double* late_p;
+    xn_q = *(late_p)&nl.late[0][ln]; xn_h = *(late_p)&nl.late[1][ln]; xn_t = *(late_p)&nl.late[2][ln];
+    xr_q = *(late_p)&nl.late[3][ln]; xr_h = *(late_p)&nl.late[4][ln]; xr_t = *(late_p)&nl.late[5][ln];
+  }
   double dyn_sse = 0.0;
   if (g < G) {
     const double bb = qg + hdt * e1.vg + hdt * e2.vg - xn_q;
     dyn_sse += bb * bb;
   }
   if (ln < 6) {
-    const double f1 = lane_pick6(e1.fh, ln), f2 = lane_pick6(e2.fh, ln);
+    const double f2 = lane_pick6(e2.fh, ln);
     const double bb = (ln < 6 ? xh[ln] : 0.0) + hdt * f1 + hdt * f2 - xn_h;
     dyn_sse += bb * bb;
   }

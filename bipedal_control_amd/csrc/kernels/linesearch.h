@@ -235,8 +235,10 @@ BP_DEVICE void linesearch_decide(double* partial /*NL*3 LDS + 2 flags + 3 sums*/
       if (idx < nxe) p.x[idx] = xv[j] + alpha * dxv[j];
       if (idx < nue) p.u[idx] = uv[j] + alpha * duv[j];
     }
-    for (int idx = (int)threadIdx.x + UPD * NL; idx < nxe; idx += NL) p.x[idx] += alpha * p.dx[idx];
-    for (int idx = (int)threadIdx.x + UPD * NL; idx < nue; idx += NL) p.u[idx] += alpha * p.du[idx];
+    int t0 = (int)threadIdx.x;          // (opaque: as an invariant of the back-tracking kernel's round loop the lane's byte offset lived across the trial evaluation - in scratch memory at nx = 24)
+    if constexpr (!PRE) asm volatile("" : "+v"(t0));
+    for (int idx = t0 + UPD * NL; idx < nxe; idx += NL) p.x[idx] += alpha * p.dx[idx];
+    for (int idx = t0 + UPD * NL; idx < nue; idx += NL) p.u[idx] += alpha * p.du[idx];
 #else
     BP_LANES(tid, NL) {
       for (int idx = tid; idx < (p.n_nodes + 1) * NX; idx += NL) p.x[idx] += alpha * p.dx[idx];
