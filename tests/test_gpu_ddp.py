@@ -12,9 +12,9 @@ from oracle import ddp_py, reference_py as rp
 from tests import oracle_bridge as ob
 
 
-def _oracle(prob, b, x0):
-    m, om = ob.model("h1"), ob.oracle("h1")
-    nodes = ob.oracle_nodes(prob, b)
+def _oracle(prob, b, x0, robot="h1"):
+    m, om = ob.model(robot), ob.oracle(robot)
+    nodes = ob.oracle_nodes(prob, b, robot=robot)
     x_nom, u_nom = rp.cold_start(m, nodes, x0)
     sched = prob["schedule"][b] if isinstance(prob["schedule"], list) else prob["schedule"]
     ev, ms = list(map(float, sched.eventTimes)), list(map(int, sched.modeSequence))
@@ -22,15 +22,15 @@ def _oracle(prob, b, x0):
     return nodes, ddp_py.ilqr_iteration(om, m, nodes, x0, x_nom, u_nom, ev, ms, np.asarray(tt.timeTrajectory), np.asarray(tt.stateTrajectory), m["ddp"], m["rollout"])
 
 
-def _check(prob, nodes_cap):
-    itf = scenarios.h1_interface()
+def _check(prob, nodes_cap, robot="h1"):
+    itf = scenarios.interface(robot)
     B = prob["x0"].shape[0]
     mpc = bp.BatchedDdpMpc(itf, B, nodes_cap)
     t, x, u, K, stats = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
     lff = mpc.read("ddp_lff").reshape(B, nodes_cap, itf.inputDim)
     upd = mpc.read("ddp_update_is")
     for b in range(B):
-        nodes, ref = _oracle(prob, b, prob["x0"][b])
+        nodes, ref = _oracle(prob, b, prob["x0"][b], robot)
         N = int(nodes["N"])
         scale_k = max(1.0, float(np.abs(ref["K"]).max()))
         assert np.abs(K[b, :N] - ref["K"]).max() < 1e-8 * scale_k, "gains"
@@ -66,6 +66,16 @@ def test_ddp_trot_with_rank_deficient_single_support_rows_matches_oracle():
     itf = scenarios.h1_interface()
     prob = scenarios.trot_problem(itf, batch=2, n_intervals=40, gait_start=0.0)
     _check(prob, 60)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,gait", [("g1", "standing_trot"), ("hunter", "trot")])
+def test_ddp_on_the_other_robots_matches_oracle(robot, gait):
+    """nx = nu = 24 (Unitree G1: the kernels' second instantiation, six joints per leg) and Hunter (`positionErrorGain 20`: the position term of the
+    zero-velocity rows enters e, so the constrained stage problems have inconsistent dependent rows - the case the pivoted elimination defines)."""
+    itf = scenarios.interface(robot)
+    prob = scenarios.trot_problem(itf, batch=2, n_intervals=30, gait=gait)
+    _check(prob, 48, robot)
 
 
 @pytest.mark.gpu
