@@ -150,63 +150,7 @@ __device__ __forceinline__ void fnmac_row_bcast(double& acc, double m) {
   if constexpr (FIRST) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(P));
   else asm volatile("v_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(P));
 }
-#ifndef BPMPC_ELIM_V2
-#define BPMPC_ELIM_V2 1
-#endif
-#if !BPMPC_ELIM_V2
-// One pivot step; `row` = pivot row P already normalised.  The reciprocal chain of pivot P + 1 (broadcast, v_rcp_f64, two
-// Newton steps, product: seven dependent instructions) is issued one instruction at a time between the independent updates of
-// this step - row P + 1 is updated first - so that it costs issue slots, not latency.
-template <int ROWS, int P>
-__device__ __forceinline__ void gauss_jordan_rows_step(double (&v)[ROWS], int nt, bool& ok, double row) {
-  constexpr bool has_next = P + 1 < ROWS;
-  constexpr int PN = has_next ? P + 1 : P;
-  double piv = 1.0, r = 0.0, e = 0.0, next_row = 0.0;
-  constexpr int F = has_next ? P + 1 : 0;        // the row updated first: the next pivot row
-  if constexpr (F != P) fnmac_row_bcast<P, true>(v[F], row);
-  int s = has_next ? 0 : 7;
-  auto chain = [&]() {
-    switch (s++) {
-      // (the empty volatile statements pin each result between the updates around it: the values are only needed by the
-      //  next step, and the compiler would otherwise sink the whole chain behind the last update; input-only, because the
-      //  hazard recogniser answers a register *defined* by inline assembly with a wait state in front of every reader)
-      case 0: piv = row_bcast<PN>(v[PN]); asm volatile("" :: "v"(piv)); break;
-      case 1: r = __builtin_amdgcn_rcp(piv); asm volatile("" :: "v"(r)); break;
-      case 2: e = __builtin_fma(-piv, r, 1.0); asm volatile("" :: "v"(e)); break;
-      case 3: r = __builtin_fma(r, e, r); asm volatile("" :: "v"(r)); break;
-      case 4: e = __builtin_fma(-piv, r, 1.0); asm volatile("" :: "v"(e)); break;
-      case 5: r = __builtin_fma(r, e, r); asm volatile("" :: "v"(r)); break;
-      case 6: next_row = v[PN] * r; asm volatile("" :: "v"(next_row)); break;
-      default: break;
-    }
-    __builtin_amdgcn_sched_barrier(0);     // the scheduler would sink the whole chain behind the updates otherwise
-  };
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i)
-    if (i != P && i != F) { chain(); fnmac_row_bcast<P, false>(v[i], row); }
-#pragma unroll
-  for (int t = 0; t < 7; ++t) chain();
-  v[P] = row;
-  if constexpr (has_next) {
-    if (P + 1 < nt) {  // wave-uniform
-      ok = ok && (piv > 0.0);
-      gauss_jordan_rows_step<ROWS, P + 1>(v, nt, ok, next_row);
-    }
-  }
-}
-template <int ROWS, bool EXACT = false>
-__device__ __forceinline__ bool gauss_jordan_rows(double (&v)[ROWS], int nt) {
-  if (nt <= 0) return true;
-  const double piv = row_bcast<0>(v[0]);
-  bool ok = piv > 0.0;
-  gauss_jordan_rows_step<ROWS, 0>(v, nt, ok, v[0] * fast_reciprocal(piv));
-  return ok;
-}
-
-#else
-// Round 5: one pivot step of the Gauss-Jordan elimination as ONE assembly statement (see forward_eliminate_rows below for the why: a lone wave
-// pays ~8 cycles per instruction whatever it is, and the compiler puts wait states around every assembly statement that touches a register another
-// one defined).  %0: the next pivot row, %1 ..: the ROWS - 2 other rows; the reciprocal chain of the next pivot (broadcast, v_rcp_f64, two Newton
+// Round 5: one pivot step of the Gauss-Jordan elimination as ONE assembly statement (why: forward_eliminate_rows_step below).  %0: the next pivot row, %1 ..: the ROWS - 2 other rows; the reciprocal chain of the next pivot (broadcast, v_rcp_f64, two Newton
 // steps, product - the operations of fast_reciprocal) stands between the updates.  Same operations on the same values: bit-identical results.
 #define BP_GJ_U(i) "v_fmac_f64_dpp %" #i ", %" #i ", -%[row] row_newbcast:%[p] row_mask:0xf bank_mask:0xf\n\t"
 #define BP_GJ_HEAD "s_nop 1\n\t" BP_GJ_U(0) BP_GJ_U(1) BP_GJ_U(2) "v_mov_b64_dpp %[piv], %0 row_newbcast:%[pn] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
@@ -267,7 +211,6 @@ __device__ __forceinline__ bool gauss_jordan_rows(double (&v)[ROWS], int nt) {
   if constexpr (EXACT) ok = ok && minhi > 0 && lastp > 0.0;
   return ok;
 }
-#endif
 
 // Forward elimination only, same row layout and pivot pipeline as gauss_jordan_rows: row P is divided by its pivot and
 // eliminated from the rows below it; emit(P, z, y) sees pivot row P before (z) and after (y) the division.  The rows end
@@ -276,62 +219,15 @@ __device__ __forceinline__ bool gauss_jordan_rows(double (&v)[ROWS], int nt) {
 // the wave is alone on its SIMD and waits for every link), so it takes ONE Newton step here: v_rcp_f64 is good to 4.6e-8,
 // one step to 2.2e-15 relative, two are correctly rounded (tools/probes/rcp_probe.hip) - a perturbation of the pivot by ten
 // ulp, the size of the rounding errors of the elimination itself.
-#ifndef BPMPC_ELIM_V2
-#define BPMPC_ELIM_V2 1
-#endif
-#if !BPMPC_ELIM_V2
-template <int ROWS, int P, class Emit>
-__device__ __forceinline__ void forward_eliminate_rows_step(double (&v)[ROWS], int nt, bool& ok, double row, Emit& emit) {
-  constexpr bool has_next = P + 1 < ROWS;
-  constexpr int PN = has_next ? P + 1 : P;
-  constexpr int CH = 5;                         // links of the chain
-  double piv = 1.0, r = 0.0, e = 0.0, next_row = 0.0;
-  if constexpr (has_next) fnmac_row_bcast<P, true>(v[PN], row);
-  int s = has_next ? 0 : CH;
-  auto chain = [&]() {
-    switch (s++) {
-      case 0: piv = row_bcast<PN>(v[PN]); asm volatile("" :: "v"(piv)); break;
-      case 1: r = __builtin_amdgcn_rcp(piv); asm volatile("" :: "v"(r)); break;
-      case 2: e = __builtin_fma(-piv, r, 1.0); asm volatile("" :: "v"(e)); break;
-      case 3: r = __builtin_fma(r, e, r); asm volatile("" :: "v"(r)); break;
-      case 4: next_row = v[PN] * r; asm volatile("" :: "v"(next_row)); break;
-      default: break;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-#pragma unroll
-  for (int i = P + 2; i < ROWS; ++i) { chain(); fnmac_row_bcast<P, false>(v[i], row); }
-  emit(P, v[P], row);
-#pragma unroll
-  for (int t = 0; t < CH; ++t) chain();
-  v[P] = row;
-  if constexpr (has_next) {
-    if (P + 1 < nt) {  // wave-uniform
-      ok = ok && (piv > 0.0);
-      forward_eliminate_rows_step<ROWS, P + 1>(v, nt, ok, next_row, emit);
-    }
-  }
-}
-template <int ROWS, bool EXACT = false, class Emit>
-__device__ __forceinline__ bool forward_eliminate_rows(double (&v)[ROWS], int nt, Emit&& emit) {
-  if (nt <= 0) return true;
-  const double piv = row_bcast<0>(v[0]);
-  bool ok = piv > 0.0;
-  forward_eliminate_rows_step<ROWS, 0>(v, nt, ok, v[0] * fast_reciprocal(piv), emit);
-  return ok;
-}
-#else
-// Round 5.  A lone wave issues one FP64 instruction in ~8 cycles whether it depends on the one before or not (tools/probes/dep_probe.hip: dependent
-// v_fma_f64 8.0, two independent chains 6.2 each), so a pivot step costs its INSTRUCTIONS, and a third of the 150 of the version above computed
-// nothing: wait states the compiler puts in front of every DPP / transcendental consumer whose producer sits in inline assembly (it does not count
-// the assembly statements in between), a compare + scalar AND + uniform branch per pivot.  Here the whole step is assembly in a fixed order - the
-// update of the next pivot row, two more updates (the two wait states a DPP read needs behind the VALU write of its register), broadcast,
-// v_rcp_f64, an update (the wait state of a transcendental result), Newton step, product, the other updates; s_nop only in the last steps, which
-// have no updates left to fill with - and with EXACT (nt == ROWS: the instantiations for 9 and 10 reduced inputs) the positivity of the pivots is
-// one v_min_f64 per step, no branch.  Same operations on the same values: bit-identical results.
-// One pivot step as ONE assembly statement (the compiler puts a wait state in front of every statement that reads a register an earlier assembly
-// statement defined - five per pivot with a statement per instruction): update of the next pivot row %0, NO more updates (%1 ..), and between
-// them the reciprocal chain of the next pivot in the order described above.
+// Round 5: a lone wave issues one FP64 instruction in ~8 cycles whether it depends on the one before or not (tools/probes/dep_probe.hip: dependent
+// v_fma_f64 8.0, two independent chains 6.2 each), so a pivot step costs its INSTRUCTIONS.  Written as one statement per instruction (rounds 3, 4:
+// ~150 instructions for nine pivots) a third of them computed nothing: the compiler puts a wait state in front of every statement that reads a
+// register an earlier assembly statement defined (it does not count the assembly statements in between), and every pivot had a compare, a
+// scalar AND and a uniform branch.  Now a step is ONE assembly statement in a fixed order - the update of the next pivot row %0, two more
+// updates (the two wait states a DPP read needs behind the VALU write of its register), broadcast, v_rcp_f64, an update (the wait state of a
+// transcendental result), Newton step, product, the other updates (%1 ..: NO of them); s_nop only where the last steps have no updates left to
+// fill with - and with EXACT (nt == ROWS: the instantiations for 9 and 10 reduced inputs) the positivity of the pivots is one integer minimum per
+// step, no branch.  Same operations on the same values as before: bit-identical results (tools/probes/elim_probe.hip: 2058 -> 1725 cycles, nt = 9).
 // (every statement opens with two wait states: the compiler may copy an operand into its register right in front of the statement, and a DPP read
 //  needs them behind a VALU write - seen: a v_mov_b64 in front of the update of the last step, wrong results)
 #define BP_PIV_U(i) "v_fmac_f64_dpp %" #i ", %" #i ", -%[row] row_newbcast:%[p] row_mask:0xf bank_mask:0xf\n\t"
@@ -419,7 +315,6 @@ __device__ __forceinline__ bool forward_eliminate_rows(double (&v)[ROWS], int nt
   if constexpr (EXACT) ok = ok && minhi > 0 && lastp > 0.0;
   return ok;
 }
-#endif
 template <int ROWS, int P>
 __device__ __forceinline__ void back_substitute_rows_step(double (&v)[ROWS], int nt) {
   if constexpr (P >= 1) {
