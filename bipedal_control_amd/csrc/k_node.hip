@@ -19,6 +19,10 @@ __global__ __launch_bounds__(kWave) void k_prepare(Launch L) {
   if (k >= n) { if (threadIdx.x == 0) L.buf.n_info[s] = 0; return; }
   const size_t gs = (size_t)g * L.N + k;
   if (threadIdx.x == 0) L.buf.n_info[s] = 8 | ((L.buf.g_mode[gs] & 3) << 1) | (L.buf.g_kind[gs] == 1 ? 1 : 0);
+  if (threadIdx.x < kNodeAux) {       // the node record: dt, zref[4], zdref[4] (launch.h Buffers::n_aux)
+    const int t = threadIdx.x;
+    L.buf.n_aux[(size_t)s * kNodeAux + t] = t == 0 ? L.buf.g_dt[gs] : t < 5 ? L.buf.g_zref[gs * 4 + t - 1] : t < 9 ? L.buf.g_zdref[gs * 4 + t - 5] : 0.0;
+  }
   prepare_node<NJ>(*L.model, L.buf.g_kind[gs], L.buf.g_mode[gs], L.buf.g_start[gs], L.cold != 0, k == n - 1, L.buf.p_tgt_n[b],
                    L.buf.p_tgt_t + (size_t)b * kMaxTargetPoints, L.buf.p_tgt_x + (size_t)b * kMaxTargetPoints * NX, L.buf.p_x0 + (size_t)b * NX,
                    L.buf.xref + (size_t)s * NX, L.buf.x + ((size_t)b * (L.N + 1) + k) * NX, L.buf.u + (size_t)s * NU,
@@ -73,14 +77,19 @@ __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linea
   const int widx = blockIdx.x * (kLinWaves * NPW) + sub;          // batch * max_nodes < 2^31 is checked at creation
   bool valid = widx < L.batch * L.klen;
   const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
-  const int act = L.buf.active[b], grid = L.buf.p_grid[b];
-  const int info = L.buf.n_info[(size_t)b * L.N + k];
+  const int act = L.buf.active[b];
+  const size_t s0 = (size_t)b * L.N + k;
+  const int info = L.buf.n_info[s0];
   constexpr int NXc = 12 + NJ;
   const double* xk = L.buf.x + ((size_t)b * (L.N + 1) + k) * NXc;
-  const LinFastPre pre = linearize_preload<C>(xk, xk + NXc, L.buf.u + ((size_t)b * L.N + k) * NXc, L.buf.xref + ((size_t)b * L.N + k) * NXc, g);
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kLinWaves * kWave);
-  NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
+  // round 6: dt and the swing references come from the node record (n_aux, written by k_prepare), not from the grid tables behind p_grid[b]:
+  // nothing a workgroup waits for before its barrier is more than one memory round trip away
+  const LinFastPre pre = linearize_preload<C>(xk, xk + NXc, L.buf.u + s0 * NXc, L.buf.xref + s0 * NXc, g, L.buf.n_aux + s0 * kNodeAux);
+  load_shared_model<kLinWaves * kWave>(*L.model, shared, threadIdx.x);
+  NodeInputs in;
   in.kind = info & 1; in.mode = (info >> 1) & 3;                  // (the same facts as the grid tables hold, one hop earlier)
+  in.dt = 0.0;                                                    // (the node record carries it: LinFastPre::aux)
+  in.x = xk; in.xnext = xk + NXc; in.u = L.buf.u + s0 * NXc; in.xref = L.buf.xref + s0 * NXc; in.zref = nullptr; in.zdref = nullptr;
   __syncthreads();
 #ifdef BPMPC_LIN_TIMELINE
   const long long tl1 = wall_clock64();
@@ -231,15 +240,16 @@ void k_trial_fast(Launch L) {
   {
     // the node's facts and the lane's entries of iterate and step are requested before the model block is staged, as in k_linearize_fast
     // (line search 0.099 -> 0.096 ms at batch 256, 1.049 -> 0.975 at 4096)
-    const int fin = L.buf.done[b], grid = L.buf.p_grid[b];
+    const int fin = L.buf.done[b];
     const double alpha = L.buf.alpha[b];
     const int info = L.buf.n_info[(size_t)b * L.N + k];
     const size_t s0 = (size_t)b * L.N + k;
     const double* xk = L.buf.x + ((size_t)b * (L.N + 1) + k) * NX;
-    const TrialPre pre = trial_preload<C>(xk, xk + NX, L.buf.u + s0 * NU, L.buf.xref + s0 * NX, dx, dx + NX, L.buf.du + s0 * NU, g);
-    load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
-    NodeInputs in = node_inputs_on_grid<NJ>(L, b, k, grid);
-    in.kind = info & 1; in.mode = (info >> 1) & 3;
+    const TrialPre pre = trial_preload<C>(xk, xk + NX, L.buf.u + s0 * NU, L.buf.xref + s0 * NX, dx, dx + NX, L.buf.du + s0 * NU, g, L.buf.n_aux + s0 * kNodeAux);
+    load_shared_model<kTrialWaves * kWave>(*L.model, shared, threadIdx.x);
+    NodeInputs in;                      // dt and the swing references come with the node record (TrialPre::x.aux)
+    in.kind = info & 1; in.mode = (info >> 1) & 3; in.dt = 0.0;
+    in.x = xk; in.xnext = xk + NX; in.u = L.buf.u + s0 * NU; in.xref = L.buf.xref + s0 * NX; in.zref = nullptr; in.zdref = nullptr;
     __syncthreads();
     valid = valid && fin == 0 && info != 0;
     const size_t s = valid ? s0 : 0;
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(kTrialWaves * kWave) void k_constraint_values(Launc
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW;
   __shared__ LinFastNodeLds<NJ, false, CHAIN> lds[kTrialWaves * NPW];
   __shared__ LinFastShared<NJ, false> shared;
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTrialWaves * kWave);
+  load_shared_model<kTrialWaves * kWave>(*L.model, shared, threadIdx.x);
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
   const int widx = blockIdx.x * (kTrialWaves * NPW) + sub;
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(kTrialWaves * kWave) void k_constraint_values(Launc
 template <int NJ>
 __global__ __launch_bounds__(kWave) void k_rollout(const DeviceModel* model, RolloutArgs a) {
   __shared__ RolloutLds<NJ> w;
-  load_shared_model<NJ>(*model, w.shared, threadIdx.x, kWave);
+  load_shared_model<kWave>(*model, w.shared, threadIdx.x);
   __syncthreads();
   rollout_policy<NJ>(*model, w, a);
 }
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int first_ro
   __shared__ LinFastNodeLds<NJ, false, CHAIN> lds[CHUNK];
   __shared__ LinFastShared<NJ, false> shared;
   __shared__ double partial[3 * kTailThreads + 5];
-  load_shared_model<NJ>(*L.model, shared, threadIdx.x, kTailThreads);
+  load_shared_model<kTailThreads>(*L.model, shared, threadIdx.x);
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
   const int n = L.buf.g_nodes[L.buf.p_grid[b]];
@@ -315,7 +325,12 @@ __global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int first_ro
       const size_t s = (size_t)b * L.N + kk;
       const NodeInputs in = node_inputs<NJ>(L, b, kk);
       const double* dx = L.buf.dx + ((size_t)b * (L.N + 1) + kk) * NX;
-      trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, al, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
+      // the model block through an offset the compiler cannot see through: its scalar constants (LinFastScalars) are loop invariant, and hoisted
+      // out of the round loop they lived in registers across the whole evaluation (256 registers + 20 .. 28 B of scratch)
+      unsigned opaque = 0;
+      asm volatile("" : "+v"(opaque));
+      const auto& sh = *reinterpret_cast<const LinFastShared<NJ, false>*>(reinterpret_cast<const char*>(&shared) + opaque);
+      trial_fast<NJ, C>(*L.model, sh, lds[sub], valid, in, al, dx, L.buf.du + s * NU, dx + NX, L.buf.trial_perf + s * 3, g);
     }
     __threadfence();
     __syncthreads();

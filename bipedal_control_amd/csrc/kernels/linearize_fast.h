@@ -14,6 +14,12 @@
 #include <hip/hip_runtime.h>
 
 #include "node_lq.h"
+#ifndef BPMPC_LIN_BCAST_DPP
+#define BPMPC_LIN_BCAST_DPP 1
+#endif
+#ifndef BPMPC_LIN_FMA_MASK
+#define BPMPC_LIN_FMA_MASK 1
+#endif
 #include "riccati_fast.h"   // lds_wave_sync
 
 namespace bpmpc {
@@ -41,29 +47,68 @@ struct LinFastCfg {
 // Model constants that the lanes index by their own coordinate, staged once per workgroup.  Reading them from global
 // memory inside the node would put vector loads behind the node's output stores (vmcnt retires in order on this
 // architecture), i.e. every such load would wait for the stores in flight.
+// The model's SCALAR constants (same field names as DeviceModel, so that cone_terms / nominal_input of node_lq.h take either).  Round 6: read
+// from the model in global memory inside the node they were VECTOR loads (the compiler cannot prove that the kernel's own stores leave the
+// model alone, so no scalar load), each followed by s_waitcnt vmcnt(0): a memory round trip of ~1 .. 2 us on a loaded chip per use - eight in
+// a row for the contact points of an evaluation (contact_body -> contact_off, dependent) - and, behind the first output row, a wait for every
+// store in flight (vmcnt retires in order).  From LDS they are broadcast reads on a counter of their own.
+struct LinFastScalars {
+  double contact_off[kNumContacts][3];
+  double friction, cone_reg, cone_grip, cone_shift, barrier_mu, barrier_delta, pos_gain, robot_mass;
+  unsigned contact_path[kNumContacts];
+  int contact_body[kNumContacts];
+  int max_depth, cone_gauss_newton;
+};
+// Layout: the scalars and the kinematic constants first, the cost weights LAST - the block of the value-only kernels (COST = false) is a prefix of the
+// full one, so both are staged from one image by a flat copy.
 template <int NJ, bool COST = true>   // COST = false: without the cost weights (the value-only kernels read them from global memory)
-struct LinFastShared {
+struct alignas(16) LinFastShared {
   using C = LinFastCfg<NJ>;
-  double Q[COST ? C::NX * C::NX : 1], R[COST ? C::NU * C::NU : 1];
+  LinFastScalars sc;
   double Rfix[C::NB][9], pfix[C::NB][3], axis[C::NB][3], com[C::NB][3], inertia[C::NB][6], mass[C::NB];
   int depth[C::NB];
   unsigned subtree[C::NB];
   int path[C::NB][NJ];
+  alignas(16) double Q[COST ? C::NX * C::NX : 2], R[COST ? C::NU * C::NU : 2];
 };
-template <int NJ, bool COST>
-__device__ __forceinline__ void load_shared_model(const DeviceModel& md, LinFastShared<NJ, COST>& sh, int tid, int nthreads) {
+// The image of LinFastShared<NJ, true> lies behind the DeviceModel in the same device allocation (solver.hip uploads both).  Round 6: the block used
+// to be gathered field by field from the DeviceModel - seven loops, each compiled to load -> s_waitcnt vmcnt(0) -> LDS store, i.e. seven
+// dependent memory round trips (5 .. 6 us of a workgroup's 40 us, tools/lin_timeline.py) before the workgroup's barrier.  Now every thread has
+// its 16-byte pieces of the image in flight together with its node's inputs and waits once.
+constexpr size_t kLinImageOffset = (sizeof(DeviceModel) + 255) / 256 * 256;
+template <int NJ>
+inline void fill_shared_image(const DeviceModel& md, LinFastShared<NJ, true>& sh) {      // host
   using C = LinFastCfg<NJ>;
-  if constexpr (COST)
-    for (int i = tid; i < C::NX * C::NX; i += nthreads) { sh.Q[i] = md.Q[i]; sh.R[i] = md.R[i]; }
-  for (int i = tid; i < C::NB * 9; i += nthreads) sh.Rfix[i / 9][i % 9] = md.Rfix[i / 9][i % 9];
-  for (int i = tid; i < C::NB * 6; i += nthreads) sh.inertia[i / 6][i % 6] = md.inertia[i / 6][i % 6];
-  for (int i = tid; i < C::NB * 3; i += nthreads) {
-    sh.pfix[i / 3][i % 3] = md.pfix[i / 3][i % 3];
-    sh.axis[i / 3][i % 3] = md.axis[i / 3][i % 3];
-    sh.com[i / 3][i % 3] = md.com[i / 3][i % 3];
+  for (int i = 0; i < C::NX * C::NX; ++i) { sh.Q[i] = md.Q[i]; sh.R[i] = md.R[i]; }
+  for (int b = 0; b < C::NB; ++b) {
+    for (int i = 0; i < 9; ++i) sh.Rfix[b][i] = md.Rfix[b][i];
+    for (int i = 0; i < 6; ++i) sh.inertia[b][i] = md.inertia[b][i];
+    for (int i = 0; i < 3; ++i) { sh.pfix[b][i] = md.pfix[b][i]; sh.axis[b][i] = md.axis[b][i]; sh.com[b][i] = md.com[b][i]; }
+    sh.mass[b] = md.mass[b]; sh.depth[b] = md.depth[b]; sh.subtree[b] = md.subtree[b];
+    for (int i = 0; i < NJ; ++i) sh.path[b][i] = md.path[b][i];
   }
-  for (int i = tid; i < C::NB; i += nthreads) { sh.mass[i] = md.mass[i]; sh.depth[i] = md.depth[i]; sh.subtree[i] = md.subtree[i]; }
-  for (int i = tid; i < C::NB * NJ; i += nthreads) sh.path[i / NJ][i % NJ] = md.path[i / NJ][i % NJ];
+  for (int c = 0; c < kNumContacts; ++c) {
+    for (int i = 0; i < 3; ++i) sh.sc.contact_off[c][i] = md.contact_off[c][i];
+    sh.sc.contact_path[c] = md.contact_path[c]; sh.sc.contact_body[c] = md.contact_body[c];
+  }
+  sh.sc.friction = md.friction; sh.sc.cone_reg = md.cone_reg; sh.sc.cone_grip = md.cone_grip; sh.sc.cone_shift = md.cone_shift;
+  sh.sc.barrier_mu = md.barrier_mu; sh.sc.barrier_delta = md.barrier_delta; sh.sc.pos_gain = md.pos_gain; sh.sc.robot_mass = md.robot_mass;
+  sh.sc.max_depth = md.max_depth; sh.sc.cone_gauss_newton = md.cone_gauss_newton;
+}
+template <int NT, int NJ, bool COST>    // NT: threads of the workgroup, all of which call
+__device__ __forceinline__ void load_shared_model(const DeviceModel& md, LinFastShared<NJ, COST>& sh, int tid) {
+  static_assert(sizeof(LinFastShared<NJ, COST>) % 16 == 0 && sizeof(LinFastShared<NJ, COST>) <= sizeof(LinFastShared<NJ, true>), "flat 16-byte copy of a prefix");
+  constexpr int N16 = sizeof(LinFastShared<NJ, COST>) / 16, K = (N16 + NT - 1) / NT;
+  const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(&md) + kLinImageOffset);
+  uint4* dst = reinterpret_cast<uint4*>(&sh);
+  uint4 v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { const int i = tid + k * NT; v[k] = src[i < N16 ? i : 0]; }      // (unconditional loads: nothing to wait for in between)
+#pragma unroll
+  for (int k = 0; k < K; ++k) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y), "+v"(v[k].z), "+v"(v[k].w));   // all of them in flight before the first store
+                                                                                                             // (else each load sinks into its store's branch)
+#pragma unroll
+  for (int k = 0; k < K; ++k) { const int i = tid + k * NT; if (i < N16) dst[i] = v[k]; }
 }
 
 // Per-node LDS tables.  FULL = false: value-only evaluation (line search trials, policy rollout): no derivative tables.
@@ -87,7 +132,7 @@ struct LinFastNodeLds {
   double x[C::NX], u[C::NU];
   union {
     double xh2[9];               // normalised momentum and base position of the second RK2 stage (the first stage reads x[0..8])
-    struct { double zref[FULL ? kNumContacts : 1], zdref[FULL ? kNumContacts : 1]; };   // value-only: swing references straight from HBM
+    struct { double zref[kNumContacts], zdref[kNumContacts]; };   // swing references of the node record (dead before the second stage starts)
   };
   union {
     double T[NT][9];             // joint-local rotation E of joint g-6 (its fixed offset is a model constant: LinFastShared::pfix)
@@ -199,18 +244,41 @@ struct LaneKin {    // what the contact part needs from the evaluation
 // CHAIN: v[] holds this lane's own body entry (zeros in the lanes without a body) and becomes the sum over the subtree its coordinate
 // moves: joints add their child's finished sum level by level from the leaf up (the additions of the table loop, in its order); the
 // base body (coordinate 5) adds the two leg heads, the other base coordinates (whole robot) copy the base body's lane.
+// lane SRC of this lane's 16-lane row to every lane of the row (DPP row_newbcast: no LDS round trip, unlike __shfl's ds_bpermute)
+template <int SRC>
+__device__ __forceinline__ double row_bcast_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x150 + SRC, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + SRC, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <class C, int SRC_COORD>      // the value of the lane that carries coordinate SRC_COORD, in every lane of the node
+__device__ __forceinline__ double node_bcast(double x) {
+#if BPMPC_LIN_BCAST_DPP
+  if constexpr (C::LPN == 16) return row_bcast_f64<SRC_COORD - C::G0>(x);
+  else
+#endif
+  return __shfl(x, SRC_COORD - C::G0, C::LPN);
+}
 template <class C, int N>
 __device__ __forceinline__ void chain_subtree_sum(double (&v)[N], int g, bool is_joint, int depth) {
+#ifdef BPMPC_ABL_SUBTREE
+  return;
+#endif
 #pragma unroll
   for (int d = C::LEG - 1; d >= 1; --d) {
     const bool on = is_joint && depth == d;
+#if BPMPC_LIN_FMA_MASK
+    const double onf = on ? 1.0 : 0.0;       // one multiply-add instead of an addition and two selects (1.0 * child is exact; 0.0 * child adds a zero)
+    for (int c = 0; c < N; ++c) { const double child = dpp_row_f64<kDppRowShl + 1>(v[c]); v[c] = fma(onf, child, v[c]); }
+#else
     for (int c = 0; c < N; ++c) { const double child = dpp_row_f64<kDppRowShl + 1>(v[c]); v[c] = on ? v[c] + child : v[c]; }
+#endif
   }
   for (int c = 0; c < N; ++c) {
     const double h1 = dpp_row_f64<kDppRowShl + 1>(v[c]), h2 = dpp_row_f64<kDppRowShl + 1 + C::LEG>(v[c]);
     v[c] = g == 5 ? (v[c] + h1) + h2 : v[c];
   }
-  for (int c = 0; c < N; ++c) { const double whole = __shfl(v[c], 5 - C::G0, C::LPN); v[c] = g < 5 ? whole : v[c]; }
+  for (int c = 0; c < N; ++c) { const double whole = node_bcast<C, 5>(v[c]); v[c] = g < 5 ? whole : v[c]; }
 }
 
 // One evaluation of the centroidal dynamics for the node owned by this lane group.  `stage` selects where the node-level
@@ -230,14 +298,15 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
   using C = Cfg;
   constexpr int NB = C::NB, G = C::G, LPN = C::LPN, G0 = C::G0;    // g = lane in node + G0: coordinate c lives in lane c - G0
   const bool is_joint = g >= 6 && g < G, is_body = g >= 5 && g < G;
-  const double mass_total = md.robot_mass;
+  const LinFastScalars& sc = sh.sc;        // the model's scalar constants, from LDS (LinFastScalars)
+  const double mass_total = sc.robot_mass;
   const double* pb = xh + 6;           // base position, read from LDS at every use (registers are the scarce resource here)
   double (*cpos)[3] = nl.cpos(stage);   // contact points of this evaluation
   // ---- sin/cos of the own angle; Euler sin/cos to everybody
   double sg = 0.0, cg = 1.0;
   if (g >= 3 && g < G) sincos(qg, &sg, &cg);
-  const double sy = __shfl(sg, 3 - G0, LPN), cy = __shfl(cg, 3 - G0, LPN), sp = __shfl(sg, 4 - G0, LPN), cp = __shfl(cg, 4 - G0, LPN),
-               sr = __shfl(sg, 5 - G0, LPN), cr = __shfl(cg, 5 - G0, LPN);
+  const double sy = node_bcast<C, 3>(sg), cy = node_bcast<C, 3>(cg), sp = node_bcast<C, 4>(sg), cp = node_bcast<C, 4>(cg),
+               sr = node_bcast<C, 5>(sg), cr = node_bcast<C, 5>(cg);
   kin.sy = sy; kin.cy = cy; kin.sp = sp; kin.cp = cp;
   if constexpr (NodeLds::kFull) { if (g == G0) { nl.trig[0] = sy; nl.trig[1] = cy; nl.trig[2] = sp; nl.trig[3] = cp; } }
   EVPROF(0);
@@ -256,7 +325,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
   double R[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
                  -sp, cp * sr, cp * cr};
   double o[3] = {pb[0], pb[1], pb[2]};
-  const int maxdepth = md.max_depth;
+  const int maxdepth = sc.max_depth;
   if constexpr (C::CHAIN) {
     // level by level: a joint of depth d composes the frame of its parent - the base (d = 1) or the lane before it, which finished at
     // level d - 1 - with its own local transform: the same two products as a step of the table walk, in the same order
@@ -326,9 +395,9 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
     cm[8] = Iwb[4] - m * d[1] * d[2];
     cm[9] = Iwb[5] + m * (dd - d[2] * d[2]);
     for (int i = 0; i < kNumContacts; ++i)
-      if (md.contact_body[i] == lb.body) {
+      if (sc.contact_body[i] == lb.body) {
         double t[3];
-        mat3_vec(R, md.contact_off[i], t);
+        mat3_vec(R, sc.contact_off[i], t);
         for (int a = 0; a < 3; ++a) cpos[i][a] = o[a] + t[a];
       }
   }
@@ -351,8 +420,8 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
   const double Ic[6] = {s[4] - Mc * (DD - Dv[0] * Dv[0]), s[5] + Mc * Dv[0] * Dv[1], s[6] + Mc * Dv[0] * Dv[2],
                         s[7] - Mc * (DD - Dv[1] * Dv[1]), s[8] + Mc * Dv[1] * Dv[2], s[9] - Mc * (DD - Dv[2] * Dv[2])};
   // whole-robot mass and com from lane 5 (the base body lane)
-  const double Mtot = __shfl(Mc, 5 - G0, LPN);
-  const double com[3] = {__shfl(Cc[0], 5 - G0, LPN), __shfl(Cc[1], 5 - G0, LPN), __shfl(Cc[2], 5 - G0, LPN)};
+  const double Mtot = node_bcast<C, 5>(Mc);
+  const double com[3] = {node_bcast<C, 5>(Cc[0]), node_bcast<C, 5>(Cc[1]), node_bcast<C, 5>(Cc[2])};
   if constexpr (DERIV) { if (g == G0) for (int i = 0; i < 3; ++i) nl.com[stage][i] = com[i]; }
   EVPROF(3);
   // ---- centroidal momentum matrix column
@@ -380,8 +449,10 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
       rhs[i] = mass_total * xh[i] - node_allreduce_add<LPN>(part);
     }
     double A12[9], A22[9], X12[9], X22[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) { A12[3 * i + j] = __shfl(Ac[i], 3 + j - G0, LPN); A22[3 * i + j] = __shfl(Ac[3 + i], 3 + j - G0, LPN); }
+    for (int i = 0; i < 3; ++i) {
+      A12[3 * i] = node_bcast<C, 3>(Ac[i]); A12[3 * i + 1] = node_bcast<C, 4>(Ac[i]); A12[3 * i + 2] = node_bcast<C, 5>(Ac[i]);
+      A22[3 * i] = node_bcast<C, 3>(Ac[3 + i]); A22[3 * i + 1] = node_bcast<C, 4>(Ac[3 + i]); A22[3 * i + 2] = node_bcast<C, 5>(Ac[3 + i]);
+    }
     const double* M = A22;
     const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
     const double idet = 1.0 / (M[0] * c00 + M[1] * c01 + M[2] * c02);
@@ -496,7 +567,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
       for (int c = 0; c < 6; ++c) hs[c] += sel * nl.hb[m][c];
     }
   }
-  const double ltot[3] = {__shfl(hs[0], 5 - G0, LPN), __shfl(hs[1], 5 - G0, LPN), __shfl(hs[2], 5 - G0, LPN)};
+  const double ltot[3] = {node_bcast<C, 5>(hs[0]), node_bcast<C, 5>(hs[1]), node_bcast<C, 5>(hs[2])};
   EVPROF(6);
   // ---- column 6+g: d(A v)/dq_g -> d v_base/dq_g, angular-momentum-rate row; joint-velocity column
   {
@@ -542,7 +613,7 @@ __device__ __forceinline__ void eval_lane(const DeviceModel& md, const Shared& s
     for (int i = 0; i < kNumContacts; ++i) {
       double jcol[3] = {0.0, 0.0, 0.0};
       if (g < 3) { jcol[0] = g == 0 ? 1.0 : 0.0; jcol[1] = g == 1 ? 1.0 : 0.0; jcol[2] = g == 2 ? 1.0 : 0.0; }
-      else if (g < G && (g < 6 || ((md.contact_path[i] >> (g - 5)) & 1u))) {
+      else if (g < G && (g < 6 || ((sc.contact_path[i] >> (g - 5)) & 1u))) {
         const double r[3] = {cpos[i][0] - o[0], cpos[i][1] - o[1], cpos[i][2] - o[2]};
         cross3(ah, r, jcol);
       }
@@ -575,19 +646,23 @@ constexpr size_t kLinDumpDoubles = (size_t)kLinDumpNodes * 16 + kLinDumpSlack;
 // (column-major inside the block row: 3 * column + row % 3)], so that the change of variables need not read 7.7 KB of mostly
 // constant numbers per node.
 constexpr int kQrdStride = 40;
+// The node record of the lane-per-coordinate kernels (Buffers::n_aux): dt, zref[4], zdref[4], padded to a 128-byte line
+constexpr int kNodeAux = 16;
 
 // What a lane needs of the node's iterate, loaded by the kernel wrapper BEFORE the model block is staged (and before the node is known to
 // exist: the addresses only depend on the slot), so that the memory round trips of a workgroup's start overlap instead of following
 // each other: x / u elements ln and ln + 16, and the entries of x_next and x_ref of the lane's rows.
 struct LinFastPre {
   double x0, x1, u0, u1, xn_q, xn_h, xn_t, xr_q, xr_h, xr_t;
+  double aux;       // lane ln: entry ln of the node record (kNodeAux: dt, zref[4], zdref[4])
 };
 template <class Cfg>
-__device__ __forceinline__ LinFastPre linearize_preload(const double* x, const double* xnext, const double* u, const double* xref, int ln) {
+__device__ __forceinline__ LinFastPre linearize_preload(const double* x, const double* xnext, const double* u, const double* xref, int ln, const double* aux = nullptr) {
   constexpr int G = Cfg::G, NX = Cfg::NX, G0 = Cfg::G0;
   const int g = ln + G0;
   const bool tr = G0 > 0 && ln < 3;
   LinFastPre p;
+  p.aux = (aux && ln < kNodeAux) ? aux[ln] : 0.0;
   p.x0 = x[ln]; p.u0 = u[ln];
   p.x1 = ln + 16 < NX ? x[ln + 16] : 0.0; p.u1 = ln + 16 < NX ? u[ln + 16] : 0.0;
   p.xn_q = g < G ? xnext[6 + g] : 0.0; p.xn_h = ln < 6 ? xnext[ln] : 0.0; p.xn_t = tr ? xnext[6 + ln] : 0.0;
@@ -698,9 +773,11 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     return;
   }
   const bool is_joint = g >= 6 && g < G;
-  const double dt = in.dt, hdt = 0.5 * in.dt;
+  static_assert(LPN == 16, "the node record is spread over sixteen lanes");
+  const double dt = row_bcast_f64<0>(pre.aux), hdt = 0.5 * dt;      // entry 0 of the node record (kNodeAux)
   const int mode = in.mode;
-  const double mass_total = md.robot_mass, imt = 1.0 / md.robot_mass;
+  const LinFastScalars& sc = sh.sc;
+  const double mass_total = sc.robot_mass, imt = 1.0 / sc.robot_mass;
   using Slots = RoleSlots<C>;
   constexpr int NS = Slots::NS;
   const Slots slots{ln, g, o.dump + ((o.s & (size_t)(kLinDumpNodes - 1)) * 16 + ln)};
@@ -710,7 +787,8 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   if (ln + 16 < NX) { nl.x[ln + 16] = pre.x1; nl.u[ln + 16] = pre.u1; }
   // the entries of x_next and x_ref this lane needs later (rows 6+g, ln and - packed lanes 0..2 - 6+ln)
   const double xn_q = pre.xn_q, xn_h = pre.xn_h, xr_q = pre.xr_q, xr_h = pre.xr_h, xn_t = pre.xn_t, xr_t = pre.xr_t;
-  if (ln < kNumContacts) { nl.zref[ln] = in.zref[ln]; nl.zdref[ln] = in.zdref[ln]; }
+  if (ln >= 1 && ln < 1 + kNumContacts) nl.zref[ln - 1] = pre.aux;
+  if (ln >= 1 + kNumContacts && ln < 1 + 2 * kNumContacts) nl.zdref[ln - 1 - kNumContacts] = pre.aux;
   LaneBody lb;
   {
     const int body = (g >= 5 && g < G) ? g - 5 : 0;
@@ -752,7 +830,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   lds_wave_sync();
   if (g >= 5 && g < G)
     for (int i = 0; i < kNumContacts; ++i)
-      if (md.contact_body[i] == lb.body) {
+      if (sc.contact_body[i] == lb.body) {
         const double r[3] = {cpos1[i][0] - kin.og[0], cpos1[i][1] - kin.og[1], cpos1[i][2] - kin.og[2]};
         double t[3];
         cross3(kin.omg, r, t);
@@ -774,7 +852,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     }
     double hcol[6];                     // own momentum column (rows 6..11 of df/dx, lanes 0..5): the same for every contact
     for (int l = 0; l < 6; ++l) hcol[l] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, ln, 3 + l);
-    const double pos_gain = md.pos_gain;
+    const double pos_gain = sc.pos_gain;
     int row = 0;
 #if BPMPC_LIN_UNROLL_CONTACTS
 #pragma unroll
@@ -786,7 +864,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
       const double cp_i[3] = {cpos1[i][0], cpos1[i][1], cpos1[i][2]};
       const double cv_i[3] = {cvel1[i][0], cvel1[i][1], cvel1[i][2]};
       // own columns of J_i and d(J_i v)/dq
-      const bool on_path = g >= 3 && g < G && (g < 6 || ((md.contact_path[i] >> (g - 5)) & 1u));
+      const bool on_path = g >= 3 && g < G && (g < 6 || ((sc.contact_path[i] >> (g - 5)) & 1u));
       double Jc[3], DJ[3];
       {
         const double r[3] = {cp_i[0] - kin.og[0], cp_i[1] - kin.og[1], cp_i[2] - kin.og[2]};
@@ -945,17 +1023,17 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   LFPROF(4);
   // =========================== cost ===========================
   lds_wave_sync();   // a2 is dead: its storage becomes dx / du; the twist tables are dead: their storage becomes the cone terms
-  if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(md, &nl.u[3 * ln], true, nl.cone[ln]);
+  if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(sc, &nl.u[3 * ln], true, nl.cone[ln]);
   const double pt = tr ? pb[ln] : 0.0;       // read before dx / du overwrite nothing of x (x lives in its own array) - kept for symmetry
   if (g < G) nl.dx[6 + g] = qg - xr_q;
   if (tr) nl.dx[6 + ln] = pt - xr_t;
   if (ln < 6) nl.dx[ln] = (ln < 6 ? xh[ln] : 0.0) - xr_h;
-  if (ln < 12) nl.du[ln] = nl.u[ln] - nominal_input(md, mode, ln);
+  if (ln < 12) nl.du[ln] = nl.u[ln] - nominal_input(sc, mode, ln);
   if (is_joint) nl.du[12 + g - 6] = ujg;
   lds_wave_sync();
   double shift = 0.0;
   for (int i = 0; i < kNumContacts; ++i)
-    if (stance_flag(mode, i)) shift += -nl.cone[i][2] * md.cone_shift;
+    if (stance_flag(mode, i)) shift += -nl.cone[i][2] * sc.cone_shift;
   double cost = 0.0;
   {
     const int cq = 6 + g, ch = ln, cf = ln, cj = 12 + g - 6, ct = 6 + ln;
@@ -1053,9 +1131,9 @@ struct TrialPre {
 };
 template <class Cfg>
 __device__ __forceinline__ TrialPre trial_preload(const double* x, const double* xnext, const double* u, const double* xref, const double* dx,
-                                                  const double* dxn, const double* du, int ln) {
+                                                  const double* dxn, const double* du, int ln, const double* aux = nullptr) {
   TrialPre p;
-  p.x = linearize_preload<Cfg>(x, xnext, u, xref, ln);
+  p.x = linearize_preload<Cfg>(x, xnext, u, xref, ln, aux);
   p.d = linearize_preload<Cfg>(dx, dxn, du, dx /* unused */, ln);
   return p;
 }
@@ -1079,11 +1157,15 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
     return;
   }
   const bool is_joint = g >= 6 && g < G;
-  const double dt = in.dt, hdt = 0.5 * in.dt;
+  double dt = in.dt;
   const int mode = in.mode;
+  const LinFastScalars& sc = sh.sc;
   double xn_q, xn_h, xr_q, xr_h, xn_t, xr_t;
   if (pre) {                            // (compile-time after inlining) the same expressions on values that arrived before the model block
     static_assert(LPN == 16 && NX <= 32, "two elements of x and of u per lane");
+    dt = row_bcast_f64<0>(pre->x.aux);                                  // the node record (kNodeAux): dt, zref[4], zdref[4]
+    if (ln >= 1 && ln < 1 + kNumContacts) nl.zref[ln - 1] = pre->x.aux;
+    if (ln >= 1 + kNumContacts && ln < 1 + 2 * kNumContacts) nl.zdref[ln - 1 - kNumContacts] = pre->x.aux;
     nl.x[ln] = pre->x.x0 + alpha * pre->d.x0; nl.u[ln] = pre->x.u0 + alpha * pre->d.u0;
     if (ln + 16 < NX) { nl.x[ln + 16] = pre->x.x1 + alpha * pre->d.x1; nl.u[ln + 16] = pre->x.u1 + alpha * pre->d.u1; }
     xn_q = g < G ? pre->x.xn_q + alpha * pre->d.xn_q : 0.0; xn_h = ln < 6 ? pre->x.xn_h + alpha * pre->d.xn_h : 0.0;
@@ -1098,6 +1180,7 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
     xr_q = g < G ? in.xref[6 + g] : 0.0; xr_h = ln < 6 ? in.xref[ln] : 0.0;
     xn_t = tr ? in.xnext[6 + ln] + alpha * dxn[6 + ln] : 0.0; xr_t = tr ? in.xref[6 + ln] : 0.0;
   }
+  const double hdt = 0.5 * dt;
   if constexpr (NL::kLate) {
     static_assert(LPN == 16, "one slot per lane of the node");
     nl.late[0][ln] = xn_q; nl.late[1][ln] = xn_h; nl.late[2][ln] = xn_t; nl.late[3][ln] = xr_q; nl.late[4][ln] = xr_h; nl.late[5][ln] = xr_t;
@@ -1121,14 +1204,14 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   const double v1t = ln == 0 ? kin.vb[0] : (ln == 1 ? kin.vb[1] : kin.vb[2]);
   if (g >= 5 && g < G)
     for (int i = 0; i < kNumContacts; ++i)
-      if (md.contact_body[i] == lb.body) {
+      if (sc.contact_body[i] == lb.body) {
         const double r[3] = {nl.cpos_v[i][0] - kin.og[0], nl.cpos_v[i][1] - kin.og[1], nl.cpos_v[i][2] - kin.og[2]};
         double t[3];
         cross3(kin.omg, r, t);
         for (int a = 0; a < 3; ++a) nl.cvel_v[i][a] = kin.vog[a] + t[a];
       }
   double cone_own[4] = {0.0, 0.0, 0.0, 0.0};          // h, barrier value, first and second derivative of this lane's contact
-  if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(md, &nl.u[3 * ln], false, cone_own);
+  if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(sc, &nl.u[3 * ln], false, cone_own);
   lds_wave_sync();
   double eq_sse = 0.0;
   int row = 0;
@@ -1137,14 +1220,14 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
     if (stance_flag(mode, i)) {
       for (int a = 0; a < 3; ++a) {
         double ev = nl.cvel_v[i][a];
-        if (md.pos_gain != 0.0 && a == 2) ev += md.pos_gain * cz;
+        if (sc.pos_gain != 0.0 && a == 2) ev += sc.pos_gain * cz;
         eq_sse += ev * ev;
         if constexpr (EQV) { if (ln == 0) eqv[row] = ev; ++row; }
       }
     } else {
       for (int a = 0; a < 3; ++a) { const double ev = nl.u[3 * i + a]; eq_sse += ev * ev; if constexpr (EQV) { if (ln == 0) eqv[row] = ev; ++row; } }
-      double ev = nl.cvel_v[i][2] - in.zdref[i];
-      if (md.pos_gain != 0.0) ev += md.pos_gain * (cz - in.zref[i]);
+      double ev = nl.cvel_v[i][2] - (pre ? nl.zdref[i] : in.zdref[i]);      // (without the preload - back-tracking tail, observers - straight from the grid tables)
+      if (sc.pos_gain != 0.0) ev += sc.pos_gain * (cz - (pre ? nl.zref[i] : in.zref[i]));
       eq_sse += ev * ev;
       if constexpr (EQV) { if (ln == 0) eqv[row] = ev; ++row; }
     }
@@ -1188,7 +1271,7 @@ __device__ __forceinline__ void trial_fast(const DeviceModel& md, const LinFastS
   if (g < G) nl.dx[6 + g] = qg - xr_q;
   if (tr) nl.dx[6 + ln] = pt - xr_t;
   if (ln < 6) nl.dx[ln] = (ln < 6 ? xh[ln] : 0.0) - xr_h;
-  if (ln < 12) nl.du[ln] = nl.u[ln] - nominal_input(md, mode, ln);
+  if (ln < 12) nl.du[ln] = nl.u[ln] - nominal_input(sc, mode, ln);
   if (is_joint) nl.du[12 + g - 6] = ujg;
   lds_wave_sync();
   double cost = cone_pen;

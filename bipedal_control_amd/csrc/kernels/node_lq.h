@@ -62,7 +62,8 @@ BP_DEVICE void relaxed_barrier(double mu, double delta, double h, double* p, dou
 }
 
 // weight-compensating nominal input (include/ocs2_bipedal_robot/common/utils.h:63-76), component idx
-BP_DEVICE double nominal_input(const DeviceModel& md, int mode, int idx) {
+template <class Model>   // DeviceModel or its scalar constants staged in LDS (linearize_fast.h LinFastScalars)
+BP_DEVICE double nominal_input(const Model& md, int mode, int idx) {
   if (idx >= 12 || (idx % 3) != 2) return 0.0;
   const int c = idx / 3;
   if (!stance_flag(mode, c)) return 0.0;
@@ -71,7 +72,8 @@ BP_DEVICE double nominal_input(const DeviceModel& md, int mode, int idx) {
 }
 
 // friction cone value / derivatives of one contact force (src/constraint/FrictionConeConstraint.cpp:129-160, t_R_w = I)
-BP_DEVICE void cone_terms(const DeviceModel& md, const double* F, bool deriv, double* out /*16*/) {
+template <class Model>
+BP_DEVICE void cone_terms(const Model& md, const double* F, bool deriv, double* out /*16*/) {
   const double Fx2 = F[0] * F[0], Fy2 = F[1] * F[1];
   const double T2 = Fx2 + Fy2 + md.cone_reg, T = sqrt(T2);
   const double h = md.friction * (F[2] + md.cone_grip) - T;

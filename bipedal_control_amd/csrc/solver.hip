@@ -454,6 +454,7 @@ void allocate(bpmpc_solver* s) {
   b.Px = s->alloc<double>("Px", S * NU * NX); b.Pu = s->alloc<double>("Pu", S * NU * NU); b.Pe = s->alloc<double>("Pe", S * NU);
   b.nut = s->alloc<int>("nut", S, true);
   b.n_info = s->alloc<int>("n_info", S, true);
+  b.n_aux = s->alloc<double>("n_aux", S * kNodeAux);
   b.At = b.Bt = b.bt = b.Qt = b.Rt = b.Pt = b.qt = b.rt = b.Kt = b.kt = b.Wt = b.Qp = b.Mt = b.Vt = nullptr;
   if (s->settings.reference_kernels) {      // the projected model as plain matrices and the gain scratch of the reference sweep (24 KB per node)
     b.At = s->alloc<double>("At", S * NX * NX); b.Bt = s->alloc<double>("Bt", S * NX * NU); b.bt = s->alloc<double>("bt", S * NX);
@@ -928,8 +929,14 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_go, hipEventDisableTiming));
     s->ev_chunk.resize(s->settings.pipeline_chunks);
     for (auto& e : s->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s->d_model), sizeof(DeviceModel)));
-    HIP_CHECK(hipMemcpy(s->d_model, &s->dm, sizeof(DeviceModel), hipMemcpyHostToDevice));
+    {   // the model and, behind it, the image of the lane-per-coordinate kernels' LDS model block (linearize_fast.h: kLinImageOffset, fill_shared_image)
+      std::vector<char> host(kLinImageOffset + sizeof(LinFastShared<12, true>), 0);
+      std::memcpy(host.data(), &s->dm, sizeof(DeviceModel));
+      if (s->rm.nj == 10) fill_shared_image<10>(s->dm, *reinterpret_cast<LinFastShared<10, true>*>(host.data() + kLinImageOffset));
+      else if (s->rm.nj == 12) fill_shared_image<12>(s->dm, *reinterpret_cast<LinFastShared<12, true>*>(host.data() + kLinImageOffset));
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s->d_model), host.size()));
+      HIP_CHECK(hipMemcpy(s->d_model, host.data(), host.size(), hipMemcpyHostToDevice));
+    }
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_remaining), sizeof(int)));
     const SqpConfig& q = s->rm.sqp;
     s->ls = LineSearchSettings{q.g_max, q.g_min, q.alpha_decay, q.alpha_min, q.gamma_c, q.armijo_factor, q.delta_tol, q.cost_tol,
