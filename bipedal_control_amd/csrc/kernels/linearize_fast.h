@@ -149,7 +149,7 @@ struct LinFastNodeLds {
   // node-level results of the two stages: A_b^{-1} blocks, contact points, com, flow-map rows 0..5, base linear velocity, Euler sin / cos
   double X12[FULL ? 2 : 1][FULL ? 9 : 1], X22[FULL ? 2 : 1][FULL ? 9 : 1], cps[FULL ? 2 : 1][FULL ? kNumContacts : 1][3], com[FULL ? 2 : 1][3];
   double fh[FULL ? 2 : 1][FULL ? 6 : 1], vlin[FULL ? 2 : 1][FULL ? 3 : 1], trig[FULL ? 4 : 1];
-  double park[(FULL && PARK) ? 15 : 1][(FULL && PARK) ? 16 : 1];   // [row][lane]: rows 3..11 of x column 6+g, rows 6..11 of the joint-velocity column
+  double park[(FULL && PARK) ? 16 : 1][(FULL && PARK) ? 16 : 1];   // [row][lane]: rows 3..11 of x column 6+g, rows 6..11 of the joint-velocity column, f[6+g] of the first stage
   // value-only evaluation at nx = 24: the lane's entries of x_next and x_ref, known at the top and used at the bottom, wait here - at three waves per SIMD
   // (168 registers) the allocator put exactly these six values into scratch memory
   static constexpr bool kLate = !FULL && NJ > 10;
@@ -762,11 +762,15 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
       for (int idx = ln; idx < kMaxEqRows * NU; idx += LPN) (o.D + o.s * (kMaxEqRows * NU))[idx] = 0.0;
       for (int idx = ln; idx < kMaxEqRows; idx += LPN) (o.e + o.s * (kMaxEqRows))[idx] = 0.0;
     }
-    for (int idx = ln; idx < NX; idx += LPN) {
-      const double d = in.x[idx] - in.xnext[idx];
-      (o.b + o.s * (NX))[idx] = d;
-      if constexpr (MAT) { (o.q + o.s * (NX))[idx] = 0.0; (o.r + o.s * (NU))[idx] = 0.0; }
-      d2 += d * d;
+    {   // b = x - x_next from the lane's preloaded entries (rows 6 + g, ln and - packed lanes 0..2 - 6 + ln): no load behind the node's own stores
+      static_assert(LPN == 16 && NX <= 32, "two elements of x per lane");
+      const double xq_lo = __shfl(pre.x0, (6 + g) & 15, LPN), xq_hi = __shfl(pre.x1, (6 + g - 16) & 15, LPN);      // (both by every lane of the node)
+      const double xq = 6 + g < 16 ? xq_lo : xq_hi;
+      const double xt = __shfl(pre.x0, (6 + ln) & 15, LPN);       // (used by the packed lanes 0..2 only: 6 + ln < 16)
+      if (g < G) { const double d = xq - pre.xn_q; (o.b + o.s * (NX))[6 + g] = d; d2 += d * d; }
+      if (ln < 6) { const double d = pre.x0 - pre.xn_h; (o.b + o.s * (NX))[ln] = d; d2 += d * d; }
+      if (tr) { const double d = xt - pre.xn_t; (o.b + o.s * (NX))[6 + ln] = d; d2 += d * d; }
+      if constexpr (MAT) for (int idx = ln; idx < NX; idx += LPN) { (o.q + o.s * (NX))[idx] = 0.0; (o.r + o.s * (NU))[idx] = 0.0; }
     }
     d2 = node_allreduce_add<LPN>(d2);
     if (ln == 0) { if constexpr (MAT) (o.c + o.s * (1))[0] = 0.0; (o.nc + o.s * (1))[0] = 0; (o.perf + o.s * (3))[0] = 0.0; (o.perf + o.s * (3))[1] = d2; (o.perf + o.s * (3))[2] = 0.0; }
@@ -822,7 +826,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     for (int rr = 0; rr < 9; ++rr) pk[rr * LPN + ln] = e1.ar_q[rr];
     for (int rr = 0; rr < 6; ++rr) pk[9 * LPN + rr * LPN + ln] = is_joint ? e1.br_j[rr] : 0.0;   // whole 128-byte lines
   }
-  const double v1g = e1.vg;
+  if constexpr (NL::kPark) nl.park[15][ln] = e1.vg;      // (the lane's own slot: no barrier) - waits there for b instead of in a register across the second evaluation
 
   // =========================== contact part (first stage only) ===========================
   double (*cpos1)[3] = nl.cps[0];
@@ -852,6 +856,16 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     }
     double hcol[6];                     // own momentum column (rows 6..11 of df/dx, lanes 0..5): the same for every contact
     for (int l = 0; l < 6; ++l) hcol[l] = momentum_col(nl.X12[0], nl.X22[0], imt, mass_total, ln, 3 + l);
+    // J_i,base (d v_base / d column) = d(pdot) + d(omega_base) x (p_i - o0),  d(omega_base) = W d(thetadot): the angular part W d(thetadot) of the lane's three
+    // columns does not depend on the contact - formed once here, not once per contact
+    auto omega_of = [&](const double* col6, double* w) {
+      const double th0 = col6[3], th1 = col6[4], th2 = col6[5];
+      w[0] = -tsy * th1 + tcy * tcp * th2; w[1] = tcy * th1 + tsy * tcp * th2; w[2] = th0 - tsp * th2;
+    };
+    double wq[3], wh[3], wj[3];
+    omega_of(&e1.ar_q[3], wq);
+    omega_of(hcol, wh);
+    omega_of(e1.br_j, wj);
     const double pos_gain = sc.pos_gain;
     int row = 0;
 #if BPMPC_LIN_UNROLL_CONTACTS
@@ -880,19 +894,16 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
           DJ[k] = on_path ? t1[k] + t2[k] : 0.0;
         }
       }
-      // J_i,base (d v_base / d column) = d(pdot) + d(omega_base) x (p_i - o0),  d(omega_base) = W d(thetadot)
       const double rb[3] = {cp_i[0] - pb[0], cp_i[1] - pb[1], cp_i[2] - pb[2]};
-      auto base_part = [&](const double* col6, double* outv) {
-        const double th0 = col6[3], th1 = col6[4], th2 = col6[5];
-        const double w[3] = {-tsy * th1 + tcy * tcp * th2, tcy * th1 + tsy * tcp * th2, th0 - tsp * th2};
+      auto base_part = [&](const double* col6, const double* w, double* outv) {
         double t[3];
         cross3(w, rb, t);
         for (int a = 0; a < 3; ++a) outv[a] = col6[a] + t[a];
       };
       double bq[3], bh[3], bj[3];
-      base_part(&e1.ar_q[3], bq);
-      base_part(hcol, bh);
-      base_part(e1.br_j, bj);
+      base_part(&e1.ar_q[3], wq, bq);
+      base_part(hcol, wh, bh);
+      base_part(e1.br_j, wj, bj);
       // velocity row of axis a: zero velocity of a stance contact (a = 0..2), normal velocity of a swing contact (a = 2)
       double vqa[3], vja[3];
       for (int a = 0; a < 3; ++a) { vqa[a] = bq[a] + DJ[a]; vja[a] = bj[a] + Jc[a]; }
@@ -1006,7 +1017,9 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   // b = x + dt/2 (f1 + f2) - x_next
   double dyn_sse = 0.0;
   if (g < G) {
-    const double bb = qg + hdt * v1g + hdt * e2.vg - xn_q;
+    // the lane's own q and first-stage rate come back from LDS (nl.x, the park): two values less alive across the second evaluation
+    const double v1g = NL::kPark ? nl.park[15][ln] : e1.vg;
+    const double bb = nl.x[6 + g] + hdt * v1g + hdt * e2.vg - xn_q;
     (o.b + o.s * (NX))[6 + g] = bb;
     dyn_sse += bb * bb;
   }
@@ -1025,7 +1038,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   lds_wave_sync();   // a2 is dead: its storage becomes dx / du; the twist tables are dead: their storage becomes the cone terms
   if (ln < kNumContacts && stance_flag(mode, ln)) cone_terms(sc, &nl.u[3 * ln], true, nl.cone[ln]);
   const double pt = tr ? pb[ln] : 0.0;       // read before dx / du overwrite nothing of x (x lives in its own array) - kept for symmetry
-  if (g < G) nl.dx[6 + g] = qg - xr_q;
+  if (g < G) nl.dx[6 + g] = nl.x[6 + g] - xr_q;
   if (tr) nl.dx[6 + ln] = pt - xr_t;
   if (ln < 6) nl.dx[ln] = (ln < 6 ? xh[ln] : 0.0) - xr_h;
   if (ln < 12) nl.du[ln] = nl.u[ln] - nominal_input(sc, mode, ln);
