@@ -23,7 +23,7 @@ def csrc_hash(csrc=CSRC):
     stores it beside the counter traffic of a profiled run; bench.py reports that traffic only while the hash still matches (a kernel
     change without a re-collected profile would otherwise carry stale bytes into the bench line)."""
     h = hashlib.sha1()
-    for root, dirs, files in sorted(os.walk(csrc)):
+    for root, dirs, files in os.walk(csrc):           # (dirs pruned and ordered in place: the walk itself is deterministic)
         dirs[:] = sorted(d for d in dirs if d != "build")
         for f in sorted(files):
             if f.endswith((".h", ".hip", ".cpp")):
@@ -87,5 +87,22 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_probes(force=False, verbose=False):
+    """Measurement helpers outside the product library: tools/probes/libwrite_roof.so, the write-only stream with the lineariser's store pattern
+    that bench.py runs beside the timed region to calibrate `roofline.frac` (roofline.write_roof)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "probes", "write_roof.hip")
+    lib = os.path.join(root, "tools", "probes", "libwrite_roof.so")
+    if not os.path.exists(src):
+        return None
+    if force or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-DWRITE_ROOF_LIB", src, "-o", lib]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_probes(force="--force" in sys.argv, verbose=True))

@@ -8,9 +8,6 @@
 #include "kernels/riccati.h"
 #include "kernels/riccati_mfma.h"
 #include "kernels/riccati_mfma8.h"
-#include "kernels/riccati_mfma8s.h"
-
-#include <cstdlib>
 
 namespace bpmpc {
 
@@ -58,16 +55,6 @@ __global__ __launch_bounds__(kRiccati8Threads) void k_riccati_fast8(Launch L) {
   riccati_mfma8<NJ, JW>(ws, io);
 }
 
-// The same sweep with the value function kept in the registers of the chain waves between two stages and three sets of stage data
-// (riccati_mfma8s.h; nx = 22: three sets fit the LDS)
-template <int NJ, bool JW>
-__global__ __launch_bounds__(kRiccati8Threads) void k_riccati_fast8s(Launch L) {
-  __shared__ RiccatiMfma8sWorkspace<NJ> ws;
-  RiccatiFastIO io;
-  if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;
-  riccati_mfma8s<NJ, JW>(ws, io);
-}
-
 #define KL_NJ(nj, ...)                                                          \
   do {                                                                          \
     if ((nj) == 10) { constexpr int NJ = 10; __VA_ARGS__; }                     \
@@ -88,12 +75,6 @@ void riccati_fast(int nj, bool double_buffered, bool joint_rows, int batch, hipS
   });
 }
 void riccati_fast8(int nj, bool joint_rows, int batch, hipStream_t st, const Launch& L) {
-  static const bool in_registers = [] { const char* e = std::getenv("BPMPC_RICCATI8_S"); return e && e[0] == '1'; }();     // BPMPC_RICCATI8_S=1: riccati_mfma8s.h (work in progress)
-  if (nj == 10 && in_registers) {
-    if (joint_rows) hipLaunchKernelGGL((k_riccati_fast8s<10, true>), dim3(batch), dim3(kRiccati8Threads), 0, st, L);
-    else hipLaunchKernelGGL((k_riccati_fast8s<10, false>), dim3(batch), dim3(kRiccati8Threads), 0, st, L);
-    return;
-  }
   KL_NJ(nj, {
     if (joint_rows) hipLaunchKernelGGL((k_riccati_fast8<NJ, true>), dim3(batch), dim3(kRiccati8Threads), 0, st, L);
     else hipLaunchKernelGGL((k_riccati_fast8<NJ, false>), dim3(batch), dim3(kRiccati8Threads), 0, st, L);

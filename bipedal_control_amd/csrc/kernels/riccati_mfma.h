@@ -36,6 +36,30 @@ namespace bpmpc {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// Where element (row, col) of an LDS matrix lives.  LdsRows<LD>: row major with leading dimension LD.
+// LdsSwz<NBC> (round 6, the eight-wave sweep): NBC block columns of 16; rows 2j and 2j + 1 share a PAIR ROW of 32 NBC + 2 doubles in which the
+// 16-column chunks of the two rows alternate, the order inside a chunk pair exchanged for odd block columns:
+//     ix = (row / 2) PS + 32 (col / 16) + 16 ((row ^ (col / 16)) & 1) + col % 16,   PS = 32 NBC + 2.
+// ds_read_b64 serves a wave in two groups of 32 lanes over 64 banks of 4 B, i.e. the 32 doubles of a group must differ mod 32.  The operand loads of
+// v_mfma_f64_16x16x4_f64 come in two lane patterns (li = lane % 16, lk = lane / 16; a group = lk in {0, 1} or {2, 3}):
+//     (1) rows r0 + li, columns 4 ks + lk   (A operand of a row-stored matrix)          (2) rows 4 ks + lk, columns c0 + li   (B operand; accumulator layout)
+// Row major serves (1) with LD = 2 mod 32 and (2) with LD = 16 mod 32, never both: at LD = 34 / 50 / 66 every load of pattern (2) - 250 of the
+// sweep's 300 operand loads per stage - was a two-way conflict (SQ_LDS_BANK_CONFLICT 0.24 of SQ_LDS_IDX_ACTIVE, profiles/r05_sq_counters.csv).
+// Swizzled: (1) 2 (li / 2) + 16 (li & 1) + lk + const, (2) 16 (lk ^ chunk) + (c0 + li) % 16 + const (also across a chunk boundary) - both hit 32
+// different doubles mod 32; a row read by one column per lane (the elimination) separates columns c and c + 16.  Pairs (col even) stay 16-byte aligned.
+template <int LD>
+struct LdsRows {
+  static constexpr int kCols = LD;
+  __host__ __device__ static constexpr int ix(int row, int col) { return row * LD + col; }
+  static constexpr int size(int rows) { return rows * LD; }
+};
+template <int NBC>
+struct LdsSwz {
+  static constexpr int kCols = 16 * NBC, PS = 32 * NBC + 2;
+  __host__ __device__ static constexpr int ix(int row, int col) { return (row >> 1) * PS + ((col >> 4) << 5) + (((row ^ (col >> 4)) & 1) << 4) + (col & 15); }
+  static constexpr int size(int rows) { return ((rows + 1) / 2) * PS; }
+};
+
 // DB: the staged operands are double buffered (stage k-1 is staged while the updates of stage k still read theirs, which
 // saves a barrier per stage).  At nx = 22 that costs 98 KB of LDS (one workgroup per CU) against 66 KB single buffered (two
 // workgroups per CU): the solver double buffers when the batch does not exceed the number of CUs.
@@ -106,13 +130,13 @@ constexpr int kModeEvent = 4;                 // contact mode code of an event n
 // force-row pair is LOADED (Pe_c for the pair that opens at column nx, otherwise 0.0 or 1.0 from a two-entry table), the second is a
 // register set there; stage() is four ds_write_b128 with fixed addresses.  (First version: masks, mode look-ups and selects in stage(),
 // +60 instructions = +0.5 k cycles per stage, 0.334 -> 0.354 ms per sweep.)
-template <int NJ, int NLD, int LDW>
+template <int NJ, int NLD, int LDW, class LW = LdsRows<LDW>>
 struct PwVtLoader {
   using PL = PackedLq<NJ>;
   static constexpr int NX = PL::NX, NU = PL::NU, WP = PL::WP, BC = NX + 1, HW = WP / 2;
   static constexpr int NPV = NJ * HW, NPF = 12 * HW;
   static constexpr int SV = (NPV + NLD - 1) / NLD, SF = (NPF + NLD - 1) / NLD;
-  static_assert(NX % 2 == 0 && LDW % 2 == 0 && WP <= LDW, "column nx opens a pair; pairs stay aligned and inside the rows");
+  static_assert(NX % 2 == 0 && LDW % 2 == 0 && WP <= LW::kCols, "column nx opens a pair; pairs stay aligned and inside the rows");
   double vx[SV], vy[SV], fx[SF], fy[SF];
   const double2* gV;
   const double* gPe;
@@ -130,11 +154,11 @@ struct PwVtLoader {
     gPe = io.base.Pe + k * NU;
     zero_one = io.zero_one;
 #pragma unroll
-    for (int e = 0; e < SV; ++e) { const int p = tp + e * NLD; vo[e] = p < NPV ? (12 + p / HW) * LDW + 2 * (p % HW) : -1; }
+    for (int e = 0; e < SV; ++e) { const int p = tp + e * NLD; vo[e] = p < NPV ? LW::ix(12 + p / HW, 2 * (p % HW)) : -1; }
 #pragma unroll
     for (int e = 0; e < SF; ++e) {
       const int p = tp + e * NLD, c = p < NPF ? p / HW : 0, col = 2 * (p % HW);
-      fo[e] = p < NPF ? (p / HW) * LDW + 2 * (p % HW) : -1;
+      fo[e] = p < NPF ? LW::ix(p / HW, 2 * (p % HW)) : -1;
       pe_off[e] = col == NX ? c : -1;
       ux[e] = 0; uy[e] = 0;
 #pragma unroll
@@ -162,8 +186,7 @@ struct PwVtLoader {
     }
     gV -= (NJ * WP) / 2; gPe -= NU;
   }
-  __device__ __forceinline__ void stage(double (*PW)[LDW]) const {
-    double* PWf = &PW[0][0];
+  __device__ __forceinline__ void stage(double* PWf) const {
 #pragma unroll
     for (int e = 0; e < SV; ++e)
       if ((e + 1) * NLD <= NPV || vo[e] >= 0) { double2 v; v.x = vx[e]; v.y = vy[e]; *reinterpret_cast<double2*>(PWf + vo[e]) = v; }
@@ -183,7 +206,7 @@ struct PwVtLoader {
 //   staging time - the staging sits between the S update and S W of the sweep, the requests do not (riccati_mfma8.h, round 4).
 //   JR: Wt holds no joint rows (k_project_fast<.., WJ = false>): they are [I | b | 0] + dt x (joint rows of [Px | Pe | Pu]) and are completed at
 //   staging time from the pairs of Vt this thread holds anyway - the same pair index, the same LDS offset, in W instead of PW (round 4).
-template <int NJ, int NLD, int MR, int LDW, int LDN, bool AM = false, bool JR = false>
+template <int NJ, int NLD, int MR, int LDW, int LDN, bool AM = false, bool JR = false, class LW = LdsRows<LDW>, class LN = LdsRows<LDN>>
 struct PackedStageLoader {
   using PL = PackedLq<NJ>;
   static constexpr int NX = PL::NX, NU = PL::NU, WP = PL::WP, QP = PL::QP, BC = NX + 1, NXX = NX * NX;
@@ -191,16 +214,16 @@ struct PackedStageLoader {
   static constexpr int HQU = (NX + 2) / 2;                          // pairs per row of Qp that carry anything ([Q~ | q~]: nx + 1 columns)
   static constexpr int NPW = (JR ? 12 : NX) * HW, NPQ = NX * HQU, NPM = MR * HW;
   static constexpr int SW = (NPW + NLD - 1) / NLD, SQ = (NPQ + NLD - 1) / NLD, SM = (NPM + NLD - 1) / NLD;
-  static_assert(LDW % 2 == 0 && LDN % 2 == 0 && NX % 2 == 0 && WP <= LDW && QP <= LDN && MR <= NU, "pairs stay aligned and inside the rows");
+  static_assert(LDW % 2 == 0 && LDN % 2 == 0 && NX % 2 == 0 && WP <= LW::kCols && QP <= LN::kCols && MR <= NU, "pairs stay aligned and inside the rows");
   // (x / y halves in separate arrays of doubles: arrays of double2 that live across the stage loop end up in scratch memory)
   double wx[SW], wy[SW], qx[SQ], qy[SQ], mx[SM], my[SM];
   const double2 *gW, *gQ, *gM;
-  PwVtLoader<NJ, NLD, LDW> pw;                                      // [Px | Pe | Pu]
+  PwVtLoader<NJ, NLD, LDW, LW> pw;                                      // [Px | Pe | Pu]
   // per slot, fixed for the whole sweep: LDS element offset of the pair, its column (and row, for Mt) for the masks; -1: no pair
   int wo[SW], wc[SW], qo[SQ], mo[SM], mc[SM], mr[SM];
   int tl;
   // JR: per pair of Vt: the identity entries of the joint row inside the pair, the row whose b the pair carries (the pair that opens at column nx; -1: none)
-  static constexpr int SVJ = PwVtLoader<NJ, NLD, LDW>::SV;
+  static constexpr int SVJ = PwVtLoader<NJ, NLD, LDW, LW>::SV;
   double jix[SVJ], jiy[SVJ], jb[SVJ], dtk;
   int jbo[SVJ];
   const double *gB, *gDt;
@@ -225,11 +248,11 @@ struct PackedStageLoader {
       }
     }
 #pragma unroll
-    for (int e = 0; e < SW; ++e) { const int p = tp + e * NLD; const bool ok = p < NPW; wo[e] = ok ? (p / HW) * LDW + 2 * (p % HW) : -1; wc[e] = 2 * (p % HW); }
+    for (int e = 0; e < SW; ++e) { const int p = tp + e * NLD; const bool ok = p < NPW; wo[e] = ok ? LW::ix(p / HW, 2 * (p % HW)) : -1; wc[e] = 2 * (p % HW); }
 #pragma unroll
-    for (int e = 0; e < SQ; ++e) { const int p = tp + e * NLD; const bool ok = p < NPQ; qo[e] = ok ? (p / HQU) * LDN + 2 * (p % HQU) : -1; }
+    for (int e = 0; e < SQ; ++e) { const int p = tp + e * NLD; const bool ok = p < NPQ; qo[e] = ok ? LN::ix(p / HQU, 2 * (p % HQU)) : -1; }
 #pragma unroll
-    for (int e = 0; e < SM; ++e) { const int p = tp + e * NLD; const bool ok = p < NPM; mo[e] = ok ? (p / HW) * LDW + 2 * (p % HW) : -1; mc[e] = 2 * (p % HW); mr[e] = p / HW; }
+    for (int e = 0; e < SM; ++e) { const int p = tp + e * NLD; const bool ok = p < NPM; mo[e] = ok ? LW::ix(p / HW, 2 * (p % HW)) : -1; mc[e] = 2 * (p % HW); mr[e] = p / HW; }
   }
   // loads of the stage the pointers stand on (its reduced input dimension: nt), then one stage down
   __device__ __forceinline__ void prefetch(int nt, int mode) {
@@ -256,14 +279,13 @@ struct PackedStageLoader {
     gW -= PL::W_SIZE / 2; gQ -= PL::Q_SIZE / 2; gM -= PL::M_SIZE / 2;
   }
   // registers -> LDS: W = [A~ | b~ | B~], Qq = [Q~ | q~], M = [P~ | r~ | R~] (MR rows), PW = [Px | Pe | Pu], r~ also to rvec
-  __device__ __forceinline__ void stage(double (*W)[LDW], double (*PW)[LDW], double (*Qq)[LDN], double (*M)[LDW], double* rvec, int nt) const {
+  __device__ __forceinline__ void stage(double* W, double* PW, double* Qq, double* M, double* rvec, int nt) const {      // (flat: element (r, c) at LW / LN::ix)
     stage_wm(W, M, rvec, nt);
     stage_pq(PW, Qq);
   }
   // the two halves of stage(): what the first products of a stage read (W, M) and what is read a phase later or by the outputs only (PW, Qq)
-  __device__ __forceinline__ void stage_wm(double (*W)[LDW], double (*M)[LDW], double* rvec, int nt) const {
+  __device__ __forceinline__ void stage_wm(double* Wf, double* Mf, double* rvec, int nt) const {
     const int cend = 16 * ((BC + nt + 15) >> 4);
-    double* Wf = &W[0][0]; double* Mf = &M[0][0];
 #pragma unroll
     for (int e = 0; e < SW; ++e)
       if ((e + 1) * NLD <= NPW || wo[e] >= 0) {     // only the last slot of a stream is partial; (a select between two double2 goes through scratch memory: component-wise)
@@ -286,8 +308,7 @@ struct PackedStageLoader {
         }
     }
   }
-  __device__ __forceinline__ void stage_pq(double (*PW)[LDW], double (*Qq)[LDN]) const {
-    double* Qf = &Qq[0][0];
+  __device__ __forceinline__ void stage_pq(double* PW, double* Qf) const {
 #pragma unroll
     for (int e = 0; e < SQ; ++e)
       if ((e + 1) * NLD <= NPQ || qo[e] >= 0) { double2 v; v.x = qx[e]; v.y = qy[e]; *reinterpret_cast<double2*>(Qf + qo[e]) = v; }
@@ -579,7 +600,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
     const int nbc = (BC + nt + 15) >> 4;             // block columns of the packed width nx + 1 + nt
     const int ntb = (nt + 15) >> 4;                  // block rows of the reduced input
     // ---- P0: registers -> packed LDS layouts; what the projection kernel does not write (block columns >= nbc, rows >= nt) is staged as zero
-    if (loader) ld.stage(W, PW, Qq, M, rvec, nt);
+    if (loader) ld.stage(&W[0][0], &PW[0][0], &Qq[0][0], &M[0][0], rvec, nt);
     lds_barrier();
     RMPROF(0);
     RMPROF(1);

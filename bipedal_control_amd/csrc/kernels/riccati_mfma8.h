@@ -37,30 +37,46 @@ namespace bpmpc {
 typedef unsigned int bp8_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kRiccati8Threads = 512;
 
+// LDS matrices in the swizzled layout LdsSwz (riccati_mfma.h): every operand load of the sweep, whichever of the two lane patterns it follows, meets 32
+// different bank pairs per lane group.  Flat arrays; element (r, c) of a matrix with nx + 1 (+ spare) columns is at LN::ix(r, c), of a packed-width matrix at LW::ix(r, c).
 template <int NJ>
 struct RiccatiMfma8Workspace {
   static constexpr int NX = 12 + NJ, NU = 12 + NJ;
   static constexpr int RB = 32;                                  // two full 16-row blocks: plain block loads / stores
   static constexpr int RE = 16;                                  // rows of the reduced-input matrices (nut <= 16, checked)
-  static constexpr int LDN = 34;
   static constexpr int WC = NX + 1 + NU;
-  static constexpr int LDW = ((WC + 15) / 16) * 16 + 2;
+  using LN = LdsSwz<2>;                                          // [.. | vector] blocks: nx + 1 <= 32 columns; column 31 is never written (a zero column)
+  using LW = LdsSwz<(WC + 15) / 16>;                             // packed width [A | b | B]
+  static constexpr int ZN = 31;
   static_assert(NX + 1 <= 32 && NU <= 32, "two block rows / columns");
-  alignas(16) double S[RB][LDN];        // [S | s], not symmetrised
-  alignas(16) double Qq[2][RB][LDN];    // [Q~ | q~]
-  alignas(16) double Sn[RB][LDN];       // [Sn | sn]
-  alignas(16) double Zt[RE][LDN];       // pivot rows of the forward elimination of [G | g]
-  alignas(16) double Yn[RE][LDN];       // the same rows divided by their pivots
-  alignas(16) double W[2][RB][LDW];     // [A~ | b~ | B~]
-  alignas(16) double PW[2][RB][LDW];    // [Px | Pe | Pu]
-  alignas(16) double SW[RB][LDW];       // sym(S) W
-  alignas(16) double M[2][RE][LDW];     // [P~ | r~ | R~] -> its sum with the first part of B' SW -> Y in the first nx + 1 columns
-  alignas(16) double Mb[RE][LDW];       // the second part of B' SW (state rows 16 ..): [G | g | H] = M + Mb
+  alignas(16) double S[LN::size(RB)];        // [S | s], not symmetrised
+  alignas(16) double Qq[2][LN::size(RB)];    // [Q~ | q~]
+  alignas(16) double Sn[LN::size(RB)];       // [Sn | sn]
+  alignas(16) double Zt[LN::size(RE)];       // pivot rows of the forward elimination of [G | g]
+  alignas(16) double Yn[LN::size(RE)];       // the same rows divided by their pivots
+  alignas(16) double W[2][LW::size(RB)];     // [A~ | b~ | B~]
+  alignas(16) double PW[2][LW::size(RB)];    // [Px | Pe | Pu]
+  alignas(16) double SW[LW::size(RB)];       // sym(S) W
+  alignas(16) double M[2][LW::size(RE)];     // [P~ | r~ | R~] -> its sum with the first part of B' SW -> Y in the first nx + 1 columns
+  alignas(16) double Mb[LW::size(RE)];       // the second part of B' SW (state rows 16 ..): [G | g | H] = M + Mb
   double r[2][NU];
   int status;
   unsigned char nut[kMaxRiccatiStages];
   unsigned char mode[kMaxRiccatiStages];
 };
+// block of the accumulator layout (lane (li, lk), register r <-> row r0 + lk + 4 r, column c0 + li) from / to a swizzled matrix
+template <class L>
+__device__ __forceinline__ v4d sblk_load(const double* Mx, int r0, int c0, int l) {
+  v4d c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = lds1(Mx[L::ix(r0 + (l >> 4) + 4 * r, c0 + (l & 15))]);
+  return c;
+}
+template <class L>
+__device__ __forceinline__ void sblk_store(double* Mx, int r0, int c0, int l, v4d c) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Mx[L::ix(r0 + (l >> 4) + 4 * r, c0 + (l & 15))] = c[r];
+}
 
 // Forward elimination of [H | G g], one column per lane (layout of gauss_jordan_wave).  After step p row p is divided by its
 // pivot and eliminated from the rows below; emit(p, z, y) sees the pivot row before (z) and after (y) the division.
@@ -101,7 +117,8 @@ __device__ __forceinline__ void back_substitute_wave(double (&v)[ROWS], int nt) 
 template <int NJ, bool JW = true>     // JW: Wt holds its joint rows (off: the loaders complete them from Vt, PackedStageLoader JR)
 __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, const RiccatiFastIO& io) {
   using WS = RiccatiMfma8Workspace<NJ>;
-  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccati8Threads, LDN = WS::LDN, LDW = WS::LDW, RB = WS::RB, RE = WS::RE;
+  using LN = typename WS::LN; using LW = typename WS::LW;
+  constexpr int NX = WS::NX, NU = WS::NU, NT = kRiccati8Threads, RE = WS::RE, ZN = WS::ZN;
   constexpr int NXX = NX * NX, NXU = NX * NU;
   constexpr int KS = (NX + 3) / 4;          // k-steps over the state dimension
   constexpr int BC = NX + 1;                // first column of B~ / Pu / R~ in the packed layouts
@@ -110,33 +127,22 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   const int li = l & 15, lk = l >> 4;       // operand row/column index and k index of this lane
   const int N = io.base.N;
-  #ifndef BPMPC_RICCATI8_LOADERS
-#define BPMPC_RICCATI8_LOADERS 3     // loader waves: L4, L5, F (3) and C3 (4), which has no part in the S update then (C2 takes block (1, 1)): two loaders on either SIMD pair
-#endif
-  constexpr bool kC3Loads = BPMPC_RICCATI8_LOADERS == 4;
-  const bool role_c = w < 4, role_l = (w >= 4 && w < 4 + (kC3Loads ? 3 : BPMPC_RICCATI8_LOADERS)) || (kC3Loads && w == 3), role_f = w == 6, role_e = w == 7;
-#ifndef BPMPC_RICCATI8_PRIO_CHAIN
-#define BPMPC_RICCATI8_PRIO_CHAIN 0    // s_setprio of the chain waves C0..C3 / of the elimination wave E over the loader waves that share their SIMDs
-#endif
-#ifndef BPMPC_RICCATI8_PRIO_E
-#define BPMPC_RICCATI8_PRIO_E 0
-#endif
-  if (BPMPC_RICCATI8_PRIO_CHAIN > 0 && role_c) __builtin_amdgcn_s_setprio(BPMPC_RICCATI8_PRIO_CHAIN);
-  if (BPMPC_RICCATI8_PRIO_E > 0 && role_e) __builtin_amdgcn_s_setprio(BPMPC_RICCATI8_PRIO_E);
+  constexpr int kLoaders = 3;          // loader waves: L4, L5, F (a fourth, C3, was measured in round 5: no gain)
+  const bool role_c = w < 4, role_l = w >= 4 && w < 4 + kLoaders, role_f = w == 6, role_e = w == 7;
 
   const int k_top = (io.k_hi < N ? io.k_hi : N) - 1;
   const bool resumed = io.k_hi < N;
   {
-    double* z = &ws.S[0][0];
+    double* z = &ws.S[0];
     constexpr int total = (int)(offsetof(WS, status) / sizeof(double));
     for (int idx = tid; idx < total; idx += NT) z[idx] = 0.0;     // every matrix and its padding
   }
   __syncthreads();
   if (tid == 0) ws.status = resumed ? (int)io.carry[NXX + NX] : 0;
-  if (!resumed && io.reg != 0.0 && tid < NX) ws.S[tid][tid] = io.reg;
+  if (!resumed && io.reg != 0.0 && tid < NX) ws.S[LN::ix(tid, tid)] = io.reg;
   if (resumed) {
-    for (int idx = tid; idx < NXX; idx += NT) ws.S[idx / NX][idx % NX] = io.carry[idx];
-    if (tid < NX) ws.S[tid][NX] = io.carry[NXX + tid];
+    for (int idx = tid; idx < NXX; idx += NT) ws.S[LN::ix(idx / NX, idx % NX)] = io.carry[idx];
+    if (tid < NX) ws.S[LN::ix(tid, NX)] = io.carry[NXX + tid];
   }
   int too_wide = 0;
   for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) {
@@ -152,14 +158,14 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     }
     // the roll-out, which normally opens the line search of this problem, is skipped: open it here, otherwise done / alpha / base keep the
     // previous iteration's values and k_ls_decide would skip the problem instead of reporting the failure (advisor r02)
-    if (io.k_lo == 0 && io.with_ls && tid < kWave) linesearch_begin_wave<NJ>(&ws.S[0][0], io.ls, tid);
+    if (io.k_lo == 0 && io.with_ls && tid < kWave) linesearch_begin_wave<NJ>(&ws.S[0], io.ls, tid);
     return;
   }
 
   // Prefetch registers and staging of the loader waves (PackedStageLoader, riccati_mfma.h): 128 threads, pairs t, t + 128, ..
-  constexpr int NLD = BPMPC_RICCATI8_LOADERS * kWave;
-  PackedStageLoader<NJ, NLD, RE, LDW, LDN, true, !JW> ld;
-  ld.init(io, (w == 3 ? 3 : w - 4) * kWave + l, role_l, (size_t)(k_top > 0 ? k_top : 0));
+  constexpr int NLD = kLoaders * kWave;
+  PackedStageLoader<NJ, NLD, RE, LW::kCols, LN::kCols, true, !JW, LW, LN> ld;
+  ld.init(io, (w - 4) * kWave + l, role_l, (size_t)(k_top > 0 ? k_top : 0));
   if (role_l && k_top >= io.k_lo) {     // the stage the loader's pointers stand on (the LDS copies of nut and mode may not be visible yet)
     const int kt = k_top > 0 ? k_top : 0, n0 = io.base.nut[kt];
     ld.prefetch(n0, n0 > 0 ? (io.mode[kt] & 3) : kModeEvent);
@@ -168,15 +174,46 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #ifdef BPMPC_RICCATI_PROFILE
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = clock64();
-#define RM8PROF(slot) do { if (BPMPC_RICCATI_PROFILE != 20) { const long long tn_ = clock64(); tacc[slot] += tn_ - tprev; tprev = tn_; } } while (0)
+#define RM8PROF(slot) do { const long long tn_ = clock64(); tacc[slot] += tn_ - tprev; tprev = tn_; } while (0)
 #define RM8OWN(phase) do { if (BPMPC_RICCATI_PROFILE == 10 + (phase)) tacc[7] += clock64() - tprev; } while (0)   /* own work of a phase, before its barrier */
-  long long tsub = 0;                   /* BPMPC_RICCATI_PROFILE == 20: steps of an output block (entry, loads issued, loads here, products, stores issued) */
-#define RM8SUB(i) do { if (BPMPC_RICCATI_PROFILE == 20) { const long long tn_ = clock64(); if ((i) > 0) tacc[i] += tn_ - tsub; tsub = tn_; } } while (0)
 #else
-#define RM8SUB(i) ((void)0)
 #define RM8PROF(slot) ((void)0)
 #define RM8OWN(phase) ((void)0)
 #endif
+
+  // Lane parts of the swizzled addresses (element offsets, formed once: an access is lane part + a constant that fits the instruction's offset field).
+  //   pattern (2): rows R + lk, columns C + li (R a multiple of 4, C of 16): (R / 2) PS + 2 C + p2[(C / 16) & 1]
+  //   pattern (1): rows R + li, columns C + lk (R a multiple of 16, C of 4, no chunk boundary inside C .. C + 3): (R / 2) PS + 2 (C & ~15) + (C & 15) + p1[(C / 16) & 1]
+  constexpr int PSN = LN::PS, PSW = LW::PS;
+  const int hk = lk >> 1, pk = lk & 1, hl = li >> 1, pl = li & 1;
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  const int nP2a = opaque(hk * PSN + 16 * pk + li), nP2b = opaque(hk * PSN + 16 * (pk ^ 1) + li);     // LN matrices, pattern (2), even / odd block column
+  const int wP2a = opaque(hk * PSW + 16 * pk + li), wP2b = opaque(hk * PSW + 16 * (pk ^ 1) + li);     // LW matrices
+  const int nP1a = opaque(hl * PSN + 16 * pl + lk), nP1b = opaque(hl * PSN + 16 * (pl ^ 1) + lk);     // LN matrices, pattern (1)
+  const int nSV = opaque(hk * PSN + 16 * (pk ^ 1) + 32 + (NX & 15));                                   // column nx (s) of rows R + lk
+  static_assert(NX >= 16 && NX < 32, "column nx lies in block column 1");
+  int wBC;                                                                                             // rows R + lk, columns BC + li of an LW matrix
+  { const int c = BC + li, cb = c >> 4; wBC = opaque(hk * PSW + 32 * cb + 16 * ((pk ^ cb) & 1) + (c & 15)); }
+  // per wave, fixed for the sweep: the output block bw (C0..C2: 0..2, F: 3), the Sn block of L4 / L5 (sid = w - 4: block row 0), block 3 of Sn, the S-update block (blk = w)
+  int foW, foY, foB[4], snN, snP, wA3, suN, suZ, suY;
+  {
+    const int bw = w < 3 ? w : 3, r0 = 16 * (bw >> 1), c0 = 16 * (bw & 1);
+    foW = opaque((r0 / 2) * PSW + 2 * c0 + ((bw & 1) ? wP2b : wP2a));
+    foY = opaque(2 * c0 + ((bw & 1) ? wP2b : wP2a));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foB[ks] = opaque(LW::ix(r0 + li, BC + 4 * ks + lk));
+    const int sid = w & 1;                                   // (w = 4, 5)
+    snN = opaque(32 * sid + (sid ? nP2b : nP2a));
+    snP = opaque(32 * sid + (sid ? wP2b : wP2a));
+    const int ac3 = 16 + li < NX ? 16 + li : NX - 1;         // block row 1 of A': rows >= nx do not exist - those lanes read a column that does (and multiply it by zero)
+    wA3 = opaque(hk * PSW + 32 + 16 * (pk ^ 1) + (ac3 & 15));
+    const int blk = w & 3, ur0 = 16 * (blk >> 1), uc0 = 16 * (blk & 1);
+    suN = opaque((ur0 / 2) * PSN + 2 * uc0 + ((blk & 1) ? nP2b : nP2a));
+    suY = opaque(2 * uc0 + ((blk & 1) ? nP2b : nP2a));
+    const int gcol = ur0 + li < NX ? ur0 + li : ZN;           // column 31 of Z is never written: always zero
+    suZ = opaque(hk * PSN + 32 * (gcol >> 4) + 16 * ((pk ^ (gcol >> 4)) & 1) + (gcol & 15));
+  }
+  const double amask3 = 16 + li < NX ? 1.0 : 0.0;
 
   // Outputs of a stage that are not on the chain (block bw of each): [Acl | bcl] = [A | b] - B Y, [K | kff] = [Px | Pe] - Pu Y,
   // from the buffer set `buf` that stage was staged into.  A wave always forms the same block: C0..C2 the blocks 0..2, F block 3.
@@ -194,29 +231,22 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     }
   }
   auto finish_outputs = [&](int k, int buf, int nt, int bw) {
-    RM8SUB(0);
-    double (*const W)[LDW] = ws.W[buf];
-    double (*const PW)[LDW] = ws.PW[buf];
-    double (*const M)[LDW] = ws.M[buf];
+    const double* const W = ws.W[buf];
+    const double* const PW = ws.PW[buf];
+    const double* const M = ws.M[buf];
     const int ksn = (nt + 3) >> 2;
-    const int r0 = 16 * (bw >> 1), c0 = 16 * (bw & 1);
-    const int row = r0 + li;
-    v4d acl = blk_load<LDW, 32, 0>(&W[0][0], r0, c0, l);
-    v4d kf = blk_load<LDW, 32, 0>(&PW[0][0], r0, c0, l);
+    const int c0 = 16 * (bw & 1);
+    v4d acl, kf;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acl[r] = lds1(W[foW + 2 * r * PSW]); kf[r] = lds1(PW[foW + 2 * r * PSW]); }      // rows r0 + lk + 4 r, columns c0 + li
     double ab[4], ap[4], yb[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int kk = 4 * ks + lk;
-      yb[ks] = lds1(M[kk][c0 + li]);                             // -Y (E stores the gain negated); rows >= nt are zero
-      ab[ks] = lds1(W[row][BC + kk]);                                // B(i, kk); rows >= nx of W and PW are zero
-      ap[ks] = lds1(PW[row][BC + kk]);                               // Pu(i, kk)
+      yb[ks] = lds1(M[foY + 2 * ks * PSW]);                      // -Y(4 ks + lk, c0 + li) (E stores the gain negated); rows >= nt are zero
+      ab[ks] = lds1(W[foB[ks]]);                                 // B(i, kk) = W(r0 + li, BC + 4 ks + lk); rows >= nx of W and PW are zero
+      ap[ks] = lds1(PW[foB[ks]]);                                // Pu(i, kk)
     }
     __builtin_amdgcn_sched_barrier(0);
-    RM8SUB(1);
-#if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 20
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    RM8SUB(2);
-#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks < ksn) {                                            // wave-uniform
@@ -224,11 +254,6 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         kf = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[ks], yb[ks], kf, 0, 0, 0);
       }
     }
-#if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 20
-    asm volatile("v_mov_b64 %0, %0\n\ts_nop 4" : "+v"(acl[3]));
-    asm volatile("v_mov_b64 %0, %0\n\ts_nop 4" : "+v"(kf[3]));
-    RM8SUB(3);
-#endif
     // buffer stores: where a register of the block goes is a byte offset that is fixed for the whole sweep (Acl and K share it; column nx goes to
     // bcl / kff), an element that goes nowhere has an offset beyond the resource, the stage is the scalar offset of the instruction.  (As predicated
     // plain stores with 64-bit addresses the eight stores of a block were most of the 2.2 k cycles a block took beside the elimination.)
@@ -246,17 +271,17 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         __builtin_amdgcn_raw_buffer_store_b64(vk, rkff, oov[r], sv, 0);
       }
     }
-    RM8SUB(4);
   };
 
   // m = q~ - Y' r~, m0 = -r~' H^-1 g of a finished stage (one wave).  Rows >= nt of Y and of r~ are zero (the projection kernel pads
   // with zeros): all loads first, no branch per row.
   auto finish_m = [&](int k, int buf) {
     if (l <= NX) {
+      const int fm0 = 32 * (l >> 4) + 16 * ((l >> 4) & 1) + (l & 15);      // column l of an even row of an LW matrix (odd rows: bit 4 flipped)
       double yv[RE], rv[RE];
 #pragma unroll
-      for (int i = 0; i < RE; ++i) { yv[i] = ws.M[buf][i][l]; rv[i] = ws.r[buf][i]; }
-      double m0 = l < NX ? ws.Qq[buf][l][NX] : 0.0, m1 = 0.0;
+      for (int i = 0; i < RE; ++i) { yv[i] = ws.M[buf][(i >> 1) * PSW + ((i & 1) ? (fm0 ^ 16) : fm0)]; rv[i] = ws.r[buf][i]; }
+      double m0 = l < NX ? ws.Qq[buf][LN::ix(l, NX)] : 0.0, m1 = 0.0;
 #pragma unroll
       for (int i = 0; i < RE; i += 2) { m0 += yv[i] * rv[i]; m1 += yv[i + 1] * rv[i + 1]; }     // yv: -Y
       if (l < NX) io.mvec[(size_t)k * NX + l] = m0 + m1; else io.mscal[k] = m0 + m1;
@@ -267,46 +292,40 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   for (int k = k_top; k >= io.k_lo; --k) {
     const int nt = ws.nut[k];            // max_nodes <= kMaxRiccatiStages is checked when the solver is created
     const int cur = k & 1;
-    double (*const W)[LDW] = ws.W[cur];
-    double (*const PW)[LDW] = ws.PW[cur];
-    double (*const Qq)[LDN] = ws.Qq[cur];
-    double (*const M)[LDW] = ws.M[cur];
+    double* const W = ws.W[cur];
+    double* const PW = ws.PW[cur];
+    double* const Qq = ws.Qq[cur];
+    double* const M = ws.M[cur];
     double* const rvec = ws.r[cur];
     const int ksn = (nt + 3) >> 2;                   // k-steps over the reduced input
     const int nbc = (BC + nt + 15) >> 4;             // block columns of the packed width nx + 1 + nt
-    auto sn_block = [&](int sid) {     // [Sn | sn] = [Q | q] + A' SW(:, 0..nx), block sid of four
-      const int r0 = 16 * (sid >> 1), c0 = 16 * (sid & 1);
-      v4d acc = blk_load<LDN, 32, 0>(&Qq[0][0], r0, c0, l);
-      const int acol = r0 + li < NX ? r0 + li : LDW - 1;             // the last padding column of W is always zero
+    // [Sn | sn] = [Q | q] + A' SW(:, 0..nx), one block of four: TOP: block row 0 (block column w - 4 on L4 / L5), else block (1, 1); block (1, 0) is the mirror of (0, 1)
+    auto sn_block = [&](auto top_c) {
+      constexpr bool TOP = decltype(top_c)::value;
+      const int nb = TOP ? snN : 8 * PSN + 32 + nP2b;                // rows r0 + lk + 4 r, columns c0 + li of Qq / Sn
+      const int wa = TOP ? wP2a : wA3;                                // A'(i, kk) = W(4 ks + lk, r0 + li)
+      const int wb = TOP ? snP : 32 + wP2b;                           // SW(4 ks + lk, c0 + li)
+      v4d acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = lds1(Qq[nb + 2 * r * PSN]);
       double a[KS], b[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const int kk = 4 * ks + lk;
-        a[ks] = lds1(W[kk][acol]);                                  // A'(i, kk)
-        b[ks] = lds1(ws.SW[kk][c0 + li]);
+        a[ks] = lds1(W[wa + 2 * ks * PSW]);
+        b[ks] = lds1(ws.SW[wb + 2 * ks * PSW]);
+      }
+      if constexpr (!TOP) {          // rows >= nx of A' do not exist: their lanes have read a column that does (finite numbers; x 1.0 is exact)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[ks] *= amask3;
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-      blk_store<LDN, 32>(&ws.Sn[0][0], r0, c0, l, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ws.Sn[nb + 2 * r * PSN] = acc[r];
     };
     // ---- P0 (L): registers -> packed LDS layouts; what the projection kernel does not write (block columns >= nbc, rows >= nt) is staged as zero
-#if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 20      // how long the loader waves wait for their prefetch (and for whatever they stored since)
-    if (role_l) { const long long tw0 = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tacc[7] += clock64() - tw0; }
-#endif
-#if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 21      // the staging writes alone
-    const long long ts0 = clock64();
-#endif
-#ifndef BPMPC_RICCATI8_SPLIT_STAGE
-#define BPMPC_RICCATI8_SPLIT_STAGE 0     // 1: only W and M are staged before B0; PW (read by the outputs a stage later) and Qq (read by the Sn blocks behind B2) follow behind it
-#endif
-#ifndef BPMPC_RICCATI8_ABLATE
-#define BPMPC_RICCATI8_ABLATE 0      // timing experiments (wrong results): bit 0: stage / prefetch only once; bit 1: no outputs beside the elimination; bit 2: no elimination
-#endif
-    if (role_l && (!(BPMPC_RICCATI8_ABLATE & 1) || k == k_top)) { if (BPMPC_RICCATI8_SPLIT_STAGE) ld.stage_wm(W, M, rvec, nt); else ld.stage(W, PW, Qq, M, rvec, nt); }
-#if defined(BPMPC_RICCATI_PROFILE) && BPMPC_RICCATI_PROFILE == 21
-    tacc[7] += clock64() - ts0;
-#endif
+    if (role_l) ld.stage(W, PW, Qq, M, rvec, nt);
     RM8OWN(0);
     lds_barrier();                     // B0
     RM8PROF(0);
@@ -314,8 +333,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
     //      while it is still in the accumulators (their layout is the B-operand layout: lane (li, lk), register r <-> SW[r0 + lk + 4 r][c0 + li]),
     //      its part of [G | g | H](:, bj) = [P | r | R] + B' SW(:, bj): state rows 0..15 (block row 0, added to M) or 16.. (block row 1, to Mb).
     //      Round 3 had a phase of its own for G (a barrier, SW back from LDS, six matrix instructions on three waves); the elimination adds the two parts.
-    if (BPMPC_RICCATI8_SPLIT_STAGE && role_l) ld.stage_pq(PW, Qq);
-    if (role_l && w != 3 && k > io.k_lo && !(BPMPC_RICCATI8_ABLATE & 1)) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
+    if (role_l && k > io.k_lo) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);     // never beyond the chunk: earlier stages may not be projected yet
     if (w != 4 && w != 5) {
       const int id = w < 4 ? w : w - 2;
       if (id < 2 * nbc) {
@@ -324,35 +342,43 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         const int row = r0 + li;
         const double half = row < NX ? 0.5 : 0.0;
         constexpr int KG1 = KS - 4;                                      // k-steps of the second block row (state rows 16 .. nx - 1)
+        const int odd = (c0 >> 4) & 1;
+        const int wb = 2 * c0 + (odd ? wP2b : wP2a);                      // rows 4 ks + lk (or lk + 4 r), columns c0 + li of W, M, Mb, SW
+        const int sx0 = 8 * bi * PSN + nP1a, sx1 = 8 * bi * PSN + 32 + nP1b;     // S(row, 4 ks + lk): ks < 4 / ks >= 4
+        const int sy = 32 * bi + (bi ? nP2b : nP2a);                      // S(4 ks + lk, row)
         double a[KS], b[KS], sv[4], ga[4];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const int kk = 4 * ks + lk;
           // sym(S): the mean of the two triangles inside the diagonal blocks; block (1, 0) of S is never computed (the S update leaves it out, as
           // the wave-per-problem sweeps do) - its elements are read from block (0, 1): both terms of the mean are then the same element
           const bool up = (bi == 0 && ks >= 4), lo = (bi != 0 && ks < 4);
-          a[ks] = half * (lds1(ws.S[lo ? kk : row][lo ? row : kk]) + lds1(ws.S[up ? row : kk][up ? kk : row]));
-          b[ks] = lds1(W[kk][c0 + li]);
+          const int ex = (ks < 4 ? sx0 : sx1) + 4 * (ks & 3), ey = sy + 2 * ks * PSN;
+          a[ks] = half * (lds1(ws.S[lo ? ey : ex]) + lds1(ws.S[up ? ex : ey]));
+          b[ks] = lds1(W[wb + 2 * ks * PSW]);
         }
         const double smask = (c0 + li == NX) ? 1.0 : 0.0;              // s rides in the b column; rows >= nx of S are zero
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sv[r] = smask * lds1(ws.S[r0 + lk + 4 * r][NX]);
+        for (int r = 0; r < 4; ++r) sv[r] = smask * lds1(ws.S[nSV + (8 * bi + 2 * r) * PSN]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ga[ks] = (bi == 0 || ks < KG1) ? lds1(W[r0 + 4 * ks + lk][BC + li]) : 0.0;     // B'(i, kk); columns >= nt and rows >= nx of B~ are zero
-        v4d g = blk_load<LDW, 32, 0>(&M[0][0], 0, c0, l);
+        for (int ks = 0; ks < 4; ++ks) ga[ks] = (bi == 0 || ks < KG1) ? lds1(W[wBC + (8 * bi + 2 * ks) * PSW]) : 0.0;     // B'(i, kk) = W(r0 + 4 ks + lk, BC + li); columns >= nt and rows >= nx of B~ are zero
+        v4d g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[r] = lds1(M[wb + 2 * r * PSW]);
         if (bi != 0) g = v4d{0.0, 0.0, 0.0, 0.0};
         __builtin_amdgcn_sched_barrier(0);
         v4d acc = {sv[0], sv[1], sv[2], sv[3]};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-        blk_store<LDW, 32>(&ws.SW[0][0], r0, c0, l, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws.SW[wb + (8 * bi + 2 * r) * PSW] = acc[r];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
           if (bi == 0 || ks < KG1) g = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[ks], acc[ks], g, 0, 0, 0);
-        blk_store<LDW, 32>(bi == 0 ? &M[0][0] : &ws.Mb[0][0], 0, c0, l, g);
+        double* const gd = bi == 0 ? M : ws.Mb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gd[wb + 2 * r * PSW] = g[r];
       }
     }
-    if (role_l && w == 3 && k > io.k_lo) ld.prefetch(ws.nut[k - 1], ws.mode[k - 1]);      // C3 as a loader: its requests follow its block
     RM8OWN(1);
     lds_barrier();                     // B2 (there is no B1 any more)
     RM8PROF(1);
@@ -374,13 +400,17 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       bool ok;
       // rows nt .. of Z and Yn up to the k-step boundary must read as zero (an earlier stage may have had more reduced inputs)
       if (rhs) {
-        for (int i = nt; i < 4 * ksn; ++i) { ws.Zt[i][col] = 0.0; ws.Yn[i][col] = 0.0; }
+        for (int i = nt; i < 4 * ksn; ++i) { ws.Zt[LN::ix(i, col)] = 0.0; ws.Yn[LN::ix(i, col)] = 0.0; }
       }
       // every lane stores, the ones without a right-hand side into four spare columns (nx + 2 ..: never read as Z; as Yn they only make
       // columns > nx + 1 of S, which no product reads): a lane predicate here is an s_and_saveexec / branch pair per pivot on the critical wave
-      static_assert(NX + 2 + 3 < LDN - 1 && 4 * KS <= NX + 2, "spare columns of Z / Yn");
+      static_assert(NX + 2 + 3 < ZN && 4 * KS <= NX + 2, "spare columns of Z / Yn");
       const int ecol = rhs ? col : NX + 2 + (l & 3);
-      auto emit = [&](int p, double z, double y) { ws.Zt[p][ecol] = z; ws.Yn[p][ecol] = y; };
+      // element (i, column of this lane): the lane part for even rows; odd rows exchange the halves of the chunk pair (bit 4 - the lane parts are below 32 + 16 + 16)
+      const int eM0 = 32 * (col >> 4) + 16 * ((col >> 4) & 1) + (col & 15), eM1 = eM0 ^ 16;
+      const int eN0 = 32 * (ecol >> 4) + 16 * ((ecol >> 4) & 1) + (ecol & 15), eN1 = eN0 ^ 16;
+      auto emit = [&](int p, double z, double y) { const int at = (p >> 1) * PSN + ((p & 1) ? eN1 : eN0); ws.Zt[at] = z; ws.Yn[at] = y; };
+#define BP_EM(i) (((i) >> 1) * PSW + (((i) & 1) ? eM1 : eM0))
 #define BP_GJ_CASE(ROWS, FWD, BWD)                                                            \
       {                                                                                       \
         double v[ROWS];                                                                       \
@@ -388,26 +418,25 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
                part arrives in two groups - 15 instead of 20 values in flight, or the kernel needs scratch -, which starts the elimination an LDS round trip later */ \
           constexpr int H1 = NJ <= 10 ? ROWS : (ROWS + 1) / 2;                                \
           double ta[ROWS], tb[H1];                                                            \
-          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) ta[i] = lds1(M[i][col]);           \
-          _Pragma("unroll") for (int i = 0; i < H1; ++i) tb[i] = lds1(ws.Mb[i][col]);         \
+          _Pragma("unroll") for (int i = 0; i < ROWS; ++i) ta[i] = lds1(M[BP_EM(i)]);         \
+          _Pragma("unroll") for (int i = 0; i < H1; ++i) tb[i] = lds1(ws.Mb[BP_EM(i)]);       \
           _Pragma("unroll") for (int i = 0; i < ROWS; ++i) asm volatile("" : "+v"(ta[i]));    \
           _Pragma("unroll") for (int i = 0; i < H1; ++i) asm volatile("" : "+v"(tb[i]));      \
           /* (no masks: rows >= nt of M and Mb are zero - they are staged as zeros and B~ has no columns there -, and a lane without a column eliminates column 0 into a spare column) */ \
           _Pragma("unroll") for (int i = 0; i < H1; ++i) v[i] = ta[i] + tb[i];              \
           if constexpr (H1 < ROWS) {                                                          \
-            _Pragma("unroll") for (int i = H1; i < ROWS; ++i) tb[i - H1] = ws.Mb[i][col];     \
+            _Pragma("unroll") for (int i = H1; i < ROWS; ++i) tb[i - H1] = ws.Mb[BP_EM(i)];       \
             _Pragma("unroll") for (int i = H1; i < ROWS; ++i) asm volatile("" : "+v"(tb[i - H1])); \
             _Pragma("unroll") for (int i = H1; i < ROWS; ++i) v[i] = ta[i] + tb[i - H1];     \
           }                                                                                   \
         }                                                                                     \
-        if (BPMPC_RICCATI8_ABLATE & 4) ok = true; else                                        \
         ok = FWD(v, nt, emit);                                                          \
         if (l == 0 && !ok) ws.status = 1;                                                     \
         RM8PROF(6);                                                                           \
         lds_barrier();                 /* B3 */                                               \
         RM8PROF(3);                                                                           \
         BWD<ROWS>(v, nt);                                                                     \
-        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (rhs && i < nt) M[i][col] = -v[i];    /* -Y: saves the negations of the four output blocks */ \
+        _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (rhs && i < nt) M[BP_EM(i)] = -v[i];    /* -Y: saves the negations of the four output blocks */ \
       }
       // the elimination is the longest dependent chain of a stage: instantiate it for the actual number of rows
       if (rows_layout) {
@@ -419,31 +448,31 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
         else BP_GJ_CASE(RE, forward_eliminate_wave<RE>, back_substitute_wave)
       }
 #undef BP_GJ_CASE
+#undef BP_EM
     } else {
-      if (w == 4 || w == 5) sn_block(w - 4);
-      if (w == 4) sn_block(3);         // (not C3: a block of Sn beside E on SIMD 3 slowed the elimination from 2290 to 2720 cycles; block 2 = (1, 0) is not needed)
-      if (w == 5 && pend_k >= 0 && !(BPMPC_RICCATI8_ABLATE & 2)) finish_m(pend_k, cur ^ 1);      // (not E after its back substitution: the staging barrier waited for it)
-      if ((w < 3 || role_f) && pend_k >= 0 && !(BPMPC_RICCATI8_ABLATE & 2)) finish_outputs(pend_k, cur ^ 1, pend_nt, w < 3 ? w : 3);
+      if (w == 4 || w == 5) sn_block(std::true_type{});
+      if (w == 4) sn_block(std::false_type{});         // (not C3: a block of Sn beside E on SIMD 3 slowed the elimination from 2290 to 2720 cycles; block 2 = (1, 0) is not needed)
+      if (w == 5 && pend_k >= 0) finish_m(pend_k, cur ^ 1);      // (not E after its back substitution: the staging barrier waited for it)
+      if ((w < 3 || role_f) && pend_k >= 0) finish_outputs(pend_k, cur ^ 1, pend_nt, w < 3 ? w : 3);
       RM8PROF(6);
       lds_barrier();                   // B3
       RM8PROF(3);
-      if (kC3Loads ? w < 3 : (role_c && w != 2)) {          // block (1, 0) of S is the mirror of (0, 1): nobody reads it
-        const int blk = kC3Loads && w == 2 ? 3 : w;
-        const int r0 = 16 * (blk >> 1), c0 = 16 * (blk & 1);
-        v4d acc = blk_load<LDN, 32, 0>(&ws.Sn[0][0], r0, c0, l);
-        const int gcol = r0 + li < NX ? r0 + li : LDN - 1;              // the last padding column of Z is always zero
+      if (role_c && w != 2) {          // block (1, 0) of S is the mirror of (0, 1): nobody reads it
+        v4d acc;                                                         // block blk = w: rows r0 + lk + 4 r, columns c0 + li of Sn
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = lds1(ws.Sn[suN + 2 * r * PSN]);
         double ag[4], yb[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const int kk = 4 * ks + lk;
-          ag[ks] = -lds1(ws.Zt[kk][gcol]);                                    // -Z'(i, kk)
-          yb[ks] = lds1(ws.Yn[kk][c0 + li]);
+          ag[ks] = -lds1(ws.Zt[suZ + 2 * ks * PSN]);                          // -Z'(i, kk) = -Zt(4 ks + lk, r0 + li)
+          yb[ks] = lds1(ws.Yn[suY + 2 * ks * PSN]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
           if (ks < ksn) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[ks], yb[ks], acc, 0, 0, 0);
-        blk_store<LDN, 32>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, two barriers ago
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws.S[suN + 2 * r * PSN] = acc[r];      // S was last read in P1, two barriers ago
       }
     }
     pend_k = k; pend_nt = nt;
@@ -454,9 +483,6 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #ifdef BPMPC_RICCATI_PROFILE
 #if BPMPC_RICCATI_PROFILE == 2      // own work of every wave between B2 and B3
   if (io.prof && l == 0) io.prof[w] = (double)tacc[6];
-#elif BPMPC_RICCATI_PROFILE == 20   // steps of an output block, per wave: slots 1..4 of waves 0 (C0) and 6 (F)
-  if (io.prof && l == 0 && w == 0) for (int i = 1; i < 5; ++i) io.prof[i - 1] = (double)tacc[i];
-  if (io.prof && l == 0 && w == 6) for (int i = 1; i < 5; ++i) io.prof[3 + i] = (double)tacc[i];
 #elif BPMPC_RICCATI_PROFILE >= 10   // own work of every wave in phase BPMPC_RICCATI_PROFILE - 10 (0: staging, 1: SW, 2: G, 4: S update incl. E's back substitution)
   if (io.prof && l == 0) io.prof[w] = (double)tacc[7];
 #else
@@ -470,8 +496,8 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   if (w == 5 && pend_k >= 0) finish_m(pend_k, pend_k & 1);
   __syncthreads();
   if (io.k_lo > 0) {                                   // hand over to the launch that sweeps the earlier stages
-    for (int idx = tid; idx < NXX; idx += NT) { const int r = idx / NX, c = idx % NX; io.carry[idx] = (r >= 16 && c < 16) ? ws.S[c][r] : ws.S[r][c]; }
-    if (tid < NX) io.carry[NXX + tid] = ws.S[tid][NX];
+    for (int idx = tid; idx < NXX; idx += NT) { const int r = idx / NX, c = idx % NX; io.carry[idx] = (r >= 16 && c < 16) ? ws.S[LN::ix(c, r)] : ws.S[LN::ix(r, c)]; }
+    if (tid < NX) io.carry[NXX + tid] = ws.S[LN::ix(tid, NX)];
     if (tid == 0) io.carry[NXX + NX] = (double)ws.status;
     return;
   }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Riccati-only A/B of libraries tools/probes/lib_<name>.bin on one box: per-class kernel times of the headline bench (wrong results allowed: ablations)
 # usage: bash tools/probes/ab_ric.sh "name1 name2 ..." [bench args]
-export TMPDIR=/tmp PYTHONPATH=. BPMPC_RICCATI8_S=${BPMPC_RICCATI8_S:-1}
+export TMPDIR=/tmp PYTHONPATH=.
 cp bipedal_control_amd/libbpmpc.so /tmp/keep.so
 NAMES=$1; shift
 timeout 300 python bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-fused >/dev/null 2>&1

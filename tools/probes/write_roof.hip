@@ -6,7 +6,7 @@
 //              instructions of 8 B per lane through the role pointers of linearize_fast.h:RoleSlots (unaligned 48 .. 128-byte pieces of
 //              176-byte rows, the dump line for lanes without a role), then e, b, q, r, the compact Q / R record and the scalars - at the
 //              lineariser's geometry (256-thread workgroups, 76 KB of LDS each: two per CU) and without the LDS (occupancy by registers only)
-// Standalone:  hipcc --offload-arch=gfx950 -O3 tools/probes/write_roof.hip -o /tmp/write_roof && /tmp/write_roof [batch] [nodes per problem]
+// Standalone:  hipcc --offload-arch=gfx950 -O3 tools/probes/write_roof.hip -o /tmp/write_roof && /tmp/write_roof [batch] [nodes per problem] [nx: 22 | 24]
 // As a library (bench.py loads it over ctypes and reports `write_roof_GBs` beside roofline.frac):
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -DWRITE_ROOF_LIB tools/probes/write_roof.hip -o tools/probes/libwrite_roof.so
 #include <hip/hip_runtime.h>
@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int NX = 22, NU = 22, EQ = 16, QRD = 40;      // H1: the shape the roofline unit is defined on
+constexpr int EQ = 16, QRD = 40;      // NX = NU = 22 (H1: the shape the roofline unit is defined on) or 24 (G1 class)
 constexpr int kDumpNodes = 1024;
 
 __global__ __launch_bounds__(256) void k_fill16(double2* p, size_t n2) {
@@ -36,8 +36,9 @@ struct Out {
 
 // the role pointers of an unpacked node (16 coordinates): slot 0 = x column 6 + ln | slot 1 = momentum column (lanes 0..5) or joint-velocity
 // column | slot 2 = force column (lanes 0..11) or the dump
-template <int LDS_BYTES>
+template <int LDS_BYTES, int NX>
 __global__ __launch_bounds__(256) void k_pattern(Out o, int nodes) {
+  constexpr int NU = NX;
   __shared__ char pad[LDS_BYTES > 0 ? LDS_BYTES : 1];
   if (LDS_BYTES > 0 && threadIdx.x == 0) pad[blockIdx.x % LDS_BYTES] = 1;      // keep the allocation
   const int ln = threadIdx.x % 16;
@@ -46,13 +47,26 @@ __global__ __launch_bounds__(256) void k_pattern(Out o, int nodes) {
   double* dump = o.dump + ((s & (size_t)(kDumpNodes - 1)) * 16 + ln);
   const double v = (double)(s + ln);
   auto rows = [&](double* X, double* U, int nrows) {
-    double* p0 = X + (6 + ln);
-    double* p1 = ln < 6 ? X + ln : U + (12 + ln - 6);
-    double* p2 = ln < 12 ? U + ln : dump;
+    if constexpr (NX == 22) {
+      double* p0 = X + (6 + ln);
+      double* p1 = ln < 6 ? X + ln : U + (12 + ln - 6);
+      double* p2 = ln < 12 ? U + ln : dump;
 #pragma unroll
-    for (int r = 0; r < nrows; ++r) {
-      p0[r * NX] = v; p1[r * NX] = v; p2[r * NX] = v;
-      __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < nrows; ++r) {
+        p0[r * NX] = v; p1[r * NX] = v; p2[r * NX] = v;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {                      // packed lanes (linearize_fast.h RoleSlots, G0 = 3): lane ln carries coordinate g = ln + 3; four role slots
+      const int g = ln + 3, G = NX - 6;
+      double* p0 = g < G ? X + (6 + g) : dump;
+      double* p1 = ln < 3 ? X + (6 + ln) : (g < G ? U + (12 + g - 6) : dump);
+      double* p2 = ln < 12 ? U + ln : dump;
+      double* p3 = ln < 6 ? X + ln : dump;
+#pragma unroll
+      for (int r = 0; r < nrows; ++r) {
+        p0[r * NX] = v; p1[r * NX] = v; p2[r * NX] = v; p3[r * NX] = v;
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   rows(o.C + s * (EQ * NX), o.D + s * (EQ * NU), EQ);
@@ -60,10 +74,12 @@ __global__ __launch_bounds__(256) void k_pattern(Out o, int nodes) {
   rows(o.A + s * (NX * NX), o.B + s * (NX * NU), NX);
   o.b[s * NX + 6 + ln] = v;
   if (ln < 6) o.b[s * NX + ln] = v;
+  if (NX > 22 && ln < NX - 22) o.b[s * NX + 22 + ln] = v;
   rows(o.Q + s * (NX * NX), o.R + s * (NU * NU), NX);
   if (ln < 12) for (int a = 0; a < 3; ++a) o.qrd[s * QRD + 1 + 3 * ln + a] = v;
   o.q[s * NX + 6 + ln] = v;
   if (ln < 6) o.q[s * NX + ln] = v;
+  if (NX > 22 && ln < NX - 22) { o.q[s * NX + 22 + ln] = v; o.r[s * NU + 22 + ln] = v; }
   if (ln < 12) o.r[s * NU + ln] = v;
   if (ln >= 6) o.r[s * NU + 12 + ln - 6] = v;
   if (ln == 0) { o.qrd[s * QRD] = v; o.c[s] = v; o.nc[s] = 12; o.perf[s * 3] = v; o.perf[s * 3 + 1] = v; o.perf[s * 3 + 2] = v; }
@@ -93,7 +109,9 @@ int time_ms(F&& launch, int reps, float* ms) {
   return 0;
 }
 
+template <int NX>
 int measure(int batch, int nodes_per_problem, Roof* out) {
+  constexpr int NU = NX;
   const size_t nodes = (size_t)batch * nodes_per_problem;
   // bytes a node's stores carry (dump lanes excluded): the lineariser's output, 21 784 B at H1 + the 320-byte record's written part
   const size_t per_node = (size_t)(EQ * (NX + NU) + EQ + NX * (NX + NU) + NX + NX * (NX + NU) + NX + NU + 37 + 4) * 8 + 4;
@@ -115,9 +133,9 @@ int measure(int batch, int nodes_per_problem, Roof* out) {
   if (time_ms([&] { hipLaunchKernelGGL(k_fill8, dim3(fill_grid), dim3(256), 0, 0, flat, total / 8); }, reps, &ms)) return 1;
   out->fill8_GBs = total / 8 * 8 / (ms * 1e6);
   const int grid = (int)((nodes + 15) / 16);
-  if (time_ms([&] { hipLaunchKernelGGL(k_pattern<76264>, dim3(grid), dim3(256), 0, 0, o, (int)nodes); }, reps, &ms)) return 1;
+  if (time_ms([&] { hipLaunchKernelGGL((k_pattern<76264, NX>), dim3(grid), dim3(256), 0, 0, o, (int)nodes); }, reps, &ms)) return 1;
   out->pattern_ms = ms; out->pattern_GBs = total / (ms * 1e6);
-  if (time_ms([&] { hipLaunchKernelGGL(k_pattern<0>, dim3(grid), dim3(256), 0, 0, o, (int)nodes); }, reps, &ms)) return 1;
+  if (time_ms([&] { hipLaunchKernelGGL((k_pattern<0, NX>), dim3(grid), dim3(256), 0, 0, o, (int)nodes); }, reps, &ms)) return 1;
   out->pattern_free_ms = ms; out->pattern_free_GBs = total / (ms * 1e6);
   out->bytes_fill = (double)total; out->bytes_pattern = (double)total;
   for (double* p : {o.A, o.B, o.b, o.Q, o.R, o.q, o.r, o.c, o.C, o.D, o.e, o.perf, o.qrd, o.dump, flat}) CK(hipFree(p));
@@ -129,9 +147,10 @@ int measure(int batch, int nodes_per_problem, Roof* out) {
 
 // out[0..8]: fill16 GB/s, fill8 GB/s, pattern GB/s at the lineariser's occupancy, pattern GB/s at free occupancy, bytes per launch,
 // pattern ms, pattern ms (free), fill16 ms, 0
-extern "C" int write_roof_measure(int batch, int nodes_per_problem, double* out) {
+extern "C" int write_roof_measure(int batch, int nodes_per_problem, int nx, double* out) {
   Roof r{};
-  if (measure(batch, nodes_per_problem, &r)) return 1;
+  if (nx != 22 && nx != 24) return 2;
+  if (nx == 22 ? measure<22>(batch, nodes_per_problem, &r) : measure<24>(batch, nodes_per_problem, &r)) return 1;
   out[0] = r.fill16_GBs; out[1] = r.fill8_GBs; out[2] = r.pattern_GBs; out[3] = r.pattern_free_GBs; out[4] = r.bytes_pattern;
   out[5] = r.pattern_ms; out[6] = r.pattern_free_ms; out[7] = r.fill16_ms; out[8] = 0.0;
   return 0;
@@ -139,9 +158,9 @@ extern "C" int write_roof_measure(int batch, int nodes_per_problem, double* out)
 
 #ifndef WRITE_ROOF_LIB
 int main(int argc, char** argv) {
-  const int batch = argc > 1 ? std::atoi(argv[1]) : 256, npp = argc > 2 ? std::atoi(argv[2]) : 103;
+  const int batch = argc > 1 ? std::atoi(argv[1]) : 256, npp = argc > 2 ? std::atoi(argv[2]) : 103, nx = argc > 3 ? std::atoi(argv[3]) : 22;
   double o[9];
-  if (write_roof_measure(batch, npp, o)) return 1;
+  if (write_roof_measure(batch, npp, nx, o)) return 1;
   std::printf("{\"batch\": %d, \"nodes_per_problem\": %d, \"bytes_per_launch\": %.0f, \"fill16_GBs\": %.1f, \"fill8_GBs\": %.1f, "
               "\"pattern_GBs\": %.1f, \"pattern_ms\": %.4f, \"pattern_free_occupancy_GBs\": %.1f, \"pattern_free_occupancy_ms\": %.4f, \"fill16_ms\": %.4f}\n",
               batch, npp, o[4], o[0], o[1], o[2], o[5], o[3], o[6], o[7]);
