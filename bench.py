@@ -44,6 +44,7 @@ ROBOT_LABEL = {"h1": "Unitree H1", "openloong": "OpenLoong (nx = nu = 24)", "g1"
                "h1:hard": "Unitree H1 with useHardFrictionConeConstraint (cones as inequality constraints, sqp.inequalityConstraintMu / Delta)",
                "hunter:hard": "Hunter with useHardFrictionConeConstraint"}
 KERNEL_CLASSES = ("linearize", "project_lu", "project", "riccati", "linesearch")
+DDP_KERNEL_CLASSES = ("linearize", "project_lu", "project", "riccati", "ddp_rollout", "ddp_search")      # --solver ddp: the line search is roll-outs + cost / decision
 
 
 def parse_args():
@@ -75,6 +76,14 @@ def parse_args():
                     help="collective of the solved trajectories per step: all-gather (every rank holds every block) or gather to rank 0; auto = "
                          "root for --scaling strong and --workload gait-sweep (the north-star's \"final gather\": one job, one owner of the "
                          "result), all for weak scaling (independent per-GPU batches, the contract's default line)")
+    ap.add_argument("--gather-report", action="store_true",
+                    help="report what RCCL chose for the per-solve gather (algorithm, protocol, transports, channels) in config.distributed.collective: "
+                         "switches NCCL_DEBUG=INFO on before the process group exists and parses rank 0's log after the run (off by default: the log costs time)")
+    ap.add_argument("--gather-algo", default=None, help="passed through as NCCL_ALGO (e.g. Ring, Tree) before the process group exists; recorded in the line")
+    ap.add_argument("--gather-proto", default=None, help="passed through as NCCL_PROTO (LL, LL128, Simple); recorded in the line")
+    ap.add_argument("--solver", default="sqp", choices=["sqp", "ddp"],
+                    help="sqp: the reference's SqpMpc (the headline metric); ddp: its second solver, GaussNewtonDDP_MPC as configured (one ILQR iteration, "
+                         "line search over eight policy roll-outs per problem): a line of its own, `metric` says DDP")
     ap.add_argument("--chunks", type=int, default=0, help="horizon chunks of the linearise/project || Riccati pipeline (0 = library default, 1 = off)")
     return ap.parse_args()
 
@@ -123,6 +132,17 @@ def main():
     torch.cuda.set_device(device)
     use_dist = world > 1 or os.environ.get("BPMPC_BENCH_FORCE_DIST") == "1"   # the latter exercises RCCL with one rank
     backend = os.environ.get("BPMPC_BENCH_BACKEND", "gloo" if (one_device and world > 1) else "nccl")
+    nccl_log = None
+    if use_dist and backend == "nccl" and (args.gather_report or args.gather_algo or args.gather_proto):
+        from bipedal_control_amd import distributed as bd0
+        if args.gather_report:
+            nccl_log = os.path.join(os.environ.get("TMPDIR", "/tmp"), "bpmpc_nccl_%d_rank%d.log" % (os.getpid(), rank))
+            os.environ.update(bd0.nccl_debug_env(nccl_log, args.gather_algo, args.gather_proto))
+        else:
+            if args.gather_algo:
+                os.environ["NCCL_ALGO"] = args.gather_algo
+            if args.gather_proto:
+                os.environ["NCCL_PROTO"] = args.gather_proto
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -163,6 +183,8 @@ def main():
         scaling = args.scaling
         prob = scenarios.trot_problem(itf, batch=B, n_intervals=NI, offset=lo, gait=gait, gait_start=args.gait_start)
         max_nodes = NI + 16
+        if args.solver == "ddp":
+            max_nodes = 2 * NI + 32      # a DDP solution lives on the time points of its roll-out (70 .. 130 at this horizon): the arrays must hold them
     if B < 1:
         raise SystemExit("rank %d owns no problems (more ranks than work units)" % rank)
 
@@ -173,8 +195,14 @@ def main():
     # sweep the north-star asks to profile and the one the roofline unit (algorithmic bytes per node linearisation) is defined on.
     # The engine's default, fused solve mode (the lineariser leaves only what the solve reads; identical solution bits) is timed in a
     # second region of the same length and reported as `fused` ("report both").
-    mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=max_nodes, profile=(0 if args.no_profile else (1 if args.profile_all else 2)), device=device,
-                           stream=s.cuda_stream, pipeline_chunks=args.chunks, materialize_lq=True)
+    ddp = args.solver == "ddp"
+    if ddp and sweep:
+        raise SystemExit("--solver ddp runs the trot workload")
+    global KERNEL_CLASSES
+    if ddp:
+        KERNEL_CLASSES = DDP_KERNEL_CLASSES
+    mpc = (bp.BatchedDdpMpc if ddp else bp.BatchedSqpMpc)(itf, max_batch=B, max_nodes=max_nodes, profile=(0 if args.no_profile else (1 if args.profile_all else 2)), device=device,
+                                                          stream=s.cuda_stream, pipeline_chunks=args.chunks, materialize_lq=True)
     if sweep:
         lay = mpc.setup_commands(cp["t0"], cp["x0"], cp["gaits"], cp["gait_of_problem"], cp["gait_start"], cp["cmd_vel"], horizon=cp["horizon"])
     else:
@@ -238,6 +266,8 @@ def main():
 
         t, x, u, _, stats = mpc.fetch()
         ok = sum(1 for st in stats if st.status == 0)
+        if ddp:     # status 1 = no step length passed the Armijo test, the baseline roll-out (new gains, no feedforward increment) is the solution: a valid solve
+            ok = sum(1 for st in stats if st.status in (0, 1))
         lin_timed = mpc.kernel_time("linearize", reset=False)         # HIP events attached to the kernel's dispatches on the launch stream, over exactly the timed steps
         # error bar of `value`: the same region of `steps` steps four more times (the line's value stays the FIRST region, the contract's)
         spread = [elapsed / args.steps * 1e3]
@@ -320,19 +350,22 @@ def main():
             achieved = alg_bytes / avg_s / 1e9
             # HBM bytes seen by the PMC counters for this workload, when a committed pass of the same command exists (builder run, not
             # measured in this process: counters need rocprofv3 around the whole command)
-            prof = committed_traffic(args.robot, gait, sweep, B, NI)
+            prof = None if ddp else committed_traffic(args.robot, gait, sweep, B, NI)      # (the committed counter passes are of the SQP command)
             traffic = prof["kernels"].get("linearize_materialised") if prof else None
             if fused is not None and prof:
                 fused["hbm_bytes_per_step"] = prof.get("fused_hbm_bytes_per_step")
                 fused["materialised_hbm_bytes_per_step"] = prof.get("materialised_hbm_bytes_per_step")
                 fused["hbm_bytes_source"] = prof["source"]
-            roofline = {"kernel": "k_linearize_fast<%d, true, ..>" % (nx - 12), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"kernel": "k_linearize_fast<%d, true, true%s>" % (nx - 12, ", ILQR" if ddp else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_stale": bool(prof and prof.get("stale")), "traffic_source": (prof["source"] if prof else None),
                         "avg_launch_us": round(1e6 * avg_s, 2),
                         "timing": "HIP events attached to the kernel's dispatch on its launch stream (hipExtLaunchKernelGGL start / stop events), every "
                                   "launch of the timed region: the kernel's duration, the figure the rocprofv3 kernel trace reports",
                         "algorithmic_bytes_per_launch": round(alg_bytes), "launches_per_step": launches_per_step,
                         "node_linearizations_per_s": round(n_intermediate_total / launches_per_step / avg_s, 1), "measured_on": "rank 0"}
+            # calibration of `frac` for a kernel whose HBM traffic is 97 % stores: what a write-only stream of the same bytes achieves on this
+            # device, measured here, outside the timed region (tools/probes/write_roof.hip: the lineariser's own store pattern without arithmetic)
+            roofline["write_roof"] = write_roof(B, int(round(n_intermediate_total / max(1.0, launches_per_step) / B)), nx, achieved)
         headline = (args.robot, gait, sweep, NI) == ("h1", "trot", False, 100)
         if sweep:
             wl = "%s gait-library sweep: %d gaits (%s) x %d velocity commands, horizon=%d intervals (dt 0.015), generated on the device, " \
@@ -340,10 +373,12 @@ def main():
         else:
             wl = "%s %s (template tiled from t = %g), horizon=%d intervals (dt 0.015), %s perturbed initial states, cold start, 1 SQP iteration (%s)" % (
                 ROBOT_LABEL[args.robot], gait, args.gait_start, NI, ("batch=%d per GPU" % args.batch) if scaling == "weak" else ("global batch %d in contiguous slices" % total),
+                "the shape of BASELINE.json configs[1] through the reference's second solver, GaussNewtonDDP_MPC: 1 ILQR iteration, %d policy roll-outs per problem in the line search" % (
+                    1 + sum(1 for k in range(16) if 0.5 ** k >= 1e-2)) if ddp else
                 "BASELINE.json configs[1]" if headline and scaling == "weak" and args.batch == 256 else
                 "BASELINE.json configs[2]" if headline and scaling == "strong" and total == 4096 else
                 "BASELINE.json configs[3]" if (args.robot, gait, NI) == ("g1", "standing_trot", 100) else "not the headline workload")
-        out = {"metric": "MPC solves/s (%s, horizon=%d)" % ({"h1": "H1", "g1": "G1", "h1:hard": "H1 hard cones"}.get(args.robot, args.robot), NI), "value": round(value, 2), "unit": "solves/s", "n_gpus": world,
+        out = {"metric": ("DDP (ILQR) " if ddp else "") + "MPC solves/s (%s, horizon=%d)" % ({"h1": "H1", "g1": "G1", "h1:hard": "H1 hard cones"}.get(args.robot, args.robot), NI), "value": round(value, 2), "unit": "solves/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "settle_steps": max(0, args.settle), "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": wl, "global_batch": total, "problems_on_rank0": B, "shooting_nodes": n_nodes,
@@ -353,7 +388,9 @@ def main():
                           "accepted_steps_rank0": ok,
                           "distributed": {"backend": (dist.get_backend() if use_dist else None), "world_size_seen": (dist.get_world_size() if use_dist else 1),
                                           "gather": args.gather if use_dist else None, "devices": ("one shared device" if one_device and world > 1 else "one per rank"),
-                                          "rank_ms_per_step_min": round(rank_ms_min, 4), "rank_ms_per_step_max": round(elapsed / args.steps * 1e3, 4)},
+                                          "rank_ms_per_step_min": round(rank_ms_min, 4), "rank_ms_per_step_max": round(elapsed / args.steps * 1e3, 4),
+                                          "gather_algo_requested": args.gather_algo, "gather_proto_requested": args.gather_proto,
+                                          "collective": collective_report(nccl_log, backend if use_dist else None, args.gather_report)},
                           "job_report": {"merit_sum": report[0], "dynamics_sse_sum": report[1], "equality_sse_sum": report[2], "failures": int(report[3]),
                                          "gather_consistent": bool(gathered_ok)}},
                "ms_per_solve": round(ms_per_step / max(1, total // world), 6),
@@ -366,10 +403,10 @@ def main():
         n_all_nodes = int(sum(g_nodes[p_grid])) if world == 1 else None
         if world == 1:
             out["roofline_fp64"] = roofline_fp64("h1" if nx == 22 else "g1", kms, n_intermediate_total, n_all_nodes, n_all_nodes,
-                                                 applicable=headline and scaling == "weak" and args.batch == 256)
+                                                 applicable=headline and scaling == "weak" and args.batch == 256 and not ddp)
             nut_mean = float(mpc.read("nut").reshape(B, max_nodes)[:, :n_nodes][kinds[p_grid][:, :n_nodes] == 0].mean())
             out["roofline_all"] = roofline_all(nx, nu, nut_mean, kms, n_intermediate_total, n_all_nodes, out.get("roofline_fp64"),
-                                               committed_traffic(args.robot, gait, sweep, B, NI))
+                                               None if ddp else committed_traffic(args.robot, gait, sweep, B, NI))
         if roofline is not None:
             # what binds the roofline kernel: the largest of the fractions of the three roofs it could sit under, "latency" when none of them
             # is half used (then the kernel waits: low occupancy / dependent chains, see roofline_fp64.<kernel>.wave_time_split)
@@ -383,7 +420,13 @@ def main():
             roofline["bound_fracs"] = fr
             roofline["bound_note"] = ("`frac` stays achieved / HBM peak (the roof the north-star names); fp64-issue / mfma fractions use executed-instruction "
                                       "counts from profiles/%s (builder run) at this run's kernel time" % sq_counters_file())
-        if world == 1 and args.cpu_sample > 0:
+        if ddp:
+            out["config"]["solver"] = "ddp"
+            out["config"]["step_lengths"] = {str(a): int(sum(1 for st in stats if st.step_size == a)) for a in sorted({st.step_size for st in stats}, reverse=True)}
+            out["config"]["roll_out_points_mean"] = round(float(np.mean([st.n_nodes + 1 for st in stats])), 1)
+        if world == 1 and args.cpu_sample > 0 and ddp:
+            out["cpu_baseline"] = cpu_baseline_ddp(prob, min(args.cpu_sample, 2), t, x, stats, args.robot)
+        elif world == 1 and args.cpu_sample > 0:
             if sweep:
                 out["cpu_baseline"] = cpu_baseline_sweep(itf, cp, min(args.cpu_sample, 16), x, stats, args.robot)
             else:
@@ -406,6 +449,45 @@ def sq_counters_file():
         return json.load(open(os.path.join(ROOT, "profiles", "traffic_index.json"))).get("sq_counters", "r03_sq_counters.json")
     except Exception:
         return "r03_sq_counters.json"
+
+
+def collective_report(nccl_log, backend, requested):
+    """config.distributed.collective: what the backend chose for the per-solve gather (rank 0's RCCL INFO log, bench.py --gather-report)."""
+    if not requested:
+        return {"reported": False, "why": "run with --gather-report (NCCL_DEBUG=INFO costs time: off in the default line)"}
+    if backend != "nccl" or not nccl_log:
+        return {"reported": False, "why": "backend %s: no RCCL algorithm to report (RCCL refuses two ranks on one device; the one-device dry runs gather over gloo)" % backend}
+    try:
+        from bipedal_control_amd.distributed import parse_nccl_debug
+        with open(nccl_log) as f:
+            rep = parse_nccl_debug(f.read())
+        rep["reported"] = True
+        rep["log"] = nccl_log
+        return rep
+    except Exception as e:
+        return {"reported": False, "why": "%s: %s" % (type(e).__name__, e)}
+
+
+def write_roof(batch, nodes_per_problem, nx, achieved_gbs):
+    """What a write-only stream reaches on this device (tools/probes/write_roof.hip, built by bipedal_control_amd.build.build_probes): a plain fill
+    and the lineariser's own store pattern - 4 nodes per wave, three (four at nx = 24) 8-byte store instructions per output row through its role
+    pointers - with no arithmetic and the same bytes per launch.  `frac_of_write_roof` = the lineariser's achieved rate / the pattern's."""
+    import ctypes
+    lib = os.path.join(ROOT, "tools", "probes", "libwrite_roof.so")
+    if not os.path.exists(lib):
+        return {"pattern_GBs": None, "why": "tools/probes/libwrite_roof.so is not built (python -m bipedal_control_amd.build)"}
+    try:
+        h = ctypes.CDLL(lib)
+        out = (ctypes.c_double * 9)()
+        rc = h.write_roof_measure(ctypes.c_int(int(batch)), ctypes.c_int(int(nodes_per_problem)), ctypes.c_int(int(nx)), out)
+        if rc != 0:
+            return {"pattern_GBs": None, "why": "write_roof_measure returned %d" % rc}
+        return {"pattern_GBs": round(out[2], 1), "pattern_free_occupancy_GBs": round(out[3], 1), "fill16_GBs": round(out[0], 1), "fill8_GBs": round(out[1], 1),
+                "bytes_per_launch": int(out[4]), "pattern_us": round(1e3 * out[5], 2), "frac_of_write_roof": round(achieved_gbs / out[2], 4) if out[2] > 0 else None,
+                "note": "store pattern of k_linearize_fast (materialised) without arithmetic at its geometry (256-thread workgroups, 76 KB of LDS); "
+                        "measured in this process after the timed region; `frac` above stays achieved / 8 TB/s"}
+    except Exception as e:        # a calibration figure must never cost the measured line
+        return {"pattern_GBs": None, "why": "%s: %s" % (type(e).__name__, e)}
 
 
 def committed_traffic(robot, gait, sweep, batch, intervals):
@@ -592,6 +674,35 @@ def cpu_baseline(prob, sample, x_gpu, u_gpu, stats, robot="h1"):
             "note": "the port differentiates with 44-direction dual numbers where the reference runs CppAD-generated sparse code: likely 2-4x slower than "
                     "the reference's own LQ approximation; a large GPU/CPU ratio says nothing about kernel quality",
             "host_cpu": _host_cpu(), "host_cores": os.cpu_count(), "max_abs_x_diff_vs_gpu": worst, "value_3_threads": threads3}
+
+
+def cpu_baseline_ddp(prob, sample, t_gpu, x_gpu, stats, robot="h1"):
+    """--solver ddp: the restatement of the ILQR iteration (oracle/ddp_py.py: numpy over the C++ oracle's LQ model, python roll-outs) on the first
+    `sample` problems; doubles as a parity check of the timed run.  A python port: context only."""
+    import numpy as np
+    from tests import oracle_bridge as ob
+    from oracle import ddp_py, reference_py as rp
+    m, om = ob.model(robot), ob.oracle(robot)
+    sched = prob["schedule"]
+    worst, spent = 0.0, 0.0
+    for b in range(sample):
+        nodes = ob.oracle_nodes(prob, b, robot=robot)
+        x_nom, u_nom = rp.cold_start(m, nodes, prob["x0"][b])
+        sc = sched[b] if isinstance(sched, list) else sched
+        tt = prob["targets"][b if len(prob["targets"]) > 1 else 0]
+        t0 = time.perf_counter()
+        ref = ddp_py.ilqr_iteration(om, m, nodes, prob["x0"][b], x_nom, u_nom, list(map(float, sc.eventTimes)), list(map(int, sc.modeSequence)),
+                                    np.asarray(tt.timeTrajectory), np.asarray(tt.stateTrajectory), m["ddp"], m["rollout"])
+        spent += time.perf_counter() - t0
+        n = len(ref["times"])
+        if stats[b].n_nodes == n - 1:
+            worst = max(worst, float(np.abs(x_gpu[b, :n] - ref["states"]).max()), float(np.abs(t_gpu[b, :n] - ref["times"]).max()))
+        else:
+            worst = float("inf")
+    return {"value": round(sample / spent, 4), "unit": "solves/s", "cores": 1, "kind": "port", "ms_per_solve": round(1e3 * spent / sample, 1),
+            "sample": "%d of the same problems, one ILQR iteration each incl. its eight roll-outs" % sample,
+            "note": "python / numpy restatement (oracle/ddp_py.py) over the C++ oracle's LQ model: a checker, not a tuned CPU solver",
+            "host_cpu": _host_cpu(), "host_cores": os.cpu_count(), "max_abs_diff_vs_gpu": worst}
 
 
 def cpu_baseline_analytic(prob, sample, x_gpu, stats, robot="h1"):

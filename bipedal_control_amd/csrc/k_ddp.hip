@@ -1,11 +1,13 @@
 // Kernels of the DDP slice (GaussNewtonDDP_MPC of ocs2_bipedal_robot_ros/src/BipedalRobotDdpMpcNode.cpp:70-71 with
 // `algorithm ILQR`, settings task.info:115-156): what one ILQR iteration needs beside the kernels the SQP path already has.
-//   backward pass   k_linearize with Launch::ilqr (Euler discretisation of the continuous-time model, Hessian shift; kernels/node_lq.h),
-//                   then the constraint elimination and the Riccati sweep of the reference kernel set - any exact solution of the
-//                   equality-constrained stage problems is THE ILQR policy; k_ddp_policy reads it back as du = lff + K dx
-//   line search     per step length: k_ddp_controller (u_nom + alpha lff), the policy roll-out of kernels/rollout.h with its observer
-//                   (TimeTriggeredRollout, ODE45; every accepted step is a time point), k_ddp_cost (intermediate cost at every time point),
-//                   k_ddp_select (trapezoidal performance index, Armijo test against the step-length-0 baseline, the largest accepted step)
+//   backward pass   the lineariser with Launch::ilqr (Euler discretisation of the continuous-time model, Hessian shift; linearize_fast.h ILQR,
+//                   reference body node_lq.h), then the constraint elimination, change of variables and Riccati sweep of the SQP path (round 6:
+//                   the fast kernels) - any exact solution of the equality-constrained stage problems is THE ILQR policy; k_ddp_policy reads it
+//                   back as du = lff + K dx
+//   line search     ALL step lengths in one launch each of: the policy roll-out of kernels/rollout.h with its observer (TimeTriggeredRollout,
+//                   ODE45; every accepted step is a time point; planned inputs u_nom + alpha lff formed where they are loaded), k_ddp_cost
+//                   (intermediate cost at every time point), k_ddp_select (trapezoidal performance indices, Armijo test against the
+//                   step-length-0 baseline, the largest accepted step)
 //   result          k_ddp_finish: the accepted roll-out ON ITS OWN TIME POINTS becomes the solution (x, u, times, stats)
 // [OCS2-upstream, recalled] throughout (oracle/ddp_py.py states what is and what is not restated; tests/test_recalled_behaviours.py names it).
 #include <hip/hip_runtime.h>
@@ -67,22 +69,18 @@ __global__ __launch_bounds__(kWave) void k_ddp_policy(Launch L, DdpBuffers d) {
   }
 }
 
-// planned inputs of a step length: u_nom + alpha lff
-__global__ void k_ddp_controller(const double* u_nom, const double* lff, double alpha, double* u_out, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) u_out[i] = u_nom[i] + alpha * lff[i];
-}
-
-// intermediate cost at every time point of a recorded roll-out: the node metric of the transcription with dt = 1 (tracking + soft cones)
+// intermediate cost at every time point of every recorded roll-out: the node metric of the transcription with dt = 1 (tracking + soft cones)
 template <int NJ>
 __global__ __launch_bounds__(kWave) void k_ddp_cost(Launch L, DdpBuffers d) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   __shared__ NodeWorkspace<NJ> ws;
   __shared__ double xref[NX], zero4[4], perf[3];
-  const int b = blockIdx.x / d.cap, i = blockIdx.x % d.cap, tid = threadIdx.x;
-  if (i >= d.rec_n[b]) return;
+  const int vb = blockIdx.x / d.cap, i = blockIdx.x % d.cap, tid = threadIdx.x;      // vb: step length * batch + problem
+  if (i >= d.rec_n[vb]) return;
+  const int b = vb % L.batch;
+  if (d.failed[b]) return;
   const int grid = L.buf.p_grid[b], n = L.buf.g_nodes[grid];
-  const size_t at = (size_t)b * d.cap + i;
+  const size_t at = (size_t)vb * d.cap + i;
   const double t = d.rec_t[at];
   const int j = ddp_interval(L.buf.g_time + (size_t)grid * (L.N + 1), n, t);
   // x_ref(t): TargetTrajectories::getDesiredState (clamped linear interpolation), as prepare_node
@@ -113,39 +111,51 @@ __global__ __launch_bounds__(kWave) void k_ddp_cost(Launch L, DdpBuffers d) {
   if (tid == 0) d.cost[at] = perf[0];
 }
 
-// performance index of the recorded roll-out (trapezoidalIntegration over its time points), Armijo test, the record becomes the solution when
-// it is the baseline (alpha == 0) or the first - largest - accepted step
+// performance index of every recorded roll-out (trapezoidalIntegration over its time points), Armijo test of the step lengths against the
+// step-length-0 baseline in descending order - the LARGEST accepted step wins ([OCS2-upstream] LineSearchStrategy evaluates them concurrently
+// and keeps the largest that passes) -, and the winner (else the baseline) becomes the solution record
 template <int NJ>
-__global__ __launch_bounds__(kWave) void k_ddp_select(Launch L, DdpBuffers d, double alpha, double armijo, const int* roll_status) {
+__global__ __launch_bounds__(kWave) void k_ddp_select(Launch L, DdpBuffers d, double armijo) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   const int b = blockIdx.x, tid = threadIdx.x;
   __shared__ int take;
   if (tid == 0) {
-    const int n = d.rec_n[b];
-    const double* t = d.rec_t + (size_t)b * d.cap;
-    const double* c = d.cost + (size_t)b * d.cap;
-    double merit = 0.0;
-    for (int i = 0; i + 1 < n; ++i) merit += 0.5 * (c[i + 1] + c[i]) * (t[i + 1] - t[i]);
-    const bool ok = roll_status[b] == 0 && n >= 2 && !d.failed[b];
-    int tk = 0;
-    if (alpha == 0.0) {
-      d.merit0[b] = ok ? merit : 0.0;
-      d.merit[b] = merit;
-      if (!ok) d.failed[b] = 1;                         // no baseline: nothing to compare with, the nominal trajectories stay
-      tk = ok ? 1 : 0;
-    } else if (ok && !d.accepted[b] && merit < d.merit0[b] - armijo * alpha * d.update_is[b]) {
-      d.accepted[b] = 1; d.alpha[b] = alpha; d.merit[b] = merit;
-      tk = 1;
+    auto merit_of = [&](int v) {
+      const size_t vb = (size_t)v * L.batch + b;
+      const int n = d.rec_n[vb];
+      const double* t = d.rec_t + vb * d.cap;
+      const double* c = d.cost + vb * d.cap;
+      double m = 0.0;
+      for (int i = 0; i + 1 < n; ++i) m += 0.5 * (c[i + 1] + c[i]) * (t[i + 1] - t[i]);
+      return m;
+    };
+    auto rolled = [&](int v) { const size_t vb = (size_t)v * L.batch + b; return d.roll_status[vb] == 0 && d.rec_n[vb] >= 2; };
+    int tk = -1;
+    if (!d.failed[b]) {
+      if (!rolled(0)) {
+        d.failed[b] = 2;                                  // no baseline: nothing to compare with, the nominal trajectories stay (2: the roll-out failed, 1: the sweep)
+        d.merit0[b] = 0.0; d.merit[b] = 0.0;
+      } else {
+        const double m0 = merit_of(0);
+        d.merit0[b] = m0; d.merit[b] = m0;
+        tk = 0;
+        for (int v = 1; v < d.nv; ++v) {
+          if (!rolled(v)) continue;
+          const double m = merit_of(v);
+          if (m < m0 - armijo * d.alpha_v[v] * d.update_is[b]) { d.accepted[b] = 1; d.alpha[b] = d.alpha_v[v]; d.merit[b] = m; tk = v; break; }
+        }
+      }
     }
     take = tk;
   }
   __syncthreads();
-  if (!take) return;
-  const int n = d.rec_n[b];
+  if (take < 0) return;
+  const size_t vb = (size_t)take * L.batch + b;
+  const int n = d.rec_n[vb];
   if (tid == 0) d.sol_n[b] = n;
-  for (int i = tid; i < n; i += kWave) d.sol_t[(size_t)b * d.cap + i] = d.rec_t[(size_t)b * d.cap + i];
-  for (int i = tid; i < n * NX; i += kWave) d.sol_x[(size_t)b * d.cap * NX + i] = d.rec_x[(size_t)b * d.cap * NX + i];
-  for (int i = tid; i < n * NU; i += kWave) d.sol_u[(size_t)b * d.cap * NU + i] = d.rec_u[(size_t)b * d.cap * NU + i];
+  for (int i = tid; i < n; i += kWave) d.sol_t[(size_t)b * d.cap + i] = d.rec_t[vb * d.cap + i];
+  for (int i = tid; i < n * NX; i += kWave) d.sol_x[(size_t)b * d.cap * NX + i] = d.rec_x[vb * d.cap * NX + i];
+  for (int i = tid; i < n * NU; i += kWave) d.sol_u[(size_t)b * d.cap * NU + i] = d.rec_u[vb * d.cap * NU + i];
 }
 
 // the solution in the solver's own arrays: x[b][i], u[b][i] at the roll-out's time points (the input at the last point is dropped: the
@@ -154,7 +164,8 @@ template <int NJ>
 __global__ __launch_bounds__(kWave) void k_ddp_finish(Launch L, DdpBuffers d) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   const int b = blockIdx.x, tid = threadIdx.x;
-  const bool failed = d.failed[b] != 0;
+  const int why = d.failed[b];
+  const bool failed = why != 0;
   const int n = failed ? 0 : d.sol_n[b];
   double* x = L.buf.x + (size_t)b * (L.N + 1) * NX;
   double* u = L.buf.u + (size_t)b * L.N * NU;
@@ -166,7 +177,9 @@ __global__ __launch_bounds__(kWave) void k_ddp_finish(Launch L, DdpBuffers d) {
     L.buf.iterations[b] = it;
     s[0] = (double)(failed ? L.buf.g_nodes[L.buf.p_grid[b]] : n - 1);
     s[1] = (double)it;
-    s[2] = failed ? 2.0 : (d.accepted[b] ? 0.0 : 1.0);          // 0: a step was accepted, 1: none (the baseline roll-out is the solution), 2: numerical failure (nominal kept)
+    // 0: a step was accepted, 1: none (the baseline roll-out is the solution), 2: numerical failure in the Riccati sweep (nominal kept),
+    // 3: the baseline roll-out failed - integrator out of steps or more time points than the record holds (nominal kept)
+    s[2] = failed ? (why == 2 ? 3.0 : 2.0) : (d.accepted[b] ? 0.0 : 1.0);
     s[3] = d.merit0[b]; s[4] = 0.0; s[5] = 0.0;
     s[6] = d.merit[b]; s[7] = 0.0; s[8] = 0.0;
     s[9] = d.alpha[b];
@@ -183,6 +196,7 @@ __global__ void k_ddp_keep_times(DdpBuffers d, int batch, int N, double* tp_time
   const int b = blockIdx.x;
   if (b >= batch) return;
   const int n = d.n_points[b];
+  if (n <= 0) return;      // a failed problem keeps its nominal trajectories ON THE GRID: the copies preserve_previous made of the grid tables stay
   for (int i = threadIdx.x; i < N + 1; i += blockDim.x) tp_time[(size_t)b * (N + 1) + i] = i < n ? d.sol_t[(size_t)b * d.cap + i] : 0.0;
   for (int i = threadIdx.x; i < N; i += blockDim.x) tp_kind[(size_t)b * N + i] = 0;
   if (threadIdx.x == 0) { tp_nodes[b] = n - 1; tp_grid[b] = b; }
@@ -198,12 +212,9 @@ __global__ void k_ddp_keep_times(DdpBuffers d, int batch, int N, double* tp_time
 namespace kl {
 
 void ddp_policy(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d) { KL_NJ(nj, hipLaunchKernelGGL(k_ddp_policy<NJ>, dim3(batch), dim3(kWave), 0, st, L, d)); }
-void ddp_controller(hipStream_t st, const double* u_nom, const double* lff, double alpha, double* u_out, size_t n) {
-  hipLaunchKernelGGL(k_ddp_controller, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, u_nom, lff, alpha, u_out, n);
-}
-void ddp_cost(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d) { KL_NJ(nj, hipLaunchKernelGGL(k_ddp_cost<NJ>, dim3(batch * d.cap), dim3(kWave), 0, st, L, d)); }
-void ddp_select(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d, double alpha, double armijo, const int* roll_status) {
-  KL_NJ(nj, hipLaunchKernelGGL(k_ddp_select<NJ>, dim3(batch), dim3(kWave), 0, st, L, d, alpha, armijo, roll_status));
+void ddp_cost(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d) { KL_NJ(nj, hipLaunchKernelGGL(k_ddp_cost<NJ>, dim3(batch * d.nv * d.cap), dim3(kWave), 0, st, L, d)); }
+void ddp_select(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d, double armijo) {
+  KL_NJ(nj, hipLaunchKernelGGL(k_ddp_select<NJ>, dim3(batch), dim3(kWave), 0, st, L, d, armijo));
 }
 void ddp_keep_times(int batch, int N, hipStream_t st, const DdpBuffers& d, double* tp_time, int* tp_kind, int* tp_nodes, int* tp_grid) {
   hipLaunchKernelGGL(k_ddp_keep_times, dim3(batch), dim3(kWave), 0, st, d, batch, N, tp_time, tp_kind, tp_nodes, tp_grid);

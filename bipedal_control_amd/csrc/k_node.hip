@@ -58,7 +58,7 @@ template <int NJ> constexpr int lin_waves() { return BPMPC_LIN_WAVES; }
 #ifndef BPMPC_LIN_WPE
 #define BPMPC_LIN_WPE __attribute__((amdgpu_waves_per_eu(2, BPMPC_LIN_WAVES > 4 ? 3 : 2)))
 #endif
-template <int NJ, bool MAT, bool CHAIN>
+template <int NJ, bool MAT, bool CHAIN, bool ILQR = false>      // ILQR: the DDP solver's Euler-discretised model (linearize_fast.h)
 __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linearize_fast(Launch L) {
   using C = LinFastCfg<NJ, true, CHAIN>;
   constexpr int LPN = C::LPN, NPW = C::NPW, kLinWaves = lin_waves<NJ>();
@@ -103,11 +103,12 @@ __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linea
   out.dump = L.buf.lin_dump;
   out.qrd = L.buf.qrd;
   out.s = s;
+  out.ilqr_shift = L.ilqr_shift;
 #ifndef BPMPC_LIN_PROF_PROBLEM
 #define BPMPC_LIN_PROF_PROBLEM 0     // the problem whose first 64 nodes report their phase cycles (-DBPMPC_LINFAST_PROFILE): 0 runs on an empty chip, batch / 2 in steady state
 #endif
   out.prof = (valid && b == BPMPC_LIN_PROF_PROBLEM && k < 64) ? L.buf.rprof + 8 * k : nullptr;
-  linearize_fast<NJ, MAT, C, NL>(*L.model, shared, lds[sub], valid, in, pre, out, g);      // g: lane inside the node's group
+  linearize_fast<NJ, MAT, C, NL, ILQR>(*L.model, shared, lds[sub], valid, in, pre, out, g);      // g: lane inside the node's group
 #ifdef BPMPC_LIN_TIMELINE
   if (threadIdx.x % kWave == 0 && blockIdx.x < 2048) {      // every wave: the workgroup's end is the latest of its waves
     double* t = L.buf.rprof + 16 * blockIdx.x + 4 * (threadIdx.x / kWave);
@@ -383,7 +384,11 @@ void linearize_fast(int nj, bool materialise, int nodes, hipStream_t st, const L
       if (ev_start && ev_stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev_start, ev_stop, 0, L);
       else hipLaunchKernelGGL(kernel, grid, block, 0, st, L);
     };
-    if (L.serial_legs) {            // two serial legs in lane order (DeviceModel::serial_legs): tree walks by DPP row shifts
+    if (L.ilqr) {                   // the DDP solver (solver.hip run_ddp)
+      if (!L.serial_legs) throw std::runtime_error("linearize_fast: the ILQR lineariser is instantiated for serial-leg robots only");
+      if (materialise) launch(k_linearize_fast<NJ, true, true, true>);
+      else launch(k_linearize_fast<NJ, false, true, true>);
+    } else if (L.serial_legs) {     // two serial legs in lane order (DeviceModel::serial_legs): tree walks by DPP row shifts
       if (materialise) launch(k_linearize_fast<NJ, true, true>);
       else launch(k_linearize_fast<NJ, false, true>);
     } else {                        // any tree: walks over LDS tables

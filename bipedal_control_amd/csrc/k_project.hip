@@ -97,6 +97,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PK ? BPMP
   out.Qt = L.buf.Qt + s * NX * NX; out.Rt = L.buf.Rt + s * NU * NU; out.Pt = L.buf.Pt + s * NU * NX; out.qt = L.buf.qt + s * NX;
   out.rt = L.buf.rt + s * NU;
   in.qrd = L.buf.qrd + s * kQrdStride;
+  in.r_shift_at = L.ilqr ? kQrdRShift : 0;
   const double dt = L.buf.g_dt[(size_t)g * L.N + k];
   out.Wt = L.buf.Wt + s * PackedLq<NJ>::W_SIZE; out.Qp = L.buf.Qp + s * PackedLq<NJ>::Q_SIZE; out.Mt = L.buf.Mt + s * PackedLq<NJ>::M_SIZE;
   if constexpr (PK) { in.zero = L.buf.zero_page; in.Vt = L.buf.Vt + s * NJ * PackedLq<NJ>::WP; in.mode = L.buf.g_mode[(size_t)g * L.N + k] & 3; }   // written by the structured elimination

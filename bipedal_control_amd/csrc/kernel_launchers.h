@@ -47,9 +47,8 @@ void riccati_rollout(int nj, int batch, hipStream_t st, const Launch& L);
 
 // ---- k_ddp.hip: the DDP slice (one ILQR iteration; backward pass on the reference kernel set, line search over policy roll-outs)
 void ddp_policy(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
-void ddp_controller(hipStream_t st, const double* u_nom, const double* lff, double alpha, double* u_out, size_t n);
 void ddp_cost(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
-void ddp_select(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d, double alpha, double armijo, const int* roll_status);
+void ddp_select(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d, double armijo);
 void ddp_finish(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
 void ddp_keep_times(int batch, int N, hipStream_t st, const DdpBuffers& d, double* tp_time, int* tp_kind, int* tp_nodes, int* tp_grid);
 

@@ -646,8 +646,11 @@ constexpr size_t kLinDumpDoubles = (size_t)kLinDumpNodes * 16 + kLinDumpSlack;
 // (column-major inside the block row: 3 * column + row % 3)], so that the change of variables need not read 7.7 KB of mostly
 // constant numbers per node.
 constexpr int kQrdStride = 40;
+constexpr int kQrdRShift = 37;     // ILQR lineariser only: the shift of the diagonal of R (the Hessian shift + DIAGONAL_SHIFT / dt), read by project_mfma.h
 // The node record of the lane-per-coordinate kernels (Buffers::n_aux): dt, zref[4], zdref[4], padded to a 128-byte line
 constexpr int kNodeAux = 16;
+// step lengths of the DDP line search incl. the baseline 0 (task.info:147-155: 1, 0.5, .. >= minStepLength 1e-2 - eight), rolled out in one launch (rollout.h)
+constexpr int kMaxDdpSteps = 16;
 
 // What a lane needs of the node's iterate, loaded by the kernel wrapper BEFORE the model block is staged (and before the node is known to
 // exist: the addresses only depend on the slot), so that the memory round trips of a workgroup's start overlap instead of following
@@ -678,6 +681,7 @@ struct LinFastOut {
   double* qrd;       // kQrdStride doubles per node: the node-dependent part of Q and R in compact form (read by project_mfma.h)
   double* prof;      // this node's debug slot or nullptr
   size_t s;          // node slot (problem * max_nodes + node)
+  double ilqr_shift; // ILQR only: ddp.lineSearch.hessianCorrectionMultiple, added to every diagonal entry of the dt-scaled R (DIAGONAL_SHIFT)
 };
 
 // A lane owns up to four columns of the node's matrices ("roles"): x column 6+g (its coordinate), x column 6+ln (base translation: packed
@@ -735,7 +739,10 @@ struct RoleSlots {
 // of variables), b, q, r, the nc rows of C, D, e, the 320-byte record of the node-dependent part of Q and R; 9.6 instead of 21.8 KB per
 // node.  The numbers that are written are the same bits in both modes.
 // `ln`: lane inside the node's lane group; it carries coordinate g = ln + G0 (LinFastCfg) and the lane-numbered roles.
-template <int NJ, bool MAT = true, class Cfg = LinFastCfg<NJ, true>, class NL = LinFastNodeLds<NJ, true, Cfg::CHAIN, false>>
+// ILQR (the DDP solver, solver.hip run_ddp; reference body: node_lq.h linearize_node with `ilqr`): the continuous-time model at the node discretised
+// by ONE Euler step - A = I + dt A_c, B = dt B_c: no second evaluation -, no dynamics bias (b = 0: the nominal trajectory of a DDP is a roll-out),
+// o.ilqr_shift on the diagonal of the dt-scaled R; cost and constraints as in the multiple-shooting transcription.
+template <int NJ, bool MAT = true, class Cfg = LinFastCfg<NJ, true>, class NL = LinFastNodeLds<NJ, true, Cfg::CHAIN, false>, bool ILQR = false>
 __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinFastShared<NJ>& sh, NL& nl, bool valid,
                                                const NodeInputs& in, const LinFastPre& pre, const LinFastOut& o, int ln) {
 #ifdef BPMPC_LINFAST_PROFILE
@@ -767,9 +774,9 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
       const double xq_lo = __shfl(pre.x0, (6 + g) & 15, LPN), xq_hi = __shfl(pre.x1, (6 + g - 16) & 15, LPN);      // (both by every lane of the node)
       const double xq = 6 + g < 16 ? xq_lo : xq_hi;
       const double xt = __shfl(pre.x0, (6 + ln) & 15, LPN);       // (used by the packed lanes 0..2 only: 6 + ln < 16)
-      if (g < G) { const double d = xq - pre.xn_q; (o.b + o.s * (NX))[6 + g] = d; d2 += d * d; }
-      if (ln < 6) { const double d = pre.x0 - pre.xn_h; (o.b + o.s * (NX))[ln] = d; d2 += d * d; }
-      if (tr) { const double d = xt - pre.xn_t; (o.b + o.s * (NX))[6 + ln] = d; d2 += d * d; }
+      if (g < G) { const double d = ILQR ? 0.0 : xq - pre.xn_q; (o.b + o.s * (NX))[6 + g] = d; d2 += d * d; }
+      if (ln < 6) { const double d = ILQR ? 0.0 : pre.x0 - pre.xn_h; (o.b + o.s * (NX))[ln] = d; d2 += d * d; }
+      if (tr) { const double d = ILQR ? 0.0 : xt - pre.xn_t; (o.b + o.s * (NX))[6 + ln] = d; d2 += d * d; }
       if constexpr (MAT) for (int idx = ln; idx < NX; idx += LPN) { (o.q + o.s * (NX))[idx] = 0.0; (o.r + o.s * (NU))[idx] = 0.0; }
     }
     d2 = node_allreduce_add<LPN>(d2);
@@ -940,8 +947,8 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   LFPROF(2);
   // =========================== second RK2 stage ===========================
   LaneEval e2;
-  double v2t;                        // base linear velocity component ln of the second stage (translation role)
-  {
+  double v2t = 0.0;                  // base linear velocity component ln of the second stage (translation role)
+  if constexpr (!ILQR) {
     lds_wave_sync();                 // the constraint rows have read the swing references, whose storage becomes xh2
     if (ln < 6) nl.xh2[ln] = xh[ln] + dt * nl.fh[0][ln];
     if (ln < 3) nl.xh2[6 + ln] = pb[ln] + dt * nl.vlin[0][ln];
@@ -957,12 +964,14 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   // A2[rows 3..11][x columns 0..11] to LDS (a2 shares storage with the chain tables, dead now): columns 0..5 are the
   // momentum columns of lanes 0..5, columns 6..11 the q columns of lanes 0..5
   lds_wave_sync();
-  if (ln < 6)
-    for (int r = 0; r < 9; ++r) nl.a2[r][ln] = momentum_col(nl.X12[1], nl.X22[1], imt, mass_total, ln, r);
-  if (g < 6)
-    for (int r = 0; r < 9; ++r) nl.a2[r][6 + g] = e2.ar_q[r];
-  if (tr)
-    for (int r = 0; r < 9; ++r) nl.a2[r][6 + ln] = 0.0;      // nothing depends on the base position
+  if constexpr (!ILQR) {
+    if (ln < 6)
+      for (int r = 0; r < 9; ++r) nl.a2[r][ln] = momentum_col(nl.X12[1], nl.X22[1], imt, mass_total, ln, r);
+    if (g < 6)
+      for (int r = 0; r < 9; ++r) nl.a2[r][6 + g] = e2.ar_q[r];
+    if (tr)
+      for (int r = 0; r < 9; ++r) nl.a2[r][6 + ln] = 0.0;      // nothing depends on the base position
+  }
   lds_wave_sync();
   // rows of A and B;  A = I + dt/2 (A1 + A2 + dt A2 A1),  B = dt/2 (B1 + B2 + dt A2 B1)
   double c1q[9], c1h[9], c1f[9], c1j[9];
@@ -991,6 +1000,12 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
         ah_ = (r == ln) ? 1.0 : 0.0;
         bf = (r < 3 && (ln % 3) == r) ? dt * imt : 0.0;
         bj = (r >= 12 && r == 12 + g - 6) ? dt : 0.0;
+      } else if constexpr (ILQR) {       // A = I + dt A_c, B = dt B_c: the stage-one columns are the model
+        const int rr = r - 3;
+        aq = ((r == 6 + g) ? 1.0 : 0.0) + dt * c1q[rr];
+        ah_ = ((r == ln) ? 1.0 : 0.0) + dt * c1h[rr];
+        bf = dt * c1f[rr];
+        bj = dt * c1j[rr];
       } else {
         const int rr = r - 3;
         double sq = 0.0, sh = 0.0, sf = 0.0, sj = 0.0;
@@ -1019,17 +1034,17 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   if (g < G) {
     // the lane's own q and first-stage rate come back from LDS (nl.x, the park): two values less alive across the second evaluation
     const double v1g = NL::kPark ? nl.park[15][ln] : e1.vg;
-    const double bb = nl.x[6 + g] + hdt * v1g + hdt * e2.vg - xn_q;
+    const double bb = ILQR ? 0.0 : nl.x[6 + g] + hdt * v1g + hdt * e2.vg - xn_q;
     (o.b + o.s * (NX))[6 + g] = bb;
     dyn_sse += bb * bb;
   }
   if (ln < 6) {
-    const double bb = (ln < 6 ? xh[ln] : 0.0) + hdt * nl.fh[0][ln] + hdt * nl.fh[1][ln] - xn_h;
+    const double bb = ILQR ? 0.0 : (ln < 6 ? xh[ln] : 0.0) + hdt * nl.fh[0][ln] + hdt * nl.fh[1][ln] - xn_h;
     (o.b + o.s * (NX))[ln] = bb;
     dyn_sse += bb * bb;
   }
   if (tr) {                          // base position: the same expression as a coordinate lane (q + dt/2 v1 + dt/2 v2 - x_next)
-    const double bb = pb[ln] + hdt * nl.vlin[0][ln] + hdt * v2t - xn_t;
+    const double bb = ILQR ? 0.0 : pb[ln] + hdt * nl.vlin[0][ln] + hdt * v2t - xn_t;
     (o.b + o.s * (NX))[6 + ln] = bb;
     dyn_sse += bb * bb;
   }
@@ -1076,8 +1091,9 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
           const double wc = w + (cn[3] * cn[4 + a] * cn[4 + b2] + cn[2] * cn[7 + sidx]);
           w = (cf_stance && r / 3 == cfs / 3) ? wc : w;
         }
+        const double isf = (ILQR && r == cf) ? o.ilqr_shift : 0.0, isj = (ILQR && r == cj) ? o.ilqr_shift : 0.0;
         slots.store(pqr, r * NX, dt * (sh.Q[r * NX + cqs] + (r == cq ? shift : 0.0)), dt * (sh.Q[r * NX + cts] + (r == ct ? shift : 0.0)),
-                    dt * (sh.Q[r * NX + chs] + (r == ch ? shift : 0.0)), dt * w, dt * (sh.R[r * NU + cjs] + (r == cj ? shift : 0.0)));
+                    dt * (sh.Q[r * NX + chs] + (r == ch ? shift : 0.0)), dt * w + isf, dt * (sh.R[r * NU + cjs] + (r == cj ? shift : 0.0)) + isj);
       }
       // the sums are needed behind the loop only: left alone, their multiply-adds sink there and the 88 weights they read wait in registers
       asm volatile("" : "+v"(accq), "+v"(acch), "+v"(accf), "+v"(accj));
@@ -1098,7 +1114,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
           const int sidx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
           w += cn[3] * cn[4 + a] * cn[4 + b2] + cn[2] * cn[7 + sidx];
         }
-        (o.qrd + o.s * kQrdStride)[1 + 3 * cf + a] = dt * w;
+        (o.qrd + o.s * kQrdStride)[1 + 3 * cf + a] = dt * w + ((ILQR && r == cf) ? o.ilqr_shift : 0.0);
       }
     }
     if (g < G) { (o.q + o.s * (NX))[cq] = dt * accq; cost += 0.5 * nl.dx[cq] * accq; }
@@ -1117,6 +1133,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
   dyn_sse = node_allreduce_add<LPN>(dyn_sse);
   if (ln == 0) {
     (o.qrd + o.s * kQrdStride)[0] = shift;
+    if constexpr (ILQR) (o.qrd + o.s * kQrdStride)[kQrdRShift] = shift + o.ilqr_shift / dt;      // dt (R_ii + this) = dt (R_ii + shift) + DIAGONAL_SHIFT up to rounding
     if constexpr (MAT) (o.c + o.s * (1))[0] = dt * cost;
     (o.nc + o.s * (1))[0] = nc;
     (o.perf + o.s * (3))[0] = dt * cost; (o.perf + o.s * (3))[1] = dt * dyn_sse; (o.perf + o.s * (3))[2] = dt * eq_sse;

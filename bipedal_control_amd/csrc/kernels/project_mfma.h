@@ -61,6 +61,7 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ, PK
   // on a loaded value makes the wave wait for that load, and interleaved with the loads it serialised the latency several times over.
   issue_x();
   const double shift = in.qrd[0];
+  const double shift_r = in.qrd[in.r_shift_at];        // (the same entry except for the DDP solver's ILQR lineariser)
   // A-operands from HBM: rows 16 bi + li of R and of B, k = 4 ks + lk (out-of-range lanes read element 0 and are masked)
   double aR[2][KS], aB[2][KS];
   // accumulator initial values in the D layout: [A | b | 0] (2 x NBC blocks), [Q | q | 0] (block row 0 and, for rows < nx, 1),
@@ -195,7 +196,7 @@ __device__ __forceinline__ void project_apply_blocks(ProjectMfmaWorkspace<NJ, PK
       const bool ok = row < NU && kk < NU;
       const bool r_block = ok && row < 12 && kk < 12 && row / 3 == kk / 3;
       const double rv = aR[bi][ks];
-      aR[bi][ks] = ok ? (r_block ? rv : dt * (row == kk ? rv + shift : rv)) : 0.0;
+      aR[bi][ks] = ok ? (r_block ? rv : dt * (row == kk ? rv + shift_r : rv)) : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

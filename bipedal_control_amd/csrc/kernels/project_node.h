@@ -20,6 +20,7 @@ struct ProjectIn {
   const double *C, *D, *e;        // 16*NX, 16*NU, 16
   const double *A, *B, *b, *Q, *R, *P, *q, *r;
   const double* qrd = nullptr;    // compact node-dependent part of Q, R (linearize_fast.h kQrdStride), fast kernels only
+  int r_shift_at = 0;             // entry of the record that holds the shift of R's diagonal: 0 (the Hessian shift, as Q's) or kQrdRShift (ILQR: + DIAGONAL_SHIFT / dt)
   int mode = 3;                   // contact mode of the node (fast kernels after the structured elimination: the force rows of [Px | Pe | Pu] are generated from it)
   const double* zero = nullptr;   // a 0.0 in global memory (masked loads by address)
   const double* Vt = nullptr;     // joint rows of the packed [Px | Pe | Pu] (project_lu_s.h, row stride PackedLq::WP), structured fast path only

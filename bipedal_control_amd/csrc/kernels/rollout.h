@@ -51,6 +51,13 @@ struct RolloutArgs {
   double *rec_t, *rec_x, *rec_u;
   int* rec_n;
   int rec_cap;
+  // optional variants of the planned inputs (the DDP line search rolls every step length out in ONE launch): `batch` counts virtual problems
+  // bq = variant * n_problems + problem; everything that is read (solution, grid, start) is indexed by the problem, everything that is written
+  // (x_end, u_end, steps, status, rec_*) by bq; the planned input of variant v is u + alpha[v] lff.  n_problems = 0: no variants.
+  int n_problems;
+  const double* lff;                  // [n_problems][N][NU]
+  double alpha[kMaxDdpSteps];
+  // t_start = nullptr: every problem starts at the first time of its grid; duration < 0: ... and runs to the last
 };
 
 template <int NJ>
@@ -78,7 +85,10 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
   const int bq = blockIdx.x * NPW + sub;
   const bool valid = bq < a.batch;
-  const int b = valid ? bq : 0;
+  const int ob = valid ? bq : 0;                                    // where this roll-out writes
+  const int b = a.n_problems > 0 ? ob % a.n_problems : ob;          // the problem it reads
+  const double step_len = a.n_problems > 0 ? a.alpha[ob / a.n_problems] : 0.0;
+  const double* lf = a.n_problems > 0 ? a.lff + (size_t)b * a.N * NU : nullptr;
   LinFastNodeLds<NJ, false>& nl = w.node[sub];
   const LinFastShared<NJ, false>& sh = w.shared;
   const int N = a.N, grid = a.p_grid[b], n = a.g_nodes[grid];
@@ -96,7 +106,7 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
     lb.subtree = sh.subtree[body];
   }
   const int* path = sh.path[lb.body];
-  const double t0 = a.t_start[b], tf = t0 + a.duration;
+  const double t0 = a.t_start ? a.t_start[b] : tp[0], tf = a.duration < 0.0 ? tp[n] : t0 + a.duration;
   // events of the window: the pre-event nodes of the solution grid with t0 < t <= tf (upper_bound on both ends)
   if (g == 0) {
     int cnt = 0;
@@ -135,7 +145,8 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
         w.Kc[sub][0][idx] = Kp[(size_t)e0 * NU * NX + idx];
         w.Kc[sub][1][idx] = Kp[(size_t)e1 * NU * NX + idx];
       }
-      for (int idx = g; idx < NU; idx += LPN) { w.uc[sub][0][idx] = up[(size_t)e0 * NU + idx]; w.uc[sub][1][idx] = up[(size_t)e1 * NU + idx]; }
+      if (lf) for (int idx = g; idx < NU; idx += LPN) { w.uc[sub][0][idx] = up[(size_t)e0 * NU + idx] + step_len * lf[(size_t)e0 * NU + idx]; w.uc[sub][1][idx] = up[(size_t)e1 * NU + idx] + step_len * lf[(size_t)e1 * NU + idx]; }
+      else for (int idx = g; idx < NU; idx += LPN) { w.uc[sub][0][idx] = up[(size_t)e0 * NU + idx]; w.uc[sub][1][idx] = up[(size_t)e1 * NU + idx]; }
       for (int idx = g; idx < NX; idx += LPN) { w.xc[sub][0][idx] = xp[(size_t)j * NX + idx]; w.xc[sub][1][idx] = xp[(size_t)(j + 1) * NX + idx]; }
     }
     lds_wave_sync();
@@ -177,7 +188,7 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
     controller(ts);
     if (mine) {
       if (valid && n_rec < a.rec_cap) {
-        const size_t at = (size_t)b * a.rec_cap + n_rec;
+        const size_t at = (size_t)ob * a.rec_cap + n_rec;
         if (g == 0) a.rec_t[at] = ts;
         if (g < 6) a.rec_x[at * NX + g] = vh;
         if (g < G) a.rec_x[at * NX + 6 + g] = vq;
@@ -260,13 +271,13 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
   publish(xh, xq);
   controller(t);
   if (valid) {
-    if (g < 6) a.x_end[(size_t)b * NX + g] = xh;
-    if (g < G) a.x_end[(size_t)b * NX + 6 + g] = xq;
-    for (int r = g; r < NU; r += LPN) a.u_end[(size_t)b * NU + r] = nl.u[r];
+    if (g < 6) a.x_end[(size_t)ob * NX + g] = xh;
+    if (g < G) a.x_end[(size_t)ob * NX + 6 + g] = xq;
+    for (int r = g; r < NU; r += LPN) a.u_end[(size_t)ob * NU + r] = nl.u[r];
     if (g == 0) {
-      a.steps[2 * b] = accepted; a.steps[2 * b + 1] = rejected;
-      if (a.rec_t) { a.rec_n[b] = n_rec < a.rec_cap ? n_rec : a.rec_cap; if (status == 0 && n_rec > a.rec_cap) status = 4; }
-      a.status[b] = status;
+      a.steps[2 * ob] = accepted; a.steps[2 * ob + 1] = rejected;
+      if (a.rec_t) { a.rec_n[ob] = n_rec < a.rec_cap ? n_rec : a.rec_cap; if (status == 0 && n_rec > a.rec_cap) status = 4; }
+      a.status[ob] = status;
     }
   }
 }

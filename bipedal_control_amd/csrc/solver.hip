@@ -39,6 +39,7 @@ namespace bpmpc {
   } while (0)
 
 struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };      // -> BPMPC_ERR_UNSUPPORTED
 
 // ------------------------------------------------------------------------------------------------ solver object
 struct KernelTimer {
@@ -156,7 +157,8 @@ struct bpmpc_solver {
     L.feedback = feedback();
     L.ls = ls;
     L.reg_prim = settings.reg_prim;
-    L.ilqr = 0; L.ilqr_shift = 0.0;
+    L.ilqr = is_ddp() ? 1 : 0;                                  // the DDP solver: every kernel of the backward pass works on the Euler-discretised model
+    L.ilqr_shift = is_ddp() ? rm.ddp.ls_hessian_correction_multiple : 0.0;
     return L;
   }
 
@@ -341,7 +343,12 @@ void bpmpc_solver::pipelined_backward() {
 
 void bpmpc_solver::run_iterations() {
   if (rm.nj != 10 && rm.nj != 12) throw std::runtime_error("unsupported joint count");
-  if (is_ddp()) { run_ddp(); has_solution = true; return; }
+  if (is_ddp()) {
+    // a DDP solution lives on the adaptive time points of its roll-out (k_ddp_finish rewrites x / u there): a second iteration on the same setup
+    // would linearise a trajectory that is not on the grid.  setup / setup_from_previous / reset put a nominal trajectory back on the grid.
+    if (has_solution) throw Unsupported("DDP: one ILQR iteration per setup (the solution lives on the roll-out's own time points); call setup, setup_from_previous or reset before the next run");
+    run_ddp(); has_solution = true; return;
+  }
   const int iters = ls.max_iterations;
   for (int it = 0; it < iters; ++it) {
     if (!settings.reference_kernels && settings.pipeline_chunks > 1) {
@@ -356,56 +363,35 @@ void bpmpc_solver::run_iterations() {
   has_solution = true;
 }
 
-// One ILQR iteration of the DDP slice (k_ddp.hip; oracle/ddp_py.py is its restatement, step for step).  Everything is enqueued on the solver's
-// stream; the host only walks the step lengths.
+// One ILQR iteration of the DDP solver (k_ddp.hip; oracle/ddp_py.py is its restatement, step for step).  Everything is enqueued on the solver's
+// stream, nothing is read back or waited for.  Round 6: the backward pass runs on the kernels of the SQP path - the fast lineariser in its ILQR
+// form, structured elimination, change of variables on the matrix cores, the Riccati sweep of the batch's regime (launch_params() carries the
+// ILQR switch) - and the line search rolls ALL step lengths out in one launch (batch x nv virtual problems), as upstream evaluates them concurrently.
 void bpmpc_solver::run_ddp() {
-  const DdpConfig& dc = rm.ddp;
-  Launch L = launch_params();
-  L.ilqr = 1; L.ilqr_shift = dc.ls_hessian_correction_multiple;
-  const int slots = batch * settings.max_nodes;
-  // backward pass: Euler-discretised LQ model, constraint elimination, Riccati recursion (its linear roll-out gives du = lff + K dx)
-  TIMED("linearize", kl::linearize_reference(nj(), slots, stream, L));
-  TIMED("project", kl::project_reference(nj(), slots, stream, L));
-  TIMED("riccati", kl::riccati_reference(nj(), batch, stream, L));
+  stage_linearize();            // Euler-discretised LQ model, DIAGONAL_SHIFT on R
+  stage_project();              // constraint elimination
+  stage_riccati();              // Riccati recursion from S_N = 0; its linear roll-out gives du = lff + K dx
+  const Launch L = launch_params();
   kl::ddp_policy(nj(), batch, stream, L, ddp);
   HIP_CHECK(hipGetLastError());
-  // line search: the baseline (step length 0: the new gains, no feedforward increment), then maxStepLength, x contractionRate, .. >= minStepLength
-  std::vector<double> alphas{0.0};
-  constexpr double kContractionRate = 0.5, kArmijoCoefficient = 1e-4;       // [OCS2-upstream] line_search::Settings defaults (not in task.info)
-  for (double a = dc.ls_max_step_length; a >= dc.ls_min_step_length && alphas.size() < 64; a *= kContractionRate) alphas.push_back(a);
-  const int N = settings.max_nodes, NX = nx, NU = nu;
+  // line search: the baseline (step length 0: the new gains, no feedforward increment) and maxStepLength, x contractionRate, .. >= minStepLength
+  constexpr double kArmijoCoefficient = 1e-4;                                 // [OCS2-upstream] line_search::Settings default (not in task.info)
+  const int N = settings.max_nodes;
   RolloutArgs a{};
-  a.batch = batch; a.N = N; a.p_grid = buf.p_grid; a.g_nodes = buf.g_nodes; a.g_kind = buf.g_kind; a.g_time = buf.g_time;
-  a.x = buf.x; a.u = ddp.u_alpha; a.K = buf.K; a.t_start = buf.roll_t; a.x_start = buf.p_x0;
+  a.batch = batch * ddp.nv; a.n_problems = batch; a.lff = ddp.lff;
+  for (int v = 0; v < ddp.nv; ++v) a.alpha[v] = ddp.alpha_v[v];
+  a.N = N; a.p_grid = buf.p_grid; a.g_nodes = buf.g_nodes; a.g_kind = buf.g_kind; a.g_time = buf.g_time;
+  a.x = buf.x; a.u = buf.u; a.K = buf.K; a.x_start = buf.p_x0;
+  a.t_start = nullptr; a.duration = -1.0;                                      // every problem over its own horizon [t_0, t_N]
   a.abs_tol = rm.rollout.abs_tol; a.rel_tol = rm.rollout.rel_tol; a.time_step = rm.rollout.time_step;
   a.feedback = 1;                                                            // the search rolls out the FEEDBACK policy whatever controller is handed out
-  a.x_end = buf.roll_x; a.u_end = buf.roll_u; a.steps = buf.roll_steps; a.status = buf.roll_status;
+  a.x_end = ddp.end_x; a.u_end = ddp.end_u; a.steps = ddp.roll_steps; a.status = ddp.roll_status;
   a.rec_t = ddp.rec_t; a.rec_x = ddp.rec_x; a.rec_u = ddp.rec_u; a.rec_n = ddp.rec_n; a.rec_cap = ddp.cap;
-  {   // every problem rolls out over its own horizon [t_0, t_N]: the kernel takes ONE duration, so the horizons must agree (they do: one `horizon` per setup)
-    std::vector<double> ts(batch);
-    double dur = -1.0;
-    for (int b = 0; b < batch; ++b) {
-      const int g = grid_of_problem[b];
-      ts[b] = node_times[(size_t)g * (N + 1)];
-      const double d = node_times[(size_t)g * (N + 1) + grid_nodes[g]] - ts[b];
-      if (dur >= 0.0 && std::fabs(d - dur) > 1e-9) throw std::invalid_argument("DDP: the problems of a batch must share the horizon length");
-      dur = d;
-    }
-    HIP_CHECK(hipMemcpyAsync(buf.roll_t, ts.data(), ts.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));      // (ts is a local: the copy must have left it)
-    a.duration = dur;
-    a.max_steps = (int)(rm.rollout.max_steps_per_second * std::max(1.0, dur));
-  }
-  for (double alpha : alphas) {
-    kl::ddp_controller(stream, buf.u, ddp.lff, alpha, ddp.u_alpha, (size_t)batch * N * NU);
-    kl::rollout(rm.nj, batch, stream, d_model, a);
-    kl::ddp_cost(nj(), batch, stream, L, ddp);
-    kl::ddp_select(nj(), batch, stream, L, ddp, alpha, kArmijoCoefficient, buf.roll_status);
-    HIP_CHECK(hipGetLastError());
-  }
-  kl::ddp_finish(nj(), batch, stream, L, ddp);
-  HIP_CHECK(hipGetLastError());
-  (void)NX;
+  double longest = 0.0;
+  for (size_t g = 0; g < grid_nodes.size(); ++g) longest = std::max(longest, node_times[g * (N + 1) + grid_nodes[g]] - node_times[g * (N + 1)]);
+  a.max_steps = (int)(rm.rollout.max_steps_per_second * std::max(1.0, longest));
+  TIMED("ddp_rollout", kl::rollout(rm.nj, batch * ddp.nv, stream, d_model, a));
+  TIMED("ddp_search", { kl::ddp_cost(nj(), batch, stream, L, ddp); kl::ddp_select(nj(), batch, stream, L, ddp, kArmijoCoefficient); kl::ddp_finish(nj(), batch, stream, L, ddp); });
 }
 
 namespace {
@@ -413,6 +399,7 @@ namespace {
 int translate(const std::exception& e) {
   set_last_error(e.what());
   if (dynamic_cast<const DeviceError*>(&e)) return BPMPC_ERR_DEVICE;
+  if (dynamic_cast<const Unsupported*>(&e)) return BPMPC_ERR_UNSUPPORTED;
   if (dynamic_cast<const std::invalid_argument*>(&e)) return BPMPC_ERR_INVALID_ARGUMENT;
   if (dynamic_cast<const std::length_error*>(&e)) return BPMPC_ERR_CAPACITY;
   return BPMPC_ERR_IO;
@@ -479,11 +466,18 @@ void allocate(bpmpc_solver* s) {
   if (s->is_ddp()) {
     DdpBuffers& d = s->ddp;
     d.cap = (int)N + 1;
-    const size_t P = B * (size_t)d.cap;
-    d.lff = s->alloc<double>("ddp_lff", S * NU); d.u_alpha = s->alloc<double>(nullptr, S * NU);
-    d.rec_t = s->alloc<double>(nullptr, P); d.rec_x = s->alloc<double>(nullptr, P * NX); d.rec_u = s->alloc<double>(nullptr, P * NU); d.rec_n = s->alloc<int>(nullptr, B);
+    {   // step lengths of the line search: the baseline, then maxStepLength, x contractionRate, .. >= minStepLength (task.info:147-155: eight roll-outs)
+      constexpr double kContractionRate = 0.5;                                  // [OCS2-upstream] line_search::Settings default (not in task.info)
+      d.nv = 0; d.alpha_v[d.nv++] = 0.0;
+      for (double al = s->rm.ddp.ls_max_step_length; al >= s->rm.ddp.ls_min_step_length && d.nv < kMaxDdpSteps; al *= kContractionRate) d.alpha_v[d.nv++] = al;
+    }
+    const size_t P = B * (size_t)d.cap, V = (size_t)d.nv;
+    d.lff = s->alloc<double>("ddp_lff", S * NU);
+    d.rec_t = s->alloc<double>(nullptr, V * P); d.rec_x = s->alloc<double>(nullptr, V * P * NX); d.rec_u = s->alloc<double>(nullptr, V * P * NU); d.rec_n = s->alloc<int>("ddp_rec_n", V * B, true);
+    d.cost = s->alloc<double>(nullptr, V * P);
+    d.end_x = s->alloc<double>(nullptr, V * B * NX); d.end_u = s->alloc<double>(nullptr, V * B * NU); d.roll_steps = s->alloc<int>("ddp_roll_steps", V * B * 2, true); d.roll_status = s->alloc<int>("ddp_roll_status", V * B, true);
     d.sol_t = s->alloc<double>("ddp_t", P); d.sol_x = s->alloc<double>(nullptr, P * NX); d.sol_u = s->alloc<double>("ddp_u", P * NU); d.sol_n = s->alloc<int>(nullptr, B);
-    d.cost = s->alloc<double>(nullptr, P); d.merit0 = s->alloc<double>(nullptr, B); d.merit = s->alloc<double>(nullptr, B); d.alpha = s->alloc<double>(nullptr, B);
+    d.merit0 = s->alloc<double>(nullptr, B); d.merit = s->alloc<double>(nullptr, B); d.alpha = s->alloc<double>(nullptr, B);
     d.update_is = s->alloc<double>("ddp_update_is", B);
     d.accepted = s->alloc<int>(nullptr, B); d.failed = s->alloc<int>(nullptr, B); d.n_points = s->alloc<int>("ddp_points", B, true);
   }
@@ -790,6 +784,7 @@ void check_rollout_status(bpmpc_solver* s, int* steps) {
 // under the LinearController of the last solve.  NULL t_start / x_start: the initial time / measured state of that solve.
 void rollout(bpmpc_solver* s, const double* t_start, const double* x_start, double duration, double* x_end, double* u_end, int* steps) {
   if (!s->has_solution) throw std::invalid_argument("bpmpc_solver_rollout needs a completed solve on the handle");
+  if (s->is_ddp()) throw Unsupported("bpmpc_solver_rollout: the DDP solution is a FeedforwardController on the time points of its own roll-out (fetch them with bpmpc_solver_fetch), not on the shooting grid this roll-out interpolates on");
   if (!(duration >= 0)) throw std::invalid_argument("bpmpc_solver_rollout: negative duration");
   Buffers& bf = s->buf;
   if (!bf.K) throw std::invalid_argument("bpmpc_solver_rollout needs the feedback gains (return_gains with reference kernels)");
@@ -819,6 +814,7 @@ void rollout(bpmpc_solver* s, const double* t_start, const double* x_start, doub
 
 void reset(bpmpc_solver* s) {
   const size_t N = s->settings.max_nodes;
+  if (s->is_ddp()) s->has_solution = false;      // the initial iterate of the setup is back on the grid: the next run is a first iteration again
   copy_pairs(s, s->buf.x_init, s->buf.x, (size_t)s->batch * (N + 1) * s->nx, s->buf.u_init, s->buf.u, (size_t)s->batch * N * s->nu, true);
 }
 
@@ -904,7 +900,8 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
       if (!(d.ls_min_step_length > 0.0) || !(d.ls_max_step_length >= d.ls_min_step_length)) { set_last_error("DDP: lineSearch.minStepLength / maxStepLength"); return BPMPC_ERR_INVALID_ARGUMENT; }
       if (d.use_feedback_policy && settings->feedback_policy != 2) { set_last_error("DDP: ddp.useFeedbackPolicy true is not implemented (the gains live on the nominal grid, the solution on the roll-out's time points)"); return BPMPC_ERR_UNSUPPORTED; }
       if (settings->feedback_policy == 1) { set_last_error("DDP: feedback_policy 1 (LinearController) is not implemented for the DDP solution"); return BPMPC_ERR_UNSUPPORTED; }
-      s->settings.reference_kernels = 1;
+      // round 6: the backward pass runs on the fast kernels (reference_kernels = 1 keeps the lane-emulated bodies: cross-check); the ILQR form of the
+      // fast lineariser exists for serial-leg robots (every robot of the reference), any other tree runs the reference bodies
       s->settings.return_gains = 1;
       s->settings.pipeline_chunks = 1;
     }
@@ -921,6 +918,7 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
       const char* e = std::getenv("BPMPC_DENSE_PROJECT");
       s->structured_project = block_diagonal && !(e && e[0] == '1');
     }
+    if (s->is_ddp() && !(s->dm.serial_legs && !s->force_tables)) s->settings.reference_kernels = 1;
     if (settings->stream) { s->stream = static_cast<hipStream_t>(settings->stream); }
     else { HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
     if (s->settings.pipeline_chunks <= 0) s->settings.pipeline_chunks = 1;
@@ -1097,6 +1095,7 @@ int bpmpc_solver_constraint_values(bpmpc_solver* s, double* values, int* rows, i
   API_GUARD(s, {
     if (!values || s->batch < 1) throw std::invalid_argument("bpmpc_solver_constraint_values: null output or no setup");
     if (s->settings.reference_kernels) throw std::invalid_argument("bpmpc_solver_constraint_values needs the fast kernels");
+    if (s->is_ddp() && s->has_solution) throw Unsupported("bpmpc_solver_constraint_values: the DDP solution lives on the time points of its roll-out, not on the shooting grid the constraint rows are evaluated on");
     const size_t N = s->settings.max_nodes, S = (size_t)s->batch * N;
     double* d_eqv = nullptr;
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_eqv), S * kMaxEqRows * sizeof(double)));     // a debugging path (solver observers): allocated per call

@@ -111,3 +111,50 @@ def reduce_stats(values, group=None, op="sum"):
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=group)
         t = t.cpu()
     return t
+
+
+# ---- which algorithm / protocol RCCL picks for the per-solve gather ------------------------------------------------------
+# xGMI is point to point (7 links per GPU): for the 9.5 .. 18 MB block of a solve SURVEY.md section 8(e) argues for direct all-pairs transfers over a ring.
+# What RCCL really chooses is only visible in its debug log, so `bench.py --gather-report` switches the log on (before the process group exists - the
+# variables are read at init), and rank 0 parses its own file after the run into config.distributed.collective.  NCCL_ALGO / NCCL_PROTO pass through
+# `--gather-algo` / `--gather-proto`.
+_NCCL_ALGOS = {0: "TREE", 1: "RING", 2: "COLLNET_DIRECT", 3: "COLLNET_CHAIN", 4: "NVLS", 5: "NVLS_TREE", 6: "PAT"}
+_NCCL_PROTOS = {0: "LL", 1: "LL128", 2: "SIMPLE"}
+
+
+def nccl_debug_env(log_path, algo=None, proto=None):
+    """Environment for an RCCL process group whose choices are to be reported: returns the dict of variables to set BEFORE init_process_group."""
+    env = {"NCCL_DEBUG": "INFO", "NCCL_DEBUG_SUBSYS": "INIT,GRAPH,TUNING,COLL", "NCCL_DEBUG_FILE": log_path}
+    if algo:
+        env["NCCL_ALGO"] = str(algo)
+    if proto:
+        env["NCCL_PROTO"] = str(proto)
+    return env
+
+
+def parse_nccl_debug(text):
+    """What an NCCL / RCCL INFO log says about the collectives that ran: per collective name the (algorithm, protocol, bytes) choices seen, the
+    transports of the channels (P2P/IPC = xGMI peer access, SHM, NET), the number of channels / rings and the library version.  Tolerant of the two
+    spellings of the tuning line (`Algo 1 proto 2` of older releases, `Algo RING proto SIMPLE` of newer ones)."""
+    import re
+    out = {"version": None, "collectives": {}, "transports": {}, "channels": None, "forced": {}}
+    m = re.search(r"(?:NCCL|RCCL) version ([0-9][0-9A-Za-z.+\-]*)", text)
+    if m:
+        out["version"] = m.group(1)
+    for name, nbytes, algo, proto in re.findall(r"(\w+): (\d+) Bytes -> Algo (\w+) proto (\w+)", text):
+        a = _NCCL_ALGOS.get(int(algo), algo) if algo.isdigit() else algo.upper()
+        p = _NCCL_PROTOS.get(int(proto), proto) if proto.isdigit() else proto.upper()
+        entry = out["collectives"].setdefault(name, [])
+        rec = {"bytes": int(nbytes), "algo": a, "proto": p}
+        if rec not in entry:
+            entry.append(rec)
+    for via in re.findall(r"Channel \d+(?:/\d+)? : \d+\[[0-9a-fx]+\] -> \d+\[[0-9a-fx]+\] (?:\[\w+\] )?via ([\w/]+)", text):
+        out["transports"][via] = out["transports"].get(via, 0) + 1
+    m = re.search(r"(\d+) coll channels", text) or re.search(r"Connected all rings.*?(\d+) channels", text)
+    if m:
+        out["channels"] = int(m.group(1))
+    for var in ("NCCL_ALGO", "NCCL_PROTO"):
+        m = re.search(var + r" set by environment to (\S+)", text)
+        if m:
+            out["forced"][var] = m.group(1).rstrip(".")
+    return out

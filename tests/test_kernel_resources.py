@@ -50,7 +50,7 @@ def test_no_product_kernel_uses_scratch_memory():
             bad.append((name, scratch, limit))
     assert not bad, bad
     # the kernels the bench line runs exist under the names the profiles carry
-    for must in ("k_linearize_fast<10, true, true>", "k_project_lu_s<10, 8, true>", "k_project_fast<10, true, false>", "k_riccati_fast8<10, false>",
+    for must in ("k_linearize_fast<10, true, true, false>", "k_linearize_fast<10, false, true, true>", "k_project_lu_s<10, 8, true>", "k_project_fast<10, true, false>", "k_riccati_fast8<10, false>",
                  "k_trial_fast<12, true>", "k_ls_tail<12, true>"):
         assert any(n.startswith(must) for n, *_ in kernels), must
 
