@@ -75,8 +75,34 @@ __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linea
   // the node - are in flight while (2) the model block is staged; (3) what hangs on the grid (dt, swing references) follows.
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;       // sub: node slot of the workgroup
   const int widx = blockIdx.x * (kLinWaves * NPW) + sub;          // batch * max_nodes < 2^31 is checked at creation
-  bool valid = widx < L.batch * L.klen;
-  const int b = valid ? widx / L.klen : 0, k = valid ? L.k0 + widx % L.klen : 0;
+  bool valid, event_wg = false;
+  int b, k;
+  if (L.lin_ev_n >= 0) {            // one grid for the batch: intermediate nodes first, the event nodes on workgroups of their own behind them (Launch::lin_ev)
+    constexpr int per_wg = kLinWaves * NPW;
+    const int n_comp = L.batch * L.lin_inter, wg_comp = (n_comp + per_wg - 1) / per_wg;
+    if ((int)blockIdx.x < wg_comp) {
+      valid = widx < n_comp;
+      b = valid ? widx / L.lin_inter : 0;
+      const int j = valid ? widx % L.lin_inter : 0;
+      int kk = j;                   // the j-th intermediate node: every event i with ev_i - i <= j lies before it
+#pragma unroll
+      for (int i = 0; i < kLinMaxEvents; ++i) kk += (i < L.lin_ev_n && L.lin_ev[i] - i <= j) ? 1 : 0;
+      k = kk;
+    } else {
+      event_wg = true;              // nothing but event nodes: no evaluation, no model block
+      const int e = widx - wg_comp * per_wg;
+      valid = e < L.batch * L.lin_ev_n;
+      b = valid ? e / L.lin_ev_n : 0;
+      const int i = valid ? e % L.lin_ev_n : 0;
+      int kk = L.lin_ev[0];
+#pragma unroll
+      for (int q = 1; q < kLinMaxEvents; ++q) kk = (i == q) ? L.lin_ev[q] : kk;
+      k = kk;
+    }
+  } else {
+    valid = widx < L.batch * L.klen;
+    b = valid ? widx / L.klen : 0; k = valid ? L.k0 + widx % L.klen : 0;
+  }
   const int act = L.buf.active[b];
   const size_t s0 = (size_t)b * L.N + k;
   const int info = L.buf.n_info[s0];
@@ -85,7 +111,7 @@ __global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linea
   // round 6: dt and the swing references come from the node record (n_aux, written by k_prepare), not from the grid tables behind p_grid[b]:
   // nothing a workgroup waits for before its barrier is more than one memory round trip away
   const LinFastPre pre = linearize_preload<C>(xk, xk + NXc, L.buf.u + s0 * NXc, L.buf.xref + s0 * NXc, g, L.buf.n_aux + s0 * kNodeAux);
-  load_shared_model<kLinWaves * kWave>(*L.model, shared, threadIdx.x);
+  if (!event_wg) load_shared_model<kLinWaves * kWave>(*L.model, shared, threadIdx.x);
   NodeInputs in;
   in.kind = info & 1; in.mode = (info >> 1) & 3;                  // (the same facts as the grid tables hold, one hop earlier)
   in.dt = 0.0;                                                    // (the node record carries it: LinFastPre::aux)
@@ -379,7 +405,8 @@ void linearize_reference(int nj, int slots, hipStream_t st, const Launch& L) { K
 void linearize_fast(int nj, bool materialise, int nodes, hipStream_t st, const Launch& L, hipEvent_t ev_start, hipEvent_t ev_stop) {
   KL_NJ(nj, {
     constexpr int per_wg = lin_waves<NJ>() * LinFastCfg<NJ, true>::NPW;
-    const dim3 grid((nodes + per_wg - 1) / per_wg), block(lin_waves<NJ>() * kWave);
+    const int wgs = L.lin_ev_n >= 0 ? (L.batch * L.lin_inter + per_wg - 1) / per_wg + (L.batch * L.lin_ev_n + per_wg - 1) / per_wg : (nodes + per_wg - 1) / per_wg;
+    const dim3 grid(wgs), block(lin_waves<NJ>() * kWave);
     auto launch = [&](auto kernel) {
       if (ev_start && ev_stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev_start, ev_stop, 0, L);
       else hipLaunchKernelGGL(kernel, grid, block, 0, st, L);

@@ -101,6 +101,7 @@ struct bpmpc_solver {
   // BPMPC_RICCATI_WAVE: 0 never a wave per problem; 1 (default) as described; 2 riccati_wave.h at every batch size, 4 riccati_wave2.h at every
   // batch size (tests); 3 riccati_wave2.h whenever a wave per problem is used
   int riccati_wave = 1;
+  bool lin_compact = true;                                  // BPMPC_LIN_COMPACT=0: the lineariser keeps the event nodes in line (A/B, tests)
   bool force_tables = false;                                // BPMPC_LIN_TABLES=1: the table walks also on a robot of two serial legs (tests)
   bool wt_joint_rows = false;                               // BPMPC_WT_JOINT_ROWS=1: the change of variables always writes the joint rows of Wt (A/B of the byte cut below)
   // which sweep runs the current batch (see launch_riccati)
@@ -157,6 +158,15 @@ struct bpmpc_solver {
     L.feedback = feedback();
     L.ls = ls;
     L.reg_prim = settings.reg_prim;
+    L.lin_ev_n = -1; L.lin_inter = 0;
+    for (int i = 0; i < kLinMaxEvents; ++i) L.lin_ev[i] = 0;
+    if (n_grids == 1 && lin_compact && !grid_kind.empty() && (int)grid_nodes.size() == 1) {
+      const int n = grid_nodes[0];
+      int ne = 0;
+      for (int k = 0; k < n; ++k)
+        if (grid_kind[k] == 1) { if (ne < kLinMaxEvents) L.lin_ev[ne] = k; ++ne; }
+      if (ne <= kLinMaxEvents && n == L.klen) { L.lin_ev_n = ne; L.lin_inter = n - ne; }
+    }
     L.ilqr = is_ddp() ? 1 : 0;                                  // the DDP solver: every kernel of the backward pass works on the Euler-discretised model
     L.ilqr_shift = is_ddp() ? rm.ddp.ls_hessian_correction_multiple : 0.0;
     return L;
@@ -330,6 +340,7 @@ void bpmpc_solver::pipelined_backward() {
     Launch L = launch_params();
     L.k0 = lo;
     L.klen = hi - lo;
+    L.lin_ev_n = -1;                 // a chunk of the horizon: node slot = launch index
     const int nodes = batch * L.klen;
     launch_linearize_fast(producer_stream, L, nodes);
     HIP_CHECK(hipGetLastError());
@@ -910,6 +921,7 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, settings->device)); s->num_cus = prop.multiProcessorCount; }
     { const char* e = std::getenv("BPMPC_WT_JOINT_ROWS"); s->wt_joint_rows = e && e[0] == '1'; }
     { const char* e = std::getenv("BPMPC_LIN_TABLES"); s->force_tables = e && e[0] == '1'; }
+    { const char* e = std::getenv("BPMPC_LIN_COMPACT"); s->lin_compact = !(e && e[0] == '0'); }
     { const char* e = std::getenv("BPMPC_RICCATI_WAVE"); s->riccati_wave = e ? std::atoi(e) : 1; }
     {
       bool block_diagonal = true;
