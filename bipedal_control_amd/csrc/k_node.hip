@@ -51,15 +51,9 @@ __global__ __launch_bounds__(kWave) void k_linearize(Launch L) {
 constexpr int kTrialWaves = 4; // same for the value-only trial kernel (smaller per-node LDS: four waves, 8 waves per CU)
 // wavefronts per workgroup of the linearisation kernel: they share one copy of the model block in LDS.  Four: 74.3 KB at nx = 22, 79.1 KB
 // at nx = 24 (a wave serves four nodes of 4.2 KB each, packed lanes, LinFastCfg) - two workgroups, eight waves per CU
-#ifndef BPMPC_LIN_WAVES
-#define BPMPC_LIN_WAVES 4      // five (two workgroups = ten waves per CU fit since the node tables share one storage): 0.302 against 0.223 ms at batch
-#endif                        // 256, 4.22 against 3.20 at 4096 - the kernel is not short of waves (experiments/LOG.md)
-template <int NJ> constexpr int lin_waves() { return BPMPC_LIN_WAVES; }
-#ifndef BPMPC_LIN_WPE
-#define BPMPC_LIN_WPE __attribute__((amdgpu_waves_per_eu(2, BPMPC_LIN_WAVES > 4 ? 3 : 2)))
-#endif
+template <int NJ> constexpr int lin_waves() { return 4; }      // (five - ten waves per CU - was measured: 0.302 against 0.223 ms at batch 256; the kernel is not short of waves, experiments/LOG.md)
 template <int NJ, bool MAT, bool CHAIN, bool ILQR = false>      // ILQR: the DDP solver's Euler-discretised model (linearize_fast.h)
-__global__ __launch_bounds__(lin_waves<NJ>() * kWave) BPMPC_LIN_WPE void k_linearize_fast(Launch L) {
+__global__ __launch_bounds__(lin_waves<NJ>() * kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linearize_fast(Launch L) {
   using C = LinFastCfg<NJ, true, CHAIN>;
   constexpr int LPN = C::LPN, NPW = C::NPW, kLinWaves = lin_waves<NJ>();
   // the stage-one columns wait in LDS when two workgroups per CU (eight waves: the registers allow no more) still fit, else in HBM scratch

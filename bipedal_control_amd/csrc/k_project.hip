@@ -33,11 +33,9 @@ __global__ __launch_bounds__(kWave) void k_project(Launch L) {
   project_node<NJ>(ws, in, out);
 }
 
-#ifndef BPMPC_LUS_WPE
-#define BPMPC_LUS_WPE __attribute__((amdgpu_waves_per_eu(4, 6)))     // 68 registers; 9 KB of LDS per wave: four waves per SIMD (0.107 -> 0.095 ms), 5.9 KB with the compact tile of the packed outputs: six
-#endif
+// 68 registers; 9 KB of LDS per wave: four waves per SIMD (0.107 -> 0.095 ms), 5.9 KB with the compact tile of the packed outputs: six
 template <int NJ, int RM, bool PK>
-__global__ __launch_bounds__(kWave) BPMPC_LUS_WPE void k_project_lu_s(Launch L) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 6))) void k_project_lu_s(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ, WP = PackedLq<NJ>::WP;
   __shared__ ProjectLuSLds<NJ, PK> lds[kLuNodes];
   const int sub = threadIdx.x / kLuLanes, j = threadIdx.x % kLuLanes;
@@ -73,11 +71,8 @@ __global__ __launch_bounds__(kWave) BPMPC_LUS_WPE void k_project_lu_s(Launch L) 
 
 // (amdgpu_waves_per_eu(3): 168 registers and 60 B of scratch instead of 186 registers, three waves per SIMD instead of two - measured
 //  slower, 0.272 against 0.255 ms on the same box)
-#ifndef BPMPC_PROJECT_WPE
-#define BPMPC_PROJECT_WPE 3
-#endif
 template <int NJ, bool PK, bool WJ>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PK ? BPMPC_PROJECT_WPE : 2, 4))) void k_project_fast(Launch L) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PK ? 3 : 2, 4))) void k_project_fast(Launch L) {
   constexpr int NX = 12 + NJ, NU = 12 + NJ;
   __shared__ ProjectMfmaWorkspace<NJ, PK> ws;
   const int b = blockIdx.x / L.klen, k = L.k0 + blockIdx.x % L.klen;

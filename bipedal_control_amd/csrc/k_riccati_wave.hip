@@ -13,17 +13,8 @@ namespace bpmpc {
 
 // Batches larger than the chip (riccati_wave.h): one wavefront per problem, alone on its SIMD with the whole register file; the roll-out is
 // a launch of its own.
-#ifndef BPMPC_WAVE_WPE
-#define BPMPC_WAVE_WPE 1
-#endif
-#ifndef BPMPC_ROLLOUT_PAIR
-#define BPMPC_ROLLOUT_PAIR 1       // roll-out behind the wave sweeps in two-wave workgroups, four per CU (0: four-wave workgroups, two per CU)
-#endif
-#ifndef BPMPC_RICCATI_WAVE_DEFAULT
-#define BPMPC_RICCATI_WAVE_DEFAULT 1     // BPMPC_RICCATI_WAVE unset: 1 = batches larger than the chip use the wave-per-problem sweep
-#endif
 template <int NJ, bool JW>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(BPMPC_WAVE_WPE, 2))) void k_riccati_wave(Launch L) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_riccati_wave(Launch L) {
   __shared__ RiccatiWaveWorkspace<NJ> ws;
   RiccatiFastIO io;
   if (!riccati_fast_io<NJ>(L, io, reinterpret_cast<double*>(&ws))) return;

@@ -14,12 +14,6 @@
 #include <hip/hip_runtime.h>
 
 #include "node_lq.h"
-#ifndef BPMPC_LIN_BCAST_DPP
-#define BPMPC_LIN_BCAST_DPP 1
-#endif
-#ifndef BPMPC_LIN_FMA_MASK
-#define BPMPC_LIN_FMA_MASK 1
-#endif
 #include "riccati_fast.h"   // lds_wave_sync
 
 namespace bpmpc {
@@ -253,26 +247,17 @@ __device__ __forceinline__ double row_bcast_f64(double x) {
 }
 template <class C, int SRC_COORD>      // the value of the lane that carries coordinate SRC_COORD, in every lane of the node
 __device__ __forceinline__ double node_bcast(double x) {
-#if BPMPC_LIN_BCAST_DPP
   if constexpr (C::LPN == 16) return row_bcast_f64<SRC_COORD - C::G0>(x);
   else
-#endif
   return __shfl(x, SRC_COORD - C::G0, C::LPN);
 }
 template <class C, int N>
 __device__ __forceinline__ void chain_subtree_sum(double (&v)[N], int g, bool is_joint, int depth) {
-#ifdef BPMPC_ABL_SUBTREE
-  return;
-#endif
 #pragma unroll
   for (int d = C::LEG - 1; d >= 1; --d) {
     const bool on = is_joint && depth == d;
-#if BPMPC_LIN_FMA_MASK
     const double onf = on ? 1.0 : 0.0;       // one multiply-add instead of an addition and two selects (1.0 * child is exact; 0.0 * child adds a zero)
     for (int c = 0; c < N; ++c) { const double child = dpp_row_f64<kDppRowShl + 1>(v[c]); v[c] = fma(onf, child, v[c]); }
-#else
-    for (int c = 0; c < N; ++c) { const double child = dpp_row_f64<kDppRowShl + 1>(v[c]); v[c] = on ? v[c] + child : v[c]; }
-#endif
   }
   for (int c = 0; c < N; ++c) {
     const double h1 = dpp_row_f64<kDppRowShl + 1>(v[c]), h2 = dpp_row_f64<kDppRowShl + 1 + C::LEG>(v[c]);
@@ -694,12 +679,7 @@ struct LinFastOut {
 //   packed (G0 = 3):          slot 0 = coordinate (0..14) | slot 1 = translation (0..2) + joint velocity (3..14) | slot 2 = force | slot 3 = momentum
 // The row loops are fully unrolled (compile-time row offsets); without a fence between the rows the scheduler hoists the LDS reads of
 // all of them to the top (hundreds of registers, spills).
-#ifndef BPMPC_LIN_UNROLL_CONTACTS
-#define BPMPC_LIN_UNROLL_CONTACTS 0      // 1: 254 registers + 44 B of scratch, 0.218 against 0.211 ms at batch 256 (the four contacts rolled: 219, none)
-#endif
-#ifndef BPMPC_LIN_ROW_FENCE
-#define BPMPC_LIN_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
+#define LIN_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 template <class Cfg>
 struct RoleSlots {
   static constexpr bool PACKED = Cfg::G0 > 0;
@@ -875,11 +855,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     omega_of(e1.br_j, wj);
     const double pos_gain = sc.pos_gain;
     int row = 0;
-#if BPMPC_LIN_UNROLL_CONTACTS
-#pragma unroll
-#else
 #pragma nounroll
-#endif
     for (int i = 0; i < kNumContacts; ++i) {
       const bool stance = stance_flag(mode, i);
       const double cp_i[3] = {cpos1[i][0], cpos1[i][1], cpos1[i][2]};
@@ -938,7 +914,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
         eq_sse = stance ? eq_sse : eq_sse + ev * ev;
       }
       row += stance ? 3 : 4;
-      BPMPC_LIN_ROW_FENCE();
+      LIN_ROW_FENCE();
     }
     nc = row;
     (o.e + o.s * (kMaxEqRows))[ln] = e_mine;      // all kMaxEqRows = LPN entries: zeros beyond nc
@@ -956,7 +932,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
     const double qg2 = qg + dt * e1.vg;
     LaneKin<NJ> kin2;
     eval_lane<NJ, true, true, NL, LinFastShared<NJ>, C>(md, sh, nl, 1, lb, path, g, xh2, qg2, ujg, e2, kin2);
-    BPMPC_LIN_ROW_FENCE();           // keeps the loads of the combination phase (parked columns, stage-one blocks) out of the evaluation's registers
+    LIN_ROW_FENCE();           // keeps the loads of the combination phase (parked columns, stage-one blocks) out of the evaluation's registers
     lds_wave_sync();
     v2t = tr ? nl.vlin[1][ln] : 0.0;
   }
@@ -1026,7 +1002,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
       }
       // base translation (packed layout, lanes 0..2): identity column
       slots.store(pab, r * NX, aq, (r == 6 + ln) ? 1.0 : 0.0, ah_, bf, bj);
-      BPMPC_LIN_ROW_FENCE();
+      LIN_ROW_FENCE();
     }
   }
   // b = x + dt/2 (f1 + f2) - x_next
@@ -1098,7 +1074,7 @@ __device__ __forceinline__ void linearize_fast(const DeviceModel& md, const LinF
       // the sums are needed behind the loop only: left alone, their multiply-adds sink there and the 88 weights they read wait in registers
       asm volatile("" : "+v"(accq), "+v"(acch), "+v"(accf), "+v"(accj));
       if constexpr (PACKED) asm volatile("" : "+v"(acct));
-      BPMPC_LIN_ROW_FENCE();
+      LIN_ROW_FENCE();
     }
     // the node-dependent part of R in compact form: the three rows of the own 3 x 3 force block (lanes 0..11)
     if (ln < 12) {

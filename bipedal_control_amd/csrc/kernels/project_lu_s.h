@@ -59,12 +59,9 @@ __device__ __forceinline__ unsigned long long lus_force_rows(int mode) {
   return mode == 0 ? p0 : (mode == 1 ? p1 : (mode == 2 ? p2 : p3));
 }
 
-#ifndef BPMPC_LUS_COMPACT
-#define BPMPC_LUS_COMPACT 1                  // packed outputs: tile of nj rows x 16 columns, three passes (5.9 KB of LDS per wave instead of 9.0: six waves per SIMD)
-#endif
 template <int NJ, bool PK = false>
 struct ProjectLuSLds {                       // per node
-  static constexpr bool kCompact = PK && BPMPC_LUS_COMPACT;
+  static constexpr bool kCompact = PK;
   static constexpr int UC = kCompact ? NJ : kMaxJoints;
   static constexpr int TR = kCompact ? NJ : (12 + NJ) / 2, TC = kCompact ? 16 : 12 + NJ + 2;
   union {

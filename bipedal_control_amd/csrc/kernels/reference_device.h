@@ -56,7 +56,7 @@ struct DevSchedule {
   double keep_from;      // events more than one phase in front of this time are never looked at again (GaitSchedule::getModeSchedule drops them)
 };
 
-#define BPMPC_EXACT_FP _Pragma("clang fp contract(off)")   // first statement of a body: no fused multiply-add, as on the host
+#define EXACT_FP_BODY _Pragma("clang fp contract(off)")   // first statement of a body: no fused multiply-add, as on the host
 
 __device__ inline int ref_lower_bound(const double* a, int n, double t) {   // first index with a[i] >= t
   int lo = 0, hi = n;
@@ -80,7 +80,7 @@ __device__ inline void ref_push_ev(DevSchedule& s, double t) { if (s.ne < s.cap 
 __device__ inline void ref_push_ms(DevSchedule& s, int m) { if (s.nm < s.cap + 1 || ref_compact(s)) s.ms[s.nm++] = m; }
 
 __device__ inline void ref_tile(DevSchedule& s, const double* sw, const int* modes, int phases, double start, double final_time) {
-  BPMPC_EXACT_FP
+  EXACT_FP_BODY
   if (phases == 0) return;
   if (s.ne > 0 && start <= s.ev[s.ne - 1]) { s.status = kRefTileOrder; return; }
   ref_push_ev(s, start);
@@ -95,7 +95,7 @@ __device__ inline void ref_tile(DevSchedule& s, const double* sw, const int* mod
 // GaitSchedule(initial, default template).insert_template(gait, start, t0 + 2 H) [if gait >= 0] followed by
 // mode_schedule(t0 - H, t0 + 2 H): what SwitchedModelReferenceManager::modifyReferences asks for at solve time.
 __device__ inline void ref_build_schedule(RefGenLds& w, const GaitLibraryView& lib, int gait, double start, double t0, double horizon) {
-  BPMPC_EXACT_FP
+  EXACT_FP_BODY
   DevSchedule s{w.ev, w.ms, 0, 0, kRefMaxEvents, kRefOk, t0 - horizon};
   for (int i = 0; i < lib.init_n_events; ++i) ref_push_ev(s, lib.init_events[i]);
   for (int i = 0; i <= lib.init_n_events; ++i) ref_push_ms(s, lib.init_modes[i]);
@@ -140,7 +140,7 @@ __device__ inline void ref_build_schedule(RefGenLds& w, const GaitLibraryView& l
 // timeDiscretizationWithEvents: dt steps from t0, event times inserted as a pre-event / post-event pair, nodes closer than
 // dt_min merged.  Returns the number of intervals (which may exceed what was stored; the caller reports that).
 __device__ inline int ref_shooting_grid(RefGenLds& w, double t0, double tf, double dt, double dt_min) {
-  BPMPC_EXACT_FP
+  EXACT_FP_BODY
   const double* ev = w.ev + w.base;
   int cnt = 1;
   double last_t = t0;
@@ -163,7 +163,7 @@ __device__ inline int ref_shooting_grid(RefGenLds& w, double t0, double tf, doub
 
 struct RefCubic { double t0, dt, c0, c1, c2, c3; };
 __device__ inline RefCubic ref_cubic(double ta, double za, double va, double tb, double zb, double vb) {
-  BPMPC_EXACT_FP
+  EXACT_FP_BODY
   RefCubic s;
   s.t0 = ta;
   s.dt = tb - ta;
@@ -175,14 +175,14 @@ __device__ inline RefCubic ref_cubic(double ta, double za, double va, double tb,
   return s;
 }
 __device__ inline void ref_cubic_eval(const RefCubic& s, double t, double* z, double* zd) {
-  BPMPC_EXACT_FP
+  EXACT_FP_BODY
   const double tn = (t - s.t0) / s.dt;
   *z = s.c3 * tn * tn * tn + s.c2 * tn * tn + s.c1 * tn + s.c0;
   *zd = (3.0 * s.c3 * tn * tn + 2.0 * s.c2 * tn + s.c1) / s.dt;
 }
 
 __device__ inline void ref_swing(const RefGenLds& w, const ReferenceGenArgs& a, int c, int p, double t, double* z, double* zd) {
-  BPMPC_EXACT_FP
+  EXACT_FP_BODY
   const double* ev = w.ev + w.base;
   const int* ms = w.ms + w.base;
   const double terrain = 0.0;
@@ -202,7 +202,7 @@ __device__ inline void ref_swing(const RefGenLds& w, const ReferenceGenArgs& a, 
 }
 
 __global__ __launch_bounds__(64) void k_reference_grids(ReferenceGenArgs a) {
-  BPMPC_EXACT_FP
+  EXACT_FP_BODY
   __shared__ RefGenLds w;
   const int g = blockIdx.x, l = threadIdx.x;
   const double t0 = a.t0[g];
@@ -266,7 +266,7 @@ struct CommandTargetArgs {
 
 // cmdVelToTargetTrajectories (TargetTrajectoriesPublisher.cpp:40-62 restated in reference_gen.cpp cmd_vel_to_targets)
 __global__ __launch_bounds__(64) void k_command_targets(CommandTargetArgs a) {
-  BPMPC_EXACT_FP
+  EXACT_FP_BODY
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= a.batch) return;
   const int nx = a.nx;
@@ -301,6 +301,6 @@ __global__ __launch_bounds__(64) void k_command_targets(CommandTargetArgs a) {
   a.tgt_n[b] = 2;
 }
 
-#undef BPMPC_EXACT_FP
+#undef EXACT_FP_BODY
 
 }  // namespace bpmpc

@@ -86,13 +86,10 @@ __device__ __forceinline__ void linesearch_begin_wave(double* partial /*kWave*3 
 // LDS operand loads of the workgroup sweeps.  The compiler pairs neighbouring 8-byte LDS loads into ds_read2_b64, which costs 8 LDS-array cycles per
 // pair and is banked mod 32 in 16-lane groups (a lane-per-row access with an even row stride is 2-way conflicted there); ds_read_b64 costs 2 cycles
 // each and is banked mod 64 in 32-lane groups (MI355X_MICROARCH.md, LDS table).  A volatile load through an LDS-address-space pointer cannot be
-// paired (a volatile GENERIC pointer would become a flat load).  BPMPC_LDS_SINGLE=0: plain loads (A/B).
-#ifndef BPMPC_LDS_SINGLE
-#define BPMPC_LDS_SINGLE 1
-#endif
+// paired (a volatile GENERIC pointer would become a flat load).
 __device__ __forceinline__ double lds1(const double& r) {
   typedef const volatile __attribute__((address_space(3))) double* lds_cvp;
-  if constexpr (BPMPC_LDS_SINGLE) return *(lds_cvp)(&r); else return r;
+  return *(lds_cvp)(&r);
 }
 struct d2 { double x, y; };
 __device__ __forceinline__ d2 lds_pair(const double* p) {  // 16-byte aligned pair
@@ -342,9 +339,6 @@ __device__ __forceinline__ double quad_swap_pairs(double v) {       // value of 
 // cache lines of its 11 KB, eleven times over, with eight waves thrashing the 16 KB L1: 23 us of a 340 us kernel.  Now a wave
 // copies 32 consecutive rows (one contiguous 5.6 KB piece of K, each byte requested once, the next piece already in flight) into
 // its own LDS tile and works from there with two lanes per row; the partial sums meet through a DPP quad permutation.
-#ifndef BPMPC_STEP_NORMS_STAGED
-#define BPMPC_STEP_NORMS_STAGED 1
-#endif
 constexpr int kMaxRiccatiStages = 512;            // longest horizon of a solver handle (node tables of the sweeps, bpmpc_solver_create)
 constexpr int kStepNormsScratch = 32 * 26;     // doubles of LDS per wave (StepNormsTile)
 template <int NJ>
@@ -363,7 +357,6 @@ __device__ __forceinline__ void riccati_step_norms(int status, const RiccatiFast
   const int tid = threadIdx.x;
   const int N = io.base.N;
   double acc_arm = 0.0, acc_x = 0.0, acc_u = 0.0;
-#if BPMPC_STEP_NORMS_STAGED
   using T = StepNormsTile<NJ>;
   constexpr int NCH = T::NCH, CP = T::CP, ROWS = T::ROWS, LDR = T::LDR, CPI = T::CPI, LPL = T::LPL, NW = NT / kWave;
   const int w = tid >> 6, l = tid & 63;
@@ -442,25 +435,6 @@ __device__ __forceinline__ void riccati_step_norms(int status, const RiccatiFast
     }
     lds_wave_sync();                                     // the tile is rewritten by the next pass
   }
-#else
-  (void)scratch; (void)hist;
-  // ---- du_k = K_k dx_k + kff_k for every stage in parallel, Armijo metric and step norms
-  for (int idx = tid; idx < N * NU; idx += NT) {
-    const int k = idx / NU, i = idx % NU;
-    const double* dxk = io.base.dx + (size_t)k * NX;
-    const double* Kr = io.Kfull + (size_t)k * NXU + (size_t)i * NX;
-    double t = io.kff[(size_t)k * NU + i];
-#pragma unroll
-    for (int l = 0; l < NX; ++l) t += Kr[l] * dxk[l];
-    if (io.base.nut[k] == 0) t = 0.0;   // event node: no input
-    io.base.du[idx] = t;
-    acc_u += t * t;
-    const double d = dxk[i];            // NU == NX: the same index walks the state vector
-    acc_x += d * d;
-    acc_arm += io.mvec[(size_t)k * NX + i] * d;
-    if (i == 0) acc_arm += io.mscal[k];
-  }
-#endif
   if (tid < NX) { const double d = io.base.dx[(size_t)N * NX + tid]; acc_x += d * d; }
   __shared__ double red3[3][NT / kWave];
   for (int off = kWave / 2; off >= 1; off >>= 1) {

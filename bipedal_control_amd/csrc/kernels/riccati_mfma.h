@@ -22,15 +22,6 @@
 
 #include "riccati_fast.h"
 
-#ifndef BPMPC_RICCATI_GJ_DPP
-#define BPMPC_RICCATI_GJ_DPP 1   // riccati_mfma8.h: pivot columns broadcast with DPP row_newbcast (riccati_fast.h); 0: v_readlane version only
-#endif
-#ifndef BPMPC_RICCATI4_GJ_DPP
-#define BPMPC_RICCATI4_GJ_DPP 0  // the same in this kernel: measured slower here (0.427 against 0.393 ms, batch 256), the elimination is not the
-#endif                           // long pole of its phase P3 - the wave that stores, prefetches and computes two blocks of Sn is
-#ifndef BPMPC_RICCATI_ABLATE
-#define BPMPC_RICCATI_ABLATE 0   // timing experiments: 1 no Gauss-Jordan, 2 no Acl/K stores, 3 no prefetch, 4 no mvec (wrong results)
-#endif
 
 namespace bpmpc {
 
@@ -327,10 +318,6 @@ struct PackedStageLoader {
 // (Two lanes per row - half the loads, LDS reads and FMAs per lane, partial sums joined by a DPP quad permutation - was measured:
 //  0.3412 -> 0.339 ms at batch 256, 4.48 -> 4.51 ms at batch 4096; the step is bound by the LDS round trip of the state, not by its
 //  instruction count.  Not kept.)
-#ifndef BPMPC_ROLLOUT_SPARSE
-#define BPMPC_ROLLOUT_SPARSE 0     // 1: the workgroup kernels use riccati_rollout_sparse (below) too - measured 0.341 against 0.337 ms at
-                                   // batch 256 (the du shuffles sit on the recurrence's chain), 0.592 against 0.593 at 512: not used there
-#endif
 template <int NJ, int NT = kRiccatiThreads>
 __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 4) * nx doubles*/, int cap, int status, const RiccatiFastIO& io) {
   constexpr int NX = 12 + NJ, NXX = NX * NX;
@@ -570,7 +557,6 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
   int held_k = -1;
   auto flush_held = [&]() {
     if (held_k < 0) return;                            // uniform
-#if BPMPC_RICCATI_ABLATE != 2
     const int r0 = 16 * (w >> 1), c0 = 16 * (w & 1);
     double* Acl = io.Acl + (size_t)held_k * NXX;
     double* Kf = io.Kfull + (size_t)held_k * NXU;
@@ -585,7 +571,6 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
     }
     if (w == 3 && l < NX) io.mvec[(size_t)held_k * NX + l] = held_m;
     if (w == 3 && l == NX) io.mscal[held_k] = held_m;
-#endif
   };
 
   for (int k = k_top; k >= io.k_lo; --k) {
@@ -659,17 +644,9 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
     //          the other waves: [Sn | sn] = [Q | q] + A' SW(:, 0..nx)
     // row layout of the elimination (riccati_fast.h): 16 - nt right-hand sides per 16-lane row, 4 rows per wave
     const int rpr = 16 - nt;
-#if BPMPC_RICCATI4_GJ_DPP
-    const int gj_waves = 4 * rpr >= NX + 1 ? 1 : (8 * rpr >= NX + 1 && nt <= 12 ? 2 : 0);   // 0: the v_readlane version on wave 3
-#else
     const int gj_waves = 0;
-#endif
     const int sn_waves = gj_waves == 2 ? 2 : 3;
-#if BPMPC_RICCATI_ABLATE == 1
-    if (false) {
-#else
     if (w == 3 && gj_waves == 0) {
-#endif
       const int col = l < nt ? BC + l : l - nt;
       const bool used = l < nt + NX + 1;
       bool ok;
@@ -680,24 +657,18 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
         ok = gauss_jordan_wave<ROWS>(v, nt);                                                  \
         _Pragma("unroll") for (int i = 0; i < ROWS; ++i) if (used && i < nt && l >= nt) M[i][col] = v[i]; \
       }
-#if BPMPC_RICCATI4_GJ_DPP
-      BP_GJ_CASE(NU)
-#else
       // the elimination is the longest dependent chain of a stage: instantiate it for the actual number of rows
       if (nt <= 8) BP_GJ_CASE(8)
       else if (nt == 9) BP_GJ_CASE(9)          // single support of this robot class: 14 rows of rank 13
       else if (nt <= 10) BP_GJ_CASE(10)
       else if (nt <= 12) BP_GJ_CASE(12)
       else BP_GJ_CASE(NU)
-#endif
 #undef BP_GJ_CASE
       if (l == 0 && !ok) ws.status = 1;
     } else if (w >= 4 - gj_waves && gj_waves > 0) {
       if (w != 3) {                    // wave 2 is a loader: its share of the global memory traffic first
         flush_held();
-#if BPMPC_RICCATI_ABLATE != 3
         if (loader && k > io.k_lo) prefetch_next(k);
-#endif
       }
       const int c16 = l & 15;
       const int rhs = ((3 - w) * 4 + (l >> 4)) * rpr + (c16 - nt);      // right-hand side of this lane (lanes >= nt of the row)
@@ -725,9 +696,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
       // global memory traffic of the stage, off the critical path (the elimination is the long pole of P3) and
       // as early as possible: outputs of the previous stage, then the operands of the next one
       flush_held();
-#if BPMPC_RICCATI_ABLATE != 3
       if (loader && k > io.k_lo) prefetch_next(k);     // never beyond the chunk: earlier stages may not be projected yet
-#endif
       for (int id = w; id < 4; id += sn_waves) {
         const int r0 = 16 * (id >> 1), c0 = 16 * (id & 1);
         v4d acc = blk_load<LDN, RCL, ZR>(&Qq[0][0], r0, c0, l);
@@ -793,7 +762,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
       blk_store<LDN, RB>(&ws.S[0][0], r0, c0, l, acc);    // S was last read in P1, three barriers ago
       // m = q~ - Y' r~ (Kt = -Y), m0 = -r~' H^-1 g
       double mt = 0.0;
-      if (BPMPC_RICCATI_ABLATE != 4 && w == 3 && l <= NX) {
+      if (w == 3 && l <= NX) {
         mt = l < NX ? Qq[l][NX] : 0.0;
         if (nt <= 12) {
 #pragma unroll
@@ -827,13 +796,7 @@ __device__ __forceinline__ void riccati_mfma(RiccatiMfmaWorkspace<NJ, DB>& ws, c
     __syncthreads();                                   // the workspace is dead from here on: it holds the state history
     constexpr int kHistCap = ((int)(sizeof(WS) / sizeof(double)) - kStepNormsScratch * kRiccatiThreads / kWave) / NX - 8;
     static_assert(kHistCap >= 64, "roll-out history");
-#if BPMPC_ROLLOUT_SPARSE
-    constexpr int kCapSparse = ((int)(sizeof(WS) / sizeof(double)) - 264 - 4 * NX) / (2 * NX);
-    static_assert(kCapSparse >= 64, "roll-out history");
-    riccati_rollout_sparse<NJ>(reinterpret_cast<double*>(&ws), kCapSparse, st, io);
-#else
     riccati_rollout_deep<NJ>(reinterpret_cast<double*>(&ws), kHistCap, st, io);
-#endif
   }
 }
 

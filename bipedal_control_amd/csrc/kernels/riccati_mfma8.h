@@ -390,7 +390,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
       // lane layout: with at most 4 (16 - nt) >= nx + 1 right-hand sides the DPP row layout of riccati_fast.h (every 16-lane row
       // holds H in its lanes 0..nt-1 and 16 - nt right-hand sides), otherwise one column per lane of the wave (v_readlane)
       const int rpr = 16 - nt;
-      const bool rows_layout = BPMPC_RICCATI_GJ_DPP && 4 * rpr >= NX + 1;
+      const bool rows_layout = 4 * rpr >= NX + 1;
       const int c16 = l & 15;
       const int rid = rows_layout ? (l >> 4) * rpr + (c16 - nt) : l - nt;          // right-hand side of this lane
       const bool is_h = rows_layout ? c16 < nt : l < nt;
@@ -509,13 +509,7 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
 #ifdef BPMPC_RICCATI_PROFILE
     const long long tr0 = clock64();
 #endif
-#if BPMPC_ROLLOUT_SPARSE
-    constexpr int kCapSparse = ((int)(offsetof(WS, status) / sizeof(double)) - 264 - 4 * NX) / (2 * NX);
-    static_assert(kCapSparse >= 64, "roll-out history");
-    riccati_rollout_sparse<NJ, NT>(reinterpret_cast<double*>(&ws), kCapSparse, st, io);
-#else
     riccati_rollout_deep<NJ, NT>(reinterpret_cast<double*>(&ws), kHistCap, st, io);
-#endif
 #ifdef BPMPC_RICCATI_PROFILE
     if (BPMPC_RICCATI_PROFILE == 1 && io.prof && tid == 0) { const long long te = clock64(); io.prof[5] = (double)(te - tr0); io.prof[6] = (double)te - io.prof[6]; }     // roll-out + step norms, whole horizon; [6]: the step norms alone
 #endif

@@ -36,7 +36,7 @@ struct Out {
 
 // the role pointers of an unpacked node (16 coordinates): slot 0 = x column 6 + ln | slot 1 = momentum column (lanes 0..5) or joint-velocity
 // column | slot 2 = force column (lanes 0..11) or the dump
-template <int LDS_BYTES, int NX>
+template <int LDS_BYTES, int NX, bool NT = false>
 __global__ __launch_bounds__(256) void k_pattern(Out o, int nodes) {
   constexpr int NU = NX;
   __shared__ char pad[LDS_BYTES > 0 ? LDS_BYTES : 1];
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void k_pattern(Out o, int nodes) {
       double* p2 = ln < 12 ? U + ln : dump;
 #pragma unroll
       for (int r = 0; r < nrows; ++r) {
-        p0[r * NX] = v; p1[r * NX] = v; p2[r * NX] = v;
+        if constexpr (NT) { __builtin_nontemporal_store(v, p0 + r * NX); __builtin_nontemporal_store(v, p1 + r * NX); __builtin_nontemporal_store(v, p2 + r * NX); }
+        else { p0[r * NX] = v; p1[r * NX] = v; p2[r * NX] = v; }
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {                      // packed lanes (linearize_fast.h RoleSlots, G0 = 3): lane ln carries coordinate g = ln + 3; four role slots
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void k_pattern(Out o, int nodes) {
 }
 
 struct Roof {
-  double fill16_GBs, fill8_GBs, pattern_GBs, pattern_free_GBs;
+  double fill16_GBs, fill8_GBs, pattern_GBs, pattern_free_GBs, pattern_nt_GBs;
   double bytes_fill, bytes_pattern;
   double pattern_ms, pattern_free_ms, fill16_ms;
 };
@@ -137,6 +138,8 @@ int measure(int batch, int nodes_per_problem, Roof* out) {
   out->pattern_ms = ms; out->pattern_GBs = total / (ms * 1e6);
   if (time_ms([&] { hipLaunchKernelGGL((k_pattern<0, NX>), dim3(grid), dim3(256), 0, 0, o, (int)nodes); }, reps, &ms)) return 1;
   out->pattern_free_ms = ms; out->pattern_free_GBs = total / (ms * 1e6);
+  if (time_ms([&] { hipLaunchKernelGGL((k_pattern<76264, NX, true>), dim3(grid), dim3(256), 0, 0, o, (int)nodes); }, reps, &ms)) return 1;
+  out->pattern_nt_GBs = total / (ms * 1e6);
   out->bytes_fill = (double)total; out->bytes_pattern = (double)total;
   for (double* p : {o.A, o.B, o.b, o.Q, o.R, o.q, o.r, o.c, o.C, o.D, o.e, o.perf, o.qrd, o.dump, flat}) CK(hipFree(p));
   CK(hipFree(o.nc));
@@ -146,13 +149,13 @@ int measure(int batch, int nodes_per_problem, Roof* out) {
 }  // namespace
 
 // out[0..8]: fill16 GB/s, fill8 GB/s, pattern GB/s at the lineariser's occupancy, pattern GB/s at free occupancy, bytes per launch,
-// pattern ms, pattern ms (free), fill16 ms, 0
+// pattern ms, pattern ms (free), fill16 ms, pattern GB/s with non-temporal stores (NX = 22 rows only)
 extern "C" int write_roof_measure(int batch, int nodes_per_problem, int nx, double* out) {
   Roof r{};
   if (nx != 22 && nx != 24) return 2;
   if (nx == 22 ? measure<22>(batch, nodes_per_problem, &r) : measure<24>(batch, nodes_per_problem, &r)) return 1;
   out[0] = r.fill16_GBs; out[1] = r.fill8_GBs; out[2] = r.pattern_GBs; out[3] = r.pattern_free_GBs; out[4] = r.bytes_pattern;
-  out[5] = r.pattern_ms; out[6] = r.pattern_free_ms; out[7] = r.fill16_ms; out[8] = 0.0;
+  out[5] = r.pattern_ms; out[6] = r.pattern_free_ms; out[7] = r.fill16_ms; out[8] = r.pattern_nt_GBs;
   return 0;
 }
 
@@ -162,8 +165,8 @@ int main(int argc, char** argv) {
   double o[9];
   if (write_roof_measure(batch, npp, nx, o)) return 1;
   std::printf("{\"batch\": %d, \"nodes_per_problem\": %d, \"bytes_per_launch\": %.0f, \"fill16_GBs\": %.1f, \"fill8_GBs\": %.1f, "
-              "\"pattern_GBs\": %.1f, \"pattern_ms\": %.4f, \"pattern_free_occupancy_GBs\": %.1f, \"pattern_free_occupancy_ms\": %.4f, \"fill16_ms\": %.4f}\n",
-              batch, npp, o[4], o[0], o[1], o[2], o[5], o[3], o[6], o[7]);
+              "\"pattern_GBs\": %.1f, \"pattern_ms\": %.4f, \"pattern_free_occupancy_GBs\": %.1f, \"pattern_free_occupancy_ms\": %.4f, \"fill16_ms\": %.4f, \"pattern_nontemporal_GBs\": %.1f}\n",
+              batch, npp, o[4], o[0], o[1], o[2], o[5], o[3], o[6], o[7], o[8]);
   return 0;
 }
 #endif
