@@ -381,7 +381,7 @@ def main():
         out = {"metric": ("DDP (ILQR) " if ddp else "") + "MPC solves/s (%s, horizon=%d)" % ({"h1": "H1", "g1": "G1", "h1:hard": "H1 hard cones"}.get(args.robot, args.robot), NI), "value": round(value, 2), "unit": "solves/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "settle_steps": max(0, args.settle), "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
-               "config": {"workload": wl, "global_batch": total, "problems_on_rank0": B, "shooting_nodes": n_nodes,
+               "config": {"workload": wl, "gait_start": (None if sweep else args.gait_start), "solver": args.solver, "global_batch": total, "problems_on_rank0": B, "shooting_nodes": n_nodes,
                           "node_linearizations_per_step": int(report[4]), "nx": nx, "nu": nu,
                           "parallelism": "problem-sharded x%d, one %s of trajectories per solve (%s), overlapped with the next solve" % (
                               world, "all-gather" if args.gather == "all" else "gather to rank 0", backend if use_dist else "none at N = 1"),
@@ -421,7 +421,6 @@ def main():
             roofline["bound_note"] = ("`frac` stays achieved / HBM peak (the roof the north-star names); fp64-issue / mfma fractions use executed-instruction "
                                       "counts from profiles/%s (builder run) at this run's kernel time" % sq_counters_file())
         if ddp:
-            out["config"]["solver"] = "ddp"
             out["config"]["step_lengths"] = {str(a): int(sum(1 for st in stats if st.step_size == a)) for a in sorted({st.step_size for st in stats}, reverse=True)}
             out["config"]["roll_out_points_mean"] = round(float(np.mean([st.n_nodes + 1 for st in stats])), 1)
         if world == 1 and args.cpu_sample > 0 and ddp:

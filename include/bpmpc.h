@@ -154,8 +154,11 @@ typedef struct {
                            returns them in out_t, stats.n_nodes = points - 1 (at most max_nodes), stats.step_size = the accepted step length,
                            merit_before / merit_after = performance index of the baseline / accepted roll-out; the controller is a
                            FeedforwardController (ddp.useFeedbackPolicy false) - out_K of a DDP solve holds the gains of the policy on the
-                           nominal grid, for inspection.  Runs on the reference kernel set (reference_kernels is implied).  SLQ, later
-                           iterations on the roll-out's grid and the continuous-time backward pass are not implemented. */
+                           nominal grid, for inspection.  The backward pass runs on the kernels of the SQP path (reference_kernels = 1: the
+                           lane-emulated bodies), all step lengths of the line search are rolled out in one launch.  A DDP solution is NOT on the
+                           shooting grid: bpmpc_solver_rollout, bpmpc_solver_constraint_values and a second bpmpc_solver_run without a new setup /
+                           reset return BPMPC_ERR_UNSUPPORTED.  SLQ, later iterations on the roll-out's grid and the continuous-time backward pass
+                           are not implemented. */
   int feedback_policy;  /* 0 (default): sqp.useFeedbackPolicy of task.info decides for the warm start, the policy rollout AND the controller a caller
                            builds from the solution; 1: LinearController, 2: FeedforwardController - one value for all three, as the single
                            sqp::Settings of the reference */
@@ -178,7 +181,8 @@ typedef struct {
 typedef struct {
   int n_nodes;                /* shooting intervals of this problem */
   int iterations;             /* SQP iterations performed */
-  int status;                 /* 0 ok, 1 line search took no step, 2 numerical failure */
+  int status;                 /* 0 ok, 1 line search took no step, 2 numerical failure (non-positive pivot in the Riccati sweep), 3 (DDP solver) the baseline
+                                 roll-out failed or recorded more time points than max_nodes + 1: the nominal trajectories stay */
   int reserved;
   double merit_before, dynamics_sse_before, equality_sse_before;   /* PerformanceIndex of the last linearisation */
   double merit_after, dynamics_sse_after, equality_sse_after;      /* after the accepted step */

@@ -154,6 +154,10 @@ class HipSqpSolver final : public SolverBase {
       haveSolution_ = false;
       throw std::runtime_error("[HipSqpSolver] numerical failure in the Riccati sweep (non positive-definite stage Hessian)");
     }
+    if (stats_.status == 3) {   // DDP solver: no baseline roll-out to compare the step lengths with
+      haveSolution_ = false;
+      throw std::runtime_error("[HipSqpSolver] DDP: the roll-out of the nominal policy failed (integrator out of steps, or more time points than max_nodes + 1)");
+    }
     haveSolution_ = true;
     fillPrimalSolution(ms);
     if (settings_.computeSolutionMetrics) fillSolutionMetrics();
