@@ -201,3 +201,44 @@ def test_ddp_solution_on_its_own_time_points_refuses_grid_based_calls():
     mpc.enqueue(); mpc.synchronize()                            # a first iteration again
     _, x2, _, _, st2 = mpc.fetch()
     assert st2[0].n_nodes >= 2 and np.isfinite(x2[0, :st2[0].n_nodes + 1]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["h1", "g1"])
+def test_ilqr_lineariser_lq_model_matches_oracle(robot):
+    """The ILQR form of the fast lineariser (kernels/linearize_fast.h, ILQR = true; materialised) against the oracle's Euler-discretised LQ model
+    (oracle/ddp_py.py euler_lq: A = I + dt A_c, B = dt B_c from the dual-number flow map; cost and constraint rows of the transcription) plus the
+    DIAGONAL_SHIFT on R: every block to 1e-11, b = 0, at a generic (warm) iterate, stance and swing modes."""
+    itf = scenarios.interface(robot)
+    prob = scenarios.trot_problem(itf, batch=2, n_intervals=30, gait=("standing_trot" if robot == "g1" else "trot"))
+    cap = 48
+    nx = nu = itf.stateDim
+    # a generic iterate: one SQP iteration first (its x, u are then fed to the DDP handle as the warm start)
+    sqp = bp.BatchedSqpMpc(itf, 2, cap)
+    _, xs, us, _, _ = sqp.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+    mpc = bp.BatchedDdpMpc(itf, 2, cap, materialize_lq=True)
+    lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], warm_x=xs, warm_u=us)
+    mpc.stage("linearize"); mpc.synchronize()
+    x = mpc.read("x").reshape(2, cap + 1, nx); u = mpc.read("u").reshape(2, cap, nu)
+    shapes = dict(A=(nx, nx), B=(nx, nu), b=(nx,), Q=(nx, nx), R=(nu, nu), q=(nx,), r=(nu,), C=(16, nx), D=(16, nu), e=(16,))
+    dev = {k: mpc.read(k).reshape(2, cap, *s) for k, s in shapes.items()}
+    nc = mpc.read("nc").reshape(2, cap)
+    om, m = ob.oracle(robot), ob.model(robot)
+    shift = float(m["ddp"]["hessianCorrectionMultiple"])
+    worst = {}
+    rel = lambda a, o: float(np.abs(np.asarray(a) - np.asarray(o)).max() / max(1.0, np.abs(np.asarray(o)).max()))      # noqa: E731
+    for b in range(2):
+        nodes = ob.oracle_nodes(prob, b, robot=robot)
+        lq = ddp_py.euler_lq(om, nodes, x[b], u[b])
+        for k in range(int(nodes["N"])):
+            if nodes["kind"][k] == 1:
+                assert np.array_equal(dev["A"][b, k], np.eye(nx)) and not dev["b"][b, k].any()
+                continue
+            n = lq["C"][k].shape[0]
+            assert int(nc[b, k]) == n
+            ref = dict(A=lq["A"][k], B=lq["B"][k], b=np.zeros(nx), Q=lq["Q"][k], R=lq["R"][k] + shift * np.eye(nu), q=lq["q"][k], r=lq["r"][k])
+            for name, o in ref.items():
+                worst[name] = max(worst.get(name, 0.0), rel(dev[name][b, k], o))
+            worst["C"] = max(worst.get("C", 0.0), rel(dev["C"][b, k, :n], lq["C"][k])); worst["D"] = max(worst.get("D", 0.0), rel(dev["D"][b, k, :n], lq["D"][k]))
+            worst["e"] = max(worst.get("e", 0.0), rel(dev["e"][b, k, :n], lq["e"][k]))
+    assert max(worst.values()) < 1e-11, worst

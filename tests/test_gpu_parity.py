@@ -595,3 +595,28 @@ def test_indefinite_hessian_is_reported_by_every_sweep(ctx, variant, monkeypatch
     assert all(s.status == 2 for s in st), [s.status for s in st]
 
 
+
+
+def test_lineariser_with_the_event_nodes_out_of_the_way_is_bit_identical(ctx, monkeypatch):
+    """Round 6: when the batch lies on one grid the lineariser maps its lane groups onto the intermediate nodes first (closed-form slot -> node map) and
+    the event nodes onto workgroups of their own (Launch::lin_ev; BPMPC_LIN_COMPACT=0 keeps them in line): the same LQ model, bit for bit, in both
+    output modes - and a batch on several grids (different gait phases) takes the in-line map and still matches itself."""
+    bp, sc, itf = ctx["bp"], ctx["sc"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=21, n_intervals=60, gait_start=0.0)          # 21 x 64 node slots: a last workgroup that is partly empty
+    out = {}
+    for compact in ("1", "0"):
+        monkeypatch.setenv("BPMPC_LIN_COMPACT", compact)
+        for mat in (True, False):
+            mpc = bp.BatchedSqpMpc(itf, max_batch=21, max_nodes=72, materialize_lq=mat)
+            lay = mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
+            assert lay["n_grids"] == 1
+            kinds = mpc.read("g_kind").reshape(21, 72)[0, :lay["n_nodes_max"]]
+            assert 1 <= int((kinds == 1).sum()) <= 8
+            mpc.stage("linearize"); mpc.synchronize()
+            names = ("A", "B", "b", "Q", "R", "q", "r", "c", "C", "D", "e", "perf", "qrd", "nc") if mat else ("b", "q", "r", "e", "perf", "qrd", "nc")
+            out[(compact, mat)] = {k: mpc.read(k).copy() for k in names}
+            t, x, u, _, st = (mpc.enqueue(), mpc.synchronize(), mpc.fetch())[2]
+            out[(compact, mat)]["x"] = x.copy(); out[(compact, mat)]["u"] = u.copy()
+    for mat in (True, False):
+        for k, v in out[("1", mat)].items():
+            assert np.array_equal(v, out[("0", mat)][k]), (mat, k)
