@@ -141,9 +141,22 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
       seg_j = j; seg_lo = tp[j]; seg_hi = tp[j + 1];
       const int e0 = effective(j), e1 = effective(j + 1);
       lds_wave_sync();                                  // earlier readers of the cached rows are done
-      for (int idx = g; idx < NU * NX; idx += LPN) {
-        w.Kc[sub][0][idx] = Kp[(size_t)e0 * NU * NX + idx];
-        w.Kc[sub][1][idx] = Kp[(size_t)e1 * NU * NX + idx];
+      // Round 6: the gains of the two nodes arrive in batches of kBatch requests per lane and node (all issued before the first is stored: one memory
+      // round trip per batch, where the plain copy loop paid one per element - 30 dependent trips per segment change, and a roll-out changes segment
+      // at nearly every step: the DDP line search spent most of its 22 ms here)
+      {
+        constexpr int kBatch = 8, kTotal = NU * NX;
+        const double* K0g = Kp + (size_t)e0 * kTotal;
+        const double* K1g = Kp + (size_t)e1 * kTotal;
+        for (int base = g; base < kTotal; base += LPN * kBatch) {
+          double r0[kBatch], r1[kBatch];
+#pragma unroll
+          for (int c = 0; c < kBatch; ++c) { const int idx = base + c * LPN; const int at = idx < kTotal ? idx : 0; r0[c] = K0g[at]; r1[c] = K1g[at]; }
+#pragma unroll
+          for (int c = 0; c < kBatch; ++c) asm volatile("" : "+v"(r0[c]), "+v"(r1[c]));
+#pragma unroll
+          for (int c = 0; c < kBatch; ++c) { const int idx = base + c * LPN; if (idx < kTotal) { w.Kc[sub][0][idx] = r0[c]; w.Kc[sub][1][idx] = r1[c]; } }
+        }
       }
       if (lf) for (int idx = g; idx < NU; idx += LPN) { w.uc[sub][0][idx] = up[(size_t)e0 * NU + idx] + step_len * lf[(size_t)e0 * NU + idx]; w.uc[sub][1][idx] = up[(size_t)e1 * NU + idx] + step_len * lf[(size_t)e1 * NU + idx]; }
       else for (int idx = g; idx < NU; idx += LPN) { w.uc[sub][0][idx] = up[(size_t)e0 * NU + idx]; w.uc[sub][1][idx] = up[(size_t)e1 * NU + idx]; }
@@ -266,6 +279,7 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
       }
     }
     if (a.rec_t && __any(stepped)) { record(t, xh, xq, stepped); stepped = false; }
+    if (a.rec_t && !done && n_rec > a.rec_cap) { status = 4; done = true; }      // the record is full: this roll-out cannot become a solution, its wave need not wait for it
   }
   // inputTrajectory.back() = computeInput(final time, final state)
   publish(xh, xq);

@@ -30,9 +30,14 @@ timeout 600 python bench.py --batch 512 --cpu-sample 0 > $O/bench_512.json 2>> $
 timeout 600 python bench.py --robot hunter --cpu-sample 16 > $O/bench_hunter.json 2>> $O/bench_h1.err
 timeout 600 python bench.py --robot h1:hard --cpu-sample 16 > $O/bench_h1_hard.json 2>> $O/bench_h1.err
 timeout 600 python bench.py --gait-start -1.225 --cpu-sample 0 > $O/bench_h1_midswing.json 2>> $O/bench_h1.err      # round 4's input: nobody back-tracks
+timeout 600 python bench.py --solver ddp --cpu-sample 2 > $O/bench_ddp.json 2>> $O/bench_h1.err                          # the reference's second solver at the configs[1] shape
+rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_ddp_stats -o run -- python bench.py --solver ddp --steps 5 --warmup 2 --cpu-sample 0 --no-fused > gpurun_out/${TAG}_ddp_bench_under_rocprof.json 2> gpurun_out/${TAG}_ddp_stats.log
+python tools/summarize_rocpd.py "$(find gpurun_out/${TAG}_ddp_stats -name '*.db' | head -1)" gpurun_out/${TAG}_ddp_kernel_stats.csv > /dev/null
+tools/probes/write_roof.bin 256 103 > $O/write_roof.json 2>&1; tools/probes/write_roof.bin 4096 103 >> $O/write_roof.json 2>&1; tools/probes/write_roof.bin 1024 103 24 >> $O/write_roof.json 2>&1
+timeout 600 python tools/closed_loop_soak.py > $O/soak.log 2>&1
 timeout 300 python tools/latency_probe.py > $O/latency.log 2>&1
 timeout 300 python tools/wbc_probe.py > $O/wbc.log 2>&1
-cat $O/pytest.log; tail -n 2 $O/latency.log; for f in h1 g1 sweep 4096 512 hunter h1_hard h1_midswing; do python -c "
+cat $O/pytest.log; tail -n 2 $O/latency.log; for f in h1 g1 sweep 4096 512 hunter h1_hard h1_midswing ddp; do python -c "
 import json,sys
 try:
     d=json.loads(open('$O/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], (d.get('fused') or {}).get('value'), d['kernel_ms_per_step'])
