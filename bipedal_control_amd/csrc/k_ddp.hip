@@ -18,6 +18,7 @@
 #include "launch.h"
 #include "kernels/node_lq.h"
 #include "kernels/linesearch.h"
+#include "kernels/rollout.h"
 
 namespace bpmpc {
 
@@ -190,6 +191,31 @@ __global__ __launch_bounds__(kWave) void k_ddp_finish(Launch L, DdpBuffers d) {
   }
 }
 
+// Nominal trajectories of a receding-horizon tick ([OCS2-upstream, recalled] GaussNewtonDDP::rolloutInitialTrajectory with a controller from the
+// previous run: the previous controller - a FeedforwardController, here already shifted onto the new grid by k_warm_shift, the initializer's input
+// beyond its end - is ROLLED OUT from the measured state; the state trajectory of that roll-out, not the previous solution, is what the LQ
+// approximation is built on, so that the dynamics bias vanishes as ILQR assumes).  The roll-out lives on its own time points; the backward pass of
+// this engine on the shooting grid: node k takes LinearInterpolation(t_k) of the record (the states are continuous across the events, pre- and
+// post-event node share their time).  A problem whose roll-out failed keeps the shifted previous solution.  One wave per (problem, node).
+template <int NJ>
+__global__ __launch_bounds__(kWave) void k_ddp_nominal(Launch L, DdpBuffers d) {
+  constexpr int NX = 12 + NJ;
+  const int b = blockIdx.x / (L.N + 1), k = blockIdx.x % (L.N + 1), l = threadIdx.x;
+  const int grid = L.buf.p_grid[b], n = L.buf.g_nodes[grid];
+  if (k > n) return;
+  const int np = d.rec_n[b];
+  if (d.roll_status[b] != 0 || np < 2) return;
+  const double* rt = d.rec_t + (size_t)b * d.cap;
+  const double tq = L.buf.g_time[(size_t)grid * (L.N + 1) + k];
+  int i;
+  double al;
+  time_segment(rt, np, tq, &i, &al);
+  if (l < NX) {
+    const double* r0 = d.rec_x + ((size_t)b * d.cap + i) * NX;
+    L.buf.x[((size_t)b * (L.N + 1) + k) * NX + l] = k == 0 ? L.buf.p_x0[(size_t)b * NX + l] : al * r0[l] + (1.0 - al) * r0[NX + l];
+  }
+}
+
 // receding-horizon warm start of the next run: the previous solution is a FeedforwardController on the roll-out's own time points, one time
 // trajectory per problem (k_warm_shift reads tp_* per grid: problem b becomes its own "grid"), no pre-event entries
 __global__ void k_ddp_keep_times(DdpBuffers d, int batch, int N, double* tp_time, int* tp_kind, int* tp_nodes, int* tp_grid) {
@@ -216,6 +242,7 @@ void ddp_cost(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffe
 void ddp_select(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d, double armijo) {
   KL_NJ(nj, hipLaunchKernelGGL(k_ddp_select<NJ>, dim3(batch), dim3(kWave), 0, st, L, d, armijo));
 }
+void ddp_nominal(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d) { KL_NJ(nj, hipLaunchKernelGGL(k_ddp_nominal<NJ>, dim3(batch * (L.N + 1)), dim3(kWave), 0, st, L, d)); }
 void ddp_keep_times(int batch, int N, hipStream_t st, const DdpBuffers& d, double* tp_time, int* tp_kind, int* tp_nodes, int* tp_grid) {
   hipLaunchKernelGGL(k_ddp_keep_times, dim3(batch), dim3(kWave), 0, st, d, batch, N, tp_time, tp_kind, tp_nodes, tp_grid);
 }

@@ -49,6 +49,7 @@ void riccati_rollout(int nj, int batch, hipStream_t st, const Launch& L);
 void ddp_policy(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
 void ddp_cost(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
 void ddp_select(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d, double armijo);
+void ddp_nominal(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
 void ddp_finish(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
 void ddp_keep_times(int batch, int N, hipStream_t st, const DdpBuffers& d, double* tp_time, int* tp_kind, int* tp_nodes, int* tp_grid);
 

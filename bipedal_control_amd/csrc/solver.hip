@@ -231,6 +231,7 @@ struct bpmpc_solver {
   void pipelined_backward();
   void run_iterations();
   void run_ddp();
+  void ddp_nominal_rollout();
   DdpBuffers ddp{};                                       // the DDP slice (settings.solver = BPMPC_SOLVER_DDP)
   bool is_ddp() const { return settings.solver == BPMPC_SOLVER_DDP; }
   // one value for the warm start, the policy rollout and the controller a caller builds (sqp.useFeedbackPolicy / ddp.useFeedbackPolicy of task.info, or the override)
@@ -405,6 +406,26 @@ void bpmpc_solver::run_ddp() {
   TIMED("ddp_search", { kl::ddp_cost(nj(), batch, stream, L, ddp); kl::ddp_select(nj(), batch, stream, L, ddp, kArmijoCoefficient); kl::ddp_finish(nj(), batch, stream, L, ddp); });
 }
 
+// GaussNewtonDDP::rolloutInitialTrajectory of a warm tick (k_ddp.hip k_ddp_nominal): the shifted previous FeedforwardController integrated from the
+// measured state over the new horizon (TimeTriggeredRollout, ODE45), its states interpolated onto the shooting grid as the nominal trajectory.
+void bpmpc_solver::ddp_nominal_rollout() {
+  const int N = settings.max_nodes;
+  RolloutArgs a{};
+  a.batch = batch; a.N = N; a.p_grid = buf.p_grid; a.g_nodes = buf.g_nodes; a.g_kind = buf.g_kind; a.g_time = buf.g_time;
+  a.x = buf.x; a.u = buf.u; a.K = buf.K; a.x_start = buf.p_x0;
+  a.t_start = nullptr; a.duration = -1.0;
+  a.abs_tol = rm.rollout.abs_tol; a.rel_tol = rm.rollout.rel_tol; a.time_step = rm.rollout.time_step;
+  a.feedback = 0;                                      // ddp.useFeedbackPolicy false: the previous controller is its input trajectory
+  a.x_end = ddp.end_x; a.u_end = ddp.end_u; a.steps = ddp.roll_steps; a.status = ddp.roll_status;
+  a.rec_t = ddp.rec_t; a.rec_x = ddp.rec_x; a.rec_u = ddp.rec_u; a.rec_n = ddp.rec_n; a.rec_cap = ddp.cap;
+  double longest = 0.0;
+  for (size_t g = 0; g < grid_nodes.size(); ++g) longest = std::max(longest, node_times[g * (N + 1) + grid_nodes[g]] - node_times[g * (N + 1)]);
+  a.max_steps = (int)(rm.rollout.max_steps_per_second * std::max(1.0, longest));
+  kl::rollout(rm.nj, batch, stream, d_model, a);
+  kl::ddp_nominal(nj(), batch, stream, launch_params(), ddp);
+  HIP_CHECK(hipGetLastError());
+}
+
 namespace {
 
 int translate(const std::exception& e) {
@@ -442,7 +463,7 @@ void allocate(bpmpc_solver* s) {
   b.p_tgt_t = s->alloc<double>(nullptr, B * kMaxTargetPoints); b.p_tgt_x = s->alloc<double>(nullptr, B * kMaxTargetPoints * NX);
   b.p_tgt_n = s->alloc<int>(nullptr, B);
   b.x = s->alloc<double>("x", B * (N + 1) * NX); b.u = s->alloc<double>("u", S * NU);
-  b.x_init = s->alloc<double>(nullptr, B * (N + 1) * NX); b.u_init = s->alloc<double>(nullptr, S * NU);
+  b.x_init = s->alloc<double>("x_init", B * (N + 1) * NX); b.u_init = s->alloc<double>("u_init", S * NU);
   b.xref = s->alloc<double>("xref", S * NX);
   b.A = s->alloc<double>("A", S * NX * NX); b.B = s->alloc<double>("B", S * NX * NU); b.b = s->alloc<double>("b", S * NX);
   b.Q = s->alloc<double>("Q", S * NX * NX); b.R = s->alloc<double>("R", S * NU * NU); b.P = s->alloc<double>("P", S * NU * NX);
@@ -550,6 +571,7 @@ void finish_setup(bpmpc_solver* s, int batch, const double* warm_x, const double
     const Launch L = s->launch_params();
     kl::warm_shift(s->rm.nj, batch * L.N, s->stream, L);
     HIP_CHECK(hipGetLastError());
+    if (s->is_ddp()) s->ddp_nominal_rollout();      // the nominal state trajectory of a DDP tick is the roll-out of the previous controller from the measured state
   }
   copy_pairs(s, bf.x, bf.x_init, (size_t)batch * (N + 1) * NX, bf.u, bf.u_init, (size_t)batch * N * NU, true);
   // only the caller's warm-start arrays are still being read at this point: everything else was uploaded before the callers' own

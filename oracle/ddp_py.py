@@ -124,6 +124,25 @@ def step_lengths(ddp):
     return out
 
 
+def nominal_rollout(om, nodes, x_measured, x_shifted, u_shifted, event_times, rollout):
+    """Nominal trajectories of a warm MPC tick.  [OCS2-upstream, recalled] GaussNewtonDDP::rolloutInitialTrajectory: the controller of the previous run
+    (ddp.useFeedbackPolicy false: a FeedforwardController, here the input trajectory already shifted onto the new grid - warm_start_from_previous with
+    feedback=False -, the initializer's input beyond its end) is rolled out from the measured state with TimeTriggeredRollout; the state trajectory of
+    that roll-out is the nominal one.  The backward pass of this engine works on the shooting grid: node k takes LinearInterpolation(t_k) of the
+    roll-out (the first node the measured state).  Follows csrc/k_ddp.hip k_ddp_nominal / solver.hip ddp_nominal_rollout.  Returns x_nom [N + 1, nx]."""
+    N = int(nodes["N"])
+    tp = np.asarray(nodes["times"], float)
+    tpa, _, uff, KK = rp.primal_solution_arrays(nodes, x_shifted, u_shifted, np.zeros((N, om.nu, om.nx)))
+    ctrl = lambda t, x: rp.linear_controller_input(tpa, uff, KK, t, x)      # K = 0: the interpolated input trajectory
+    ro = rp.time_triggered_rollout(lambda x, u: om.flow_map(x, u), ctrl, float(tp[0]), x_measured, float(tp[-1]), list(event_times), rollout)
+    x_nom = np.array(x_shifted, float)
+    for k in range(N + 1):
+        i, al = rp.time_segment(ro["times"], float(tp[k]))
+        x_nom[k] = al * ro["states"][i] + (1.0 - al) * ro["states"][i + 1]
+    x_nom[0] = x_measured
+    return x_nom
+
+
 def ilqr_iteration(om, model, nodes, x_measured, x_nom, u_nom, event_times, mode_sequence, target_times, target_states, ddp, rollout):
     """One GaussNewtonDDP / ILQR iteration.  Returns dict(alpha, times, states, inputs, K, lff, merit0, merits, update_is)."""
     N = int(nodes["N"])

@@ -90,10 +90,10 @@ def test_ddp_refuses_what_the_slice_does_not_implement():
 
 @pytest.mark.gpu
 def test_ddp_receding_horizon_tick_warm_starts_from_the_roll_out_of_the_previous_one():
-    """MPC loop (mpc.coldStart false): the second run's nominal trajectories are the previous solution - a FeedforwardController on the
-    roll-out's own time points (ddp.useFeedbackPolicy false) - interpolated onto the new grid, as the SQP path warm-starts
-    (oracle/reference_py.py warm_start_from_previous with feedback = False).  [Upstream rolls the previous controller out from the measured
-    state instead: stated in DESIGN.md section 0.]"""
+    """MPC loop (mpc.coldStart false): the second run's nominal INPUTS are the previous solution - a FeedforwardController on the roll-out's own
+    time points (ddp.useFeedbackPolicy false) - interpolated onto the new grid (oracle/reference_py.py warm_start_from_previous with
+    feedback = False), its nominal STATES the roll-out of that controller from the measured state (round 6; [OCS2-upstream, recalled]
+    GaussNewtonDDP::rolloutInitialTrajectory; oracle/ddp_py.py nominal_rollout)."""
     itf = scenarios.h1_interface()
     prob = scenarios.stance_problem(itf, 20)
     x0 = prob["x0"].copy(); x0[0, 8] -= 0.02; x0[0, 1] += 0.03
@@ -114,9 +114,14 @@ def test_ddp_receding_horizon_tick_warm_starts_from_the_roll_out_of_the_previous
     prob2 = dict(prob, t0=tn, x0=xm[None, :])
     nodes2 = ob.oracle_nodes(prob2, 0)
     prev = dict(N=n1 - 1, times=t1[0, :n1].copy(), kind=np.zeros(n1 - 1, np.int32))
-    x_nom, u_nom = rp.warm_start_from_previous(m, nodes2, xm, prev, x1[0, :n1], u1[0, :n1 - 1], np.zeros((n1 - 1, m["nu"], m["nx"])), feedback=False)
+    x_sh, u_nom = rp.warm_start_from_previous(m, nodes2, xm, prev, x1[0, :n1], u1[0, :n1 - 1], np.zeros((n1 - 1, m["nu"], m["nx"])), feedback=False)
     sched = prob["schedule"]
     ev, ms = list(map(float, sched.eventTimes)), list(map(int, sched.modeSequence))
+    # round 6: the nominal STATES are the roll-out of that input trajectory from the measured state (what GaussNewtonDDP_MPC does), not the shifted solution
+    x_nom = ddp_py.nominal_rollout(om, nodes2, xm, x_sh, u_nom, ev, m["rollout"])
+    x_init = mpc.read("x_init").reshape(1, cap + 1, m["nx"])      # the initial iterate of the tick as the device built it (after the run `x` holds the solution)
+    assert np.abs(x_init[0, :int(nodes2["N"]) + 1] - x_nom).max() < 1e-7, np.abs(x_init[0, :int(nodes2["N"]) + 1] - x_nom).max()
+    assert np.abs(x_nom - x_sh).max() > 1e-4                       # (and it is not the shifted solution)
     tt = prob["targets"][0]
     ref = ddp_py.ilqr_iteration(om, m, nodes2, xm, x_nom, u_nom, ev, ms, np.asarray(tt.timeTrajectory), np.asarray(tt.stateTrajectory), m["ddp"], m["rollout"])
     n = len(ref["times"])

@@ -261,3 +261,30 @@ def test_recalled_ddp_stance_rows_have_no_full_row_rank():
     assert D.shape[0] == 14 and np.linalg.matrix_rank(D) == 13
     w = np.linalg.svd(D)[0][:, 13:]                                                     # the dependent combination of the rows
     assert np.abs(w.T @ D).max() < 1e-12 and np.abs(w.T @ lq["C"][1]).max() > 1e-3      # ... which the state part of the rows does not share
+
+
+def test_recalled_ddp_warm_tick_nominal_states_are_the_roll_out_of_the_previous_controller():
+    """[OCS2-upstream, recalled] GaussNewtonDDP::rolloutInitialTrajectory: with a controller from the previous run the nominal trajectories of a tick are
+    that controller ROLLED OUT from the measured state - not the previous solution shifted in time.  Chosen form here (oracle/ddp_py.py nominal_rollout,
+    csrc/k_ddp.hip k_ddp_nominal): the shifted input trajectory as a FeedforwardController, TimeTriggeredRollout, LinearInterpolation onto the shooting
+    grid.  What it buys: the nominal trajectory starts AT the measured state and satisfies the dynamics (ILQR carries no dynamics bias), where the
+    shifted solution keeps the disturbance as a defect at its first node."""
+    import numpy as np
+    from bipedal_control_amd import scenarios
+    from oracle import ddp_py, reference_py as rp
+    from tests import oracle_bridge as ob
+    itf = scenarios.h1_interface()
+    prob = scenarios.stance_problem(itf, 12)
+    m, om = ob.model("h1"), ob.oracle("h1")
+    nodes = ob.oracle_nodes(prob, 0)
+    N = int(nodes["N"])
+    x0 = prob["x0"][0].copy(); x0[8] -= 0.02
+    xc, uc = rp.cold_start(m, nodes, x0)
+    measured = x0.copy(); measured[2] += 0.05; measured[12] += 0.03            # a disturbance since the last tick
+    x_nom = ddp_py.nominal_rollout(om, nodes, measured, xc, uc, [], m["rollout"])
+    assert np.array_equal(x_nom[0], measured)
+
+    def defect(x):      # one explicit Euler step per interval is enough to tell a trajectory of the dynamics from one that is not
+        return max(float(np.abs(x[k + 1] - x[k] - nodes["dt"][k] * om.flow_map(x[k], uc[k])).max()) for k in range(N))
+    shifted = xc.copy(); shifted[0] = measured
+    assert defect(x_nom) < 0.2 * defect(shifted)      # (what remains is the difference between one Euler step and the ODE45 roll-out)
