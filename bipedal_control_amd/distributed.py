@@ -138,7 +138,7 @@ def parse_nccl_debug(text):
     spellings of the tuning line (`Algo 1 proto 2` of older releases, `Algo RING proto SIMPLE` of newer ones)."""
     import re
     out = {"version": None, "collectives": {}, "transports": {}, "channels": None, "forced": {}}
-    m = re.search(r"(?:NCCL|RCCL) version ([0-9][0-9A-Za-z.+\-]*)", text)
+    m = re.search(r"(?:NCCL|RCCL) version\s*:?\s*([0-9][0-9A-Za-z.+:\-]*)", text)      # "NCCL version 2.21.5+hip6.3" / "RCCL version : 2.26.6-HEAD:64f48b6"
     if m:
         out["version"] = m.group(1)
     for name, nbytes, algo, proto in re.findall(r"(\w+): (\d+) Bytes -> Algo (\w+) proto (\w+)", text):

@@ -42,3 +42,11 @@ def test_empty_log_and_environment():
     assert r["collectives"] == {} and r["version"] is None
     env = bd.nccl_debug_env("/tmp/x.log", algo="Ring")
     assert env["NCCL_DEBUG"] == "INFO" and env["NCCL_ALGO"] == "Ring" and env["NCCL_DEBUG_FILE"] == "/tmp/x.log" and "NCCL_PROTO" not in env
+
+
+def test_version_line_of_the_rccl_of_this_image():
+    """ROCm 7.0's RCCL (what `bench.py --gather-report` met on the MI355X box, one rank): `RCCL version : 2.26.6-HEAD:64f48b6`; a one-rank communicator logs no
+    tuning line (nothing to choose)."""
+    r = bd.parse_nccl_debug("runc:172:172 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6\nHIP version  : 7.0.51831-7c9236b16\n"
+                            "runc:172:242 [0] NCCL INFO ncclCommInitRankConfig_impl comm 0x6151 rank 0 nranks 1 cudaDev 0 nvmlDev 0 busId d000 - Init START\n")
+    assert r["version"] == "2.26.6-HEAD:64f48b6" and r["collectives"] == {}
