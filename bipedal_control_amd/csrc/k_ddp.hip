@@ -109,7 +109,60 @@ __global__ __launch_bounds__(kWave) void k_ddp_cost(Launch L, DdpBuffers d) {
   in.x = d.rec_x + at * NX; in.xnext = in.x; in.u = d.rec_u + at * NU; in.xref = xref; in.zref = zero4; in.zdref = zero4;
   node_performance<NJ>(*L.model, ws, in, perf);
   __syncthreads();
-  if (tid == 0) d.cost[at] = perf[0];
+  if (tid == 0) d.cost[at * 3] = perf[0];
+}
+
+// The same on the lane-per-coordinate evaluation of the line search (linearize_fast.h trial_fast with a zero step and dt = 1: its cost entry is the
+// cost rate), four time points per wave, sixteen per workgroup - serial-leg robots (every robot of the reference); round 6: the last kernel of the
+// DDP path that ran on a lane-emulated body (64 B of scratch, 2.0 ms of the 20.5 ms step at 256 x 100).
+constexpr int kCostWaves = 4;
+template <int NJ>
+__global__ __launch_bounds__(kCostWaves * kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ddp_cost_fast(Launch L, DdpBuffers d) {
+  using C = LinFastCfg<NJ, true, true>;
+  constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, PTS = kCostWaves * C::NPW;
+  static_assert(LPN == 16, "sixteen lanes per time point");
+  __shared__ LinFastNodeLds<NJ, false, true> lds[PTS];
+  __shared__ LinFastShared<NJ, false> shared;
+  __shared__ double xref[PTS][NX];
+  const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
+  const long long widx = (long long)blockIdx.x * PTS + sub, total = (long long)d.nv * L.batch * d.cap;
+  bool valid = widx < total;
+  const int vb = valid ? (int)(widx / d.cap) : 0, i = valid ? (int)(widx % d.cap) : 0;      // vb: step length * batch + problem
+  const int b = vb % L.batch;
+  {   // a workgroup beyond the recorded points of its roll-out(s) has nothing to do (most of them: the record holds cap points, a roll-out ~80)
+    const long long w0 = (long long)blockIdx.x * PTS, w1 = w0 + PTS - 1 < total ? w0 + PTS - 1 : total - 1;
+    const int v0 = (int)(w0 / d.cap), v1 = (int)(w1 / d.cap);
+    if (v0 == v1 && (int)(w0 % d.cap) >= d.rec_n[v0]) return;
+  }
+  load_shared_model<kCostWaves * kWave>(*L.model, shared, threadIdx.x);
+  valid = valid && i < d.rec_n[vb] && !d.failed[b];
+  const int grid = L.buf.p_grid[b], n = L.buf.g_nodes[grid];
+  const size_t at = valid ? (size_t)vb * d.cap + i : 0;
+  const double t = d.rec_t[at];
+  const int j = ddp_interval(L.buf.g_time + (size_t)grid * (L.N + 1), n, t);
+  {   // x_ref(t): TargetTrajectories::getDesiredState (clamped linear interpolation), as prepare_node
+    const int n_pts = L.buf.p_tgt_n[b];
+    const double* tt = L.buf.p_tgt_t + (size_t)b * kMaxTargetPoints;
+    const double* tx = L.buf.p_tgt_x + (size_t)b * kMaxTargetPoints * NX;
+    for (int c = g; c < NX; c += LPN) {
+      double val;
+      if (n_pts == 1 || t <= tt[0]) val = tx[c];
+      else if (t >= tt[n_pts - 1]) val = tx[(n_pts - 1) * NX + c];
+      else {
+        int q = 0;
+        while (q + 1 < n_pts - 1 && tt[q + 1] < t) ++q;
+        const double al = (tt[q + 1] - t) / (tt[q + 1] - tt[q]);
+        val = al * tx[q * NX + c] + (1.0 - al) * tx[(q + 1) * NX + c];
+      }
+      xref[sub][c] = val;
+    }
+  }
+  __syncthreads();
+  NodeInputs in;
+  in.kind = 0; in.mode = L.buf.g_mode[(size_t)grid * L.N + j]; in.dt = 1.0;
+  in.x = d.rec_x + at * NX; in.xnext = in.x; in.u = d.rec_u + at * NU; in.xref = xref[sub];
+  in.zref = L.buf.zero_page + 4; in.zdref = L.buf.zero_page + 4;      // (a row of zeros)
+  trial_fast<NJ, C>(*L.model, shared, lds[sub], valid, in, 0.0, in.x, in.u, in.x, d.cost + at * 3, g);
 }
 
 // performance index of every recorded roll-out (trapezoidalIntegration over its time points), Armijo test of the step lengths against the
@@ -125,9 +178,9 @@ __global__ __launch_bounds__(kWave) void k_ddp_select(Launch L, DdpBuffers d, do
       const size_t vb = (size_t)v * L.batch + b;
       const int n = d.rec_n[vb];
       const double* t = d.rec_t + vb * d.cap;
-      const double* c = d.cost + vb * d.cap;
+      const double* c = d.cost + vb * d.cap * 3;      // (three metrics per point as the trial evaluation writes them: cost rate, defect, equality SSE)
       double m = 0.0;
-      for (int i = 0; i + 1 < n; ++i) m += 0.5 * (c[i + 1] + c[i]) * (t[i + 1] - t[i]);
+      for (int i = 0; i + 1 < n; ++i) m += 0.5 * (c[3 * (i + 1)] + c[3 * i]) * (t[i + 1] - t[i]);
       return m;
     };
     auto rolled = [&](int v) { const size_t vb = (size_t)v * L.batch + b; return d.roll_status[vb] == 0 && d.rec_n[vb] >= 2; };
@@ -238,7 +291,12 @@ __global__ void k_ddp_keep_times(DdpBuffers d, int batch, int N, double* tp_time
 namespace kl {
 
 void ddp_policy(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d) { KL_NJ(nj, hipLaunchKernelGGL(k_ddp_policy<NJ>, dim3(batch), dim3(kWave), 0, st, L, d)); }
-void ddp_cost(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d) { KL_NJ(nj, hipLaunchKernelGGL(k_ddp_cost<NJ>, dim3(batch * d.nv * d.cap), dim3(kWave), 0, st, L, d)); }
+void ddp_cost(int nj, int batch, bool fast, hipStream_t st, const Launch& L, const DdpBuffers& d) {
+  if (fast) {
+    const long long pts = (long long)batch * d.nv * d.cap;
+    KL_NJ(nj, { constexpr int per = kCostWaves * LinFastCfg<NJ, true, true>::NPW; hipLaunchKernelGGL(k_ddp_cost_fast<NJ>, dim3((unsigned)((pts + per - 1) / per)), dim3(kCostWaves * kWave), 0, st, L, d); });
+  } else KL_NJ(nj, hipLaunchKernelGGL(k_ddp_cost<NJ>, dim3(batch * d.nv * d.cap), dim3(kWave), 0, st, L, d));
+}
 void ddp_select(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d, double armijo) {
   KL_NJ(nj, hipLaunchKernelGGL(k_ddp_select<NJ>, dim3(batch), dim3(kWave), 0, st, L, d, armijo));
 }

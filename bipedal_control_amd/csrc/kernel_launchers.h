@@ -47,7 +47,7 @@ void riccati_rollout(int nj, int batch, hipStream_t st, const Launch& L);
 
 // ---- k_ddp.hip: the DDP slice (one ILQR iteration; backward pass on the reference kernel set, line search over policy roll-outs)
 void ddp_policy(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
-void ddp_cost(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
+void ddp_cost(int nj, int batch, bool fast, hipStream_t st, const Launch& L, const DdpBuffers& d);
 void ddp_select(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d, double armijo);
 void ddp_nominal(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);
 void ddp_finish(int nj, int batch, hipStream_t st, const Launch& L, const DdpBuffers& d);

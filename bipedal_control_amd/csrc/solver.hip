@@ -403,7 +403,7 @@ void bpmpc_solver::run_ddp() {
   for (size_t g = 0; g < grid_nodes.size(); ++g) longest = std::max(longest, node_times[g * (N + 1) + grid_nodes[g]] - node_times[g * (N + 1)]);
   a.max_steps = (int)(rm.rollout.max_steps_per_second * std::max(1.0, longest));
   TIMED("ddp_rollout", kl::rollout(rm.nj, batch * ddp.nv, stream, d_model, a));
-  TIMED("ddp_search", { kl::ddp_cost(nj(), batch, stream, L, ddp); kl::ddp_select(nj(), batch, stream, L, ddp, kArmijoCoefficient); kl::ddp_finish(nj(), batch, stream, L, ddp); });
+  TIMED("ddp_search", { kl::ddp_cost(nj(), batch, !settings.reference_kernels, stream, L, ddp); kl::ddp_select(nj(), batch, stream, L, ddp, kArmijoCoefficient); kl::ddp_finish(nj(), batch, stream, L, ddp); });
 }
 
 // GaussNewtonDDP::rolloutInitialTrajectory of a warm tick (k_ddp.hip k_ddp_nominal): the shifted previous FeedforwardController integrated from the
@@ -506,7 +506,7 @@ void allocate(bpmpc_solver* s) {
     const size_t P = B * (size_t)d.cap, V = (size_t)d.nv;
     d.lff = s->alloc<double>("ddp_lff", S * NU);
     d.rec_t = s->alloc<double>(nullptr, V * P); d.rec_x = s->alloc<double>(nullptr, V * P * NX); d.rec_u = s->alloc<double>(nullptr, V * P * NU); d.rec_n = s->alloc<int>("ddp_rec_n", V * B, true);
-    d.cost = s->alloc<double>(nullptr, V * P);
+    d.cost = s->alloc<double>(nullptr, V * P * 3);
     d.end_x = s->alloc<double>(nullptr, V * B * NX); d.end_u = s->alloc<double>(nullptr, V * B * NU); d.roll_steps = s->alloc<int>("ddp_roll_steps", V * B * 2, true); d.roll_status = s->alloc<int>("ddp_roll_status", V * B, true);
     d.sol_t = s->alloc<double>("ddp_t", P); d.sol_x = s->alloc<double>(nullptr, P * NX); d.sol_u = s->alloc<double>("ddp_u", P * NU); d.sol_n = s->alloc<int>(nullptr, B);
     d.merit0 = s->alloc<double>(nullptr, B); d.merit = s->alloc<double>(nullptr, B); d.alpha = s->alloc<double>(nullptr, B);
