@@ -318,6 +318,19 @@ struct PackedStageLoader {
 // (Two lanes per row - half the loads, LDS reads and FMAs per lane, partial sums joined by a DPP quad permutation - was measured:
 //  0.3412 -> 0.339 ms at batch 256, 4.48 -> 4.51 ms at batch 4096; the step is bound by the LDS round trip of the state, not by its
 //  instruction count.  Not kept.)
+// acc += (x of lane P of this lane's 16-lane DPP row) * m, the broadcast as an operand modifier (riccati_rollout_deep)
+template <int P, bool NOP>
+__device__ __forceinline__ void roll_fma(double& acc, double x, double m) {
+  if constexpr (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(P));
+  else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(P));
+}
+template <int NX, int OFF, int L, int H>      // acc += sum over l = L .. H - 1 of x[lane l] * r[OFF + l]
+struct RollDot {
+  static __device__ __forceinline__ void run(double& acc, double x, const double (&r)[NX]) { roll_fma<L, false>(acc, x, r[OFF + L]); RollDot<NX, OFF, L + 1, H>::run(acc, x, r); }
+};
+template <int NX, int OFF, int H>
+struct RollDot<NX, OFF, H, H> { static __device__ __forceinline__ void run(double&, double, const double (&)[NX]) {} };
+
 template <int NJ, int NT = kRiccatiThreads>
 __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 4) * nx doubles*/, int cap, int status, const RiccatiFastIO& io) {
   constexpr int NX = 12 + NJ, NXX = NX * NX;
@@ -329,28 +342,65 @@ __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 
   for (int k0 = 0; k0 < N; k0 += cap) {                 // one pass unless the horizon exceeds the LDS history
     const int nk = N - k0 < cap ? N - k0 : cap;
     if (tid < kWave) {
-      const int ri = tid < NX ? tid : 0;                // lanes >= nx shadow row 0 (keeps the loads unconditional)
-      double rA[NX], rB[NX], rC[NX], bA, bB, bC;
-      auto load = [&](double (&r)[NX], double& b, int k) {
+      // Round 6.  What a step costs is the memory latency of its matrix row divided by the number of stages in flight: with three register sets of
+      // 23 doubles per lane a step took ~600 cycles whether the state went through LDS or stayed in registers, whether the requests were 8 or 16 bytes,
+      // one cache line or 22 per request (all measured: experiments/LOG.md) - a fourth set took 2 % off the kernel, a fifth does not fit.  So the two
+      // HALVES of the wave hold different stages in the same registers - lower half stage 2 m, upper half stage 2 m + 1 of a set - which doubles the stages in
+      // flight at the same register count, and the state never leaves the registers:
+      //   * every 16-lane DPP row holds the whole state in two registers - xlo: element p in lane position p, xhi: element H + p (H = nx / 2) - and a
+      //     lane's dot product takes its operands by `v_fmac_f64_dpp .. row_newbcast` (the broadcast costs no instruction and no memory);
+      //   * rows 0 / 2 of the wave compute the low half of dx+, rows 1 / 3 the high half; v_permlane16_swap_b32 (gfx950: swaps the odd rows of its
+      //     first operand with the even rows of its second; both operands the new value: tools/probes/permlane_probe.hip) makes the new xlo / xhi of a half;
+      //   * v_permlane32_swap_b32 hands the state of the half that owned the stage to the other half, which owns the next one.
+      // The history still goes to LDS - for the coalesced output and the step norms behind the loop - but nothing waits for it.
+      constexpr int H = NX / 2;
+      static_assert(NX % 2 == 0 && H <= 16, "two halves of the state, one per DPP row");
+      const int half = tid >> 5, q = (tid >> 4) & 1, p = tid & 15;
+      const bool has = p < H;
+      const int ri = has ? q * H + p : 0;               // lanes without an element shadow row 0 (keeps the loads unconditional)
+      double xlo = hist[has ? p : 0], xhi = hist[has ? H + p : 0];
+      double rA[NX], rB[NX], rC[NX], bA, bB, bC;      // three register sets, each holds two stages (one per half of the wave): six in flight (a fourth set: no gain)
+      auto load = [&](double (&r)[NX], double& b, int m) {            // pair m of this pass: stages k0 + 2 m (lower half), k0 + 2 m + 1 (upper half)
+        const int k = k0 + 2 * m + half;
         const int kc = k < N ? k : N - 1;               // beyond the end: a valid, unused stage
-        const double* p = io.Acl + (size_t)kc * NXX + (size_t)ri * NX;
+        const double2* p_ = reinterpret_cast<const double2*>(io.Acl + (size_t)kc * NXX + (size_t)ri * NX);      // (rows of nx doubles are 16-byte aligned: nx is even)
 #pragma unroll
-        for (int l = 0; l < NX; ++l) r[l] = p[l];
+        for (int l = 0; l < NX / 2; ++l) { const double2 v = p_[l]; r[2 * l] = v.x; r[2 * l + 1] = v.y; }
         b = io.bcl[(size_t)kc * NX + ri];
       };
-      auto step = [&](const double (&r)[NX], double b, int j) {      // j: stage index inside this pass
-        const double* cur = hist + j * NX;
-        double t0 = b, t1 = 0.0;
-#pragma unroll
-        for (int l = 0; l < NX; l += 2) { t0 += r[l] * cur[l]; t1 += r[l + 1] * cur[l + 1]; }
-        if (tid < NX) hist[(j + 1) * NX + tid] = t0 + t1;
-        lds_wave_sync();
+      auto dot = [&](const double (&r)[NX], double b) {                // b + (row of this lane) . (state); NOP: two wait states between the VALU write of
+        double t = b;                                                  // xlo / xhi (the swaps) and their first DPP read, which the compiler cannot see
+        roll_fma<0, true>(t, xlo, r[0]);
+        RollDot<NX, 0, 1, H>::run(t, xlo, r);
+        roll_fma<0, false>(t, xhi, r[H]);
+        RollDot<NX, H, 1, H>::run(t, xhi, r);
+        return t;
       };
-      load(rA, bA, k0); load(rB, bB, k0 + 1); load(rC, bC, k0 + 2);
-      for (int j = 0; j < nk; j += 3) {                 // steps past nk write history rows that are never read
-        step(rA, bA, j);     load(rA, bA, k0 + j + 3);
-        step(rB, bB, j + 1); load(rB, bB, k0 + j + 4);
-        step(rC, bC, j + 2); load(rC, bC, k0 + j + 5);
+      auto advance = [&](double t, int owner) {                        // the new state, computed by the half `owner`, in every row of the wave
+        const auto wl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(t), (unsigned)__double2loint(t), false, false);
+        const auto wh = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(t), (unsigned)__double2hiint(t), false, false);
+        // [0]: the values of rows 0 / 2 (the low half of dx+) in rows 0, 1 / 2, 3; [1]: those of rows 1 / 3 (the high half)
+        const auto ll = __builtin_amdgcn_permlane32_swap(wl[0], wl[0], false, false), lh = __builtin_amdgcn_permlane32_swap(wh[0], wh[0], false, false);
+        const auto hl = __builtin_amdgcn_permlane32_swap(wl[1], wl[1], false, false), hh = __builtin_amdgcn_permlane32_swap(wh[1], wh[1], false, false);
+        // [owner]: the lower (0) / upper (1) 32 lanes' values in both halves
+        xlo = __hiloint2double((int)lh[owner], (int)ll[owner]);
+        xhi = __hiloint2double((int)hh[owner], (int)hl[owner]);
+      };
+      auto step = [&](const double (&r)[NX], double b, int m) {       // pair m: stage j = 2 m on the lower half, j + 1 on the upper half
+        const int j = 2 * m;
+        const double t0 = dot(r, b);                                   // lower half: dx_(j+1); upper half: its row against a state it does not own yet
+        if (has && half == 0 && j < nk) hist[(j + 1) * NX + ri] = t0;  // (stages past the end of the pass run on a valid, unused stage and leave nothing behind)
+        advance(t0, 0);
+        const double t1 = dot(r, b);                                   // upper half: dx_(j+2)
+        if (has && half == 1 && j + 1 < nk) hist[(j + 2) * NX + ri] = t1;
+        advance(t1, 1);
+      };
+      const int npairs = (nk + 1) / 2;
+      load(rA, bA, 0); load(rB, bB, 1); load(rC, bC, 2);
+      for (int m = 0; m < npairs; m += 3) {
+        step(rA, bA, m);     load(rA, bA, m + 3);
+        step(rB, bB, m + 1); load(rB, bB, m + 4);
+        step(rC, bC, m + 2); load(rC, bC, m + 5);
       }
     } else if (k0 == 0 && io.with_ls && tid < 2 * kWave) {
       // wave 1 has nothing to do here: it prepares the line search of this problem (LDS: the step norms' tile area behind the history)

@@ -2,7 +2,7 @@
 # eight-wave Riccati sweep: phase cycles (ricp1), own work per wave and phase (ricp2, ricp10..14).  Libraries: tools/mkvariant.sh ricp<v> k_riccati -DBPMPC_RICCATI_PROFILE=<v>
 export TMPDIR=/tmp PYTHONPATH=.
 cp bipedal_control_amd/libbpmpc.so /tmp/keep.so
-for v in $1; do cp tools/probes/lib_ricp$v.bin bipedal_control_amd/libbpmpc.so; python - <<PY
+for v in $1; do cp tools/probes/lib_$v.bin bipedal_control_amd/libbpmpc.so; python - <<PY
 import numpy as np
 import bipedal_control_amd as bp
 from bipedal_control_amd import scenarios
