@@ -50,3 +50,17 @@ def test_three_ranks_uneven_shards_and_rccl_single_rank():
     assert g3["config"]["job_report"]["merit_sum"] == s3["config"]["job_report"]["merit_sum"]
     r1 = _bench("--gpus", "1", "--batch", "16", "--intervals", "30", env_extra={"BPMPC_BENCH_FORCE_DIST": "1", "BPMPC_BENCH_ONE_DEVICE": "0"})   # RCCL itself, one rank
     assert r1["config"]["job_report"]["gather_consistent"] and "nccl" in r1["config"]["parallelism"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_line_carries_the_write_roof_and_the_ddp_solver_has_a_line_of_its_own():
+    """Round 6: `roofline.write_roof` (the lineariser's store pattern as a write-only stream, measured in the bench process: the calibration of `frac` for a
+    kernel whose traffic is stores) and `bench.py --solver ddp` (the reference's second solver; `metric` says so, the kernel table has the roll-outs)."""
+    one = _bench("--gpus", "1", "--batch", "32", "--intervals", "30", "--no-fused", env_extra={"BPMPC_BENCH_ONE_DEVICE": "0"})
+    wr = one["roofline"]["write_roof"]
+    assert wr["pattern_GBs"] and wr["pattern_GBs"] > 500 and 0 < wr["frac_of_write_roof"] < 1.5, wr
+    assert one["config"]["gait_start"] == 0.0 and one["config"]["solver"] == "sqp"
+    ddp = _bench("--gpus", "1", "--batch", "16", "--intervals", "30", "--solver", "ddp", "--no-fused", env_extra={"BPMPC_BENCH_ONE_DEVICE": "0"})
+    assert ddp["metric"].startswith("DDP (ILQR) MPC solves/s") and ddp["config"]["solver"] == "ddp" and ddp["value"] > 0
+    assert {"ddp_rollout", "ddp_search", "linearize", "riccati"} <= set(ddp["kernel_ms_per_step"])
+    assert sum(ddp["config"]["step_lengths"].values()) == 16 and ddp["config"]["job_report"]["failures"] <= 1
