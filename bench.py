@@ -415,10 +415,14 @@ def main():
             if "issue_frac" in e:
                 fr["fp64-issue"] = e["issue_frac"]
                 fr["mfma"] = e["mfma_frac"]
+            wr = (roofline.get("write_roof") or {}).get("frac_of_write_roof")
+            if wr:      # the share of what a write-only stream with this kernel's store pattern reaches on this device (97 % of its traffic is stores)
+                fr["hbm-write-roof"] = wr
             top = max(fr, key=fr.get)
-            roofline["bound"] = top if fr[top] >= 0.5 else "latency"
+            roofline["bound"] = ("hbm" if top.startswith("hbm") else top) if fr[top] >= 0.5 else "latency"
             roofline["bound_fracs"] = fr
-            roofline["bound_note"] = ("`frac` stays achieved / HBM peak (the roof the north-star names); fp64-issue / mfma fractions use executed-instruction "
+            roofline["bound_note"] = ("`frac` stays achieved / HBM peak (the roof the north-star names); hbm-write-roof = achieved / the measured rate of a write-only stream with "
+                                      "the kernel's own store pattern (write_roof); fp64-issue / mfma fractions use executed-instruction "
                                       "counts from profiles/%s (builder run) at this run's kernel time" % sq_counters_file())
         if ddp:
             out["config"]["step_lengths"] = {str(a): int(sum(1 for st in stats if st.step_size == a)) for a in sorted({st.step_size for st in stats}, reverse=True)}
