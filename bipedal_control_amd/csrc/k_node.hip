@@ -301,12 +301,12 @@ __global__ __launch_bounds__(kTrialWaves * kWave) void k_constraint_values(Launc
   trial_fast<NJ, C, true>(*L.model, shared, lds[sub], valid, in, 0.0, dx, L.buf.du + s * NU, dx + NX, perf, g, eqv + s * kMaxEqRows);
 }
 
-template <int NJ>
+template <int NJ, bool CHAIN>
 __global__ __launch_bounds__(kWave) void k_rollout(const DeviceModel* model, RolloutArgs a) {
-  __shared__ RolloutLds<NJ> w;
+  __shared__ RolloutLds<NJ, CHAIN> w;
   load_shared_model<kWave>(*model, w.shared, threadIdx.x);
   __syncthreads();
-  rollout_policy<NJ>(*model, w, a);
+  rollout_policy<NJ, CHAIN>(*model, w, a);
 }
 
 constexpr int kDecideThreads = 256;
@@ -446,8 +446,15 @@ void constraint_values(int nj, int nodes, hipStream_t st, const Launch& L, doubl
     else hipLaunchKernelGGL((k_constraint_values<NJ, false>), dim3(grid), dim3(kTrialWaves * kWave), 0, st, L, eqv);
   });
 }
-void rollout(int nj, int batch, hipStream_t st, const DeviceModel* model, const RolloutArgs& a) {
-  KL_NJ(nj, hipLaunchKernelGGL(k_rollout<NJ>, dim3((batch + LinFastCfg<NJ>::NPW - 1) / LinFastCfg<NJ>::NPW), dim3(kWave), 0, st, model, a));
+void rollout(int nj, bool serial_legs, int batch, hipStream_t st, const DeviceModel* model, const RolloutArgs& a) {
+  KL_NJ(nj, {
+    constexpr bool kChainFits = LinFastCfg<NJ, false, true>::LPN == 16;      // 6 + nj coordinates in one DPP row (nj = 10)
+    const dim3 grid((batch + LinFastCfg<NJ>::NPW - 1) / LinFastCfg<NJ>::NPW);
+    if constexpr (kChainFits) {
+      if (serial_legs) { hipLaunchKernelGGL((k_rollout<NJ, true>), grid, dim3(kWave), 0, st, model, a); return; }
+    }
+    hipLaunchKernelGGL((k_rollout<NJ, false>), grid, dim3(kWave), 0, st, model, a);
+  });
 }
 void copy_pairs(int grid, hipStream_t st, const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb,
                 int* iterations, int* active, int batch) {

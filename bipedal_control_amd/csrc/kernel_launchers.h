@@ -27,7 +27,7 @@ void trial_fast(int nj, int nodes, hipStream_t st, const Launch& L);
 void ls_decide(int nj, int batch, hipStream_t st, const Launch& L, bool look_first = false);
 void ls_tail(int nj, int batch, hipStream_t st, const Launch& L, int first_round, int max_trials);
 void constraint_values(int nj, int nodes, hipStream_t st, const Launch& L, double* eqv);
-void rollout(int nj, int batch, hipStream_t st, const DeviceModel* model, const RolloutArgs& a);
+void rollout(int nj, bool serial_legs, int batch, hipStream_t st, const DeviceModel* model, const RolloutArgs& a);
 void copy_pairs(int grid, hipStream_t st, const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb,
                 int* iterations, int* active, int batch);
 

@@ -60,10 +60,13 @@ struct RolloutArgs {
   // t_start = nullptr: every problem starts at the first time of its grid; duration < 0: ... and runs to the last
 };
 
-template <int NJ>
+// CHAIN (round 6): the tree walks of the flow map by DPP between neighbouring lanes (linearize_fast.h), for robots of two serial legs whose 6 + nj
+// coordinates fit one 16-lane row (nj = 10: H1, Hunter); else the LDS tables
+template <int NJ, bool CHAIN = false>
 struct RolloutLds {
-  using C = LinFastCfg<NJ>;
-  LinFastNodeLds<NJ, false> node[C::NPW];
+  using C = LinFastCfg<NJ, false, CHAIN>;
+  static_assert(!CHAIN || C::LPN == 16, "the DPP walks stay inside a 16-lane row");
+  LinFastNodeLds<NJ, false, CHAIN> node[C::NPW];
   LinFastShared<NJ, false> shared;
   double event[C::NPW][kRolloutMaxEvents];
   int n_events[C::NPW];
@@ -78,9 +81,9 @@ __device__ __forceinline__ double node_allreduce_max(double x) {
   return x;
 }
 
-template <int NJ>
-__device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds<NJ>& w, const RolloutArgs& a) {
-  using C = LinFastCfg<NJ>;
+template <int NJ, bool CHAIN = false>
+__device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds<NJ, CHAIN>& w, const RolloutArgs& a) {
+  using C = LinFastCfg<NJ, false, CHAIN>;
   constexpr int G = C::G, NX = C::NX, NU = C::NU, LPN = C::LPN, NPW = C::NPW;
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
   const int bq = blockIdx.x * NPW + sub;
@@ -89,7 +92,7 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
   const int b = a.n_problems > 0 ? ob % a.n_problems : ob;          // the problem it reads
   const double step_len = a.n_problems > 0 ? a.alpha[ob / a.n_problems] : 0.0;
   const double* lf = a.n_problems > 0 ? a.lff + (size_t)b * a.N * NU : nullptr;
-  LinFastNodeLds<NJ, false>& nl = w.node[sub];
+  LinFastNodeLds<NJ, false, CHAIN>& nl = w.node[sub];
   const LinFastShared<NJ, false>& sh = w.shared;
   const int N = a.N, grid = a.p_grid[b], n = a.g_nodes[grid];
   const double* tp = a.g_time + (size_t)grid * (N + 1);
@@ -161,6 +164,16 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
       if (lf) for (int idx = g; idx < NU; idx += LPN) { w.uc[sub][0][idx] = up[(size_t)e0 * NU + idx] + step_len * lf[(size_t)e0 * NU + idx]; w.uc[sub][1][idx] = up[(size_t)e1 * NU + idx] + step_len * lf[(size_t)e1 * NU + idx]; }
       else for (int idx = g; idx < NU; idx += LPN) { w.uc[sub][0][idx] = up[(size_t)e0 * NU + idx]; w.uc[sub][1][idx] = up[(size_t)e1 * NU + idx]; }
       for (int idx = g; idx < NX; idx += LPN) { w.xc[sub][0][idx] = xp[(size_t)j * NX + idx]; w.xc[sub][1][idx] = xp[(size_t)(j + 1) * NX + idx]; }
+      if (a.feedback) {     // LinearController's own form: uff_j = u_j - K_j x_j once per segment (round 6), so that a stage costs K x instead of K (x - x_j)
+        lds_wave_sync();
+        for (int r = g; r < NU; r += LPN) {
+          const double* K0 = w.Kc[sub][0] + r * NX;
+          const double* K1 = w.Kc[sub][1] + r * NX;
+          double f0 = w.uc[sub][0][r], f1 = w.uc[sub][1][r];
+          for (int c = 0; c < NX; ++c) { f0 -= K0[c] * w.xc[sub][0][c]; f1 -= K1[c] * w.xc[sub][1][c]; }
+          w.uc[sub][0][r] = f0; w.uc[sub][1][r] = f1;
+        }
+      }
     }
     lds_wave_sync();
     double al;                                          // as time_segment: clamped outside the grid
@@ -174,8 +187,8 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
       if (a.feedback)
         for (int c = 0; c < NX; ++c) {
           const double xc = nl.x[c];
-          s0 += K0[c] * (xc - w.xc[sub][0][c]);
-          s1 += K1[c] * (xc - w.xc[sub][1][c]);
+          s0 += K0[c] * xc;
+          s1 += K1[c] * xc;
         }
       nl.u[r] = al * s0 + (1.0 - al) * s1;
     }
@@ -188,7 +201,7 @@ __device__ __forceinline__ void rollout_policy(const DeviceModel& md, RolloutLds
     const double ujg = is_joint ? nl.u[12 + g - 6] : 0.0;
     LaneEval e;
     LaneKin<NJ> kin;
-    eval_lane<NJ, false, false, LinFastNodeLds<NJ, false>>(md, sh, nl, 0, lb, path, g, nl.x, vq, ujg, e, kin);
+    eval_lane<NJ, false, false, LinFastNodeLds<NJ, false, CHAIN>, LinFastShared<NJ, false>, C>(md, sh, nl, 0, lb, path, g, nl.x, vq, ujg, e, kin);
     kh = lane_pick6(e.fh, g);
     kq = e.vg;
   };

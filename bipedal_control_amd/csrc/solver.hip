@@ -402,7 +402,7 @@ void bpmpc_solver::run_ddp() {
   double longest = 0.0;
   for (size_t g = 0; g < grid_nodes.size(); ++g) longest = std::max(longest, node_times[g * (N + 1) + grid_nodes[g]] - node_times[g * (N + 1)]);
   a.max_steps = (int)(rm.rollout.max_steps_per_second * std::max(1.0, longest));
-  TIMED("ddp_rollout", kl::rollout(rm.nj, batch * ddp.nv, stream, d_model, a));
+  TIMED("ddp_rollout", kl::rollout(rm.nj, dm.serial_legs && !force_tables, batch * ddp.nv, stream, d_model, a));
   TIMED("ddp_search", { kl::ddp_cost(nj(), batch, !settings.reference_kernels, stream, L, ddp); kl::ddp_select(nj(), batch, stream, L, ddp, kArmijoCoefficient); kl::ddp_finish(nj(), batch, stream, L, ddp); });
 }
 
@@ -421,7 +421,7 @@ void bpmpc_solver::ddp_nominal_rollout() {
   double longest = 0.0;
   for (size_t g = 0; g < grid_nodes.size(); ++g) longest = std::max(longest, node_times[g * (N + 1) + grid_nodes[g]] - node_times[g * (N + 1)]);
   a.max_steps = (int)(rm.rollout.max_steps_per_second * std::max(1.0, longest));
-  kl::rollout(rm.nj, batch, stream, d_model, a);
+  kl::rollout(rm.nj, dm.serial_legs && !force_tables, batch, stream, d_model, a);
   kl::ddp_nominal(nj(), batch, stream, launch_params(), ddp);
   HIP_CHECK(hipGetLastError());
 }
@@ -833,7 +833,7 @@ void rollout(bpmpc_solver* s, const double* t_start, const double* x_start, doub
   a.max_steps = (int)(s->rm.rollout.max_steps_per_second * std::max(1.0, duration));
   a.feedback = s->feedback();
   a.x_end = bf.roll_x; a.u_end = bf.roll_u; a.steps = bf.roll_steps; a.status = bf.roll_status;
-  kl::rollout(s->rm.nj, B, s->stream, s->d_model, a);
+  kl::rollout(s->rm.nj, s->dm.serial_legs && !s->force_tables, B, s->stream, s->d_model, a);
   HIP_CHECK(hipGetLastError());
   s->has_rollout = true;
   if (!x_end && !u_end && !steps) {                 // nothing to hand back: stay asynchronous; the status is looked at by the next
