@@ -147,3 +147,21 @@ def test_rollout_degenerate_windows(ctx):
     for b in range(2):
         r = _oracle_rollout(ob, rp, prob, b, x, u, K, n, t_start, xs[b], 0.03)
         assert (int(steps[b, 0]), int(steps[b, 1])) == (r["accepted"], r["rejected"]) and np.abs(xe[b] - r["states"][-1]).max() < 1e-9
+
+
+def test_rollout_with_dpp_tree_walks_agrees_with_the_table_walks(ctx, monkeypatch):
+    """Round 6: on a robot of two serial legs whose coordinates fit one 16-lane row (H1, Hunter) the roll-out's flow map runs its tree walks by DPP between
+    neighbouring lanes (k_rollout<NJ, true>, the lineariser's CHAIN form); BPMPC_LIN_TABLES=1 keeps the walks over LDS tables.  The same steps - identical
+    accepted / rejected counts -, end states equal to rounding (the whole-robot sums associate differently)."""
+    bp, sc, ob, rp, itf = ctx
+    B = 6
+    prob = sc.trot_problem(itf, batch=B, n_intervals=40)
+    out = []
+    for tables in ("0", "1"):
+        monkeypatch.setenv("BPMPC_LIN_TABLES", tables)
+        mpc = bp.BatchedSqpMpc(itf, max_batch=B, max_nodes=64, return_gains=True)
+        mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+        out.append(mpc.rollout(0.3, t_start=0.01, x_start=prob["x0"] + 1e-3))
+    (xa, ua, sa), (xb, ub, sb) = out
+    assert np.array_equal(sa, sb), (sa, sb)
+    assert np.abs(xa - xb).max() < 1e-10 and np.abs(ua - ub).max() < 1e-8 * max(1.0, np.abs(ub).max())
