@@ -620,3 +620,19 @@ def test_lineariser_with_the_event_nodes_out_of_the_way_is_bit_identical(ctx, mo
     for mat in (True, False):
         for k, v in out[("1", mat)].items():
             assert np.array_equal(v, out[("0", mat)][k]), (mat, k)
+
+
+@pytest.mark.parametrize("batch,n_intervals,cap", [(2, 440, 500), (258, 225, 250)])
+def test_horizons_beyond_the_roll_outs_lds_history_match_oracle(ctx, batch, n_intervals, cap):
+    """The roll-out behind the workgroup sweeps keeps its state history in LDS and walks a longer horizon in several passes (riccati_rollout_deep: ~400 stages
+    per pass in the eight-wave kernel, ~216 in the four-wave one).  Round 6 rewrote its inner loop (state in registers, two stages per register set): a horizon
+    of ~460 nodes on the eight-wave kernel and ~236 nodes on the four-wave kernel (batch > number of CUs) against the oracle."""
+    bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    prob = sc.trot_problem(itf, batch=batch, n_intervals=n_intervals)
+    mpc = bp.BatchedSqpMpc(itf, max_batch=batch, max_nodes=cap, return_gains=True)
+    t, x, u, K, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
+    n = st[0].n_nodes
+    assert n > (400 if batch <= 256 else 216) and all(s.status in (0, 1) for s in st)
+    for b in (0, batch - 1):
+        xo, uo, Ko, _ = ob.oracle_solve_like(prob, b)
+        assert rel_x(x[b, :n + 1], xo) < 1e-10 and rel_u(u[b, :n], uo) < 1e-10 and rel_K(K[b, :n], Ko) < 1e-9, (b, rel_x(x[b, :n + 1], xo), rel_u(u[b, :n], uo))
