@@ -331,6 +331,15 @@ struct RollDot {
 template <int NX, int OFF, int H>
 struct RollDot<NX, OFF, H, H> { static __device__ __forceinline__ void run(double&, double, const double (&)[NX]) {} };
 
+template <int NX, int HH, int L, int E>       // a += sum over l = L .. E - 1 of xlo[lane l] * r[l], c += the same of xhi and r[HH + l]: two independent chains, interleaved
+struct RollDot2 {
+  static __device__ __forceinline__ void run(double& a, double& c, double xlo, double xhi, const double (&r)[NX]) {
+    roll_fma<L, false>(a, xlo, r[L]); roll_fma<L, false>(c, xhi, r[HH + L]); RollDot2<NX, HH, L + 1, E>::run(a, c, xlo, xhi, r);
+  }
+};
+template <int NX, int HH, int E>
+struct RollDot2<NX, HH, E, E> { static __device__ __forceinline__ void run(double&, double&, double, double, const double (&)[NX]) {} };
+
 template <int NJ, int NT = kRiccatiThreads>
 __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 4) * nx doubles*/, int cap, int status, const RiccatiFastIO& io) {
   constexpr int NX = 12 + NJ, NXX = NX * NX;
@@ -413,9 +422,6 @@ __device__ __forceinline__ void riccati_rollout_deep(double* hist /*LDS, (cap + 
     __syncthreads();
   }
   // the history stays for the step norms when the horizon fitted one pass; their tiles of K follow it in LDS
-#ifdef BPMPC_RICCATI_PROFILE
-  if (BPMPC_RICCATI_PROFILE == 1 && io.prof && tid == 0) io.prof[6] = (double)clock64();     // start of the step norms (the caller turns it into a duration)
-#endif
   riccati_step_norms<NJ, NT>(status, io, N <= cap ? hist : nullptr, hist + (size_t)(cap + 4) * NX);
 }
 
@@ -527,6 +533,241 @@ __device__ __forceinline__ void riccati_rollout_sparse(double* lds /* (cap + 4) 
   if (tid == 0) {
     double a = 0.0, x2 = 0.0, u2 = 0.0;
     for (int w = 0; w < NT / kWave; ++w) { a += red3s[0][w]; x2 += red3s[1][w]; u2 += red3s[2][w]; }
+    io.base.summary[0] = a;
+    io.base.summary[1] = x2;
+    io.base.summary[2] = u2;
+    io.base.summary[3] = (double)status;
+  }
+}
+
+
+// Spin on an LDS word that another wave of the workgroup advances (the loads in flight of the spinning wave stay in flight: the fence orders LDS only)
+__device__ __forceinline__ void lds_wait_ge(int* flag, int v) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Roll-out of the workgroup sweeps, round 6: du inside the recurrence (riccati_rollout_sparse: the joint rows of dx+ follow from du, so only the rows 0..11
+// of [Acl | bcl] are read - 6.4 instead of 8.3 KB per stage - and no step-norm pass over K follows) fed through a RING in LDS.  With a CU per problem every
+// workgroup reaches its roll-out at the same time: the phase was a chip-wide stream (Acl, then K: 2 x 104 MB at batch 256, ~4.5 TB/s) requested by one wave
+// per CU, a row per lane - 22 cache lines per request.  Here wave 0 computes and touches no global memory; the waves 2 .. NW-1 stream chunks of C stages -
+// K, the twelve rows of Acl, kff, bcl, b: each a contiguous piece, consecutive 16-byte units on consecutive lanes - into a double buffer, two chunks ahead
+// in registers; an LDS word per loader wave counts the chunks it has stored, another the chunks consumed.  Wave 1 opens the line search as before.
+template <int NJ, int NT, int C>
+struct RolloutRing {
+  static constexpr int NX = 12 + NJ, NU = 12 + NJ, NXX = NX * NX, NXU = NX * NU;
+  static constexpr int NW = NT / kWave, NL = NW - 2, NLT = NL * kWave;
+  static constexpr int AR = 12 * NX;                                                   // rows 0..11 of Acl
+  static constexpr int OK = 0, OA = OK + C * NXU, OF = OA + C * AR, OB = OF + C * NU, OL = OB + C * NX, SIZE = OL + C * NX;   // doubles of a buffer
+  static constexpr int UT = SIZE / 2, UPL = (UT + NLT - 1) / NLT;                      // 16-byte units of a chunk, per loader lane
+  static constexpr int kScratch = 256;                                                 // opening of the line search (197 doubles), the counters (200 ..), a slot nobody reads (240)
+  static constexpr int kTab = kMaxRiccatiStages + 16;                                  // interval length per stage (negative: a stage without inputs)
+  static constexpr int kFixed = kScratch + kTab + 2 * SIZE + (2 * C + 2) * NX;         // + the slack rows of the two histories (steps past the end of a pass store too)
+  static_assert(C % 2 == 0 && C <= 14 && NX % 2 == 0 && NX == NU && NL >= 1, "16-byte units");
+  static constexpr int cap(int lds_doubles) { return ((lds_doubles - kFixed) / (NX + NU)) & ~1; }
+};
+template <int NJ, int NT, int C>
+__device__ __forceinline__ void riccati_rollout_ring(double* lds /* (2 cap + 2 C + 2) nx + RolloutRing::kFixed doubles */, int cap, int status, const RiccatiFastIO& io) {
+  using RR = RolloutRing<NJ, NT, C>;
+  constexpr int NX = RR::NX, NU = RR::NU, NXX = RR::NXX, NXU = RR::NXU, NL = RR::NL, NLT = RR::NLT, UPL = RR::UPL, UT = RR::UT;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int N = io.base.N;
+  double* const hist = lds;                                      // dx_0 .. dx_cap (+ slack), row stride nx
+  double* const duh = lds + (size_t)(cap + C + 2) * NX;          // du of the pass (+ slack), row stride nu
+  double* const scratch = duh + (size_t)(cap + C) * NU;          // opening of the line search
+  int* const flags = reinterpret_cast<int*>(scratch + 200);      // [1]: chunks consumed, [2 + i]: chunks loader wave i has stored its share of
+  double* const dtab = scratch + RR::kScratch;
+  double* const ring = dtab + RR::kTab;
+  for (int idx = tid; idx < N + C + 2 && idx < RR::kTab; idx += NT) dtab[idx] = (idx < N && io.base.nut[idx] > 0) ? io.gdt[idx] : -1.0;
+  if (tid < NX) hist[tid] = io.base.dx0[tid];
+  if (tid >= kWave && tid < kWave + NX) io.base.dx[tid - kWave] = io.base.dx0[tid - kWave];
+  if (tid < 2 + NL) flags[tid] = 0;
+  __syncthreads();
+#ifdef BPMPC_RICCATI_PROFILE
+  const long long tp1 = clock64();
+#endif
+  double acc_arm = 0.0, acc_x = 0.0, acc_u = 0.0;
+  int cb = 0;                                             // chunks of the passes before this one
+  for (int k0 = 0; k0 < N; k0 += cap) {
+    const int nk = N - k0 < cap ? N - k0 : cap;
+    const int nch = (nk + C - 1) / C;
+    if (w == 0) {
+      // A lone wave issues an instruction every 5 .. 8 cycles whatever it depends on: a step costs its instruction count.  The state never leaves the
+      // registers (as in riccati_rollout_deep): every 16-lane DPP row holds all of it - xlo: element p in lane position p, xhi: element H + p - and a lane's
+      // dot product takes its operands by `v_fmac_f64_dpp .. row_newbcast`.  Row 0 of the wave forms the elements of xlo, row 1 those of xhi, each lane in the
+      // lane position of its element - from its row of [Acl | bcl] (elements 0..11) or, the joint rows, as dx + b + dt du with du from its row of
+      // [K | kff] -, so one v_permlane32_swap + one v_permlane16_swap per half of the value broadcast the two rows to all four.  Row 2: the force inputs.
+      constexpr int H = NX / 2;
+      static_assert(H <= 12 && NX - H <= 16 && H >= 6, "elements 0..11 in row 0 and the head of row 1");
+      const int q = l >> 4, p = l & 15;
+      const int xe = q == 0 ? p : H + p;                                                         // element of dx+ a lane of the rows 0, 1 forms
+      const bool x_lane = (q == 0 && p < H) || (q == 1 && xe < NX);
+      const bool a_lane = x_lane && xe < 12;                                                      // from [Acl | bcl]
+      const bool k_lane = (x_lane && !a_lane) || (q == 2 && p < 12);                              // forms an input
+      const int ki = q == 2 ? p : xe;                                                            // its row of K
+      const int row_off = a_lane ? RR::OA + xe * NX : (k_lane ? ki * NX : 0), row_str = a_lane ? RR::AR : NXU;
+      const int sv_off = a_lane ? RR::OB + xe : RR::OF + (k_lane ? ki : 0);
+      const int bv_off = RR::OL + (x_lane && !a_lane ? xe : 0);
+      const double ownm = x_lane && !a_lane ? 1.0 : 0.0;
+      // where a step stores: the element of dx+, the input; lanes that form none write a slot nobody reads (stride 0)
+      int hp = x_lane ? NX + xe : (int)(scratch + 240 - hist), up = k_lane ? (int)(duh - hist) + ki : (int)(scratch + 242 - hist);
+      const int hs = x_lane ? NX : 0, us = k_lane ? NU : 0;
+      double xlo = hist[p < H ? p : 0], xhi = hist[H + p < NX ? H + p : 0];
+      double rA[NX], rB[NX], sA, sB, bA, bB, dA, dB;
+      // (LDS loads return in order: the scalars of a stage first, so that a step never waits for the row of the NEXT stage that is requested ahead of it)
+      auto load = [&](double (&r)[NX], double& sv, double& bv, double& dv, const double* buf, int s, int j) {
+        dv = dtab[k0 + j];
+        sv = buf[sv_off + s * NX];
+        bv = buf[bv_off + s * NX];
+        const double2* pr = reinterpret_cast<const double2*>(buf + row_off + s * row_str);
+#pragma unroll
+        for (int c = 0; c < NX / 2; ++c) { const double2 v = pr[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
+      };
+      auto step = [&](const double (&r)[NX], double sv, double bv, double dv) {
+        const bool keep = a_lane || dv >= 0.0;                                  // a stage without inputs (an event node): du = 0
+        const double dvl = a_lane ? 1.0 : dv, bvl = a_lane ? 0.0 : bv;          // dx+ = t for a row of Acl, own element + b + dt du for a joint row
+        const double base = __builtin_fma(xhi, ownm, bvl);
+        constexpr int H2 = H / 2;
+        double t = sv, t2 = 0.0, t3 = 0.0, t4 = 0.0;                            // four chains; the first DPP read of xlo / xhi two wait states behind their VALU write
+        roll_fma<0, true>(t, xlo, r[0]);
+        roll_fma<0, false>(t2, xhi, r[H]);
+        roll_fma<H2, false>(t3, xlo, r[H2]);
+        roll_fma<H2, false>(t4, xhi, r[H + H2]);
+        RollDot2<NX, H, 1, H2>::run(t, t2, xlo, xhi, r);
+        RollDot2<NX, H, H2 + 1, H>::run(t3, t4, xlo, xhi, r);
+        t = (t + t2) + (t3 + t4);
+        t = keep ? t : 0.0;
+        const double nxt = __builtin_fma(dvl, t, base);
+        hist[hp] = nxt; hp += hs;
+        hist[up] = t; up += us;
+        const auto l32 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(nxt), (unsigned)__double2loint(nxt), false, false);
+        const auto h32 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(nxt), (unsigned)__double2hiint(nxt), false, false);
+        // [0]: rows 0, 1 of the wave in both halves
+        const auto l01 = __builtin_amdgcn_permlane16_swap(l32[0], l32[0], false, false), h01 = __builtin_amdgcn_permlane16_swap(h32[0], h32[0], false, false);
+        // [0]: row 0 in all four rows, [1]: row 1
+        xlo = __hiloint2double((int)h01[0], (int)l01[0]);
+        xhi = __hiloint2double((int)h01[1], (int)l01[1]);
+      };
+      // a loader wave may be a chunk ahead of another: one word each.  The words of the NEXT chunk are read a step before its first row is requested
+      // (beside the last step but one of this chunk), so that neither the poll nor that request sits between two steps.
+      int* const f = flags + 2 + (l < NL ? l : 0);
+      auto filled = [&]() { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+      auto await = [&](int fv, int g) {
+        while (__builtin_amdgcn_ballot_w64(fv < g + 1) != 0) { __builtin_amdgcn_s_sleep(1); fv = filled(); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      };
+      await(filled(), cb);
+      load(rA, sA, bA, dA, ring + (cb & 1) * RR::SIZE, 0, 0);
+      for (int c = 0; c < nch; ++c) {
+        const double* buf = ring + ((cb + c) & 1) * RR::SIZE;
+        const double* nbuf = ring + ((cb + c + 1) & 1) * RR::SIZE;
+        const int j0 = c * C;
+        const bool more = c + 1 < nch;
+#pragma unroll
+        for (int s = 0; s < C; s += 2) {
+          load(rB, sB, bB, dB, buf, s + 1, j0 + s + 1);
+          int fv = 0;
+          if (s + 2 == C && more) fv = filled();
+          step(rA, sA, bA, dA);
+          if (s + 2 < C) load(rA, sA, bA, dA, buf, s + 2, j0 + s + 2);
+          else if (more) { await(fv, cb + c + 1); load(rA, sA, bA, dA, nbuf, 0, j0 + C); }
+          step(rB, sB, bB, dB);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (l == 0) __hip_atomic_store(&flags[1], cb + c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else if (w >= 2) {
+      const int lt = (w - 2) * kWave + l;
+      // unit u of a chunk (its doubles 2 u, 2 u + 1 of the buffer): which array, which stage of the chunk, where in the stage
+      const double* arr[UPL]; int str[UPL], st[UPL], off[UPL];
+#pragma unroll
+      for (int j = 0; j < UPL; ++j) {
+        const int u = lt + j * NLT, d = 2 * u;
+        if (d < RR::OA)        { arr[j] = io.Kfull; str[j] = NXU; st[j] = d / NXU;               off[j] = d % NXU; }
+        else if (d < RR::OF)   { arr[j] = io.Acl;   str[j] = NXX; st[j] = (d - RR::OA) / RR::AR; off[j] = (d - RR::OA) % RR::AR; }
+        else if (d < RR::OB)   { arr[j] = io.kff;   str[j] = NU;  st[j] = (d - RR::OF) / NU;     off[j] = (d - RR::OF) % NU; }
+        else if (d < RR::OL)   { arr[j] = io.bcl;   str[j] = NX;  st[j] = (d - RR::OB) / NX;     off[j] = (d - RR::OB) % NX; }
+        else if (d < RR::SIZE) { arr[j] = io.lqb;   str[j] = NX;  st[j] = (d - RR::OL) / NX;     off[j] = (d - RR::OL) % NX; }
+        else                   { arr[j] = io.lqb;   str[j] = NX;  st[j] = 0;                     off[j] = 0; }             // no unit: a valid address, nothing stored
+      }
+      double ax[UPL], ay[UPL], bx[UPL], by[UPL];
+      auto issue = [&](double (&vx)[UPL], double (&vy)[UPL], int c) {
+        const int ks = k0 + c * C;
+#pragma unroll
+        for (int j = 0; j < UPL; ++j) {
+          int k = ks + st[j];
+          k = k < N ? k : N - 1;                         // beyond the end: a valid, unused stage
+          const double2 v = *reinterpret_cast<const double2*>(arr[j] + (size_t)k * str[j] + off[j]);
+          vx[j] = v.x; vy[j] = v.y;
+        }
+      };
+      auto put = [&](const double (&vx)[UPL], const double (&vy)[UPL], int c) {
+        if (c >= nch) return;
+        lds_wait_ge(&flags[1], cb + c - 1);              // the buffer's previous chunk has been consumed
+        double* buf = ring + ((cb + c) & 1) * RR::SIZE;
+#pragma unroll
+        for (int j = 0; j < UPL; ++j)
+          if ((j + 1) * NLT <= UT || lt + j * NLT < UT) { double2 v; v.x = vx[j]; v.y = vy[j]; *reinterpret_cast<double2*>(buf + 2 * (lt + j * NLT)) = v; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (l == 0) __hip_atomic_store(&flags[w], cb + c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // flags[2 + loader]
+      };
+      issue(ax, ay, 0); issue(bx, by, 1);
+      for (int c = 0; c < nch; c += 2) {                // (the same requests in the same order on every path: the compiler can count what may stay in flight)
+        put(ax, ay, c); issue(ax, ay, c + 2);
+        put(bx, by, c + 1); issue(bx, by, c + 3);
+      }
+    } else if (k0 == 0 && io.with_ls) {
+      linesearch_begin_wave<NJ>(scratch, io.ls, l);
+    }
+#ifdef BPMPC_RICCATI_PROFILE
+    if (BPMPC_RICCATI_PROFILE == 1 && io.prof && tid == 0 && k0 == 0) io.prof[6] = (double)(clock64() - tp1);      // the recurrence of the first pass (wave 0)
+#endif
+    __syncthreads();
+    cb += nch;
+    // outputs of the pass (coalesced) and its share of the norms
+    for (int i0 = 0; i0 < nk * NX; i0 += 4 * NT) {       // (what the Armijo terms need from global memory requested for four elements at once)
+      double mv[4], ms[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = i0 + e * NT + tid, ic = idx < nk * NX ? idx : 0;
+        mv[e] = io.mvec[(size_t)k0 * NX + ic];
+        ms[e] = io.mscal[k0 + ic / NX];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = i0 + e * NT + tid;
+        if (idx < nk * NX) {
+          const double d = hist[idx];                    // dx_(k0 + idx / nx): the Armijo metric and |dx| run over the stages 0..N-1 here, dx_N below
+          const double dn = hist[NX + idx];
+          io.base.dx[(size_t)(k0 + 1) * NX + idx] = dn;
+          const double u = duh[idx];                     // nu == nx
+          io.base.du[(size_t)k0 * NU + idx] = u;
+          acc_u += u * u;
+          acc_x += d * d;
+          acc_arm += mv[e] * d;
+          if (idx % NX == 0) acc_arm += ms[e];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < NX) {
+      const double dl = hist[nk * NX + tid];             // the last state of the pass
+      if (k0 + nk < N) hist[tid] = dl;                   // input of the next pass
+      else acc_x += dl * dl;                             // dx_N
+    }
+    __syncthreads();
+  }
+  __shared__ double red3r[3][NT / kWave];
+  for (int off = kWave / 2; off >= 1; off >>= 1) {
+    acc_arm += __shfl_down(acc_arm, off);
+    acc_x += __shfl_down(acc_x, off);
+    acc_u += __shfl_down(acc_u, off);
+  }
+  if ((tid & (kWave - 1)) == 0) { red3r[0][tid / kWave] = acc_arm; red3r[1][tid / kWave] = acc_x; red3r[2][tid / kWave] = acc_u; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, x2 = 0.0, u2 = 0.0;
+    for (int ww = 0; ww < NT / kWave; ++ww) { a += red3r[0][ww]; x2 += red3r[1][ww]; u2 += red3r[2][ww]; }
     io.base.summary[0] = a;
     io.base.summary[1] = x2;
     io.base.summary[2] = u2;

@@ -504,14 +504,16 @@ __device__ __forceinline__ void riccati_mfma8(RiccatiMfma8Workspace<NJ>& ws, con
   {
     const int st = ws.status;
     __syncthreads();                                   // the workspace is dead from here on: it holds the state history
-    constexpr int kHistCap = ((int)(offsetof(WS, status) / sizeof(double)) - kStepNormsScratch * NT / kWave) / NX - 8;
-    static_assert(kHistCap >= 64, "roll-out history");
 #ifdef BPMPC_RICCATI_PROFILE
     const long long tr0 = clock64();
 #endif
-    riccati_rollout_deep<NJ, NT>(reinterpret_cast<double*>(&ws), kHistCap, st, io);
+    constexpr int kRingChunk = 4;                      // stages per chunk of the roll-out's ring (six: 20 stages less history, no faster)
+    using RR = RolloutRing<NJ, NT, kRingChunk>;
+    constexpr int kRingCap = RR::cap((int)(offsetof(WS, status) / sizeof(double)));
+    static_assert(kRingCap >= 128, "roll-out history");
+    riccati_rollout_ring<NJ, NT, kRingChunk>(reinterpret_cast<double*>(&ws), kRingCap, st, io);
 #ifdef BPMPC_RICCATI_PROFILE
-    if (BPMPC_RICCATI_PROFILE == 1 && io.prof && tid == 0) { const long long te = clock64(); io.prof[5] = (double)(te - tr0); io.prof[6] = (double)te - io.prof[6]; }     // roll-out + step norms, whole horizon; [6]: the step norms alone
+    if (BPMPC_RICCATI_PROFILE == 1 && io.prof && tid == 0) io.prof[5] = (double)(clock64() - tr0);     // the roll-out behind the sweep, whole horizon ([6]: its recurrence alone)
 #endif
   }
 }

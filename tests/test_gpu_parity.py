@@ -622,17 +622,18 @@ def test_lineariser_with_the_event_nodes_out_of_the_way_is_bit_identical(ctx, mo
             assert np.array_equal(v, out[("0", mat)][k]), (mat, k)
 
 
-@pytest.mark.parametrize("batch,n_intervals,cap", [(2, 440, 500), (258, 225, 250)])
-def test_horizons_beyond_the_roll_outs_lds_history_match_oracle(ctx, batch, n_intervals, cap):
-    """The roll-out behind the workgroup sweeps keeps its state history in LDS and walks a longer horizon in several passes (riccati_rollout_deep: ~400 stages
-    per pass in the eight-wave kernel, ~216 in the four-wave one).  Round 6 rewrote its inner loop (state in registers, two stages per register set): a horizon
-    of ~460 nodes on the eight-wave kernel and ~236 nodes on the four-wave kernel (batch > number of CUs) against the oracle."""
+@pytest.mark.parametrize("batch,n_intervals,cap,min_nodes", [(2, 440, 500, 400), (258, 225, 250, 216), (2, 171, 200, 0), (2, 173, 200, 0), (2, 176, 200, 0)])
+def test_horizons_beyond_the_roll_outs_lds_history_match_oracle(ctx, batch, n_intervals, cap, min_nodes):
+    """The roll-out behind the workgroup sweeps keeps its state history in LDS and walks a longer horizon in several passes.  Eight-wave kernel
+    (riccati_rollout_ring, round 6: one wave computes, six stream chunks of four stages into a ring in LDS): 184 stages per pass - ~460 nodes are three
+    passes, the horizons of 171 .. 176 intervals put the node count at and next to the pass length (a last chunk that is partly beyond the horizon, a second
+    pass of a few stages).  Four-wave kernel (riccati_rollout_deep, batch > number of CUs): ~216 stages per pass, ~236 nodes.  Against the oracle."""
     bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
     prob = sc.trot_problem(itf, batch=batch, n_intervals=n_intervals)
     mpc = bp.BatchedSqpMpc(itf, max_batch=batch, max_nodes=cap, return_gains=True)
     t, x, u, K, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
     n = st[0].n_nodes
-    assert n > (400 if batch <= 256 else 216) and all(s.status in (0, 1) for s in st)
+    assert n > min_nodes and all(s.status in (0, 1) for s in st)
     for b in (0, batch - 1):
         xo, uo, Ko, _ = ob.oracle_solve_like(prob, b)
         assert rel_x(x[b, :n + 1], xo) < 1e-10 and rel_u(u[b, :n], uo) < 1e-10 and rel_K(K[b, :n], Ko) < 1e-9, (b, rel_x(x[b, :n + 1], xo), rel_u(u[b, :n], uo))

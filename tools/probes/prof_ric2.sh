@@ -14,7 +14,7 @@ for st in ("linearize","project","riccati"): mpc.stage(st)
 mpc.synchronize(); mpc.stage("riccati"); mpc.synchronize()
 r=mpc.read("rprof").reshape(-1,8)[:256]
 np.set_printoptions(linewidth=200, suppress=True)
-print("ricp$v  per stage:", (r.mean(axis=0)/107).round(0), " whole horizon [5],[6]:", r[:,5].mean().round(0), r[:,6].mean().round(0))
+print("ricp$v  per stage:", (r.mean(axis=0)/107).round(0), " whole horizon: roll-out [5]", r[:,5].mean().round(0), "its recurrence [6]", r[:,6].mean().round(0))
 PY
 done
 cp /tmp/keep.so bipedal_control_amd/libbpmpc.so
