@@ -561,7 +561,8 @@ struct RolloutRing {
   static constexpr int OK = 0, OA = OK + C * NXU, OF = OA + C * AR, OB = OF + C * NU, OL = OB + C * NX, SIZE = OL + C * NX;   // doubles of a buffer
   static constexpr int UT = SIZE / 2, UPL = (UT + NLT - 1) / NLT;                      // 16-byte units of a chunk, per loader lane
   static constexpr int kScratch = 256;                                                 // opening of the line search (197 doubles), the counters (200 ..), a slot nobody reads (240)
-  static constexpr int kTab = kMaxRiccatiStages + 16;                                  // interval length per stage (negative: a stage without inputs)
+  static constexpr int kDt = kMaxRiccatiStages + 16;                                   // interval length per stage (negative: a stage without inputs)
+  static constexpr int kTab = kDt + kMaxRiccatiStages / 8;                             // + a byte per stage: which of the two feet stand
   static constexpr int kFixed = kScratch + kTab + 2 * SIZE + (2 * C + 2) * NX;         // + the slack rows of the two histories (steps past the end of a pass store too)
   static_assert(C % 2 == 0 && C <= 14 && NX % 2 == 0 && NX == NU && NL >= 1, "16-byte units");
   static constexpr int cap(int lds_doubles) { return ((lds_doubles - kFixed) / (NX + NU)) & ~1; }
@@ -577,8 +578,10 @@ __device__ __forceinline__ void riccati_rollout_ring(double* lds /* (2 cap + 2 C
   double* const scratch = duh + (size_t)(cap + C) * NU;          // opening of the line search
   int* const flags = reinterpret_cast<int*>(scratch + 200);      // [1]: chunks consumed, [2 + i]: chunks loader wave i has stored its share of
   double* const dtab = scratch + RR::kScratch;
+  unsigned char* const mtab = reinterpret_cast<unsigned char*>(dtab + RR::kDt);
   double* const ring = dtab + RR::kTab;
-  for (int idx = tid; idx < N + C + 2 && idx < RR::kTab; idx += NT) dtab[idx] = (idx < N && io.base.nut[idx] > 0) ? io.gdt[idx] : -1.0;
+  for (int idx = tid; idx < N + C + 2 && idx < RR::kDt; idx += NT) dtab[idx] = (idx < N && io.base.nut[idx] > 0) ? io.gdt[idx] : -1.0;
+  for (int idx = tid; idx < N && idx < kMaxRiccatiStages; idx += NT) mtab[idx] = (unsigned char)(io.base.nut[idx] > 0 ? (io.mode[idx] & 3) : 0);
   if (tid < NX) hist[tid] = io.base.dx0[tid];
   if (tid >= kWave && tid < kWave + NX) io.base.dx[tid - kWave] = io.base.dx0[tid - kWave];
   if (tid < 2 + NL) flags[tid] = 0;
@@ -591,6 +594,17 @@ __device__ __forceinline__ void riccati_rollout_ring(double* lds /* (2 cap + 2 C
   for (int k0 = 0; k0 < N; k0 += cap) {
     const int nk = N - k0 < cap ? N - k0 : cap;
     const int nch = (nk + C - 1) / C;
+    // what the Armijo terms behind the recurrence need from global memory: the first four elements per thread are requested before it
+    double mv[4], ms[4];
+    auto armijo_terms = [&](int i0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = i0 + e * NT + tid, ic = idx < nk * NX ? idx : 0;
+        mv[e] = io.mvec[(size_t)k0 * NX + ic];
+        ms[e] = io.mscal[k0 + ic / NX];
+      }
+    };
+    armijo_terms(0);
     if (w == 0) {
       // A lone wave issues an instruction every 5 .. 8 cycles whatever it depends on: a step costs its instruction count.  The state never leaves the
       // registers (as in riccati_rollout_deep): every 16-lane DPP row holds all of it - xlo: element p in lane position p, xhi: element H + p - and a lane's
@@ -679,11 +693,15 @@ __device__ __forceinline__ void riccati_rollout_ring(double* lds /* (2 cap + 2 C
     } else if (w >= 2) {
       const int lt = (w - 2) * kWave + l;
       // unit u of a chunk (its doubles 2 u, 2 u + 1 of the buffer): which array, which stage of the chunk, where in the stage
-      const double* arr[UPL]; int str[UPL], st[UPL], off[UPL];
+      // A force component of a foot in the air has no gain (K row = 0, written by the sweep as such): its units are requested from a page of zeros instead -
+      // same instructions, another address, 6 of the 34 rows of a single-support stage that never leave the memory
+      const double* arr[UPL]; int str[UPL], st[UPL], off[UPL], foot[UPL];
+      const double* const zeros = io.zero_one + 4;
 #pragma unroll
       for (int j = 0; j < UPL; ++j) {
         const int u = lt + j * NLT, d = 2 * u;
-        if (d < RR::OA)        { arr[j] = io.Kfull; str[j] = NXU; st[j] = d / NXU;               off[j] = d % NXU; }
+        foot[j] = 0;
+        if (d < RR::OA)        { arr[j] = io.Kfull; str[j] = NXU; st[j] = d / NXU;               off[j] = d % NXU; foot[j] = off[j] < 6 * NX ? 1 : (off[j] < 12 * NX ? 2 : 0); }
         else if (d < RR::OF)   { arr[j] = io.Acl;   str[j] = NXX; st[j] = (d - RR::OA) / RR::AR; off[j] = (d - RR::OA) % RR::AR; }
         else if (d < RR::OB)   { arr[j] = io.kff;   str[j] = NU;  st[j] = (d - RR::OF) / NU;     off[j] = (d - RR::OF) % NU; }
         else if (d < RR::OL)   { arr[j] = io.bcl;   str[j] = NX;  st[j] = (d - RR::OB) / NX;     off[j] = (d - RR::OB) % NX; }
@@ -697,7 +715,8 @@ __device__ __forceinline__ void riccati_rollout_ring(double* lds /* (2 cap + 2 C
         for (int j = 0; j < UPL; ++j) {
           int k = ks + st[j];
           k = k < N ? k : N - 1;                         // beyond the end: a valid, unused stage
-          const double2 v = *reinterpret_cast<const double2*>(arr[j] + (size_t)k * str[j] + off[j]);
+          const bool air = (foot[j] & ~mtab[k]) != 0;
+          const double2 v = *reinterpret_cast<const double2*>(air ? zeros : arr[j] + (size_t)k * str[j] + off[j]);
           vx[j] = v.x; vy[j] = v.y;
         }
       };
@@ -725,14 +744,8 @@ __device__ __forceinline__ void riccati_rollout_ring(double* lds /* (2 cap + 2 C
     __syncthreads();
     cb += nch;
     // outputs of the pass (coalesced) and its share of the norms
-    for (int i0 = 0; i0 < nk * NX; i0 += 4 * NT) {       // (what the Armijo terms need from global memory requested for four elements at once)
-      double mv[4], ms[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int idx = i0 + e * NT + tid, ic = idx < nk * NX ? idx : 0;
-        mv[e] = io.mvec[(size_t)k0 * NX + ic];
-        ms[e] = io.mscal[k0 + ic / NX];
-      }
+    for (int i0 = 0; i0 < nk * NX; i0 += 4 * NT) {
+      if (i0 > 0) armijo_terms(i0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int idx = i0 + e * NT + tid;
