@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kDecideThreads) void k_ls_decide(Launch L, int look
 // (the sums are the ones of k_ls_decide term by term while the horizon has at most kDecideThreads nodes).
 constexpr int kTailThreads = 512;
 template <int NJ, bool CHAIN>
-__global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int first_round, int max_trials) {
+__global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int first_round, int max_trials, int pending) {
   using C = LinFastCfg<NJ, true, CHAIN>;
   constexpr int NX = 12 + NJ, NU = 12 + NJ, LPN = C::LPN, NPW = C::NPW, CHUNK = (kTailThreads / kWave) * NPW;
   const int b = blockIdx.x;
@@ -331,12 +331,22 @@ __global__ __launch_bounds__(kTailThreads) void k_ls_tail(Launch L, int first_ro
   __shared__ LinFastNodeLds<NJ, false, CHAIN> lds[CHUNK];
   __shared__ LinFastShared<NJ, false> shared;
   __shared__ double partial[3 * kTailThreads + 5];
+  volatile const int* done = L.buf.done + b;
+  volatile const double* alpha = L.buf.alpha + b;
+  if (pending) {
+    // the trial of the last round that ran as a launch over all nodes has not been judged yet: that decision here, in the workgroup that would go on
+    // with the problem anyway, instead of a launch of k_ls_decide in which all but a few workgroups only read a flag
+    int bb = b;
+    asm volatile("" : "+s"(bb));
+    linesearch_decide<NJ, kTailThreads, true>(partial, problem_ls<NJ>(L, bb), L.ls);
+    __threadfence();
+    __syncthreads();
+    if (*done) return;
+  }
   load_shared_model<kTailThreads>(*L.model, shared, threadIdx.x);
   __syncthreads();
   const int sub = threadIdx.x / LPN, g = threadIdx.x % LPN;
   const int n = L.buf.g_nodes[L.buf.p_grid[b]];
-  volatile const int* done = L.buf.done + b;
-  volatile const double* alpha = L.buf.alpha + b;
   for (int round = first_round; round < max_trials; ++round) {
     const double al = *alpha;
     for (int k0 = 0; k0 < n; k0 += CHUNK) {
@@ -433,10 +443,10 @@ void trial_fast(int nj, int nodes, hipStream_t st, const Launch& L) {
   });
 }
 void ls_decide(int nj, int batch, hipStream_t st, const Launch& L, bool look_first) { KL_NJ(nj, hipLaunchKernelGGL(k_ls_decide<NJ>, dim3(batch), dim3(kDecideThreads), 0, st, L, look_first ? 1 : 0)); }
-void ls_tail(int nj, int batch, hipStream_t st, const Launch& L, int first_round, int max_trials) {
+void ls_tail(int nj, int batch, hipStream_t st, const Launch& L, int first_round, int max_trials, bool pending) {
   KL_NJ(nj, {
-    if (L.serial_legs) hipLaunchKernelGGL((k_ls_tail<NJ, true>), dim3(batch), dim3(kTailThreads), 0, st, L, first_round, max_trials);
-    else hipLaunchKernelGGL((k_ls_tail<NJ, false>), dim3(batch), dim3(kTailThreads), 0, st, L, first_round, max_trials);
+    if (L.serial_legs) hipLaunchKernelGGL((k_ls_tail<NJ, true>), dim3(batch), dim3(kTailThreads), 0, st, L, first_round, max_trials, pending ? 1 : 0);
+    else hipLaunchKernelGGL((k_ls_tail<NJ, false>), dim3(batch), dim3(kTailThreads), 0, st, L, first_round, max_trials, pending ? 1 : 0);
   });
 }
 void constraint_values(int nj, int nodes, hipStream_t st, const Launch& L, double* eqv) {

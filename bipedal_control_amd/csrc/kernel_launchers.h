@@ -25,7 +25,7 @@ void trial_reference(int nj, int slots, hipStream_t st, const Launch& L);
 int trial_fast_workgroups(int nj, int nodes);
 void trial_fast(int nj, int nodes, hipStream_t st, const Launch& L);
 void ls_decide(int nj, int batch, hipStream_t st, const Launch& L, bool look_first = false);
-void ls_tail(int nj, int batch, hipStream_t st, const Launch& L, int first_round, int max_trials);
+void ls_tail(int nj, int batch, hipStream_t st, const Launch& L, int first_round, int max_trials, bool pending);
 void constraint_values(int nj, int nodes, hipStream_t st, const Launch& L, double* eqv);
 void rollout(int nj, bool serial_legs, int batch, hipStream_t st, const DeviceModel* model, const RolloutArgs& a);
 void copy_pairs(int grid, hipStream_t st, const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb,

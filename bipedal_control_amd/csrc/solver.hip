@@ -306,11 +306,13 @@ void bpmpc_solver::stage_linesearch() {
     const int nodes = batch * L.klen;
     static const int wide_rounds = [] { const char* e = std::getenv("BPMPC_LS_WIDE_ROUNDS"); const int v = e ? std::atoi(e) : 2; return v < 1 ? 1 : v; }();
     int round = 0;
+    bool pending = false;                                  // the last of these rounds is judged by k_ls_tail (the workgroups of the few problems still open)
     for (; round < wide_rounds && round < max_trials; ++round) {
       kl::trial_fast(nj(), nodes, stream, L);
-      kl::ls_decide(nj(), batch, stream, L, round > 0);
+      pending = round > 0 && (round + 1 == wide_rounds || round + 1 == max_trials);
+      if (!pending) kl::ls_decide(nj(), batch, stream, L, round > 0);
     }
-    kl::ls_tail(nj(), batch, stream, L, round, max_trials);
+    kl::ls_tail(nj(), batch, stream, L, round, max_trials, pending);
     HIP_CHECK(hipGetLastError());
     time_end("linesearch", ev_a, ev_b);
     return;
