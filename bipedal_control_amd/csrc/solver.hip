@@ -110,7 +110,14 @@ struct bpmpc_solver {
   // the wave-per-problem sweeps (riccati_wave.h, riccati_wave2.h) and the loaders of the eight-wave sweep (riccati_mfma8.h, PackedStageLoader JR) complete the joint rows of Wt = [At | bt | Bt] from Vt ([I | b | 0] + dt Vt): the change of variables then
   // neither computes nor writes them (3.8 KB per node less each way at the batch sizes where both kernels stream)
   bool sweep_completes_joint_rows() const { return !wt_joint_rows && structured_project && !settings.reference_kernels; }     // every fast sweep does
-  bool riccati_double_buffered() const { return riccati_wave != 2 && riccati_wave != 4 && batch <= num_cus; }
+  // The eight-wave sweep holds a CU per problem; a larger batch runs it in ROUNDS (the dispatcher starts a workgroup as a CU becomes free, so the roll-outs
+  // behind the sweeps no longer stream at the same time).  Since its roll-out goes through the ring (round 6) two and three rounds of it beat what those batch
+  // sizes ran before on the 22-state robots - batch 512: 0.5447 against 0.5837 ms on the four-wave workgroups, 768: 0.807 against 0.878 on a wave per problem;
+  // 1024 in four rounds: 1.075 against 0.917, so from there on the wave sweeps - and lose on nx = 24 (G1 / 512: 0.8545 against 0.7682 on the four-wave
+  // workgroups), whose eight-wave stage is 55 % longer (`experiments/LOG.md`).  BPMPC_R8_ROUNDS overrides (1: the regimes of rounds 3 to 5; tests).
+  int r8_rounds = 0;                                        // 0: by the robot, as measured
+  int eight_wave_rounds() const { return r8_rounds > 0 ? r8_rounds : (rm.nj == 10 ? 3 : 1); }
+  bool riccati_double_buffered() const { return riccati_wave != 2 && riccati_wave != 4 && batch <= eight_wave_rounds() * num_cus; }
   bool has_solution = false;                               // a solve has completed on the current setup
   bool has_rollout = false;                                // roll_x holds the end states of a rollout
   bool rollout_unchecked = false;                          // ... whose status flags have not been read back yet
@@ -947,6 +954,7 @@ int bpmpc_solver_create(const bpmpc_model* model, const bpmpc_settings* settings
     { const char* e = std::getenv("BPMPC_LIN_TABLES"); s->force_tables = e && e[0] == '1'; }
     { const char* e = std::getenv("BPMPC_LIN_COMPACT"); s->lin_compact = !(e && e[0] == '0'); }
     { const char* e = std::getenv("BPMPC_RICCATI_WAVE"); s->riccati_wave = e ? std::atoi(e) : 1; }
+    { const char* e = std::getenv("BPMPC_R8_ROUNDS"); s->r8_rounds = e ? std::atoi(e) : 0; }
     {
       bool block_diagonal = true;
       for (int c = 0; c < 12; ++c)

@@ -59,11 +59,12 @@ def test_hunter_solve_matches_oracle(ctx, gait):
     assert rel_x(x3, x) < 1e-9 and rel_u(u3, u) < 1e-9
 
 
-def test_hunter_large_batch_and_commands(ctx):
-    """Batch 300 (four-wave sweep, two workgroups per CU) agrees with batch 3 (eight-wave sweep) to rounding; the device-side
+def test_hunter_large_batch_and_commands(ctx, monkeypatch):
+    """Batch 300 (four-wave sweep, two workgroups per CU: BPMPC_R8_ROUNDS=1) agrees with batch 3 (eight-wave sweep) to rounding; the device-side
     reference generation (gait template + velocity command) reproduces the host pre-pass on this robot's gait files (same time grid,
     solutions to 1e-9)."""
     bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    monkeypatch.setenv("BPMPC_R8_ROUNDS", "1")
     prob = sc.trot_problem(itf, batch=300, n_intervals=40)
     big = bp.BatchedSqpMpc(itf, max_batch=300, max_nodes=64, sqp_iterations=2)
     t, x, u, _, st = big.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])

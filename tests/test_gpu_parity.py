@@ -275,11 +275,14 @@ def test_solver_reuse_across_gaits_matches_fresh_solver(ctx):
     assert np.array_equal(last[1], ref[1]) and np.array_equal(last[2], ref[2]) and np.array_equal(last[3], ref[3])
 
 
-@pytest.mark.parametrize("batch", [48, 300])      # 300 > number of CUs: the single-buffered Riccati variant (two workgroups per CU)
-def test_repeated_solves_are_bit_identical(ctx, batch):
-    """Races, stale LDS or stale HBM scratch would show up as run-to-run differences; also checks the larger-batch Riccati variant
+# 300 > number of CUs: the eight-wave sweep in two rounds (the default of the 22-state robots since round 6) or, BPMPC_R8_ROUNDS=1, the four-wave workgroups
+# (two per CU; what nx = 24 runs at that batch)
+@pytest.mark.parametrize("batch,r8_rounds", [(48, None), (300, None), (300, "1"), (600, None)])
+def test_repeated_solves_are_bit_identical(ctx, batch, r8_rounds, monkeypatch):
+    """Races, stale LDS or stale HBM scratch would show up as run-to-run differences; also checks the larger-batch Riccati variants
     against the oracle."""
     bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    if r8_rounds: monkeypatch.setenv("BPMPC_R8_ROUNDS", r8_rounds)
     prob = sc.trot_problem(itf, batch=batch, n_intervals=30, gait="flying_trot")
     mpc = bp.BatchedSqpMpc(itf, max_batch=batch, max_nodes=48, sqp_iterations=2, return_gains=True)
     mpc.setup(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"])
@@ -623,12 +626,13 @@ def test_lineariser_with_the_event_nodes_out_of_the_way_is_bit_identical(ctx, mo
 
 
 @pytest.mark.parametrize("batch,n_intervals,cap,min_nodes", [(2, 440, 500, 400), (258, 225, 250, 216), (2, 171, 200, 0), (2, 173, 200, 0), (2, 176, 200, 0)])
-def test_horizons_beyond_the_roll_outs_lds_history_match_oracle(ctx, batch, n_intervals, cap, min_nodes):
+def test_horizons_beyond_the_roll_outs_lds_history_match_oracle(ctx, batch, n_intervals, cap, min_nodes, monkeypatch):
     """The roll-out behind the workgroup sweeps keeps its state history in LDS and walks a longer horizon in several passes.  Eight-wave kernel
     (riccati_rollout_ring, round 6: one wave computes, six stream chunks of four stages into a ring in LDS): 184 stages per pass - ~460 nodes are three
     passes, the horizons of 171 .. 176 intervals put the node count at and next to the pass length (a last chunk that is partly beyond the horizon, a second
     pass of a few stages).  Four-wave kernel (riccati_rollout_deep, batch > number of CUs): ~216 stages per pass, ~236 nodes.  Against the oracle."""
     bp, sc, ob, itf = ctx["bp"], ctx["sc"], ctx["ob"], ctx["itf"]
+    if batch > 256: monkeypatch.setenv("BPMPC_R8_ROUNDS", "1")       # the four-wave workgroups (by default this robot runs the eight-wave sweep in rounds up to batch 768)
     prob = sc.trot_problem(itf, batch=batch, n_intervals=n_intervals)
     mpc = bp.BatchedSqpMpc(itf, max_batch=batch, max_nodes=cap, return_gains=True)
     t, x, u, K, st = mpc.run(prob["t0"], prob["x0"], prob["schedule"], prob["targets"], horizon=prob["horizon"], gains=True)
