@@ -86,6 +86,8 @@ struct PinnedArena {
 struct bpmpc_solver {
   HostStaging staging;
   PinnedArena pin_up, pin_down;
+  char* xfer = nullptr;                                     // device staging block of the batched small transfers (upload_batch / Downloads)
+  size_t xfer_cap = 0;
   RobotModel rm;
   DeviceModel dm;
   DeviceModel* d_model = nullptr;
@@ -504,6 +506,12 @@ void allocate(bpmpc_solver* s) {
   b.stats = s->alloc<double>("stats", B * kStatsStride);
   b.done = s->alloc<int>("done", B, true); b.active = s->alloc<int>("active", B, true); b.iterations = s->alloc<int>("iterations", B, true);
   b.remaining = s->alloc<int>(nullptr, 1);
+  {   // what one setup_commands moves each way, or one fetch of a small batch (x, u, K, stats: the batch = 1 loop of the reference)
+    const size_t tick = B * (64 + NX * 8 + N * 4 + (N + 1) * 8 + 64) + (size_t)kRefLibCapacity * 16 + 4096;
+    const size_t solution = (B * ((N + 1) * NX + N * NU + N * NU * NX + kStatsStride)) * sizeof(double) + 4096;
+    s->xfer_cap = std::max(tick, std::min<size_t>(size_t(1) << 20, solution));
+    s->xfer = s->alloc<char>(nullptr, s->xfer_cap);
+  }
   if (s->is_ddp()) {
     DdpBuffers& d = s->ddp;
     d.cap = (int)N + 1;
@@ -538,6 +546,84 @@ inline void upload_pinned(bpmpc_solver* s, void* dst, const void* src, size_t by
 template <typename T>
 void upload_pinned(bpmpc_solver* s, T* dst, const std::vector<T>& src) { upload_pinned(s, dst, src.data(), src.size() * sizeof(T)); }
 
+// Small transfers in ONE copy.  Every hipMemcpyAsync is a DMA operation of its own on the stream (5 .. 8 us each whatever its size) and a runtime call on the
+// host: the nine uploads and five read-backs of a setup_commands and the four results of a fetch were most of what a batch = 1 MPC tick spent outside its
+// solve.  Here the pieces travel as one block through `xfer`; a kernel scatters the block to (gathers it from) the arrays the other kernels use.
+struct CopyTable {
+  static constexpr int kMax = 16;
+  void* dst[kMax]; const void* src[kMax]; unsigned words[kMax]; int n;
+};
+__global__ __launch_bounds__(256) void k_copy_table(CopyTable t) {
+  const int e = blockIdx.y;
+  const unsigned* src = static_cast<const unsigned*>(t.src[e]);
+  unsigned* dst = static_cast<unsigned*>(t.dst[e]);
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < t.words[e]; i += gridDim.x * 256) dst[i] = src[i];
+}
+void launch_copy_table(bpmpc_solver* s, const CopyTable& t) {
+  if (t.n == 0) return;
+  unsigned most = 0;
+  for (int i = 0; i < t.n; ++i) most = std::max(most, t.words[i]);
+  hipLaunchKernelGGL(k_copy_table, dim3(std::min(64u, (most + 255) / 256), t.n), dim3(256), 0, s->stream, t);
+  HIP_CHECK(hipGetLastError());
+}
+struct TransferPiece { void* device; const void* host_src; void* host_dst; size_t bytes; };
+inline size_t piece_span(size_t bytes) { return (bytes + 15) & ~size_t(15); }
+// host -> device, pieces of whole 4-byte words (pin_up.reset() by the caller)
+void upload_batch(bpmpc_solver* s, const TransferPiece* pc, int n) {
+  size_t total = 0;
+  int live = 0;
+  bool words = true;
+  for (int i = 0; i < n; ++i) if (pc[i].bytes) { total += piece_span(pc[i].bytes); ++live; words = words && pc[i].bytes % 4 == 0; }
+  char* pin = (words && live >= 2 && live <= CopyTable::kMax && total <= s->xfer_cap) ? static_cast<char*>(s->pin_up.take(total)) : nullptr;
+  if (!pin) {                                             // no room in the arena (its first cycle): piece by piece
+    for (int i = 0; i < n; ++i) upload_pinned(s, pc[i].device, pc[i].host_src, pc[i].bytes);
+    return;
+  }
+  CopyTable t{};
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!pc[i].bytes) continue;
+    std::memcpy(pin + off, pc[i].host_src, pc[i].bytes);
+    t.dst[t.n] = pc[i].device; t.src[t.n] = s->xfer + off; t.words[t.n] = (unsigned)(pc[i].bytes / 4); ++t.n;
+    off += piece_span(pc[i].bytes);
+  }
+  HIP_CHECK(hipMemcpyAsync(s->xfer, pin, off, hipMemcpyHostToDevice, s->stream));
+  launch_copy_table(s, t);
+}
+// device -> host: enqueue() behind the work on the stream, the caller waits for the stream, finish() hands the pieces to their owners
+struct Downloads {
+  static constexpr size_t kPackLimit = size_t(512) << 10;   // larger pieces travel on their own (a packed piece is copied once more on the device)
+  struct Item { TransferPiece pc; void* pin; };
+  std::vector<Item> items;
+  void add(void* host, const void* device, size_t bytes) { if (host && bytes) items.push_back({{const_cast<void*>(device), nullptr, host, bytes}, nullptr}); }
+  void enqueue(bpmpc_solver* s) {
+    s->pin_down.reset();
+    size_t total = 0;
+    int live = 0;
+    for (const Item& it : items) if (it.pc.bytes <= kPackLimit && it.pc.bytes % 4 == 0) { total += piece_span(it.pc.bytes); ++live; }
+    char* pin = (live >= 2 && live <= CopyTable::kMax && total <= s->xfer_cap) ? static_cast<char*>(s->pin_down.take(total)) : nullptr;
+    if (pin) {
+      CopyTable t{};
+      size_t off = 0;
+      for (Item& it : items) {
+        if (!(it.pc.bytes <= kPackLimit && it.pc.bytes % 4 == 0)) continue;
+        t.dst[t.n] = s->xfer + off; t.src[t.n] = it.pc.device; t.words[t.n] = (unsigned)(it.pc.bytes / 4); ++t.n;
+        it.pin = pin + off;
+        off += piece_span(it.pc.bytes);
+      }
+      launch_copy_table(s, t);
+      HIP_CHECK(hipMemcpyAsync(pin, s->xfer, off, hipMemcpyDeviceToHost, s->stream));
+    }
+    for (Item& it : items) {
+      if (it.pin) continue;
+      void* own = it.pc.bytes <= (size_t(4) << 20) ? s->pin_down.take(it.pc.bytes) : nullptr;      // small results land in pinned memory, large ones in the caller's arrays
+      HIP_CHECK(hipMemcpyAsync(own ? own : it.pc.host_dst, it.pc.device, it.pc.bytes, hipMemcpyDeviceToHost, s->stream));
+      it.pin = own;
+    }
+  }
+  void finish() const { for (const Item& it : items) if (it.pin) std::memcpy(it.pc.host_dst, it.pin, it.pc.bytes); }
+};
+
 void copy_pairs(bpmpc_solver* s, const double* a_src, double* a_dst, size_t na, const double* b_src, double* b_dst, size_t nb, bool rearm) {
   const size_t work = (na > nb ? na : nb) / 2;
   const int grid = (int)std::min<size_t>((work + 255) / 256, 2048);
@@ -557,10 +643,13 @@ void preserve_previous(bpmpc_solver* s, int batch, bool warm_arrays) {
   std::swap(bp.x, bp.x_prev); std::swap(bp.u, bp.u_prev); std::swap(bp.K, bp.K_prev);
   s->named["x"].first = bp.x; s->named["u"].first = bp.u; s->named["K"].first = bp.K;
   s->named["x_prev"].first = bp.x_prev; s->named["u_prev"].first = bp.u_prev; s->named["K_prev"].first = bp.K_prev;
-  HIP_CHECK(hipMemcpyAsync(bp.tp_time, bp.g_time, B * (N + 1) * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  HIP_CHECK(hipMemcpyAsync(bp.tp_kind, bp.g_kind, B * N * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
-  HIP_CHECK(hipMemcpyAsync(bp.tp_nodes, bp.g_nodes, B * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
-  HIP_CHECK(hipMemcpyAsync(bp.tp_grid, bp.p_grid, B * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
+  {   // the grid tables of the previous solve, one launch instead of four copies
+    CopyTable t{};
+    auto keep = [&](void* dst, const void* src, size_t bytes) { t.dst[t.n] = dst; t.src[t.n] = src; t.words[t.n] = (unsigned)(bytes / 4); ++t.n; };
+    keep(bp.tp_time, bp.g_time, B * (N + 1) * sizeof(double)); keep(bp.tp_kind, bp.g_kind, B * N * sizeof(int));
+    keep(bp.tp_nodes, bp.g_nodes, B * sizeof(int)); keep(bp.tp_grid, bp.p_grid, B * sizeof(int));
+    launch_copy_table(s, t);
+  }
   if (s->is_ddp()) {      // the previous DDP solution lives on the time points of its roll-out, not on the grid it was computed on
     kl::ddp_keep_times(batch, (int)N, s->stream, s->ddp, bp.tp_time, bp.tp_kind, bp.tp_nodes, bp.tp_grid);
     HIP_CHECK(hipGetLastError());
@@ -681,11 +770,14 @@ void setup(bpmpc_solver* s, int batch, double horizon, const double* t0, const d
   s->max_rows = rows_max; s->max_vel_rows = vrows_max;
   s->grid_nodes = nodes; s->grid_of_problem = pgrid; s->grid_kind = kind; s->has_solution = false;
   Buffers& bf = s->buf;
-  upload(s, bf.g_kind, kind); upload(s, bf.g_mode, mode); upload(s, bf.g_nodes, nodes); upload(s, bf.g_dt, gdt); upload(s, bf.g_start, gstart);
-  upload(s, bf.g_zref, zref); upload(s, bf.g_zdref, zdref); upload(s, bf.p_grid, pgrid);
-  upload(s, bf.p_tgt_t, tgt_t); upload(s, bf.p_tgt_x, tgt_x); upload(s, bf.p_tgt_n, tgt_n);
-  upload(s, bf.g_time, s->node_times);
-  HIP_CHECK(hipMemcpyAsync(bf.p_x0, x0, (size_t)batch * NX * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  {
+    s->pin_up.reset();                                    // the previous call waited for its transfers (the synchronisation below)
+    auto piece = [](auto* dev, const auto& v) { return TransferPiece{dev, v.data(), nullptr, v.size() * sizeof(v[0])}; };
+    const TransferPiece up[13] = {piece(bf.g_kind, kind), piece(bf.g_mode, mode), piece(bf.g_nodes, nodes), piece(bf.g_dt, gdt), piece(bf.g_start, gstart),
+                                  piece(bf.g_zref, zref), piece(bf.g_zdref, zdref), piece(bf.p_grid, pgrid), piece(bf.p_tgt_t, tgt_t), piece(bf.p_tgt_x, tgt_x),
+                                  piece(bf.p_tgt_n, tgt_n), piece(bf.g_time, s->node_times), {bf.p_x0, x0, nullptr, (size_t)batch * NX * sizeof(double)}};
+    upload_batch(s, up, 13);
+  }
   HIP_CHECK(hipStreamSynchronize(s->stream));  // the host staging vectors go out of scope
   finish_setup(s, batch, warm_x, warm_u, from_previous);
 }
@@ -744,12 +836,15 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
   if (from_previous) preserve_previous(s, batch, false);
   Buffers& bf = s->buf;
   s->pin_up.reset();                                      // the previous call waited for its transfers (the synchronisation below)
-  upload_pinned(s, bf.rg_t0, gt0); upload_pinned(s, bf.rg_gait, ggait); upload_pinned(s, bf.rg_start, gstart); upload_pinned(s, bf.lib_d, lib_d);
-  upload_pinned(s, bf.lib_i, lib_i); upload_pinned(s, bf.p_grid, pgrid);
-  upload_pinned(s, bf.p_t0, t0, (size_t)batch * sizeof(double));
-  upload_pinned(s, bf.p_cmd, cmd_vel, (size_t)batch * 4 * sizeof(double));
-  if (x0) upload_pinned(s, bf.p_x0, x0, (size_t)batch * NX * sizeof(double));
-  else HIP_CHECK(hipMemcpyAsync(bf.p_x0, bf.roll_x, (size_t)batch * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));   // closed loop on the device
+  {
+    const TransferPiece up[9] = {{bf.rg_t0, gt0.data(), nullptr, gt0.size() * sizeof(double)}, {bf.rg_gait, ggait.data(), nullptr, ggait.size() * sizeof(int)},
+                                 {bf.rg_start, gstart.data(), nullptr, gstart.size() * sizeof(double)}, {bf.lib_d, lib_d.data(), nullptr, lib_d.size() * sizeof(double)},
+                                 {bf.lib_i, lib_i.data(), nullptr, lib_i.size() * sizeof(int)}, {bf.p_grid, pgrid.data(), nullptr, pgrid.size() * sizeof(int)},
+                                 {bf.p_t0, t0, nullptr, (size_t)batch * sizeof(double)}, {bf.p_cmd, cmd_vel, nullptr, (size_t)batch * 4 * sizeof(double)},
+                                 {bf.p_x0, x0, nullptr, x0 ? (size_t)batch * NX * sizeof(double) : 0}};
+    upload_batch(s, up, 9);
+  }
+  if (!x0) HIP_CHECK(hipMemcpyAsync(bf.p_x0, bf.roll_x, (size_t)batch * NX * sizeof(double), hipMemcpyDeviceToDevice, s->stream));   // closed loop on the device
   ReferenceGenArgs a{};
   a.lib.switching = bf.lib_d; a.lib.first_mode = bf.lib_i; a.lib.modes = bf.lib_i + first_mode.size(); a.lib.n_templates = n_gaits + 1;
   a.lib.init_events = bf.lib_d + sw_count; a.lib.init_modes = bf.lib_i + first_mode.size() + mode_count; a.lib.init_n_events = (int)init.event_times.size();
@@ -772,18 +867,12 @@ void setup_commands(bpmpc_solver* s, int batch, double horizon, const double* t0
   std::vector<int> nodes(G), status(G), rows(G), kind((size_t)G * N);
   std::vector<double> node_times((size_t)G * (N + 1), 0.0);   // becomes the handle's copy once every grid has been accepted
   {
-    s->pin_down.reset();
-    struct Down { void* host; const void* dev; size_t bytes; void* pin; };
-    Down down[5] = {{nodes.data(), bf.g_nodes, G * sizeof(int), nullptr}, {status.data(), bf.rg_status, G * sizeof(int), nullptr},
-                    {rows.data(), bf.rg_rows, G * sizeof(int), nullptr}, {kind.data(), bf.g_kind, kind.size() * sizeof(int), nullptr},
-                    {node_times.data(), bf.g_time, node_times.size() * sizeof(double), nullptr}};
-    for (Down& d : down) {
-      d.pin = s->pin_down.take(d.bytes);
-      HIP_CHECK(hipMemcpyAsync(d.pin ? d.pin : d.host, d.dev, d.bytes, hipMemcpyDeviceToHost, s->stream));
-    }
+    Downloads down;
+    down.add(nodes.data(), bf.g_nodes, G * sizeof(int)); down.add(status.data(), bf.rg_status, G * sizeof(int)); down.add(rows.data(), bf.rg_rows, G * sizeof(int));
+    down.add(kind.data(), bf.g_kind, kind.size() * sizeof(int)); down.add(node_times.data(), bf.g_time, node_times.size() * sizeof(double));
+    down.enqueue(s);
     HIP_CHECK(hipStreamSynchronize(s->stream));
-    for (Down& d : down)
-      if (d.pin) std::memcpy(d.host, d.pin, d.bytes);
+    down.finish();
   }
   s->has_solution = false;
   s->batch = 0;                                           // stays unusable if a grid is rejected below
@@ -866,18 +955,12 @@ void fetch(bpmpc_solver* s, double* out_t, double* out_x, double* out_u, double*
   {
     // all transfers enqueued behind the solve, one wait; small results (the batch = 1 loop of the reference) land in pinned memory
     // and are copied out by the host, large ones go straight to the caller's (pageable) arrays
-    s->pin_down.reset();
-    struct Down { void* host; const void* dev; size_t bytes; void* pin; };
-    Down down[4] = {{out_x, s->buf.x, B * (N + 1) * NX * sizeof(double), nullptr}, {out_u, s->buf.u, B * N * NU * sizeof(double), nullptr},
-                    {out_K, s->buf.K, B * N * NU * NX * sizeof(double), nullptr}, {stats ? raw.data() : nullptr, s->buf.stats, raw.size() * sizeof(double), nullptr}};
-    for (Down& d : down) {
-      if (!d.host) continue;
-      d.pin = d.bytes <= (size_t(4) << 20) ? s->pin_down.take(d.bytes) : nullptr;
-      HIP_CHECK(hipMemcpyAsync(d.pin ? d.pin : d.host, d.dev, d.bytes, hipMemcpyDeviceToHost, s->stream));
-    }
+    Downloads down;
+    down.add(out_x, s->buf.x, B * (N + 1) * NX * sizeof(double)); down.add(out_u, s->buf.u, B * N * NU * sizeof(double));
+    down.add(out_K, s->buf.K, B * N * NU * NX * sizeof(double)); down.add(stats ? raw.data() : nullptr, s->buf.stats, raw.size() * sizeof(double));
+    down.enqueue(s);
     HIP_CHECK(hipStreamSynchronize(s->stream));
-    for (Down& d : down)
-      if (d.host && d.pin) std::memcpy(d.host, d.pin, d.bytes);
+    down.finish();
   }
   std::vector<int> ddp_points;
   if (s->is_ddp() && s->has_solution) {       // the solution lives on the time points of the accepted roll-out (k_ddp_finish); a failed problem keeps its grid
